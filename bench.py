@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py -- rendered views/s (forward + backward) of the Gaussian rasterizer hot path.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one GaussianRasterizer forward + backward over one synthetic view; with N>1 every rank
+renders its own view of the same scene (one view per GPU, "weak" scaling) and the step also contains
+the flat-buffer RCCL all-reduce (mean) of the per-Gaussian gradients.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line (contract in the task description):
+  value      views/s of the whole job = N * K / max-over-ranks(wall time of K steps)
+  roofline   dominant kernel (per-tile backward blend) against the HBM roof: algorithmic bytes per
+             launch (SURVEY.md 8(d) formula with the MEASURED R_eff) / its mean duration measured
+             with HIP events on the launch stream inside the timed region
+  cpu_baseline  the CPU oracle (a port, OpenMP on the host cores) timed on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "saro-gs_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=1_000_000, help="headline #Gaussians at 1920x1080")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--exp-mode", type=int, default=None, help="0 fixed-sequence (default), 1 ocml, 2 v_exp_f32")
+    ap.add_argument("--sweep", type=str, default="100000,300000,1000000,3000000",
+                    help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
+    ap.add_argument("--sweep-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    return ap.parse_args()
+
+
+class Workload:
+    """One view of synth(P, seed) on this rank's GPU, ready to step."""
+
+    def __init__(self, rast, scenes, P, W, H, deg, view_k, n_views, dev):
+        self.rast, self.P, self.W, self.H = rast, P, W, H
+        sc = scenes.synth(P, 0, sh_degree=deg)
+        cam = scenes.camera(view_k, n_views, W, H)
+        self.sc, self.cam = sc, cam
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+        self.rs = rast.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]),
+            scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]),
+            sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
+        self.leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        self.means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+        self.g = t(scenes.upstream_grad(H, W, 1))
+        self.raster = rast.GaussianRasterizer(self.rs)
+        self.dev = dev
+
+    def step(self, bucket=None, world=1):
+        L = self.leaves
+        for p in list(L.values()) + [self.means2D]:
+            p.grad = None
+        color, radii, depth = self.raster(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"],
+                                          shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
+        color.backward(self.g)
+        if bucket is not None and world > 1:
+            bucket.pack()
+            bucket.allreduce_mean(world)
+            bucket.unpack()
+        return radii
+
+    def stats(self):
+        """Measured R, R_eff, P_vis for the algorithmic-bytes formulas (one untimed forward)."""
+        _C = self.rast._C
+        L = self.leaves
+        e = torch.empty(0)
+        rs = self.rs
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, L["means3D"].detach(), e, L["opacities"].detach(), L["scales"].detach(), L["rotations"].detach(),
+            1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, self.H, self.W, L["shs"].detach(),
+            rs.sh_degree, rs.campos, False)
+        st = _C.debug_export(self.P, R, self.W, self.H, gb, bb, ib)
+        nc = st["n_contrib"].to(torch.int64)
+        gy, gx = (self.H + 15) // 16, (self.W + 15) // 16
+        pad = torch.zeros((gy * 16, gx * 16), dtype=torch.int64, device=nc.device)
+        pad[: self.H, : self.W] = nc
+        tile_max = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
+        return dict(R=int(R), R_eff=int(tile_max.sum().item()), P_vis=int((radii > 0).sum().item()),
+                    pairs_fwd=int(nc.sum().item()), T=gx * gy, N=self.W * self.H)
+
+
+def timed(workload, steps, warmup, bucket, world, vp, dev):
+    for _ in range(warmup):
+        workload.step(bucket, world)
+    vp.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        workload.step(bucket, world)
+    torch.cuda.synchronize(dev)
+    vp.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return vp.max_over_ranks(dt, dev)
+
+
+def cpu_baseline(scenes, P, W, H, deg, budget_s):
+    """The oracle (CPU port, fp32, OpenMP over Gaussians / tiles) on the host cores."""
+    from oracle import oracle as orc
+    orc.build()
+    orc.set_exp_mode(0)
+    cores = os.cpu_count() or 1
+
+    def run(p, w, h):
+        sc = scenes.synth(p, 0, sh_degree=deg)
+        cam = scenes.camera(0, 1, w, h)
+        g = scenes.upstream_grad(h, w, 1)
+        t0 = time.perf_counter()
+        orc.render(sc, cam, g)
+        return time.perf_counter() - t0
+
+    run(2000, 128, 96)                      # page in the library / spin up the OpenMP pool
+    t_small = run(10_000, 400, 400)         # BASELINE config 1
+    # pixel-work scales with the image area; use config 1 to predict the full view
+    predict = t_small * (W * H) / (400 * 400) * 1.5
+    if predict <= budget_s:
+        t = run(P, W, H)
+        return dict(value=1.0 / t, unit="views/s", cores=cores, kind="port",
+                    sample=f"1 view fwd+bwd of the same workload (P={P}, {W}x{H}, SH{deg}), {t:.2f} s")
+    return dict(value=1.0 / t_small, unit="views/s", cores=cores, kind="port",
+                sample=f"1 view fwd+bwd of BASELINE config 1 (P=10000, 400x400, SH{deg}), {t_small:.2f} s; "
+                       f"the full workload was predicted at {predict:.0f} s > budget")
+
+
+def main():
+    a = parse()
+    import view_parallel as vp
+    rank, local, world = vp.init_from_env()
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    import diff_gaussian_rasterization_ch3 as rast
+    import scenes
+    _C = rast._C
+    if a.exp_mode is not None:
+        _C.set_option("exp_mode", a.exp_mode)
+    exp_mode = _C.get_option("exp_mode")
+
+    P, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
+    wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)
+    bucket = None
+    if world > 1:
+        L = wl.leaves
+        bucket = vp.FlatGradBucket([L["means3D"], L["shs"], L["opacities"], L["scales"], L["rotations"], wl.means2D])
+        wl.step(None, 1)  # materialise .grad so the bucket has shapes
+
+    names = [_C.lib().gsrast_profile_kernel_name(k).decode() for k in range(_C.lib().gsrast_profile_kernel_count())]
+    kid = {n: i for i, n in enumerate(names)}
+    _C.profile_reset()
+    # only the two blend kernels are bracketed with events inside the timed region (4 records/step)
+    _C.set_option("profile", (1 << kid["blend_bwd"]) | (1 << kid["blend_fwd"]))
+    # warm-up happens inside timed(); reset the event totals after it by timing warm-up separately
+    for _ in range(a.warmup):
+        wl.step(bucket, world)
+    torch.cuda.synchronize(dev)
+    _C.profile_reset()
+    dt = timed(wl, a.steps, 0, bucket, world, vp, dev)
+    prof = _C.profile_read()
+    _C.set_option("profile", 0)
+
+    st = wl.stats()
+    result = None
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * a.steps / dt
+        bwd_ms = prof["blend_bwd"][0] / max(prof["blend_bwd"][1], 1)
+        fwd_ms = prof["blend_fwd"][0] / max(prof["blend_fwd"][1], 1)
+        # K5 = N*20 + R_eff*40 + R_eff*36 bytes per launch
+        bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
+        fwd_bytes = st["R_eff"] * 44 + st["N"] * 24
+        achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "rendered views/s (fwd+bwd) at 1080p vs #Gaussians",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
+                                   + (" + RCCL all-reduce(mean) of 62 floats/Gaussian" if world > 1 else ""),
+                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
+                       "views_per_step": world, "instances_R": st["R"], "R_eff": st["R_eff"], "visible": st["P_vis"],
+                       "blended_pairs_fwd": st["pairs_fwd"]},
+            "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bwd_bytes,
+                         "avg_launch_ms": round(bwd_ms, 4),
+                         "note": "VALU/atomic-bound kernel: see DESIGN.md; pair-evaluations/s is the telling rate",
+                         "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None},
+            "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
+                           "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
+        }
+
+    # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----
+    if world == 1 and a.sweep:
+        sweep = {}
+        for p in [int(x) for x in a.sweep.split(",") if x]:
+            if p == P:
+                sweep[str(p)] = {"views_per_s": result["value"], "ms_per_step": result["ms_per_step"]}
+                continue
+            del wl
+            torch.cuda.empty_cache()
+            wl = Workload(rast, scenes, p, W, H, deg, 0, 1, dev)
+            d = timed(wl, a.sweep_steps, 3, None, 1, vp, dev)
+            sweep[str(p)] = {"views_per_s": round(a.sweep_steps / d, 3), "ms_per_step": round(d / a.sweep_steps * 1e3, 4)}
+        result["sweep_1080p"] = sweep
+
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(scenes, P, W, H, deg, a.cpu_budget_s)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {e}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        vp.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

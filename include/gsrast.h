@@ -1,0 +1,158 @@
+/*
+ * gsrast.h -- C ABI of the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of yjb6/SaRO-GS: the three static entry
+ * points of the reference's native rasterizer,
+ *     CudaRasterizer::Rasterizer::forward      (cuda_rasterizer/rasterizer.h:34-58,  impl rasterizer_impl.cu:198-339)
+ *     CudaRasterizer::Rasterizer::backward     (cuda_rasterizer/rasterizer.h:60-89,  impl rasterizer_impl.cu:343-436)
+ *     CudaRasterizer::Rasterizer::markVisible  (cuda_rasterizer/rasterizer.h:27-32,  impl rasterizer_impl.cu:141-153)
+ * (paths relative to /root/reference/submodules/gaussian_rasterization_ch3/), which the reference
+ * binds to Python through pybind11 in ext.cpp:15-19 / rasterize_points.cu:35-215.
+ *
+ * Same argument sets, same meaning, plus an explicit HIP stream.  Differences, all deliberate:
+ *   - the three std::function<char*(size_t)> allocators become plain C callbacks + context;
+ *   - all pointers are DEVICE pointers (HBM); a NULL pointer means "absent optional input"
+ *     exactly as in the reference (shs / colors_precomp / scales / rotations / cov3D_precomp);
+ *   - functions return a status (or num_rendered) instead of throwing; gsrast_last_error() has text;
+ *   - the contents of the three state buffers are opaque and differ from the reference's chunks
+ *     (typed SoA arrays); gsrast_debug_export() copies them out in the
+ *     reference's array layout for parity tests.
+ * No torch / STL types cross this boundary.
+ */
+#ifndef GSRAST_H_INCLUDED
+#define GSRAST_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSRAST_ABI_VERSION 1
+#define GSRAST_TILE_X 16 /* reference config.h:16 */
+#define GSRAST_TILE_Y 16 /* reference config.h:17 */
+
+/* Allocation callback: must return a device pointer to at least `bytes` bytes, 256-byte aligned,
+ * that stays valid until the matching backward call has completed (the reference keeps the
+ * buffers alive through ctx.save_for_backward).  Replaces rasterize_points.cu:27-33. */
+typedef void* (*gsrast_alloc_fn)(void* ctx, size_t bytes);
+
+/* Forward pass.  Returns num_rendered (number of (Gaussian, tile) instances, >= 0) or a negative
+ * GSRAST_E_* code.  out_color [3][H][W] planar, out_depth [1][H][W] (median depth, default 15.0),
+ * radii [P] are fully written.  Blocks the host once on `stream` to learn num_rendered
+ * (the reference does the same with a cudaMemcpy, rasterizer_impl.cu:282).
+ * Replaces Rasterizer::forward, rasterizer.h:34-58. */
+int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
+                   gsrast_alloc_fn binning_alloc, void* binning_ctx,
+                   gsrast_alloc_fn image_alloc, void* image_ctx,
+                   int P, int D, int M,
+                   const float* background,
+                   int width, int height,
+                   const float* means3D,
+                   const float* shs,
+                   const float* colors_precomp,
+                   const float* opacities,
+                   const float* scales,
+                   float scale_modifier,
+                   const float* rotations,
+                   const float* cov3D_precomp,
+                   const float* viewmatrix,
+                   const float* projmatrix,
+                   const float* cam_pos,
+                   float tan_fovx, float tan_fovy,
+                   int prefiltered,
+                   float* out_color,
+                   float* out_depth,
+                   int* radii,
+                   void* stream);
+
+/* Backward pass.  Replaces Rasterizer::backward, rasterizer.h:60-89.
+ * On entry dL_dmean2D [P][3], dL_dconic [P][4], dL_dopacity [P] and dL_dcolor [P][3] must be
+ * zero (they are accumulated with atomics, like the reference); dL_dmean3D [P][3],
+ * dL_dcov3D [P][6], dL_dsh [P][M][3], dL_dscale [P][3], dL_drot [P][4] are fully overwritten
+ * (zeros for culled Gaussians), so they need not be initialised.  Returns 0 or GSRAST_E_*. */
+int gsrast_backward(int P, int D, int M, int R,
+                    const float* background,
+                    int width, int height,
+                    const float* means3D,
+                    const float* shs,
+                    const float* colors_precomp,
+                    const float* scales,
+                    float scale_modifier,
+                    const float* rotations,
+                    const float* cov3D_precomp,
+                    const float* viewmatrix,
+                    const float* projmatrix,
+                    const float* campos,
+                    float tan_fovx, float tan_fovy,
+                    const int* radii,
+                    char* geom_buffer,
+                    char* binning_buffer,
+                    char* image_buffer,
+                    const float* dL_dpix,
+                    float* dL_dmean2D,
+                    float* dL_dconic,
+                    float* dL_dopacity,
+                    float* dL_dcolor,
+                    float* dL_dmean3D,
+                    float* dL_dcov3D,
+                    float* dL_dsh,
+                    float* dL_dscale,
+                    float* dL_drot,
+                    void* stream);
+
+/* present[i] = view-space z of means3D[i] > 0.2.  Replaces Rasterizer::markVisible,
+ * rasterizer.h:27-32 (kernel checkFrustum, rasterizer_impl.cu:54-66). */
+int gsrast_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                        const float* projmatrix, unsigned char* present, void* stream);
+
+/* Sizes the library will request through the callbacks (replaces required<T>(),
+ * rasterizer_impl.h:67-73). */
+size_t gsrast_geometry_bytes(int P);
+size_t gsrast_binning_bytes(int num_rendered, int width, int height);
+size_t gsrast_image_bytes(int width, int height);
+
+/* Parity-test helper: copies internal state out in the reference's array layout
+ * (GeometryState / BinningState / ImageState members, rasterizer_impl.h:30-65).  Any output
+ * pointer may be NULL.  All pointers are device pointers.  keys_sorted is rebuilt as
+ * (tile << 32) | depth_bits from the sorted instance list. */
+int gsrast_debug_export(int P, int R, int width, int height,
+                        const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                        float* depths, float* means2D /*[P][2]*/, float* cov3D /*[P][6]*/,
+                        float* conic_opacity /*[P][4]*/, float* rgb /*[P][3]*/,
+                        unsigned char* clamped /*[P][3]*/, uint32_t* tiles_touched,
+                        uint64_t* keys_sorted /*[R]*/, uint32_t* point_list /*[R]*/,
+                        uint32_t* ranges /*[T][2]*/, float* final_T /*[H*W]*/,
+                        uint32_t* n_contrib /*[H*W]*/, void* stream);
+
+/* Options: "exp_mode" 0 = fixed-sequence exp (bit-reproducible vs the CPU oracle), 1 = libm-grade
+ * expf, 2 = hardware v_exp_f32;  "profile" = bit mask of kernel ids (gsrast_profile_kernel_name) whose launches are bracketed
+ * with HIP events on the launch stream, -1 = all, 0 = off;
+ * "debug_sync" 0/1 = synchronise + check errors after every launch.  Returns 0 or GSRAST_E_ARG. */
+int gsrast_set_option(const char* name, int value);
+int gsrast_get_option(const char* name);
+
+/* Per-kernel device timing gathered while "profile" is 1 (HIP events on the launch stream).
+ * gsrast_profile_collect() synchronises outstanding events and folds them into the totals. */
+int gsrast_profile_kernel_count(void);
+const char* gsrast_profile_kernel_name(int kernel_id);
+int gsrast_profile_collect(void);
+int gsrast_profile_read(int kernel_id, double* total_ms, long long* launches);
+void gsrast_profile_reset(void);
+
+const char* gsrast_last_error(void);
+int gsrast_abi_version(void);
+
+enum {
+    GSRAST_OK = 0,
+    GSRAST_E_ARG = -1,     /* bad argument combination / NULL required pointer */
+    GSRAST_E_ALLOC = -2,   /* allocation callback returned NULL */
+    GSRAST_E_DEVICE = -3,  /* HIP runtime error, see gsrast_last_error() */
+    GSRAST_E_OVERFLOW = -4 /* more than 2^31-1 instances */
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_H_INCLUDED */

@@ -1,0 +1,472 @@
+// gsrast_capi.hip -- host orchestration + the C ABI declared in include/gsrast.h.
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics (see build.py).
+//
+// Launch plan (all on the caller's stream; one host sync to learn num_rendered, like the
+// reference's cudaMemcpy at rasterizer_impl.cu:282):
+//   forward : preprocess_fwd -> depth sort (4 x {hist, scan, scatter}) -> gather-scan of tiles
+//             -> [D2H num_rendered] -> emit -> tile sort (2 x {hist, scan, scatter}) -> ranges
+//             -> blend_fwd
+//   backward: blend_bwd -> preprocess_bwd (reference K6 + K7 fused)
+#include "../../include/gsrast.h"
+#include "gsrast_common.h"
+#include "gsrast_preprocess.h"
+#include "gsrast_binning.h"
+#include "gsrast_blend.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gsrast;
+
+namespace {
+
+thread_local std::string g_err;
+std::atomic<int> g_exp_mode{0}, g_profile{0}, g_debug_sync{0};
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define GS_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) return fail(GSRAST_E_DEVICE, #call, e_);                \
+    } while (0)
+
+// ---- per-kernel device timing (option "profile") -------------------------------------------
+enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_COUNT };
+const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
+                                            "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
+                                            "preprocess_bwd", "mark_visible" };
+struct Pending { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<Pending> g_pending;
+double g_total_ms[K_COUNT];
+long long g_launches[K_COUNT];
+
+struct ProfScope {
+    int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(((g_profile.load() >> id_) & 1) != 0)
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_pending.push_back({ id, a, b });
+        }
+    }
+};
+
+int post_launch(const char* what, hipStream_t s)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GSRAST_E_DEVICE, what, e);
+    if (g_debug_sync.load()) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(GSRAST_E_DEVICE, what, e);
+    }
+    return GSRAST_OK;
+}
+#define GS_LAUNCHED(what)                                 \
+    do {                                                  \
+        int rc_ = post_launch(what, s);                   \
+        if (rc_ != GSRAST_OK) return rc_;                 \
+    } while (0)
+
+// ---- scan / sort drivers --------------------------------------------------------------------
+// dst[i] = scan of (idx ? src[idx[i]] : src[i]); two levels (single-block scan of block sums).
+int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst, bool inclusive,
+             uint32_t* tmp, uint32_t* total_out, hipStream_t s)
+{
+    if (n == 0) return GSRAST_OK;
+    const uint32_t nb = (n + SC_CHUNK - 1) / SC_CHUNK;
+    if (nb == 1) {
+        scan_apply_kernel<<<1, 256, 0, s>>>(src, idx, n, nullptr, dst, inclusive ? 1 : 0, total_out);
+        GS_LAUNCHED("scan_apply");
+        return GSRAST_OK;
+    }
+    scan_block_sums_kernel<<<nb, 256, 0, s>>>(src, idx, n, tmp);
+    GS_LAUNCHED("scan_block_sums");
+    scan_single_block_kernel<<<1, 256, 0, s>>>(tmp, nb);
+    GS_LAUNCHED("scan_single_block");
+    scan_apply_kernel<<<nb, 256, 0, s>>>(src, idx, n, tmp, dst, inclusive ? 1 : 0, total_out);
+    GS_LAUNCHED("scan_apply");
+    return GSRAST_OK;
+}
+
+// Stable sort of n (key,value) pairs on `passes` 8-bit digits starting at bit 0.
+// Result ends in (kA,vA) if passes is even, else in (kB,vB).
+int radix_sort(uint32_t* kA, uint32_t* vA, uint32_t* kB, uint32_t* vB, uint32_t n, int passes,
+               uint32_t* hist, uint32_t* scan_tmp, hipStream_t s)
+{
+    if (n == 0) return GSRAST_OK;
+    const uint32_t nblk = (uint32_t)rs_blocks(n);
+    for (int p = 0; p < passes; p++) {
+        radix_hist_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, n, 8 * p, hist, nblk);
+        GS_LAUNCHED("radix_hist");
+        int rc = scan_u32(hist, nullptr, 256u * nblk, hist, false, scan_tmp, nullptr, s);
+        if (rc != GSRAST_OK) return rc;
+        radix_scatter_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, 8 * p, hist, nblk);
+        GS_LAUNCHED("radix_scatter");
+        std::swap(kA, kB); std::swap(vA, vB);
+    }
+    return GSRAST_OK;
+}
+
+CamArgs make_cam(const float* view, const float* proj, const float* campos, float tanx, float tany,
+                 float scale_mod, int W, int H)
+{
+    CamArgs c;
+    c.view = view; c.proj = proj; c.campos = campos;
+    c.tanx = tanx; c.tany = tany;
+    c.fy = H / (2.0f * tany);   // reference rasterizer_impl.cu:222-223
+    c.fx = W / (2.0f * tanx);
+    c.scale_mod = scale_mod;
+    c.W = W; c.H = H; c.gx = (W + TILE_X - 1) / TILE_X; c.gy = (H + TILE_Y - 1) / TILE_Y;
+    return c;
+}
+
+template <typename T> T* at(char* base, size_t off) { return reinterpret_cast<T*>(base + off); }
+template <typename T> const T* at(const char* base, size_t off) { return reinterpret_cast<const T*>(base + off); }
+
+__global__ void __launch_bounds__(256)
+export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __restrict__ rec0,
+                   const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                   const float* __restrict__ cov3D_in, const unsigned char* __restrict__ clamped_in,
+                   const uint32_t* __restrict__ tiles_in, float* depths, float* means2D, float* cov3D,
+                   float* conic_opacity, float* rgb, unsigned char* clamped, uint32_t* tiles)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool vis = tiles_in[i] != 0;
+    const float4 a = rec0[i], b = rec1[i], c = rec2[i];
+    if (depths) depths[i] = vis ? depths_in[i] : 0.0f;
+    if (means2D) { means2D[2 * i] = vis ? a.x : 0.f; means2D[2 * i + 1] = vis ? a.y : 0.f; }
+    if (cov3D) for (int k = 0; k < 6; k++) cov3D[6 * i + k] = cov3D_in[6 * i + k];
+    if (conic_opacity) {
+        conic_opacity[4 * i] = vis ? a.z : 0.f; conic_opacity[4 * i + 1] = vis ? a.w : 0.f;
+        conic_opacity[4 * i + 2] = vis ? b.x : 0.f; conic_opacity[4 * i + 3] = vis ? b.y : 0.f;
+    }
+    if (rgb) { rgb[3 * i] = vis ? b.z : 0.f; rgb[3 * i + 1] = vis ? b.w : 0.f; rgb[3 * i + 2] = vis ? c.x : 0.f; }
+    if (clamped) {
+        const unsigned cl = vis ? clamped_in[i] : 0u;
+        clamped[3 * i] = cl & 1u; clamped[3 * i + 1] = (cl >> 1) & 1u; clamped[3 * i + 2] = (cl >> 2) & 1u;
+    }
+    if (tiles) tiles[i] = tiles_in[i];
+}
+
+__global__ void __launch_bounds__(256)
+export_keys_kernel(uint32_t R, const uint32_t* __restrict__ tile_sorted, const uint32_t* __restrict__ vals_sorted,
+                   const float* __restrict__ depths, uint64_t* keys, uint32_t* point_list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t g = vals_sorted[i];
+    if (keys) keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(depths[g]);
+    if (point_list) point_list[i] = g;
+}
+
+template <int MODE>
+void launch_blend_fwd(uint32_t grid, hipStream_t s, const uint2* ranges, const uint32_t* plist, int W, int H, int gx,
+                      uint32_t T, const float4* r0, const float4* r1, const float4* r2, const float* bg, float* oc,
+                      float* od, float* fT, uint32_t* nc, uint32_t* tm)
+{
+    blend_fwd_kernel<MODE><<<grid, 256, 0, s>>>(ranges, plist, W, H, gx, T, r0, r1, r2, bg, oc, od, fT, nc, tm);
+}
+template <int MODE>
+void launch_blend_bwd(uint32_t grid, hipStream_t s, const uint2* ranges, const uint32_t* plist, int W, int H, int gx,
+                      uint32_t T, const float4* r0, const float4* r1, const float4* r2, const float* bg,
+                      const float* fT, const uint32_t* nc, const uint32_t* tm, const float* dpix, float* dm2,
+                      float* dcon, float* dop, float* dcol)
+{
+    blend_bwd_kernel<MODE><<<grid, 256, 0, s>>>(ranges, plist, W, H, gx, T, r0, r1, r2, bg, fT, nc, tm, dpix, dm2, dcon, dop, dcol);
+}
+
+} // namespace
+
+extern "C" {
+
+int gsrast_abi_version(void) { return GSRAST_ABI_VERSION; }
+const char* gsrast_last_error(void) { return g_err.c_str(); }
+
+int gsrast_set_option(const char* name, int value)
+{
+    if (!name) return GSRAST_E_ARG;
+    if (!strcmp(name, "exp_mode")) { if (value < 0 || value > 2) return GSRAST_E_ARG; g_exp_mode = value; return 0; }
+    if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
+    if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
+    return GSRAST_E_ARG;
+}
+int gsrast_get_option(const char* name)
+{
+    if (!name) return GSRAST_E_ARG;
+    if (!strcmp(name, "exp_mode")) return g_exp_mode.load();
+    if (!strcmp(name, "profile")) return g_profile.load();
+    if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
+    return GSRAST_E_ARG;
+}
+
+int gsrast_profile_kernel_count(void) { return K_COUNT; }
+const char* gsrast_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int gsrast_profile_collect(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_total_ms[p.id] += ms; g_launches[p.id] += 1;
+        }
+        (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+    }
+    g_pending.clear();
+    return 0;
+}
+int gsrast_profile_read(int id, double* total_ms, long long* launches)
+{
+    if (id < 0 || id >= K_COUNT) return GSRAST_E_ARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (total_ms) *total_ms = g_total_ms[id];
+    if (launches) *launches = g_launches[id];
+    return 0;
+}
+void gsrast_profile_reset(void)
+{
+    gsrast_profile_collect();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < K_COUNT; i++) { g_total_ms[i] = 0; g_launches[i] = 0; }
+}
+
+size_t gsrast_geometry_bytes(int P) { return geom_layout((size_t)(P > 0 ? P : 0)).total; }
+size_t gsrast_binning_bytes(int R, int, int) { return bin_layout((size_t)(R > 0 ? R : 0)).total; }
+size_t gsrast_image_bytes(int W, int H) { return img_layout((size_t)(W > 0 ? W : 0), (size_t)(H > 0 ? H : 0)).total; }
+
+int gsrast_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                        unsigned char* present, void* stream)
+{
+    (void)projmatrix;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(GSRAST_E_ARG, "mark_visible: NULL argument");
+    if (P == 0) return GSRAST_OK;
+    ProfScope ps(K_MARK_VISIBLE, s);
+    mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, viewmatrix, present);
+    GS_LAUNCHED("mark_visible");
+    return GSRAST_OK;
+}
+
+int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_alloc_fn binning_alloc,
+                   void* binning_ctx, gsrast_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                   const float* background, int width, int height, const float* means3D, const float* shs,
+                   const float* colors_precomp, const float* opacities, const float* scales,
+                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                   float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream)
+{
+    (void)prefiltered; // the reference only traps when a prefiltered point is culled (auxiliary.h:156-160)
+    hipStream_t s = (hipStream_t)stream;
+    const int W = width, H = height;
+    if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return fail(GSRAST_E_ARG, "forward: bad P / image size / SH degree");
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(GSRAST_E_ARG, "forward: NULL allocator");
+    if (!out_color || !out_depth || !background) return fail(GSRAST_E_ARG, "forward: NULL output / background");
+    const size_t N = (size_t)W * H;
+    if (P == 0) { // reference rasterize_points.cu:81 -- nothing is rendered, outputs stay zero
+        GS_HIP(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), s));
+        GS_HIP(hipMemsetAsync(out_depth, 0, N * sizeof(float), s));
+        return 0;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii) return fail(GSRAST_E_ARG, "forward: NULL required input");
+    if (!shs && !colors_precomp) return fail(GSRAST_E_ARG, "forward: need shs or colors_precomp");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(GSRAST_E_ARG, "forward: need scales+rotations or cov3D_precomp");
+    if (shs && !colors_precomp && (!cam_pos || M < (D + 1) * (D + 1))) return fail(GSRAST_E_ARG, "forward: SH path needs campos and M >= (D+1)^2");
+
+    const CamArgs cam = make_cam(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, scale_modifier, W, H);
+    const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
+
+    const GeomLayout GL = geom_layout((size_t)P);
+    char* geom = (char*)geometry_alloc(geometry_ctx, GL.total);
+    if (!geom) return fail(GSRAST_E_ALLOC, "forward: geometry allocation failed");
+    const ImgLayout IL = img_layout((size_t)W, (size_t)H);
+    char* img = (char*)image_alloc(image_ctx, IL.total);
+    if (!img) return fail(GSRAST_E_ALLOC, "forward: image allocation failed");
+
+    float* depths = at<float>(geom, GL.depths);
+    float4* rec0 = at<float4>(geom, GL.rec0); float4* rec1 = at<float4>(geom, GL.rec1); float4* rec2 = at<float4>(geom, GL.rec2);
+    uint32_t* tiles = at<uint32_t>(geom, GL.tiles);
+    uint2* rect = at<uint2>(geom, GL.rect);
+    uint32_t *kA = at<uint32_t>(geom, GL.keyA), *kB = at<uint32_t>(geom, GL.keyB);
+    uint32_t *vA = at<uint32_t>(geom, GL.valA), *vB = at<uint32_t>(geom, GL.valB);
+    uint32_t* offsets = at<uint32_t>(geom, GL.offsets);
+    uint32_t* hist = at<uint32_t>(geom, GL.hist);
+    uint32_t* scan_tmp = at<uint32_t>(geom, GL.scan_tmp);
+    uint32_t* scalars = at<uint32_t>(geom, GL.scalars);
+
+    {
+        ProfScope ps(K_PREPROCESS_FWD, s);
+        preprocess_fwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+            P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
+            colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
+            at<unsigned char>(geom, GL.clamped), tiles, rect, kA, vA);
+        GS_LAUNCHED("preprocess_fwd");
+    }
+    {
+        ProfScope ps(K_SORT_DEPTH, s);
+        int rc = radix_sort(kA, vA, kB, vB, (uint32_t)P, 4, hist, scan_tmp, s);
+        if (rc != GSRAST_OK) return rc;
+    }
+    const uint32_t* order = vA; // 4 passes -> back in A
+    {
+        ProfScope ps(K_SCAN_TILES, s);
+        int rc = scan_u32(tiles, order, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
+        if (rc != GSRAST_OK) return rc;
+    }
+    uint32_t num_rendered = 0;
+    GS_HIP(hipMemcpyAsync(&num_rendered, scalars, sizeof(num_rendered), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    if (num_rendered > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
+    const uint32_t R = num_rendered;
+
+    const BinLayout BL = bin_layout((size_t)R);
+    char* bin = (char*)binning_alloc(binning_ctx, BL.total);
+    if (!bin) return fail(GSRAST_E_ALLOC, "forward: binning allocation failed");
+    uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
+    uint32_t *tvA = at<uint32_t>(bin, BL.valA), *tvB = at<uint32_t>(bin, BL.valB);
+    uint32_t* bhist = at<uint32_t>(bin, BL.hist);
+    uint32_t* bscan = at<uint32_t>(bin, BL.scan_tmp);
+    const int tpasses = tile_passes(T);
+
+    uint2* ranges = at<uint2>(img, IL.ranges);
+    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s)); // reference rasterizer_impl.cu:311
+    if (R > 0) {
+        {
+            ProfScope ps(K_EMIT, s);
+            emit_instances_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, offsets, tiles, rect, cam.gx, tkA, tvA);
+            GS_LAUNCHED("emit_instances");
+        }
+        {
+            ProfScope ps(K_SORT_TILE, s);
+            int rc = radix_sort(tkA, tvA, tkB, tvB, R, tpasses, bhist, bscan, s);
+            if (rc != GSRAST_OK) return rc;
+        }
+        const uint32_t* tk_sorted = (tpasses & 1) ? tkB : tkA;
+        {
+            ProfScope ps(K_RANGES, s);
+            tile_ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, tk_sorted, ranges);
+            GS_LAUNCHED("tile_ranges");
+        }
+    }
+    const uint32_t* plist = (tpasses & 1) ? tvB : tvA;
+    {
+        ProfScope ps(K_BLEND_FWD, s);
+        const uint32_t grid = ((T + 7) / 8) * 8;
+        float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
+        uint32_t* tm = at<uint32_t>(img, IL.tile_max);
+        switch (g_exp_mode.load()) {
+        case 0: launch_blend_fwd<0>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, out_color, out_depth, fT, nc, tm); break;
+        case 1: launch_blend_fwd<1>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, out_color, out_depth, fT, nc, tm); break;
+        default: launch_blend_fwd<2>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, out_color, out_depth, fT, nc, tm); break;
+        }
+        GS_LAUNCHED("blend_fwd");
+    }
+    return (int)R;
+}
+
+int gsrast_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                    float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                    const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int W = width, H = height;
+    if (P < 0 || R < 0 || W <= 0 || H <= 0) return fail(GSRAST_E_ARG, "backward: bad sizes");
+    if (P == 0) return GSRAST_OK;
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail(GSRAST_E_ARG, "backward: NULL state buffer");
+    if (!means3D || !radii || !viewmatrix || !projmatrix || !dL_dpix || !background) return fail(GSRAST_E_ARG, "backward: NULL required input");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D) return fail(GSRAST_E_ARG, "backward: NULL gradient output");
+    const bool use_sh = shs && !colors_precomp;
+    const bool use_sr = !cov3D_precomp;
+    if (use_sh && (!dL_dsh || !campos)) return fail(GSRAST_E_ARG, "backward: SH path needs dL_dsh and campos");
+    if (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot)) return fail(GSRAST_E_ARG, "backward: scale/rotation path needs their gradients");
+
+    const CamArgs cam = make_cam(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, W, H);
+    const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
+    const GeomLayout GL = geom_layout((size_t)P);
+    const BinLayout BL = bin_layout((size_t)R);
+    const ImgLayout IL = img_layout((size_t)W, (size_t)H);
+    const int tpasses = tile_passes(T);
+    char* geom = geom_buffer; char* bin = binning_buffer; char* img = image_buffer;
+    const uint32_t* plist = bin ? ((tpasses & 1) ? at<uint32_t>(bin, BL.valB) : at<uint32_t>(bin, BL.valA)) : nullptr;
+    const float4* rec0 = at<float4>(geom, GL.rec0); const float4* rec1 = at<float4>(geom, GL.rec1); const float4* rec2 = at<float4>(geom, GL.rec2);
+
+    if (R > 0) {
+        ProfScope ps(K_BLEND_BWD, s);
+        const uint32_t grid = ((T + 7) / 8) * 8;
+        const uint2* ranges = at<uint2>(img, IL.ranges);
+        const float* fT = at<float>(img, IL.final_T); const uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
+        const uint32_t* tm = at<uint32_t>(img, IL.tile_max);
+        switch (g_exp_mode.load()) {
+        case 0: launch_blend_bwd<0>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, fT, nc, tm, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor); break;
+        case 1: launch_blend_bwd<1>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, fT, nc, tm, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor); break;
+        default: launch_blend_bwd<2>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, fT, nc, tm, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor); break;
+        }
+        GS_LAUNCHED("blend_bwd");
+    }
+    {
+        ProfScope ps(K_PREPROCESS_BWD, s);
+        const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
+        preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+            P, D, M, means3D, radii, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
+            use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, dL_dmean2D, dL_dconic, dL_dcolor,
+            dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+        GS_LAUNCHED("preprocess_bwd");
+    }
+    return GSRAST_OK;
+}
+
+int gsrast_debug_export(int P, int R, int width, int height, const char* geom_buffer, const char* binning_buffer,
+                        const char* image_buffer, float* depths, float* means2D, float* cov3D, float* conic_opacity,
+                        float* rgb, unsigned char* clamped, uint32_t* tiles_touched, uint64_t* keys_sorted,
+                        uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0 || !geom_buffer) return fail(GSRAST_E_ARG, "debug_export: bad arguments");
+    const GeomLayout GL = geom_layout((size_t)P);
+    const BinLayout BL = bin_layout((size_t)(R > 0 ? R : 0));
+    const ImgLayout IL = img_layout((size_t)width, (size_t)height);
+    const uint32_t T = (uint32_t)((width + TILE_X - 1) / TILE_X) * (uint32_t)((height + TILE_Y - 1) / TILE_Y);
+    export_geom_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+        P, at<float>(geom_buffer, GL.depths), at<float4>(geom_buffer, GL.rec0), at<float4>(geom_buffer, GL.rec1),
+        at<float4>(geom_buffer, GL.rec2), at<float>(geom_buffer, GL.cov3D), at<unsigned char>(geom_buffer, GL.clamped),
+        at<uint32_t>(geom_buffer, GL.tiles), depths, means2D, cov3D, conic_opacity, rgb, clamped, tiles_touched);
+    GS_LAUNCHED("export_geom");
+    if (R > 0 && binning_buffer && (keys_sorted || point_list)) {
+        const int tpasses = tile_passes(T);
+        const uint32_t* tk = (tpasses & 1) ? at<uint32_t>(binning_buffer, BL.keyB) : at<uint32_t>(binning_buffer, BL.keyA);
+        const uint32_t* tv = (tpasses & 1) ? at<uint32_t>(binning_buffer, BL.valB) : at<uint32_t>(binning_buffer, BL.valA);
+        export_keys_kernel<<<(R + 255) / 256, 256, 0, s>>>((uint32_t)R, tk, tv, at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
+        GS_LAUNCHED("export_keys");
+    }
+    if (image_buffer) {
+        const size_t N = (size_t)width * height;
+        if (ranges) GS_HIP(hipMemcpyAsync(ranges, image_buffer + IL.ranges, (size_t)T * 8, hipMemcpyDeviceToDevice, s));
+        if (final_T) GS_HIP(hipMemcpyAsync(final_T, image_buffer + IL.final_T, N * 4, hipMemcpyDeviceToDevice, s));
+        if (n_contrib) GS_HIP(hipMemcpyAsync(n_contrib, image_buffer + IL.n_contrib, N * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return GSRAST_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,183 @@
+// gsrast_common.h -- shared constants, HBM state layout and wave64 helpers (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace gsrast {
+
+constexpr int TILE_X = 16;          // reference config.h:16-17 -- pinned by key parity
+constexpr int TILE_Y = 16;
+constexpr int TILE_PIX = TILE_X * TILE_Y;
+constexpr int WAVE = 64;            // CDNA4 wavefront
+
+// ---------------------------------------------------------------------------------------------
+// HBM layout of the three state buffers.  Every array starts on a 256-byte boundary.
+// Geometry (per Gaussian), replaces GeometryState (reference rasterizer_impl.h:30-45):
+//   depths   f32[P]      view-space z (also the low 32 key bits)
+//   rec0     float4[P]   {mean2D.x, mean2D.y, conic.x, conic.y}     \  gathered by the blend
+//   rec1     float4[P]   {conic.z, opacity, r, g}                    > kernels, 48 B / instance
+//   rec2     float4[P]   {b, depth, skip_threshold, 0}              /
+//   cov3D    f32[6P]     upper triangle (only when built from scale/rotation)
+//   clamped  u8[P]       bit c set <=> colour channel c was clamped at 0
+//   tiles    u32[P]      tiles touched
+//   rect     uint2[P]    {min.x | min.y<<16, max.x | max.y<<16} tile rectangle
+//   keyA/B   u32[P] x2   depth-sort ping-pong keys        valA/B u32[P] x2   ping-pong values
+//   offsets  u32[P]      inclusive scan of tiles[] in depth order
+//   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
+//   scalars  u32[64]     [0] = num_rendered
+struct GeomLayout {
+    size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, keyA, keyB, valA, valB, offsets,
+        hist, scan_tmp, scalars, total;
+};
+// Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
+//   keyA/B u32[R] x2  tile id ping-pong    valA/B u32[R] x2  Gaussian id ping-pong
+//   hist u32[256*nblk(R)], scan_tmp
+struct BinLayout {
+    size_t keyA, keyB, valA, valB, hist, scan_tmp, total;
+};
+// Image (per pixel / per tile), replaces ImageState (rasterizer_impl.h:47-54):
+//   final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_max u32[T] (deepest list position any
+//   pixel of the tile consumed -- bounds the backward traversal)
+struct ImgLayout {
+    size_t final_T, n_contrib, ranges, tile_max, total;
+};
+
+constexpr int RS_THREADS = 256;     // radix sort: 4 waves
+constexpr int RS_ITEMS = 16;        // keys per lane
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
+constexpr int SC_CHUNK = 4096;      // scan: elements per block (256 threads x 16)
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline size_t rs_blocks(size_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK; }
+static inline size_t scan_tmp_elems(size_t n)
+{ // partial sums for a multi-level scan of n elements
+    size_t tot = 0;
+    while (n > SC_CHUNK) { n = (n + SC_CHUNK - 1) / SC_CHUNK; tot += align256(n * 4) / 4; }
+    return tot + 64;
+}
+
+static inline GeomLayout geom_layout(size_t P)
+{
+    GeomLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    size_t Pp = P ? P : 1;
+    L.depths = take(Pp * 4); L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16);
+    L.cov3D = take(Pp * 24); L.clamped = take(Pp); L.tiles = take(Pp * 4); L.rect = take(Pp * 8);
+    L.keyA = take(Pp * 4); L.keyB = take(Pp * 4); L.valA = take(Pp * 4); L.valB = take(Pp * 4);
+    L.offsets = take(Pp * 4);
+    size_t hist_n = 256 * rs_blocks(Pp);
+    L.hist = take(hist_n * 4);
+    size_t st = scan_tmp_elems(hist_n) > scan_tmp_elems(Pp) ? scan_tmp_elems(hist_n) : scan_tmp_elems(Pp);
+    L.scan_tmp = take(st * 4);
+    L.scalars = take(256);
+    L.total = o + 256;
+    return L;
+}
+static inline BinLayout bin_layout(size_t R)
+{
+    BinLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    size_t Rp = R ? R : 1;
+    L.keyA = take(Rp * 4); L.keyB = take(Rp * 4); L.valA = take(Rp * 4); L.valB = take(Rp * 4);
+    size_t hist_n = 256 * rs_blocks(Rp);
+    L.hist = take(hist_n * 4);
+    L.scan_tmp = take(scan_tmp_elems(hist_n) * 4);
+    L.total = o + 256;
+    return L;
+}
+static inline ImgLayout img_layout(size_t W, size_t H)
+{
+    ImgLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    size_t N = W * H ? W * H : 1;
+    size_t T = ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    if (!T) T = 1;
+    L.final_T = take(N * 4); L.n_contrib = take(N * 4); L.ranges = take(T * 8); L.tile_max = take(T * 4);
+    L.total = o + 256;
+    return L;
+}
+// number of 8-bit passes needed to sort tile ids < T
+static inline int tile_passes(size_t T)
+{
+    int bits = 0;
+    while (((size_t)1 << bits) < T) bits++;
+    int p = (bits + 7) / 8;
+    return p ? p : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device helpers
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// exp(): three interchangeable implementations (option "exp_mode").
+//  0: fixed sequence of exactly rounded fp32 operations -- bit-identical to oracle det_expf().
+//  1: OCML expf (<= 1 ulp).   2: v_exp_f32(x * log2e) (fast, ~1e-6 relative for |x| < 6).
+template <int MODE>
+__device__ __forceinline__ float gs_exp(float x)
+{
+    if constexpr (MODE == 0) {
+        if (x < -80.0f) return 0.0f;
+        x = x > 80.0f ? 80.0f : x;
+        float n = __builtin_rintf(x * 1.44269504088896341f);
+        float r = __builtin_fmaf(n, -0.693359375f, x);
+        r = __builtin_fmaf(n, 2.12194440e-4f, r);
+        float p = 1.9875691500e-4f;
+        p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+        p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+        p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+        p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+        p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+        float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+        return __builtin_amdgcn_ldexpf(y, (int)n);
+    } else if constexpr (MODE == 1) {
+        return expf(x);
+    } else {
+        return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    }
+}
+
+// power of the 2D Gaussian at offset d -- same fixed contraction as oracle power_f().
+__device__ __forceinline__ float gs_power(float cx, float cy, float cz, float dx, float dy)
+{
+    float q = __builtin_fmaf(cz * dy, dy, (cx * dx) * dx);
+    return __builtin_fmaf(-0.5f, q, -((cy * dx) * dy));
+}
+
+// DPP add: v + dpp_move(v); lanes without a source (or masked off) add 0.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
+    return v + __int_as_float(t);
+}
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0x111>(v);              // row_shr:1
+    v = dpp_add<0x112>(v);              // row_shr:2
+    v = dpp_add<0x114>(v);              // row_shr:4
+    v = dpp_add<0x118>(v);              // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);         // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);         // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return v;
+}
+
+// Lanes of the wave whose 8-bit digit equals mine (among `valid` lanes).
+__device__ __forceinline__ uint64_t wave_match8(uint32_t d, bool valid)
+{
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        bool bit = (d >> b) & 1u;
+        uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+__device__ __forceinline__ uint64_t lanemask_lt() { return ((uint64_t)1 << lane_id()) - 1; }
+
+#endif // __HIPCC__
+} // namespace gsrast

@@ -1,0 +1,471 @@
+// gsrast_preprocess.h -- per-Gaussian kernels: forward projection / covariance / SH colour, and
+// their backward.  One lane per Gaussian; fp32 arithmetic in a fixed evaluation order (the
+// translation unit is built with -ffp-contract=off, FMAs appear only where written) so the
+// integer outputs (radii, tile rectangles, depth key bits) match the CPU oracle bit for bit.
+//
+// Reference behaviour restated here (RST = reference cuda_rasterizer/):
+//   forward : RST/forward.cu:155-256 preprocessCUDA, :74-113 computeCov2D, :118-152 computeCov3D,
+//             :20-71 computeColorFromSH, RST/auxiliary.h:41-56 ndc2Pix/getRect, :139-164 in_frustum
+//   backward: RST/backward.cu:144-274 computeCov2DCUDA, :346-396 preprocessCUDA,
+//             :278-341 computeCov3D, :20-139 computeColorFromSH   (fused into ONE kernel here)
+#pragma once
+#include "gsrast_common.h"
+
+namespace gsrast {
+
+__device__ constexpr float kSH0 = 0.28209479177387814f;
+__device__ constexpr float kSH1 = 0.4886025119029199f;
+__device__ constexpr float kSH2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f };
+__device__ constexpr float kSH3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f };
+
+struct Cam {            // per-call constants, passed by value in kernarg (SGPRs)
+    float view[16];     // transposed storage: view[4*c + r] = V[r][c]
+    float proj[16];
+    float campos[3];
+    float tanx, tany, fx, fy, scale_mod;
+    int W, H, gx, gy;
+};
+
+// What the host passes: the three camera arrays stay in HBM (no D2H copy, no sync); every lane
+// reads them through uniform (scalar) loads at kernel entry.
+struct CamArgs {
+    const float* view; const float* proj; const float* campos;
+    float tanx, tany, fx, fy, scale_mod;
+    int W, H, gx, gy;
+};
+__device__ __forceinline__ Cam load_cam(const CamArgs& a)
+{
+    Cam c;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { c.view[k] = a.view[k]; c.proj[k] = a.proj[k]; }
+    if (a.campos) { c.campos[0] = a.campos[0]; c.campos[1] = a.campos[1]; c.campos[2] = a.campos[2]; }
+    else { c.campos[0] = c.campos[1] = c.campos[2] = 0.0f; }
+    c.tanx = a.tanx; c.tany = a.tany; c.fx = a.fx; c.fy = a.fy; c.scale_mod = a.scale_mod;
+    c.W = a.W; c.H = a.H; c.gx = a.gx; c.gy = a.gy;
+    return c;
+}
+
+struct M3 { float m[3][3]; };  // m[c][r], column-major like the reference's glm::mat3
+
+__device__ __forceinline__ void xform4x3(const float p[3], const float* M, float o[3])
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++) o[r] = M[r] * p[0] + M[4 + r] * p[1] + M[8 + r] * p[2] + M[12 + r];
+}
+__device__ __forceinline__ void xform4x4(const float p[3], const float* M, float o[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) o[r] = M[r] * p[0] + M[4 + r] * p[1] + M[8 + r] * p[2] + M[12 + r];
+}
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{ // evaluated in double like the reference (1.0 / 0.5 literals), then narrowed
+    return (float)((((double)v + 1.0) * S - 1.0) * 0.5);
+}
+__device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, int gy, int rmin[2], int rmax[2])
+{
+    int a;
+    a = (int)((px - rad) / TILE_X); a = a > 0 ? a : 0; rmin[0] = gx < a ? gx : a;
+    a = (int)((py - rad) / TILE_Y); a = a > 0 ? a : 0; rmin[1] = gy < a ? gy : a;
+    a = (int)((px + rad + TILE_X - 1) / TILE_X); a = a > 0 ? a : 0; rmax[0] = gx < a ? gx : a;
+    a = (int)((py + rad + TILE_Y - 1) / TILE_Y); a = a > 0 ? a : 0; rmax[1] = gy < a ? gy : a;
+}
+
+__device__ __forceinline__ void quat_to_R(const float q[4], M3& R)
+{
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R.m[0][0] = 1.0f - 2.0f * (y * y + z * z); R.m[0][1] = 2.0f * (x * y - r * z); R.m[0][2] = 2.0f * (x * z + r * y);
+    R.m[1][0] = 2.0f * (x * y + r * z); R.m[1][1] = 1.0f - 2.0f * (x * x + z * z); R.m[1][2] = 2.0f * (y * z - r * x);
+    R.m[2][0] = 2.0f * (x * z - r * y); R.m[2][1] = 2.0f * (y * z + r * x); R.m[2][2] = 1.0f - 2.0f * (x * x + y * y);
+}
+// Sigma = (S R)^T (S R), upper triangle; M = S*R returned for the backward.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s_in[3], float mod, const float q[4], float c6[6], M3& M)
+{
+    M3 R; quat_to_R(q, R);
+    const float s[3] = { mod * s_in[0], mod * s_in[1], mod * s_in[2] };
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) M.m[c][r] = s[r] * R.m[c][r];
+#define GS_SIG(c, r) (M.m[r][0] * M.m[c][0] + M.m[r][1] * M.m[c][1] + M.m[r][2] * M.m[c][2])
+    c6[0] = GS_SIG(0, 0); c6[1] = GS_SIG(0, 1); c6[2] = GS_SIG(0, 2);
+    c6[3] = GS_SIG(1, 1); c6[4] = GS_SIG(1, 2); c6[5] = GS_SIG(2, 2);
+#undef GS_SIG
+}
+
+struct Cov2D { float t[3]; float txtz, tytz, limx, limy; M3 T, Wm, V; float a, b, c; };
+
+__device__ __forceinline__ void cov2d_eval(const float mean[3], const Cam& cam, const float c6[6], Cov2D& o)
+{
+    float t[3];
+    xform4x3(mean, cam.view, t);
+    o.limx = 1.3f * cam.tanx; o.limy = 1.3f * cam.tany;
+    o.txtz = t[0] / t[2]; o.tytz = t[1] / t[2];
+    float cx = o.txtz < -o.limx ? -o.limx : o.txtz; cx = o.limx < cx ? o.limx : cx;
+    float cy = o.tytz < -o.limy ? -o.limy : o.tytz; cy = o.limy < cy ? o.limy : cy;
+    t[0] = cx * t[2]; t[1] = cy * t[2];
+    o.t[0] = t[0]; o.t[1] = t[1]; o.t[2] = t[2];
+    const float J00 = cam.fx / t[2], J02 = -(cam.fx * t[0]) / (t[2] * t[2]);
+    const float J11 = cam.fy / t[2], J12 = -(cam.fy * t[1]) / (t[2] * t[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) o.Wm.m[c][r] = cam.view[4 * r + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        o.T.m[0][r] = o.Wm.m[0][r] * J00 + o.Wm.m[2][r] * J02;
+        o.T.m[1][r] = o.Wm.m[1][r] * J11 + o.Wm.m[2][r] * J12;
+        o.T.m[2][r] = 0.0f;
+    }
+    o.V.m[0][0] = c6[0]; o.V.m[0][1] = c6[1]; o.V.m[0][2] = c6[2];
+    o.V.m[1][0] = c6[1]; o.V.m[1][1] = c6[3]; o.V.m[1][2] = c6[4];
+    o.V.m[2][0] = c6[2]; o.V.m[2][1] = c6[4]; o.V.m[2][2] = c6[5];
+    float A[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            A[k][r] = o.T.m[r][0] * o.V.m[0][k] + o.T.m[r][1] * o.V.m[1][k] + o.T.m[r][2] * o.V.m[2][k];
+    const float c00 = A[0][0] * o.T.m[0][0] + A[1][0] * o.T.m[0][1] + A[2][0] * o.T.m[0][2];
+    const float c01 = A[0][1] * o.T.m[0][0] + A[1][1] * o.T.m[0][1] + A[2][1] * o.T.m[0][2];
+    const float c11 = A[0][1] * o.T.m[1][0] + A[1][1] * o.T.m[1][1] + A[2][1] * o.T.m[1][2];
+    o.a = c00 + 0.3f; o.b = c01; o.c = c11 + 0.3f;
+}
+
+// colour before clamping (SH + 0.5); sh points at this Gaussian's [M][3] block
+__device__ __forceinline__ void sh_to_rgb(int deg, const float pos[3], const float campos[3], const float* __restrict__ sh, float out[3])
+{
+    const float d0 = pos[0] - campos[0], d1 = pos[1] - campos[1], d2 = pos[2] - campos[2];
+    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float x = d0 / len, y = d1 / len, z = d2 / len;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#define SHC(k) sh[(k) * 3 + c]
+        float res = kSH0 * SHC(0);
+        if (deg > 0) {
+            res = res - kSH1 * y * SHC(1) + kSH1 * z * SHC(2) - kSH1 * x * SHC(3);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + kSH2[0] * xy * SHC(4) + kSH2[1] * yz * SHC(5) +
+                      kSH2[2] * (2.0f * zz - xx - yy) * SHC(6) + kSH2[3] * xz * SHC(7) +
+                      kSH2[4] * (xx - yy) * SHC(8);
+                if (deg > 2) {
+                    res = res + kSH3[0] * y * (3.0f * xx - yy) * SHC(9) +
+                          kSH3[1] * xy * z * SHC(10) +
+                          kSH3[2] * y * (4.0f * zz - xx - yy) * SHC(11) +
+                          kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHC(12) +
+                          kSH3[4] * x * (4.0f * zz - xx - yy) * SHC(13) +
+                          kSH3[5] * z * (xx - yy) * SHC(14) +
+                          kSH3[6] * x * (xx - 3.0f * yy) * SHC(15);
+                }
+            }
+        }
+#undef SHC
+        out[c] = res + 0.5f;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// K1 forward.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ colors_precomp, CamArgs cam_args, int* __restrict__ radii,
+                      float* __restrict__ depths, float4* __restrict__ rec0, float4* __restrict__ rec1,
+                      float4* __restrict__ rec2, float* __restrict__ cov3D, unsigned char* __restrict__ clamped,
+                      uint32_t* __restrict__ tiles, uint2* __restrict__ rect, uint32_t* __restrict__ sort_key,
+                      uint32_t* __restrict__ sort_val)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const Cam cam = load_cam(cam_args);
+    int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
+
+    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float ph[4], pv[3];
+    xform4x4(p, cam.proj, ph);
+    const float pw = 1.0f / (ph[3] + 0.0000001f);
+    const float pp0 = ph[0] * pw, pp1 = ph[1] * pw;
+    xform4x3(p, cam.view, pv);
+    if (pv[2] > 0.2f) {
+        float c6[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            const float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
+            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
+            const float q[4] = { qv.x, qv.y, qv.z, qv.w };
+            M3 Mm;
+            cov3d_from_scale_rot(s, cam.scale_mod, q, c6, Mm);
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = c6[k];
+        }
+        Cov2D cv;
+        cov2d_eval(p, cam, c6, cv);
+        const float det = cv.a * cv.c - cv.b * cv.b;
+        if (det != 0.0f) {
+            const float det_inv = 1.0f / det;
+            const float con0 = cv.c * det_inv, con1 = -cv.b * det_inv, con2 = cv.a * det_inv;
+            const float mid = 0.5f * (cv.a + cv.c);
+            float disc = mid * mid - det; disc = disc < 0.1f ? 0.1f : disc;
+            const float l1 = mid + sqrtf(disc), l2 = mid - sqrtf(disc);
+            const float lmax = l1 < l2 ? l2 : l1;
+            const float my_radius = ceilf(3.0f * sqrtf(lmax));
+            const float px = ndc2pix(pp0, cam.W), py = ndc2pix(pp1, cam.H);
+            const int rad = (int)my_radius;
+            int rmin[2], rmax[2];
+            tile_rect(px, py, rad, cam.gx, cam.gy, rmin, rmax);
+            const int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
+            if (area != 0) {
+                float col[3];
+                unsigned cl = 0;
+                if (!colors_precomp) {
+                    sh_to_rgb(D, p, cam.campos, shs + (size_t)i * M * 3, col);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
+                }
+                const float op = opacities[i];
+                // Conservative pre-test for the blend kernels: power < thr  ==>  op*exp(power) < 1/255
+                // with a 2% margin, so skipping the exp for such pairs never changes a decision.
+                const float thr = op > 0.0f ? (logf(1.0f / (255.0f * op)) - 0.02f) : 1.0f;
+                depths[i] = pv[2];
+                rec0[i] = make_float4(px, py, con0, con1);
+                rec1[i] = make_float4(con2, op, col[0], col[1]);
+                rec2[i] = make_float4(col[2], pv[2], thr, 0.0f);
+                clamped[i] = (unsigned char)cl;
+                rad_out = rad; ntiles = (uint32_t)area;
+                key = __float_as_uint(pv[2]);
+                rc = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
+            }
+        }
+    }
+    radii[i] = rad_out; tiles[i] = ntiles; rect[i] = rc;
+    sort_key[i] = key; sort_val[i] = (uint32_t)i;
+}
+
+// K0: reference rasterizer_impl.cu:54-66
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, unsigned char* __restrict__ present)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    struct { float view[16]; } cam;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cam.view[k] = view[k];
+    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float pv[3];
+    xform4x3(p, cam.view, pv);
+    present[i] = pv[2] > 0.2f ? 1 : 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// SH backward: writes dL_dsh rows [0,(deg+1)^2) and ADDS the view-direction term to dmean.
+__device__ __forceinline__ void sh_backward(int deg, const float pos[3], const float campos[3],
+                                            const float* __restrict__ sh, unsigned cl, const float dcol[3],
+                                            float dmean[3], float* __restrict__ dsh)
+{
+    const float o0 = pos[0] - campos[0], o1 = pos[1] - campos[1], o2 = pos[2] - campos[2];
+    const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+    const float x = o0 / len, y = o1 / len, z = o2 / len;
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] = dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f);
+    float dx[3] = { 0, 0, 0 }, dy[3] = { 0, 0, 0 }, dz[3] = { 0, 0, 0 };
+#define SHV(k, c) sh[(k) * 3 + (c)]
+#define PUT(k, w) { const float w_ = (w); dsh[(k) * 3 + 0] = w_ * g[0]; dsh[(k) * 3 + 1] = w_ * g[1]; dsh[(k) * 3 + 2] = w_ * g[2]; }
+    PUT(0, kSH0);
+    if (deg > 0) {
+        PUT(1, -kSH1 * y); PUT(2, kSH1 * z); PUT(3, -kSH1 * x);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { dx[c] = -kSH1 * SHV(3, c); dy[c] = -kSH1 * SHV(1, c); dz[c] = kSH1 * SHV(2, c); }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            PUT(4, kSH2[0] * xy); PUT(5, kSH2[1] * yz); PUT(6, kSH2[2] * (2.0f * zz - xx - yy));
+            PUT(7, kSH2[3] * xz); PUT(8, kSH2[4] * (xx - yy));
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dx[c] += kSH2[0] * y * SHV(4, c) + kSH2[2] * 2.0f * -x * SHV(6, c) + kSH2[3] * z * SHV(7, c) + kSH2[4] * 2.0f * x * SHV(8, c);
+                dy[c] += kSH2[0] * x * SHV(4, c) + kSH2[1] * z * SHV(5, c) + kSH2[2] * 2.0f * -y * SHV(6, c) + kSH2[4] * 2.0f * -y * SHV(8, c);
+                dz[c] += kSH2[1] * y * SHV(5, c) + kSH2[2] * 2.0f * 2.0f * z * SHV(6, c) + kSH2[3] * x * SHV(7, c);
+            }
+            if (deg > 2) {
+                PUT(9, kSH3[0] * y * (3.0f * xx - yy)); PUT(10, kSH3[1] * xy * z);
+                PUT(11, kSH3[2] * y * (4.0f * zz - xx - yy));
+                PUT(12, kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
+                PUT(13, kSH3[4] * x * (4.0f * zz - xx - yy)); PUT(14, kSH3[5] * z * (xx - yy));
+                PUT(15, kSH3[6] * x * (xx - 3.0f * yy));
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dx[c] += (kSH3[0] * SHV(9, c) * 3.0f * 2.0f * xy + kSH3[1] * SHV(10, c) * yz +
+                              kSH3[2] * SHV(11, c) * -2.0f * xy + kSH3[3] * SHV(12, c) * -3.0f * 2.0f * xz +
+                              kSH3[4] * SHV(13, c) * (-3.0f * xx + 4.0f * zz - yy) +
+                              kSH3[5] * SHV(14, c) * 2.0f * xz + kSH3[6] * SHV(15, c) * 3.0f * (xx - yy));
+                    dy[c] += (kSH3[0] * SHV(9, c) * 3.0f * (xx - yy) + kSH3[1] * SHV(10, c) * xz +
+                              kSH3[2] * SHV(11, c) * (-3.0f * yy + 4.0f * zz - xx) +
+                              kSH3[3] * SHV(12, c) * -3.0f * 2.0f * yz + kSH3[4] * SHV(13, c) * -2.0f * xy +
+                              kSH3[5] * SHV(14, c) * -2.0f * yz + kSH3[6] * SHV(15, c) * -3.0f * 2.0f * xy);
+                    dz[c] += (kSH3[1] * SHV(10, c) * xy + kSH3[2] * SHV(11, c) * 4.0f * 2.0f * yz +
+                              kSH3[3] * SHV(12, c) * 3.0f * (2.0f * zz - xx - yy) +
+                              kSH3[4] * SHV(13, c) * 4.0f * 2.0f * xz + kSH3[5] * SHV(14, c) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef PUT
+#undef SHV
+    const float dd0 = dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2];
+    const float dd1 = dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2];
+    const float dd2 = dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2];
+    const float sum2 = o0 * o0 + o1 * o1 + o2 * o2;
+    const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean[0] += ((+sum2 - o0 * o0) * dd0 - o1 * o0 * dd1 - o2 * o0 * dd2) * inv32;
+    dmean[1] += (-o0 * o1 * dd0 + (sum2 - o1 * o1) * dd1 - o2 * o1 * dd2) * inv32;
+    dmean[2] += (-o0 * o2 * dd0 - o1 * o2 * dd1 + (sum2 - o2 * o2) * dd2) * inv32;
+}
+
+// K6 + K7 fused.  Every output row is written exactly once (zeros for culled Gaussians), so the
+// caller does not have to zero-fill the five output arrays.
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
+                      const float* __restrict__ shs, const unsigned char* __restrict__ clamped,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D /* internal or precomp */, CamArgs cam_args,
+                      const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic,
+                      const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans3D,
+                      float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+                      float* __restrict__ dL_drot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int ncoef = (D + 1) * (D + 1);
+    const Cam cam = load_cam(cam_args);
+    if (!(radii[i] > 0)) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+        if (shs) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.0f;
+        if (scales) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)i + k] = 0.0f;
+            reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const float mean[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = cov3D[6 * (size_t)i + k];
+    Cov2D cv;
+    cov2d_eval(mean, cam, c6, cv);
+    const float xgm = (cv.txtz < -cv.limx || cv.txtz > cv.limx) ? 0.0f : 1.0f;
+    const float ygm = (cv.tytz < -cv.limy || cv.tytz > cv.limy) ? 0.0f : 1.0f;
+    const float a = cv.a, b = cv.b, c = cv.c;
+    const float4 dcon = reinterpret_cast<const float4*>(dL_dconic)[i];
+    const float dcx = dcon.x, dcy = dcon.y, dcz = dcon.w;
+    const float denom = a * c - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    const M3& T = cv.T; const M3& V = cv.V; const M3& Wm = cv.Wm;
+    float dcov[6];
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * dcx + 2.0f * b * c * dcy + (denom - a * c) * dcz);
+        dL_dc = denom2inv * (-a * a * dcz + 2.0f * a * b * dcy + (denom - a * c) * dcx);
+        dL_db = denom2inv * 2.0f * (b * c * dcx - (denom + 2.0f * b * b) * dcy + a * b * dcz);
+        dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+        dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+        dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+        dcov[1] = 2.0f * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2.0f * T.m[1][0] * T.m[1][1] * dL_dc;
+        dcov[2] = 2.0f * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2.0f * T.m[1][0] * T.m[1][2] * dL_dc;
+        dcov[4] = 2.0f * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2.0f * T.m[1][1] * T.m[1][2] * dL_dc;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) dcov[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    float dT[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float r0 = T.m[0][0] * V.m[k][0] + T.m[0][1] * V.m[k][1] + T.m[0][2] * V.m[k][2];
+        const float r1 = T.m[1][0] * V.m[k][0] + T.m[1][1] * V.m[k][1] + T.m[1][2] * V.m[k][2];
+        dT[0][k] = 2.0f * r0 * dL_da + r1 * dL_db;
+        dT[1][k] = 2.0f * r1 * dL_dc + r0 * dL_db;
+    }
+    const float dJ00 = Wm.m[0][0] * dT[0][0] + Wm.m[0][1] * dT[0][1] + Wm.m[0][2] * dT[0][2];
+    const float dJ02 = Wm.m[2][0] * dT[0][0] + Wm.m[2][1] * dT[0][1] + Wm.m[2][2] * dT[0][2];
+    const float dJ11 = Wm.m[1][0] * dT[1][0] + Wm.m[1][1] * dT[1][1] + Wm.m[1][2] * dT[1][2];
+    const float dJ12 = Wm.m[2][0] * dT[1][0] + Wm.m[2][1] * dT[1][1] + Wm.m[2][2] * dT[1][2];
+    const float tz = 1.0f / cv.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = xgm * -cam.fx * tz2 * dJ02;
+    const float dty = ygm * -cam.fy * tz2 * dJ12;
+    const float dtz = -cam.fx * tz2 * dJ00 - cam.fy * tz2 * dJ11 + (2.0f * cam.fx * cv.t[0]) * tz3 * dJ02 + (2.0f * cam.fy * cv.t[1]) * tz3 * dJ12;
+    float dmean[3] = { cam.view[0] * dtx + cam.view[1] * dty + cam.view[2] * dtz,
+                       cam.view[4] * dtx + cam.view[5] * dty + cam.view[6] * dtz,
+                       cam.view[8] * dtx + cam.view[9] * dty + cam.view[10] * dtz };
+    // mean gradient through the perspective projection of the 2D mean
+    float mh[4];
+    xform4x4(mean, cam.proj, mh);
+    const float mw = 1.0f / (mh[3] + 0.0000001f);
+    const float* pj = cam.proj;
+    const float mul1 = (pj[0] * mean[0] + pj[4] * mean[1] + pj[8] * mean[2] + pj[12]) * mw * mw;
+    const float mul2 = (pj[1] * mean[0] + pj[5] * mean[1] + pj[9] * mean[2] + pj[13]) * mw * mw;
+    const float g2x = dL_dmean2D[3 * (size_t)i], g2y = dL_dmean2D[3 * (size_t)i + 1];
+    dmean[0] += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
+    dmean[1] += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
+    dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
+    if (shs) {
+        const float dcol[3] = { dL_dcolor[3 * (size_t)i], dL_dcolor[3 * (size_t)i + 1], dL_dcolor[3 * (size_t)i + 2] };
+        float* dsh = dL_dsh + (size_t)i * M * 3;
+        sh_backward(D, mean, cam.campos, shs + (size_t)i * M * 3, clamped[i], dcol, dmean, dsh);
+        for (int k = ncoef * 3; k < M * 3; k++) dsh[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = dmean[k];
+    if (scales) {
+        const float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
+        const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
+        const float q[4] = { qv.x, qv.y, qv.z, qv.w };
+        float c6b[6]; M3 Mm, R;
+        cov3d_from_scale_rot(s, cam.scale_mod, q, c6b, Mm);
+        quat_to_R(q, R);
+        const float sm[3] = { cam.scale_mod * s[0], cam.scale_mod * s[1], cam.scale_mod * s[2] };
+        M3 dSig, M2, dM;
+        dSig.m[0][0] = dcov[0]; dSig.m[0][1] = 0.5f * dcov[1]; dSig.m[0][2] = 0.5f * dcov[2];
+        dSig.m[1][0] = 0.5f * dcov[1]; dSig.m[1][1] = dcov[3]; dSig.m[1][2] = 0.5f * dcov[4];
+        dSig.m[2][0] = 0.5f * dcov[2]; dSig.m[2][1] = 0.5f * dcov[4]; dSig.m[2][2] = dcov[5];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) M2.m[cc][rr] = 2.0f * Mm.m[cc][rr];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+                dM.m[cc][rr] = M2.m[0][rr] * dSig.m[cc][0] + M2.m[1][rr] * dSig.m[cc][1] + M2.m[2][rr] * dSig.m[cc][2];
+        // Rt[k][j] = R[j][k], dMt[k][j] = dM[j][k]
+        float ds[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ds[k] = R.m[0][k] * dM.m[0][k] + R.m[1][k] * dM.m[1][k] + R.m[2][k] * dM.m[2][k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)i + k] = ds[k];
+#define D_(cc, rr) (dM.m[rr][cc] * sm[cc])
+        const float r = q[0], x = q[1], y = q[2], z = q[3];
+        float4 dq;
+        dq.x = 2.0f * z * (D_(0, 1) - D_(1, 0)) + 2.0f * y * (D_(2, 0) - D_(0, 2)) + 2.0f * x * (D_(1, 2) - D_(2, 1));
+        dq.y = 2.0f * y * (D_(1, 0) + D_(0, 1)) + 2.0f * z * (D_(2, 0) + D_(0, 2)) + 2.0f * r * (D_(1, 2) - D_(2, 1)) - 4.0f * x * (D_(2, 2) + D_(1, 1));
+        dq.z = 2.0f * x * (D_(1, 0) + D_(0, 1)) + 2.0f * r * (D_(2, 0) - D_(0, 2)) + 2.0f * z * (D_(1, 2) + D_(2, 1)) - 4.0f * y * (D_(2, 2) + D_(0, 0));
+        dq.w = 2.0f * r * (D_(0, 1) - D_(1, 0)) + 2.0f * x * (D_(2, 0) + D_(0, 2)) + 2.0f * y * (D_(1, 2) + D_(2, 1)) - 4.0f * z * (D_(1, 1) + D_(0, 0));
+#undef D_
+        reinterpret_cast<float4*>(dL_drot)[i] = dq;
+    }
+}
+
+} // namespace gsrast

@@ -1,0 +1,284 @@
+"""`_C` -- the native binding layer of the drop-in package.
+
+In the reference this module is a pybind11 torch extension (ext.cpp:15-19) exposing
+``rasterize_gaussians``, ``rasterize_gaussians_backward`` and ``mark_visible``
+(rasterize_points.cu:35-215).  Here the same three callables, with the same positional argument
+lists and the same return tuples, marshal torch tensors onto the C ABI of ``include/gsrast.h``
+(``libgsrast_hip.so``, hand-written HIP for gfx950) through ctypes: raw device pointers, sizes and
+the current HIP stream -- no torch types cross the boundary.
+
+There is NO fallback: if the shared library is missing or a tensor is not on a GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsrast_hip.so")
+
+NUM_CHANNELS = 3  # reference config.h:15
+
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/gsrast.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "gsrast_forward", "gsrast_backward", "gsrast_mark_visible", "gsrast_geometry_bytes",
+    "gsrast_binning_bytes", "gsrast_image_bytes", "gsrast_debug_export", "gsrast_set_option",
+    "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
+    "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
+    "gsrast_abi_version",
+)
+
+
+def lib() -> C.CDLL:
+    """Load libgsrast_hip.so (built by saro-gs_amd/build.py / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python saro-gs_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for the rasterizer.")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.gsrast_forward.restype = ci
+    L.gsrast_forward.argtypes = [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp,
+                                 vp, cf, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp]
+    L.gsrast_backward.restype = ci
+    L.gsrast_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp,
+                                  vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.gsrast_mark_visible.restype = ci
+    L.gsrast_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    for name in ("gsrast_geometry_bytes",):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = [ci]
+    L.gsrast_binning_bytes.restype = C.c_size_t
+    L.gsrast_binning_bytes.argtypes = [ci, ci, ci]
+    L.gsrast_image_bytes.restype = C.c_size_t
+    L.gsrast_image_bytes.argtypes = [ci, ci]
+    L.gsrast_debug_export.restype = ci
+    L.gsrast_debug_export.argtypes = [ci, ci, ci, ci] + [vp] * 16
+    L.gsrast_set_option.restype = ci
+    L.gsrast_set_option.argtypes = [C.c_char_p, ci]
+    L.gsrast_get_option.restype = ci
+    L.gsrast_get_option.argtypes = [C.c_char_p]
+    L.gsrast_profile_kernel_count.restype = ci
+    L.gsrast_profile_kernel_name.restype = C.c_char_p
+    L.gsrast_profile_kernel_name.argtypes = [ci]
+    L.gsrast_profile_collect.restype = ci
+    L.gsrast_profile_read.restype = ci
+    L.gsrast_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.gsrast_profile_reset.restype = None
+    L.gsrast_last_error.restype = C.c_char_p
+    L.gsrast_abi_version.restype = ci
+    if L.gsrast_abi_version() != 1:
+        raise ImportError("libgsrast_hip.so: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _err(code: int, where: str) -> RuntimeError:
+    msg = lib().gsrast_last_error()
+    return RuntimeError(f"{where} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer, or NULL for an absent optional input (the reference passes CPU
+    ``torch.Tensor([])`` and tests for a null data pointer, __init__.py:173-183)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor, name: str, device: torch.device) -> torch.Tensor:
+    if t.numel() == 0:
+        return t
+    if t.device != device:
+        raise RuntimeError(f"{name} must live on {device} (got {t.device})")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def _require_gpu(t: torch.Tensor) -> torch.device:
+    if not t.is_cuda:
+        raise RuntimeError("gsrast: tensors must be on a GPU (HIP) device; there is no CPU fallback")
+    return t.device
+
+
+class _Arena:
+    """The three resizable state buffers of the reference (rasterize_points.cu:27-33, :71-78):
+    each allocation callback creates one uint8 tensor that is later saved for backward."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.buffers: List[Optional[torch.Tensor]] = [None, None, None]
+        self.callbacks = [_ALLOC_FN(self._make(i)) for i in range(3)]  # keep references alive
+
+    def _make(self, slot: int):
+        def alloc(_ctx, nbytes):
+            try:
+                buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            except Exception:  # out of memory -> NULL -> GSRAST_E_ALLOC
+                return None
+            self.buffers[slot] = buf
+            return buf.data_ptr()
+        return alloc
+
+    def tensor(self, slot: int) -> torch.Tensor:
+        b = self.buffers[slot]
+        return b if b is not None else torch.empty(0, dtype=torch.uint8, device=self.device)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                        image_width, sh, degree, campos, prefiltered
+                        ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Forward.  Mirrors RasterizeGaussiansCUDA (rasterize_points.cu:35-115): returns
+    ``(num_rendered, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
+    out_depth[1,H,W])``."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:56-58
+    dev = _require_gpu(means3D)
+    L = lib()
+    P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+    f = lambda t, n: _dev_f32(t, n, dev)  # noqa: E731
+    background, means3D, colors, opacity = f(background, "bg"), f(means3D, "means3D"), f(colors, "colors_precomp"), f(opacity, "opacities")
+    scales, rotations, cov3D_precomp = f(scales, "scales"), f(rotations, "rotations"), f(cov3D_precomp, "cov3D_precomp")
+    viewmatrix, projmatrix, sh, campos = f(viewmatrix, "viewmatrix"), f(projmatrix, "projmatrix"), f(sh, "shs"), f(campos, "campos")
+    M = int(sh.shape[1]) if sh.numel() != 0 else 0  # rasterize_points.cu:83-87
+
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    arena = _Arena(dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rendered = L.gsrast_forward(
+            arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
+            P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+            _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+            _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+            out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii), stream)
+    if rendered < 0:
+        raise _err(rendered, "gsrast_forward")
+    return rendered, out_color, radii, arena.tensor(0), arena.tensor(1), arena.tensor(2), out_depth
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer):
+    """Backward.  Mirrors RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-194): returns
+    ``(dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6],
+    dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])``."""
+    dev = _require_gpu(means3D)
+    L = lib()
+    P = int(means3D.shape[0])
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])  # rasterize_points.cu:141-142
+    f = lambda t, n: _dev_f32(t, n, dev)  # noqa: E731
+    background, means3D, colors = f(background, "bg"), f(means3D, "means3D"), f(colors, "colors_precomp")
+    scales, rotations, cov3D_precomp = f(scales, "scales"), f(rotations, "rotations"), f(cov3D_precomp, "cov3D_precomp")
+    viewmatrix, projmatrix, sh, campos = f(viewmatrix, "viewmatrix"), f(projmatrix, "projmatrix"), f(sh, "shs"), f(campos, "campos")
+    dL_dout_color = f(dL_dout_color, "dL_dout_color")
+    M = int(sh.shape[1]) if sh.numel() != 0 else 0
+    opts = dict(dtype=torch.float32, device=dev)
+    # accumulated with atomics -> zero-filled (44 B/Gaussian); everything else is written exactly
+    # once by the fused per-Gaussian backward kernel, so no 300 B/Gaussian memset as in the reference
+    dL_dmeans2D = torch.zeros((P, 3), **opts)
+    dL_dconic = torch.zeros((P, 2, 2), **opts)
+    dL_dopacity = torch.zeros((P, 1), **opts)
+    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **opts)
+    use_sh = sh.numel() != 0 and colors.numel() == 0
+    use_sr = cov3D_precomp.numel() == 0
+    dL_dmeans3D = torch.empty((P, 3), **opts)
+    dL_dcov3D = torch.empty((P, 6), **opts)
+    dL_dsh = torch.empty((P, M, 3), **opts) if use_sh else torch.zeros((P, M, 3), **opts)
+    dL_dscales = torch.empty((P, 3), **opts) if use_sr else torch.zeros((P, 3), **opts)
+    dL_drotations = torch.empty((P, 4), **opts) if use_sr else torch.zeros((P, 4), **opts)
+    if P != 0:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.gsrast_backward(
+                P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
+                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(),
+                dL_drotations.data_ptr(), stream)
+        if rc != 0:
+            raise _err(rc, "gsrast_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
+    """Mirrors markVisible (rasterize_points.cu:196-215): bool[P], view-space z > 0.2."""
+    dev = _require_gpu(means3D)
+    P = int(means3D.shape[0])
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        means3D, viewmatrix, projmatrix = (_dev_f32(t, n, dev) for t, n in
+                                           ((means3D, "means3D"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix")))
+        with torch.cuda.device(dev):
+            rc = lib().gsrast_mark_visible(P, means3D.data_ptr(), viewmatrix.data_ptr(), projmatrix.data_ptr(),
+                                           present.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise _err(rc, "gsrast_mark_visible")
+    return present
+
+
+# ---- not part of the reference's _C: options, profiling and the parity-test state export --------
+def set_option(name: str, value: int) -> None:
+    if lib().gsrast_set_option(name.encode(), int(value)) != 0:
+        raise ValueError(f"gsrast: unknown option or bad value: {name}={value}")
+
+
+def get_option(name: str) -> int:
+    return int(lib().gsrast_get_option(name.encode()))
+
+
+def profile_read() -> dict:
+    """{kernel name: (total_ms, launches)} gathered while option 'profile' is 1."""
+    L = lib()
+    L.gsrast_profile_collect()
+    out = {}
+    for k in range(L.gsrast_profile_kernel_count()):
+        ms, n = C.c_double(0), C.c_longlong(0)
+        L.gsrast_profile_read(k, C.byref(ms), C.byref(n))
+        out[L.gsrast_profile_kernel_name(k).decode()] = (ms.value, n.value)
+    return out
+
+
+def profile_reset() -> None:
+    lib().gsrast_profile_reset()
+
+
+def debug_export(P: int, R: int, W: int, H: int, geomBuffer, binningBuffer, imageBuffer) -> dict:
+    """Copy the opaque state out in the reference's array layout (parity tests only)."""
+    dev = geomBuffer.device
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = dict(
+        depths=torch.zeros(P, **f32), means2D=torch.zeros((P, 2), **f32), cov3D=torch.zeros((P, 6), **f32),
+        conic_opacity=torch.zeros((P, 4), **f32), rgb=torch.zeros((P, 3), **f32),
+        clamped=torch.zeros((P, 3), dtype=torch.uint8, device=dev),
+        tiles_touched=torch.zeros(P, dtype=torch.int32, device=dev),
+        keys_sorted=torch.zeros(max(R, 1), dtype=torch.int64, device=dev)[:R],
+        point_list=torch.zeros(max(R, 1), dtype=torch.int32, device=dev)[:R],
+        ranges=torch.zeros((T, 2), dtype=torch.int32, device=dev),
+        final_T=torch.zeros((H, W), **f32), n_contrib=torch.zeros((H, W), dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        rc = lib().gsrast_debug_export(
+            P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), out["depths"].data_ptr(),
+            out["means2D"].data_ptr(), out["cov3D"].data_ptr(), out["conic_opacity"].data_ptr(),
+            out["rgb"].data_ptr(), out["clamped"].data_ptr(), out["tiles_touched"].data_ptr(),
+            _ptr(out["keys_sorted"]), _ptr(out["point_list"]), out["ranges"].data_ptr(),
+            out["final_T"].data_ptr(), out["n_contrib"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_debug_export")
+    return out

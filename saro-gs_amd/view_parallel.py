@@ -1,0 +1,109 @@
+"""One-view-per-GPU data parallelism for the rasterizer hot path.
+
+The reference has no distributed code: train.py:198-226 renders the `opt.batch` views of an iteration
+one after the other on one GPU and SUMS their gradients by hand
+(scene/saro_gaussian.py:226-247 cache_gradient, :266-276 set_batch_gradient divides by the batch).
+Each view's forward + backward only reads the (replicated) Gaussian attributes, so the views shard
+with no data-path exchange; the one real exchange step is the gradient sum.  This module is that
+step: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" on
+CPU for tests), rank r renders view r, then ONE flat fp32 buffer is all-reduced.
+
+xGMI is point-to-point (7 links per GPU): a single large all-reduce over one flat buffer lets RCCL
+pick its direct reduce-scatter + all-gather schedule across all links, instead of one latency-bound
+collective per parameter tensor.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
+    Returns (rank, local_rank, world).  A single process (WORLD_SIZE unset or 1) needs no group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def views_of_rank(n_views: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment of the iteration's views to ranks (batch == world: one view each)."""
+    return list(range(rank, n_views, world))
+
+
+class FlatGradBucket:
+    """Packs the gradients of a fixed list of tensors into one contiguous fp32 buffer, all-reduces it
+    (SUM) and scatters the mean back -- semantics of set_batch_gradient (saro_gaussian.py:269-276)."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.params = list(params)
+        self.sizes = [p.numel() for p in self.params]
+        total = sum(self.sizes)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = []
+        o = 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[o:o + n].view(p.shape))
+            o += n
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+    def pack(self) -> None:
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+
+    def allreduce_mean(self, batch: int, async_op: bool = False):
+        """SUM over ranks, then / batch.  batch = number of views in the iteration (== world when
+        every rank renders one view)."""
+        work = None
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if work is None or not async_op:
+            self.flat.mul_(1.0 / batch)
+        return work
+
+    def unpack(self) -> None:
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+def reduce_densification_stats(point_grad_norm: torch.Tensor, visible_count: torch.Tensor,
+                               max_radii: torch.Tensor) -> None:
+    """In-place cross-rank reduction of the densification statistics of train.py:282-292:
+    SUM of the screen-space gradient norms and visibility counts, MAX of the radii."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(point_grad_norm, op=dist.ReduceOp.SUM)
+        dist.all_reduce(visible_count, op=dist.ReduceOp.SUM)
+        dist.all_reduce(max_radii, op=dist.ReduceOp.MAX)
+
+
+def max_over_ranks(x: float, device: torch.device) -> float:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return float(x)
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

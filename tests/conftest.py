@@ -1,0 +1,60 @@
+"""Shared pytest plumbing.
+
+* ``-m "not gpu"``: oracle vs golden vectors, host logic, C-ABI library loads + exports (no GPU).
+* ``-m gpu``: parity tests proper -- the HIP path through the C ABI against the CPU oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "saro-gs_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle as _orc
+    _orc.build()
+    _orc.set_exp_mode(0)
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    import scenes as _scenes
+    return _scenes
+
+
+@pytest.fixture(scope="session")
+def rast():
+    """The drop-in package (needs the built libgsrast_hip.so; GPU needed only for compute calls)."""
+    import diff_gaussian_rasterization_ch3 as _r
+    return _r
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch.device("cuda:0")
+
+
+def settings_from(rast_mod, cam, scene, device, bg=None):
+    import torch
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)  # noqa: E731
+    return rast_mod.GaussianRasterizationSettings(
+        image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=cam["tanfovx"],
+        tanfovy=cam["tanfovy"], bg=t(scene["bg"] if bg is None else bg), scale_modifier=cam.get("scale_modifier", 1.0),
+        viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=int(scene.get("sh_degree", 0)),
+        campos=t(cam["campos"]), prefiltered=False)

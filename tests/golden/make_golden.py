@@ -1,0 +1,106 @@
+"""Generates the committed golden vectors.  Run in the BUILD container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+1. ref_python_vectors.npz -- outputs of the REFERENCE's own Python for the pieces of the hot path
+   that exist in Python: utils/sh_utils.py:eval_sh (the SH polynomial the CUDA kernel
+   forward.cu:20-71 implements) and utils/graphics_utils.py getWorld2View2 / getProjectionMatrix
+   plus the scene/cameras.py:90-101 composition (the camera conventions every rasterizer input
+   obeys).  These pin oracle/gsrast_oracle.c:sh_to_rgb and saro-gs_amd/scenes.py against the
+   reference itself.  Only inputs and outputs are stored -- no reference source.
+2. oracle_scene_*.npz -- small seeded scenes with the ORACLE's outputs (fp32 build for the
+   bit-exact quantities, fp64 build for the gradients).  They guard against oracle drift and give
+   the GPU tests a fixture that does not depend on the oracle library being rebuilt.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "saro-gs_amd"))
+REF = "/root/reference"
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_python_vectors():
+    import torch
+    sh_utils = _load("ref_sh_utils", os.path.join(REF, "utils", "sh_utils.py"))
+    gfx = _load("ref_graphics_utils", os.path.join(REF, "utils", "graphics_utils.py"))
+    rng = np.random.default_rng(1234)
+    out = {}
+    # --- eval_sh: [n, 3, 16] coefficients (channel-major there), unit dirs ---
+    n = 257
+    pos = rng.uniform(-2, 2, size=(n, 3)).astype(np.float32)
+    campos = np.array([0.3, -1.1, 3.7], np.float32)
+    sh = rng.normal(0, 0.5, size=(n, 16, 3)).astype(np.float32)      # rasterizer layout [n, M, 3]
+    d = pos.astype(np.float64) - campos.astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out["sh_pos"], out["sh_campos"], out["sh_coeffs"] = pos, campos, sh
+    for deg in range(4):
+        res = sh_utils.eval_sh(deg, torch.from_numpy(sh.astype(np.float64)).permute(0, 2, 1), torch.from_numpy(d))
+        out[f"sh_deg{deg}_rgb_plus_half"] = (res + 0.5).numpy()    # forward.cu:60 adds 0.5 before clamping
+    out["rgb2sh_of_0_and_1"] = np.array([float(sh_utils.RGB2SH(0.0)), float(sh_utils.RGB2SH(1.0))])
+    # --- camera conventions ---
+    Rs, Ts, fovs, views, projs, fulls, centers = [], [], [], [], [], [], []
+    for k in range(6):
+        A = rng.normal(size=(3, 3))
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        T = rng.uniform(-3, 3, size=3)
+        fovx, fovy = float(rng.uniform(0.4, 1.2)), float(rng.uniform(0.4, 1.2))
+        wv = torch.tensor(gfx.getWorld2View2(Q, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)   # cameras.py:90
+        pj = gfx.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)  # cameras.py:98
+        full = (wv.unsqueeze(0).bmm(pj.unsqueeze(0))).squeeze(0)                                   # cameras.py:100
+        center = wv.inverse()[3, :3]                                                               # cameras.py:101
+        Rs.append(Q); Ts.append(T); fovs.append((fovx, fovy))
+        views.append(wv.numpy()); projs.append(pj.numpy()); fulls.append(full.numpy()); centers.append(center.numpy())
+    out.update(cam_R=np.array(Rs), cam_T=np.array(Ts), cam_fov=np.array(fovs), cam_world_view=np.array(views),
+               cam_projection=np.array(projs), cam_full_proj=np.array(fulls), cam_center=np.array(centers))
+    np.savez_compressed(os.path.join(HERE, "ref_python_vectors.npz"), **out)
+    print("wrote ref_python_vectors.npz")
+
+
+def oracle_scenes():
+    import scenes
+    from oracle import oracle as orc
+    orc.build()
+    orc.set_exp_mode(0)
+    specs = [("a", 300, 64, 48, 3, 0.8, (1, 5), 101), ("b", 1200, 112, 80, 2, 1.0, (3, 7), 202)]
+    for tag, P, W, H, deg, sm, (k, V), seed in specs:
+        sc = scenes.synth(P, seed, sh_degree=deg, scale_mul=sm)
+        sc["bg"] = np.array([0.1, 0.2, 0.3], np.float32)
+        cam = scenes.camera(k, V, W, H)
+        g = scenes.upstream_grad(H, W, seed + 1) * (H * W)
+        o32 = orc.render(sc, cam, g)
+        o64 = orc.render(sc, cam, g, f64=True)
+        d = {"sc_" + k_: v for k_, v in sc.items() if isinstance(v, np.ndarray)}
+        d["sh_degree"] = np.int32(deg)
+        d.update({"cam_" + k_: np.asarray(v) for k_, v in cam.items() if k_ != "prefiltered"})
+        d["dL_dcolor"] = g
+        for k_ in ("radii", "tiles_touched", "point_list", "ranges", "keys_sorted", "n_contrib", "out_color",
+                   "out_depth", "final_T"):
+            d[k_] = o32[k_]
+        for k_ in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations", "out_color"):
+            d["f64_" + k_] = o64[k_]
+        path = os.path.join(HERE, f"oracle_scene_{tag}.npz")
+        np.savez_compressed(path, **d)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    if os.path.isdir(REF):
+        ref_python_vectors()
+    else:
+        print("no /root/reference here: keeping the committed ref_python_vectors.npz")
+    oracle_scenes()

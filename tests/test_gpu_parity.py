@@ -1,0 +1,243 @@
+"""-m gpu: the HIP path (through the drop-in API and the C ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star):
+  * bit-exact for every integer / index quantity: radii, tiles_touched, sorted keys
+    (tile << 32 | depth bits), point_list, tile ranges, n_contrib;
+  * with exp_mode 0 (the default: fixed-sequence exp shared with the oracle) the WHOLE forward is
+    bit-exact -- per-Gaussian state, colour, depth, final transmittance;
+  * gradients: |hip - f64 truth| <= 1e-5 abs (+1e-4 relative for the few large entries); the f64
+    truth replays the fp32 control flow, so the comparison has no threshold-flip outliers.
+"""
+import numpy as np
+import pytest
+
+from gpu_harness import bits, run_hip
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5   # north_star tolerance on RGB / depth / gradients
+RTOL = 1e-4
+
+CASES = [
+    # name,            P,     W,   H,  deg, scale_mul, cam (k, V)
+    ("tiny",           64,    64,  48, 3, 1.0, (0, 1)),
+    ("ragged",         2000,  97,  83, 3, 1.0, (1, 5)),    # image not a multiple of 16
+    ("deg0",           1500,  128, 96, 0, 1.0, (2, 5)),
+    ("deg1",           1500,  128, 96, 1, 1.0, (3, 5)),
+    ("deg2",           1500,  128, 96, 2, 0.7, (4, 5)),
+    ("cfg1_10k_400",   10000, 400, 400, 3, 1.0, (0, 1)),   # BASELINE config 1
+    ("dense_small",    20000, 256, 192, 3, 0.5, (1, 3)),
+]
+
+
+def _scene(scenes, P, seed, deg, scale_mul):
+    sc = scenes.synth(P, seed, sh_degree=deg, scale_mul=scale_mul)
+    return sc
+
+
+def _check_forward_exact(o, h):
+    P = o["P"]
+    assert h["R"] == o["R"]
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    np.testing.assert_array_equal(h["tiles_touched"], o["tiles_touched"])
+    np.testing.assert_array_equal(h["keys_sorted"], o["keys_sorted"])
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    vis = o["radii"] > 0
+    for k in ("depths", "means2D", "conic_opacity", "cov3D"):
+        np.testing.assert_array_equal(bits(h[k][vis]), bits(o[k][vis]), err_msg=k)
+    np.testing.assert_array_equal(bits(h["rgb"][vis]), bits(np.ascontiguousarray(o["colors"][vis])), err_msg="rgb")
+    if "clamped" in o and o["M"] > 0:
+        np.testing.assert_array_equal(h["clamped"][vis], o["clamped"][vis])
+    np.testing.assert_array_equal(h["n_contrib"], o["n_contrib"])
+    np.testing.assert_array_equal(bits(h["final_T"]), bits(o["final_T"]))
+    np.testing.assert_array_equal(bits(h["out_color"]), bits(o["out_color"]))
+    np.testing.assert_array_equal(bits(h["out_depth"]), bits(o["out_depth"]))
+    assert P == len(h["radii"])
+
+
+def _check_grads(o64, o32, h, names):
+    for k in names:
+        ref = o64[k].astype(np.float64)
+        got = h[k].astype(np.float64).reshape(ref.shape)
+        err = np.abs(got - ref)
+        tol = ATOL + RTOL * np.abs(ref)
+        assert (err <= tol).all(), f"{k}: max abs err {err.max():.3e} (max |ref| {np.abs(ref).max():.3e})"
+        # the fp32 oracle (different summation order) must sit in the same band
+        err32 = np.abs(o32[k].astype(np.float64) - ref)
+        assert (err32 <= tol).all(), f"oracle32 {k}: {err32.max():.3e}"
+
+
+@pytest.mark.parametrize("name,P,W,H,deg,scale_mul,camkv", CASES, ids=[c[0] for c in CASES])
+def test_forward_backward_parity(name, P, W, H, deg, scale_mul, camkv, orc, scenes, rast, gpu):
+    sc = _scene(scenes, P, seed=sum(map(ord, name)) % 1000, deg=deg, scale_mul=scale_mul)
+    cam = scenes.camera(camkv[0], camkv[1], W, H)
+    g = scenes.upstream_grad(H, W, 7) * (H * W)       # O(1) upstream gradient: a harder test than 1/(3HW)
+    orc.set_exp_mode(0)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, exp_mode=0)
+    _check_forward_exact(o32, h)
+    scale = 1.0
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    assert scale == 1.0
+
+
+def test_bench_shaped_gradient_magnitude(orc, scenes, rast, gpu):
+    """Same as above with the bench's own upstream gradient N(0,1)/(3HW)."""
+    P, W, H = 5000, 320, 240
+    sc = scenes.synth(P, 11)
+    cam = scenes.camera(0, 1, W, H)
+    g = scenes.upstream_grad(H, W, 12)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+def test_white_background_and_colors_precomp(orc, scenes, rast, gpu):
+    """Segment-render call pattern (renderer/__init__.py:215-225): colors_precomp, shs=None; non-zero bg
+    exercises the background term of dL/dalpha (backward.cu:531-534)."""
+    P, W, H = 3000, 160, 120
+    sc = scenes.synth(P, 21, scale_mul=0.6)
+    sc["bg"] = np.array([1.0, 1.0, 1.0], np.float32)
+    sc["opacities"] = (sc["opacities"] * 0.3).astype(np.float32)     # keep final_T > 0 so the bg term matters
+    cam = scenes.camera(2, 7, W, H)
+    rng = np.random.default_rng(5)
+    cp = rng.uniform(0, 1, size=(P, 3)).astype(np.float32)
+    g = scenes.upstream_grad(H, W, 22) * (H * W)
+    o32 = orc.render(sc, cam, g, colors_precomp=cp)
+    o64 = orc.render(sc, cam, g, f64=True, colors_precomp=cp)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, colors_precomp=cp)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations"])
+    assert h.get("dL_dsh") is None
+
+
+def test_cov3d_precomp_path(orc, scenes, rast, gpu):
+    P, W, H = 2000, 128, 128
+    sc = scenes.synth(P, 31)
+    cam = scenes.camera(1, 4, W, H)
+    base = orc.forward(sc, cam)
+    cov = np.ascontiguousarray(base["cov3D"]).astype(np.float32)
+    g = scenes.upstream_grad(H, W, 32) * (H * W)
+    o32 = orc.render(sc, cam, g, cov3D_precomp=cov)
+    o64 = orc.render(sc, cam, g, f64=True, cov3D_precomp=cov)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, cov3D_precomp=cov)
+    np.testing.assert_array_equal(h["radii"], o32["radii"])
+    np.testing.assert_array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dcov3D"])
+
+
+def test_culling_edge_cases(orc, scenes, rast, gpu):
+    """Gaussians behind the camera, off-screen, huge (cover every tile) and degenerate-tiny."""
+    W, H = 96, 64
+    sc = scenes.synth(400, 41)
+    cam = scenes.camera(0, 1, W, H)
+    m = sc["means3D"]
+    m[:50] *= 8.0                      # far off-screen / behind
+    m[50:60] = m[50:60] * 0.01         # near the origin
+    sc["scales"][60:70] *= 40.0        # huge: rect clamps to the whole grid
+    sc["scales"][70:80] *= 1e-4        # tiny: the 0.3 low-pass dominates
+    eye = np.linalg.inv(cam["viewmatrix"].astype(np.float64))[3, :3]
+    m[80:90] = (eye + (eye / np.linalg.norm(eye)) * 2.0).astype(np.float32)  # behind the camera
+    g = scenes.upstream_grad(H, W, 42) * (H * W)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    assert (o32["radii"] == 0).sum() > 10 and (o32["radii"] > 0).sum() > 100
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    # culled Gaussians get exactly zero gradient everywhere
+    dead = o32["radii"] == 0
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert not h[k][dead].any(), k
+
+
+def test_all_culled_and_empty(rast, scenes, gpu):
+    import torch
+    from conftest import settings_from
+    W, H = 64, 48
+    cam = scenes.camera(0, 1, W, H)
+    sc = scenes.synth(32, 51)
+    sc["means3D"] = (sc["means3D"] * 0 + np.array([100.0, 0, 0], np.float32)).astype(np.float32)
+    sc["bg"] = np.array([0.25, 0.5, 0.75], np.float32)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=np.ones((3, H, W), np.float32))
+    assert h["R"] == 0 and not h["radii"].any()
+    for c in range(3):
+        assert (h["out_color"][c] == sc["bg"][c]).all()
+    assert (h["out_depth"] == 15.0).all()
+    assert not h["dL_dmeans3D"].any()
+    # P == 0: the reference skips the rasterizer and returns zero images (rasterize_points.cu:81)
+    rs = settings_from(rast, cam, sc, gpu)
+    z = lambda *s: torch.zeros(*s, device=gpu)  # noqa: E731
+    color, radii, depth = rast.GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1),
+                                                      shs=z(0, 16, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert color.shape == (3, H, W) and not color.any() and radii.numel() == 0 and not depth.any()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_other_exp_modes_within_tolerance(mode, orc, scenes, rast, gpu):
+    """exp_mode 1 (OCML expf) and 2 (v_exp_f32): integer binning still exact; colour within 1e-5 except
+    for the rare pixels where a 1-ulp difference in exp flips a threshold (alpha < 1/255, T < 1e-4,
+    median crossing) -- inherent to ANY two exp implementations, the reference's own included."""
+    P, W, H = 10000, 400, 400
+    sc = scenes.synth(P, 0)
+    cam = scenes.camera(0, 1, W, H)
+    g = scenes.upstream_grad(H, W, 1)
+    orc.set_exp_mode(1)
+    try:
+        o32 = orc.render(sc, cam, g)
+    finally:
+        orc.set_exp_mode(0)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, exp_mode=mode)
+    rast._C.set_option("exp_mode", 0)
+    np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+    bad = np.abs(h["out_color"] - o32["out_color"]).max(axis=0) > ATOL
+    assert bad.mean() < 1e-4, f"{bad.sum()} pixels off"
+    assert (h["n_contrib"] != o32["n_contrib"]).mean() < 1e-3
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
+        err = np.abs(h[k].astype(np.float64).reshape(o32[k].shape) - o32[k])
+        assert (err > ATOL + RTOL * np.abs(o32[k])).mean() < 1e-4, k
+
+
+def test_mark_visible(orc, scenes, rast, gpu):
+    import torch
+    from conftest import settings_from
+    sc = scenes.synth(5000, 61)
+    sc["means3D"] *= 3.0
+    cam = scenes.camera(3, 8, 128, 96)
+    rs = settings_from(rast, cam, sc, gpu)
+    got = rast.GaussianRasterizer(rs).markVisible(torch.as_tensor(sc["means3D"], device=gpu)).cpu().numpy()
+    want = orc.mark_visible(sc["means3D"], cam["viewmatrix"], cam["projmatrix"])
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < len(want)
+
+
+def test_golden_fixture(rast, gpu):
+    """Committed inputs + expected outputs (tests/golden/oracle_scene_*.npz, made by make_golden.py)."""
+    import glob, os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "oracle_scene_*.npz")))
+    assert files, "golden fixtures missing"
+    for f in files:
+        z = np.load(f)
+        sc = {k[3:]: z[k] for k in z.files if k.startswith("sc_")}
+        sc["sh_degree"] = int(z["sh_degree"])
+        cam = {k[4:]: z[k] for k in z.files if k.startswith("cam_")}
+        for k in ("image_height", "image_width"):
+            cam[k] = int(cam[k])
+        for k in ("tanfovx", "tanfovy", "scale_modifier"):
+            cam[k] = float(cam[k])
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=z["dL_dcolor"])
+        np.testing.assert_array_equal(h["radii"], z["radii"])
+        np.testing.assert_array_equal(h["point_list"], z["point_list"])
+        np.testing.assert_array_equal(h["ranges"], z["ranges"])
+        np.testing.assert_array_equal(h["n_contrib"], z["n_contrib"])
+        np.testing.assert_array_equal(bits(h["out_color"]), bits(z["out_color"]))
+        np.testing.assert_array_equal(bits(h["out_depth"]), bits(z["out_depth"]))
+        for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
+            ref = z["f64_" + k]
+            err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
+            assert (err <= ATOL + RTOL * np.abs(ref)).all(), (f, k, err.max())
