@@ -152,12 +152,13 @@ def forward(scene: Dict, cam: Dict, *, colors_precomp=None, cov3D_precomp=None,
     st["out_depth"] = np.zeros((1, H, W), rdt)
     st["final_T"] = np.zeros((H, W), rdt)
     st["n_contrib"] = np.zeros((H, W), np.uint32)
+    st["pair_hash"] = np.zeros((H, W), np.uint32)   # which list entries passed every test, per pixel
     if P > 0:
         getattr(L, pfx + "blend_forward")(
             C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]) if st["R"] else None,
             _p(st["means2D"]), _p(colors), _p(st["conic_opacity"]), _p(st["depths"]),
             _p(m32), _p(c32), _p(bg), _p(st["out_color"]), _p(st["out_depth"]), _p(st["final_T"]),
-            _p(st["n_contrib"]))
+            _p(st["n_contrib"]), _p(st["pair_hash"]))
     st["_ctl_means2D"], st["_ctl_conic"] = m32, c32
     return st
 

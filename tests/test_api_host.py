@@ -1,0 +1,71 @@
+"""CPU: the host-side mirror of the reference's Python interface (no GPU needed)."""
+import inspect
+
+import pytest
+import torch
+
+
+def test_settings_fields_and_order(rast):
+    """GaussianRasterizationSettings: the reference's eleven fields, in the reference's order
+    (diff_gaussian_rasterization_ch3/__init__.py:134-145), so positional construction keeps working."""
+    assert rast.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered")
+
+
+def test_forward_signature_matches_reference(rast):
+    sig = inspect.signature(rast.GaussianRasterizer.forward)
+    assert list(sig.parameters) == ["self", "means3D", "means2D", "opacities", "shs", "colors_precomp", "scales",
+                                    "rotations", "cov3D_precomp"]
+    for k in ("shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        assert sig.parameters[k].default is None
+    assert hasattr(rast.GaussianRasterizer, "markVisible")
+    assert issubclass(rast.GaussianRasterizer, torch.nn.Module)
+
+
+def _settings(rast):
+    z = torch.zeros
+    return rast.GaussianRasterizationSettings(32, 32, 0.5, 0.5, z(3), 1.0, torch.eye(4), torch.eye(4), 3, z(3), False)
+
+
+def test_exactly_one_of_checks(rast):
+    """Same two argument-combination errors as the reference (__init__.py:167-171)."""
+    r = rast.GaussianRasterizer(_settings(rast))
+    P = 4
+    m3, m2, op = torch.zeros(P, 3), torch.zeros(P, 3), torch.zeros(P, 1)
+    sh, col, sc, rot, cov = torch.zeros(P, 16, 3), torch.zeros(P, 3), torch.ones(P, 3), torch.zeros(P, 4), torch.zeros(P, 6)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(m3, m2, op, scales=sc, rotations=rot)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(m3, m2, op, shs=sh, colors_precomp=col, scales=sc, rotations=rot)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m3, m2, op, shs=sh)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m3, m2, op, shs=sh, scales=sc)                      # rotations missing
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m3, m2, op, shs=sh, scales=sc, rotations=rot, cov3D_precomp=cov)
+
+
+def test_no_cpu_fallback(rast):
+    """CPU tensors must fail loudly: the product path is the HIP library, nothing else."""
+    r = rast.GaussianRasterizer(_settings(rast))
+    P = 4
+    with pytest.raises(RuntimeError, match="GPU"):
+        r(torch.zeros(P, 3), torch.zeros(P, 3), torch.zeros(P, 1), shs=torch.zeros(P, 16, 3), scales=torch.ones(P, 3),
+          rotations=torch.zeros(P, 4))
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        rast._C.rasterize_gaussians(torch.zeros(3), torch.zeros(5, 2), torch.empty(0), torch.zeros(5, 1), torch.empty(0),
+                                    torch.empty(0), 1.0, torch.empty(0), torch.eye(4), torch.eye(4), 0.5, 0.5, 8, 8,
+                                    torch.empty(0), 0, torch.zeros(3), False)
+
+
+def test_product_does_not_import_the_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "saro-gs_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle", text, flags=re.M), f

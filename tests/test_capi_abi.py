@@ -1,0 +1,80 @@
+"""CPU: the C-ABI shared library loads without a GPU, exports every symbol include/gsrast.h declares,
+and rejects bad arguments before touching a device (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gsrast.h")
+
+
+@pytest.fixture(scope="module")
+def L(rast):
+    return rast._C.lib()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsrast_[a-z_0-9]+)\s*\(", text)) - {"gsrast_alloc_fn"})
+
+
+def test_header_and_library_agree(rast, L):
+    names = declared_functions()
+    assert len(names) >= 16
+    raw = C.CDLL(rast._C.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in gsrast.h but not exported"
+    assert sorted(rast._C.EXPORTS) == names
+    assert L.gsrast_abi_version() == 1
+
+
+def test_no_torch_or_cxx_types_in_the_boundary():
+    text = open(HEADER).read()
+    assert 'extern "C"' in text
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments cite the reference's C++ types
+    for banned in ("torch", "at::", "std::", "Tensor", "#include <vector>", "#include <functional>"):
+        assert banned not in text
+
+
+def test_state_buffer_sizes(L):
+    g = [L.gsrast_geometry_bytes(p) for p in (0, 1, 1000, 100000, 3000000)]
+    assert all(b >= a for a, b in zip(g, g[1:])) and g[0] > 0 and g[2] > g[1]
+    assert g[-1] / 3000000 < 140          # ~120 B per Gaussian of private state
+    b = [L.gsrast_binning_bytes(r, 1920, 1080) for r in (0, 10, 10**6, 5 * 10**7)]
+    assert all(y >= x for x, y in zip(b, b[1:])) and b[2] > b[1]
+    assert b[-1] / (5 * 10**7) < 20       # 16 B per instance + histograms
+    i = L.gsrast_image_bytes(1920, 1080)
+    assert 8 * 1920 * 1080 <= i <= 9 * 1920 * 1080
+    assert all(x % 256 == 0 for x in g + b + [i])
+
+
+def test_options_round_trip(L, rast):
+    for mode in (0, 1, 2, 0):
+        rast._C.set_option("exp_mode", mode)
+        assert rast._C.get_option("exp_mode") == mode
+    with pytest.raises(ValueError):
+        rast._C.set_option("exp_mode", 7)
+    with pytest.raises(ValueError):
+        rast._C.set_option("no_such_option", 1)
+    n = L.gsrast_profile_kernel_count()
+    names = [L.gsrast_profile_kernel_name(k).decode() for k in range(n)]
+    assert "blend_fwd" in names and "blend_bwd" in names and "preprocess_fwd" in names
+
+
+def test_bad_arguments_fail_before_any_device_work(L, rast):
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+    cb = ALLOC(lambda ctx, n: None)
+    # negative P / zero-size image / SH degree out of range / NULL allocators
+    base = dict(P=10, D=3, M=16, W=64, H=64)
+    for bad in (dict(P=-1), dict(W=0), dict(D=4)):
+        a = dict(base, **bad)
+        rc = L.gsrast_forward(cb, None, cb, None, cb, None, a["P"], a["D"], a["M"], None, a["W"], a["H"], None, None,
+                              None, None, None, 1.0, None, None, None, None, None, 0.5, 0.5, 0, None, None, None, None)
+        assert rc == -1 and L.gsrast_last_error()
+    rc = L.gsrast_backward(-3, 3, 16, 0, None, 64, 64, None, None, None, None, 1.0, None, None, None, None, None, 0.5, 0.5,
+                           None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
+    assert rc == -1
+    assert L.gsrast_mark_visible(-1, None, None, None, None, None) == -1
