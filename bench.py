@@ -48,6 +48,11 @@ def parse():
                     help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
     ap.add_argument("--sweep-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ablate", type=int, default=0, help="kernel ablation experiments (not a valid bench)")
+    ap.add_argument("--ppl", type=int, default=0, help="force pixels per lane of both blend kernels (0 = auto)")
+    ap.add_argument("--ppl-fwd", type=int, default=0)
+    ap.add_argument("--ppl-bwd", type=int, default=0)
+    ap.add_argument("--no-cull", action="store_true", help="disable wave-level strip culling (A/B experiments)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     return ap.parse_args()
 
@@ -163,6 +168,16 @@ def main():
     if a.exp_mode is not None:
         _C.set_option("exp_mode", a.exp_mode)
     exp_mode = _C.get_option("exp_mode")
+    if a.ablate:
+        _C.set_option("ablate", a.ablate)
+    if a.ppl:
+        _C.set_option("pixels_per_lane", a.ppl)
+    if a.ppl_fwd:
+        _C.set_option("fwd_pixels_per_lane", a.ppl_fwd)
+    if a.ppl_bwd:
+        _C.set_option("bwd_pixels_per_lane", a.ppl_bwd)
+    if a.no_cull:
+        _C.set_option("cull", 0)
 
     P, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)

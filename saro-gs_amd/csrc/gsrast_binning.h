@@ -112,7 +112,7 @@ scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__
 // rounds of 64 (coalesced).  Ranks inside a round come from a ballot match, so equal digits keep
 // their input order (stability) and LDS counters see no conflicts.
 __global__ void __launch_bounds__(RS_THREADS)
-radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ block_hist, uint32_t nblk)
+radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t* __restrict__ block_hist, uint32_t nblk)
 {
     __shared__ uint32_t cnt[4][256];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
@@ -124,7 +124,7 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        const uint32_t d = valid ? ((keys[i] >> shift) & 0xFFu) : 0u;
+        const uint32_t d = valid ? ((keys[i] >> shift) & mask) : 0u;
         const uint64_t m = wave_match8(d, valid);
         if (valid && (m & lanemask_lt()) == 0) wc[d] = wc[d] + (uint32_t)__popcll(m);
     }
@@ -135,22 +135,34 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint
 
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
                      const uint32_t* __restrict__ hist_scanned, uint32_t nblk)
 {
+    // Ranks -> block-local order in LDS -> coalesced write-out: after the exchange consecutive lanes
+    // hold consecutive elements of the same digit, whose global destinations are consecutive too.
     __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t dstart[256];       // first block-local slot of each digit
+    __shared__ uint32_t gbase[256];        // global destination of that slot
+    __shared__ uint32_t xk[RS_CHUNK];
+    __shared__ uint32_t xv[RS_CHUNK];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     __syncthreads();
     volatile uint32_t* wc = cnt[wave];
     const uint32_t wbase = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
-    uint32_t key[RS_ITEMS], rk[RS_ITEMS];
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rk[RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : 0u;
-        const uint32_t d = (key[r] >> shift) & 0xFFu;
+        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = (key[r] >> shift) & mask;
         const uint64_t m = wave_match8(d, valid);
         const uint32_t prev = wc[d];
         const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
@@ -160,19 +172,34 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     __syncthreads();
     {
         const uint32_t t = threadIdx.x;
-        uint32_t g = hist_scanned[(size_t)t * nblk + blockIdx.x];
-#pragma unroll
-        for (int w = 0; w < 4; w++) { uint32_t c = cnt[w][t]; cnt[w][t] = g; g += c; }
+        const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+        uint32_t tot;
+        const uint32_t start = block_excl_scan(c0 + c1 + c2 + c3, &tot);
+        dstart[t] = start;
+        gbase[t] = hist_scanned[(size_t)t * nblk + blockIdx.x];
+        cnt[0][t] = start; cnt[1][t] = start + c0; cnt[2][t] = start + c0 + c1; cnt[3][t] = start + c0 + c1 + c2;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
-            const uint32_t d = (key[r] >> shift) & 0xFFu;
-            const uint32_t pos = cnt[wave][d] + rk[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = vals_in[i];
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t slot = cnt[wave][d] + rk[r];
+            xk[slot] = key[r]; xv[slot] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = (n - blockIdx.x * RS_CHUNK) < (uint32_t)RS_CHUNK ? (n - blockIdx.x * RS_CHUNK) : (uint32_t)RS_CHUNK;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t slot = r * RS_THREADS + threadIdx.x;
+        if (slot < nvalid) {
+            const uint32_t k = xk[slot];
+            const uint32_t d = (k >> shift) & mask;
+            const uint32_t pos = gbase[d] + (slot - dstart[d]);
+            keys_out[pos] = k;
+            vals_out[pos] = xv[slot];
         }
     }
 }

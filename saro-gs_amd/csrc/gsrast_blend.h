@@ -27,13 +27,43 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles)
     return t;   // may be >= ntiles for the padded grid; caller checks
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-level culling of a staged batch against the wave's pixel strip.
+// Lane l takes instance (round*64 + l) of the batch and computes the EXACT minimum over the strip's
+// rectangle of  q(d) = 0.5*(A dx^2 + C dy^2) + B dx dy  (convex: the conic is positive definite), i.e.
+// the largest power = -q any pixel of the strip can see.  If even that is below the instance's skip
+// threshold no pixel of the strip can pass the per-pixel tests, so the instance is dropped for this
+// wave with ~0.5 instructions instead of a ~20-instruction evaluated-and-skipped iteration.  The
+// ballot of survivors is a 64-bit mask in SGPRs which the blend loop walks with s_ff1.
+// Safety: skip_threshold sits 0.02 below ln(1/(255*opacity)) (preprocess_fwd_kernel); culling at
+// threshold + 0.01 leaves a 0.01 band (in units of power) for the rounding of this bound, three
+// orders of magnitude more than its error -- culled instances can never contribute, so results are
+// bit-identical with and without culling.
+__device__ __forceinline__ bool strip_may_touch(const float4 a, const float cz, const float thr,
+                                                float x0, float x1, float y0, float y1)
+{
+    // d = mean - pixel:  dx in [a.x - x1, a.x - x0], dy in [a.y - y1, a.y - y0]
+    const float dx_lo = a.x - x1, dx_hi = a.x - x0, dy_lo = a.y - y1, dy_hi = a.y - y0;
+    const float dxc = __builtin_amdgcn_fmed3f(0.0f, dx_lo, dx_hi);      // box point closest to the centre
+    const float dyc = __builtin_amdgcn_fmed3f(0.0f, dy_lo, dy_hi);
+    const float A = a.z, B = a.w, C = cz;
+    // candidate 1: on the edge dx = dxc, best dy;  candidate 2: on the edge dy = dyc, best dx
+    const float dy1 = __builtin_amdgcn_fmed3f(-B * dxc * __builtin_amdgcn_rcpf(fmaxf(C, 1e-20f)), dy_lo, dy_hi);
+    const float dx2 = __builtin_amdgcn_fmed3f(-B * dyc * __builtin_amdgcn_rcpf(fmaxf(A, 1e-20f)), dx_lo, dx_hi);
+    const float q1 = 0.5f * (A * dxc * dxc + C * dy1 * dy1) + B * dxc * dy1;
+    const float q2 = 0.5f * (A * dx2 * dx2 + C * dyc * dyc) + B * dx2 * dyc;
+    const float qmin = fminf(q1, q2);
+    return -qmin >= thr + 0.01f;     // also false when thr > 0 (opacity below 1/255)
+}
+
+// Forward blend, 4 wave64 per tile, one pixel per lane, with wave-level culling (see above).
 template <int EXPMODE>
 __global__ void __launch_bounds__(256)
-blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
-                 int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                 const float4* __restrict__ rec2, const float* __restrict__ bg,
-                 float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
-                 uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max)
+blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+                      int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                      const float4* __restrict__ rec2, const float* __restrict__ bg,
+                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
+                      uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max)
 {
     __shared__ float4 s0[256];
     __shared__ float4 s1[256];
@@ -44,9 +74,13 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     if (tile >= ntiles) return;
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
+    const unsigned lane = lane_id(), wave = t >> 6;
     const uint32_t px = tx * TILE_X + (t & 15u), py = ty * TILE_Y + (t >> 4);
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const float pxf = (float)px, pyf = (float)py;
+    // this wave's strip (pixel centres): 16 columns x 4 rows
+    const float sx0 = (float)(tx * TILE_X), sx1 = sx0 + 15.0f;
+    const float sy0 = (float)(ty * TILE_Y + wave * 4u), sy1 = sy0 + 3.0f;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -65,25 +99,46 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
         }
         __syncthreads();
         const uint32_t cnt = (n - base) < 256u ? (n - base) : 256u;
-        for (uint32_t j = 0; !done && j < cnt; j++) {
-            const float4 a = s0[j];
-            const float4 c = s2[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float4 b = s1[j];
-            const float power = gs_power(a.z, a.w, b.x, dx, dy);
-            if (power > 0.0f || power < c.z) continue;   // c.z: conservative "alpha < 1/255" pre-test
-            float alpha = b.y * gs_exp<EXPMODE>(power);
-            alpha = alpha < 0.99f ? alpha : 0.99f;
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float w = alpha * T;
-            C0 = __builtin_fmaf(b.z, w, C0);
-            C1 = __builtin_fmaf(b.w, w, C1);
-            C2 = __builtin_fmaf(c.x, w, C2);
-            if (T > 0.5f && test_T < 0.5f) Dm = c.y;
-            T = test_T;
-            last = base + j + 1;
+        if (!__any(!done)) continue;                        // whole wave saturated: only helps staging
+#pragma unroll 1
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t slot = r * 64 + lane;
+            bool touch = false;
+            if (slot < cnt) {
+                const float4 a = s0[slot];
+                const float4 b = s1[slot];
+                const float4 c = s2[slot];
+                touch = strip_may_touch(a, b.x, c.z, sx0, sx1, sy0, sy1);
+            }
+            uint64_t mask = __ballot(touch);
+            while (mask) {
+                const uint32_t j = r * 64 + (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float4 a = s0[j];
+                const float4 c = s2[j];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float4 b = s1[j];
+                const float power = gs_power(a.z, a.w, b.x, dx, dy);
+                if (!done && !(power > 0.0f) && !(power < c.z)) {
+                    float alpha = b.y * gs_exp<EXPMODE>(power);
+                    alpha = alpha < 0.99f ? alpha : 0.99f;
+                    if (!(alpha < 1.0f / 255.0f)) {
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < 0.0001f) {
+                            done = true;
+                        } else {
+                            const float w = alpha * T;
+                            C0 = __builtin_fmaf(b.z, w, C0);
+                            C1 = __builtin_fmaf(b.w, w, C1);
+                            C2 = __builtin_fmaf(c.x, w, C2);
+                            if (T > 0.5f && test_T < 0.5f) Dm = c.y;
+                            T = test_T;
+                            last = base + j + 1;
+                        }
+                    }
+                }
+                if (!__any(!done)) { mask = 0; r = 4; }    // wave saturated
+            }
         }
     }
     if (inside) {
@@ -96,8 +151,147 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
         out_color[2 * plane + pid] = __builtin_fmaf(T, bg2, C2);
         out_depth[pid] = Dm;
     }
-    // deepest list position consumed by any pixel of the tile (bounds the backward traversal)
     uint32_t m = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_max, m);
+    __syncthreads();
+    if (t == 0) tile_max[tile] = s_max;
+}
+
+// PPL = pixels per lane.  A tile is 256 pixels; a workgroup has NT = 256/PPL lanes (4/PPL wave64).
+// Pixel k of lane t is tile-linear index k*NT + t, i.e. column t%16 for every k when NT is a
+// multiple of 16, rows strided by NT/16: per-Gaussian terms that depend on the column only
+// (dx, conic.x*dx*dx, conic.y*dx) are shared by the lane's PPL pixels, LDS broadcast reads, loop
+// control, wave reductions and atomics are amortised over PPL pixels.  PPL=4 -> one wave per tile,
+// no cross-wave synchronisation at all; PPL=1 -> the classic 4-wave workgroup (more waves in
+// flight for small images).
+template <int PPL> struct BlendCfg {
+    static constexpr int NT = 256 / PPL;
+    static constexpr int BATCH = (PPL == 4) ? 128 : NT;   // instances staged in LDS per round
+    static constexpr int ROWSTEP = NT / 16;
+};
+
+template <int EXPMODE, int PPL>
+__global__ void __launch_bounds__(256 / PPL)
+blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+                 int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                 const float4* __restrict__ rec2, const float* __restrict__ bg,
+                 float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
+                 uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max)
+{
+    using Cfg = BlendCfg<PPL>;
+    constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
+    __shared__ float4 s0[BATCH + 1];      // +1: the software-pipelined fetch reads one slot ahead
+    __shared__ float4 s1[BATCH + 1];
+    __shared__ float4 s2[BATCH + 1];
+    __shared__ uint32_t s_max;
+
+    const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    const uint32_t t = threadIdx.x;
+    const uint32_t px = tx * TILE_X + (t & 15u);
+    const float pxf = (float)px;
+    uint32_t py[PPL]; float pyf[PPL]; bool inside[PPL], done[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        py[k] = ty * TILE_Y + (t >> 4) + k * Cfg::ROWSTEP;
+        pyf[k] = (float)py[k];
+        inside[k] = px < (uint32_t)W && py[k] < (uint32_t)H;
+        done[k] = !inside[k];
+    }
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    if (t == 0) s_max = 0;
+
+    float T[PPL], C0[PPL], C1[PPL], C2[PPL], Dm[PPL];
+    uint32_t last[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) { T[k] = 1.0f; C0[k] = C1[k] = C2[k] = 0.0f; Dm[k] = 15.0f; last[k] = 0; }
+
+    for (uint32_t base = 0; base < n; base += BATCH) {
+        bool all_done = true;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
+        if (__syncthreads_and(all_done)) break;
+#pragma unroll
+        for (int r = 0; r < BATCH / NT; r++) {
+            const uint32_t slot = t + r * NT, i = base + slot;
+            if (i < n) {
+                const uint32_t g = point_list[range.x + i];
+                s0[slot] = rec0[g]; s1[slot] = rec1[g]; s2[slot] = rec2[g];
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
+        // Records are fetched one iteration ahead (register double buffer): the three wide LDS reads
+        // of instance j+1 are in flight while instance j is evaluated, and the compiler cannot sink
+        // them into the (rarely skipped) hit path.
+        float4 na = s0[0], nb = s1[0], nc = s2[0];
+        for (uint32_t j = 0; !all_done && j < cnt; j++) {
+            const float4 a = na, b = nb, c = nc;
+            na = s0[j + 1]; nb = s1[j + 1]; nc = s2[j + 1];
+            const float dx = a.x - pxf;
+            const float xx = (a.z * dx) * dx;      // conic.x * dx * dx   } shared by the lane's pixels
+            const float xy = a.w * dx;             // conic.y * dx        }
+            float power[PPL]; bool hit[PPL]; bool any_hit = false;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                const float dy = a.y - pyf[k];
+                const float q = __builtin_fmaf(b.x * dy, dy, xx);
+                power[k] = __builtin_fmaf(-0.5f, q, -(xy * dy));
+                // c.z: conservative "alpha < 1/255" pre-test, see preprocess_fwd_kernel
+                hit[k] = !done[k] && !(power[k] > 0.0f) && !(power[k] < c.z);
+                any_hit = any_hit || hit[k];
+            }
+            if (!any_hit) continue;
+            bool fin_any = false;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                if (hit[k]) {   // one exec-masked region per pixel slot, straight-line inside (selects, no branches)
+                    float alpha = b.y * gs_exp<EXPMODE>(power[k]);
+                    alpha = alpha < 0.99f ? alpha : 0.99f;
+                    const bool ok = !(alpha < 1.0f / 255.0f);
+                    const float test_T = T[k] * (1.0f - alpha);
+                    const bool fin = ok && (test_T < 0.0001f);
+                    const bool upd = ok && !fin;
+                    const float w = upd ? alpha * T[k] : 0.0f;      // fma(c, 0, C) == C exactly
+                    C0[k] = __builtin_fmaf(b.z, w, C0[k]);
+                    C1[k] = __builtin_fmaf(b.w, w, C1[k]);
+                    C2[k] = __builtin_fmaf(c.x, w, C2[k]);
+                    Dm[k] = (upd && T[k] > 0.5f && test_T < 0.5f) ? c.y : Dm[k];
+                    T[k] = upd ? test_T : T[k];
+                    last[k] = upd ? base + j + 1 : last[k];
+                    done[k] = done[k] || fin;
+                    fin_any = fin_any || fin;
+                }
+            }
+            if (fin_any) {
+                all_done = true;
+#pragma unroll
+                for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
+            }
+        }
+    }
+    const size_t plane = (size_t)W * H;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        if (inside[k]) {
+            const size_t pid = (size_t)W * py[k] + px;
+            final_T[pid] = T[k];
+            n_contrib[pid] = last[k];
+            out_color[pid] = __builtin_fmaf(T[k], bg0, C0[k]);
+            out_color[plane + pid] = __builtin_fmaf(T[k], bg1, C1[k]);
+            out_color[2 * plane + pid] = __builtin_fmaf(T[k], bg2, C2[k]);
+            out_depth[pid] = Dm[k];
+        }
+        m = last[k] > m ? last[k] : m;
+    }
+    // deepest list position consumed by any pixel of the tile (bounds the backward traversal)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
     __syncthreads();
@@ -106,13 +300,14 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     if (t == 0) tile_max[tile] = s_max;
 }
 
-// Backward.  Per (pixel, instance) contribution -> 9 partial derivatives; each is summed over the
-// 64 lanes of the wave with DPP row shifts / row broadcasts (no LDS, no shuffles) and committed
-// with ONE hardware float atomic per wave per quantity -- instead of the reference's 9 atomics per
-// (pixel, instance) pair (backward.cu:523-554).  A wave in which no lane contributes skips both
-// the reduction and the atomics.
-template <int EXPMODE>
-__global__ void __launch_bounds__(256)
+// Backward.  Per (pixel, instance) contribution -> 9 partial derivatives.  A lane first adds up its
+// own PPL pixels, the wave sums over its 64 lanes with DPP row shifts / row broadcasts (no LDS
+// traffic, no shuffles), lane 63 adds the 9 totals into a per-batch LDS accumulator, and after the
+// batch every lane commits ONE instance's 9 sums with hardware float atomics -- 9 atomics per
+// (tile, instance) issued 64 lanes wide, instead of the reference's 9 atomics per (pixel, instance)
+// pair (backward.cu:523-554).  A wave in which no pixel is touched skips everything.
+template <int EXPMODE, int PPL, int ABLATE = 0>
+__global__ void __launch_bounds__(256 / PPL)
 blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
                  int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                  const float4* __restrict__ rec2, const float* __restrict__ bg,
@@ -122,101 +317,344 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                  float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/)
 {
 #pragma clang fp contract(fast)
-    __shared__ float4 s0[256];
-    __shared__ float4 s1[256];
-    __shared__ float s2[256];
-    __shared__ uint32_t sid[256];
+    using Cfg = BlendCfg<PPL>;
+    constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
+    __shared__ float4 s0[BATCH];
+    __shared__ float4 s1[BATCH];
+    __shared__ float2 s2[BATCH];          // {blue, skip threshold}
+    __shared__ uint32_t sid[BATCH];
+    __shared__ float acc[9][BATCH];
 
     const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
-    const uint32_t px = tx * TILE_X + (t & 15u), py = ty * TILE_Y + (t >> 4);
-    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
-    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t px = tx * TILE_X + (t & 15u);
+    const float pxf = (float)px;
     const uint2 range = ranges[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint32_t n_all = range.y - range.x;
     const uint32_t tm = tile_max[tile];
     const uint32_t n = tm < n_all ? tm : n_all;       // instances at list position >= n touch no pixel
-    const size_t pid = (size_t)W * py + px;
     const size_t plane = (size_t)W * H;
 
-    const float T_final = inside ? final_T[pid] : 0.0f;
-    float T = T_final;
-    const uint32_t last = inside ? n_contrib[pid] : 0u;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
-    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
-    if (inside) { dp0 = dL_dpix[pid]; dp1 = dL_dpix[plane + pid]; dp2 = dL_dpix[2 * plane + pid]; }
-    const float bg_dot = bg0 * dp0 + bg1 * dp1 + bg2 * dp2;
+    float pyf[PPL], T_final[PPL], T[PPL], last_alpha[PPL], bg_dot[PPL];
+    float ac0[PPL], ac1[PPL], ac2[PPL], lc0[PPL], lc1[PPL], lc2[PPL], dp0[PPL], dp1[PPL], dp2[PPL];
+    uint32_t last[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const uint32_t py = ty * TILE_Y + (t >> 4) + k * Cfg::ROWSTEP;
+        pyf[k] = (float)py;
+        const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+        const size_t pid = (size_t)W * py + px;
+        T_final[k] = inside ? final_T[pid] : 0.0f;
+        T[k] = T_final[k];
+        last[k] = inside ? n_contrib[pid] : 0u;
+        dp0[k] = inside ? dL_dpix[pid] : 0.f; dp1[k] = inside ? dL_dpix[plane + pid] : 0.f; dp2[k] = inside ? dL_dpix[2 * plane + pid] : 0.f;
+        bg_dot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
+        ac0[k] = ac1[k] = ac2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = 0.f;
+    }
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const unsigned lane = lane_id();
 
-    // position `pos` (0-based from the FRONT of the tile list) is visited from n-1 down to 0
-    for (uint32_t base = 0; base < n; base += 256) {
+    // list position `pos` (0-based from the FRONT of the tile list) is visited from n-1 down to 0
+    for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
-        const uint32_t i = base + t;
-        if (i < n) {
-            const uint32_t g = point_list[range.x + (n - 1 - i)];
-            sid[t] = g;
-            s0[t] = rec0[g]; s1[t] = rec1[g]; s2[t] = rec2[g].x;
+#pragma unroll
+        for (int r = 0; r < BATCH / NT; r++) {
+            const uint32_t slot = t + r * NT, i = base + slot;
+            if (i < n) {
+                const uint32_t g = point_list[range.x + (n - 1 - i)];
+                sid[slot] = g;
+                s0[slot] = rec0[g]; s1[slot] = rec1[g];
+                const float4 c = rec2[g];
+                s2[slot] = make_float2(c.x, c.z);
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) acc[q][slot] = 0.0f;
         }
         __syncthreads();
-        const uint32_t cnt = (n - base) < 256u ? (n - base) : 256u;
+        const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
         for (uint32_t j = 0; j < cnt; j++) {
             const uint32_t pos = n - 1 - (base + j);
-            // wave-uniform skip: nobody in this wave reaches this deep
-            bool active = pos < last;
-            if (!__any(active)) continue;
+            bool reach = false;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) reach = reach || (pos < last[k]);
+            if (!__any(reach)) continue;               // nobody in this wave got this deep
             const float4 a = s0[j];
             const float4 b = s1[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = gs_power(a.z, a.w, b.x, dx, dy);
-            const float G = gs_exp<EXPMODE>(power);
-            float alpha = b.y * G;
-            alpha = alpha < 0.99f ? alpha : 0.99f;
-            active = active && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (!__any(active)) continue;
+            const float2 c = s2[j];
+            const float dx = a.x - pxf;
+            const float xx = (a.z * dx) * dx;
+            const float xy = a.w * dx;
+            float power[PPL], dyv[PPL]; bool hit[PPL]; bool any_hit = false;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                const float dy = a.y - pyf[k];
+                dyv[k] = dy;
+                const float q = __builtin_fmaf(b.x * dy, dy, xx);
+                power[k] = __builtin_fmaf(-0.5f, q, -(xy * dy));
+                hit[k] = pos < last[k] && !(power[k] > 0.0f) && !(power[k] < c.y);
+                any_hit = any_hit || hit[k];
+            }
+            if (!__any(any_hit)) continue;
 
             float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-            if (active) {
-                T = T * __builtin_amdgcn_rcpf(1.0f - alpha);
-                const float dch = alpha * T;
-                const float c0 = b.z, c1 = b.w, c2 = s2[j];
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
-                float dL_dalpha = (c0 - acc0) * dp0 + (c1 - acc1) * dp1 + (c2 - acc2) * dp2;
-                g_r = dch * dp0; g_g = dch * dp1; g_b = dch * dp2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(1.f - alpha)) * bg_dot;
+            bool contributed = false;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                if (!hit[k]) continue;
+                const float G = gs_exp<EXPMODE>(power[k]);
+                float alpha = b.y * G;
+                alpha = alpha < 0.99f ? alpha : 0.99f;
+                if (alpha < 1.0f / 255.0f) continue;
+                contributed = true;
+                const float dy = dyv[k];
+                const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T[k] = T[k] * rcp1ma;
+                const float dch = alpha * T[k];
+                const float c0 = b.z, c1 = b.w, c2 = c.x;
+                ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
+                ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
+                ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
+                float dL_dalpha = (c0 - ac0[k]) * dp0[k] + (c1 - ac1[k]) * dp1[k] + (c2 - ac2[k]) * dp2[k];
+                g_r += dch * dp0[k]; g_g += dch * dp1[k]; g_b += dch * dp2[k];
+                dL_dalpha *= T[k];
+                last_alpha[k] = alpha;
+                dL_dalpha += (-T_final[k] * rcp1ma) * bg_dot[k];
                 const float dL_dG = b.y * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 const float dG_ddelx = -gdx * a.z - gdy * a.w;
                 const float dG_ddely = -gdy * b.x - gdx * a.w;
-                g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                g_my = dL_dG * dG_ddely * ddely_dy;
-                g_ca = -0.5f * gdx * dx * dL_dG;
-                g_cb = -0.5f * gdx * dy * dL_dG;
-                g_cc = -0.5f * gdy * dy * dL_dG;
-                g_op = G * dL_dalpha;
+                g_mx += dL_dG * dG_ddelx;
+                g_my += dL_dG * dG_ddely;
+                g_ca += gdx * dx * dL_dG;
+                g_cb += gdx * dy * dL_dG;
+                g_cc += gdy * dy * dL_dG;
+                g_op += G * dL_dalpha;
             }
-            g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-            g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-            g_op = wave_sum_to_lane63(g_op);
-            g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-            if (lane == 63) {
-                const uint32_t gid = sid[j];
-                atomicAdd(&dL_dmean2D[3 * (size_t)gid], g_mx);
-                atomicAdd(&dL_dmean2D[3 * (size_t)gid + 1], g_my);
-                atomicAdd(&dL_dconic[4 * (size_t)gid], g_ca);
-                atomicAdd(&dL_dconic[4 * (size_t)gid + 1], g_cb);
-                atomicAdd(&dL_dconic[4 * (size_t)gid + 3], g_cc);
-                atomicAdd(&dL_dopacity[gid], g_op);
-                atomicAdd(&dL_dcolors[3 * (size_t)gid], g_r);
-                atomicAdd(&dL_dcolors[3 * (size_t)gid + 1], g_g);
-                atomicAdd(&dL_dcolors[3 * (size_t)gid + 2], g_b);
+            if (!__any(contributed)) continue;
+            if constexpr (ABLATE < 2) {
+                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
+                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+                g_op = wave_sum_to_lane63(g_op);
+                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+            }
+            if constexpr (ABLATE >= 1) {
+                asm volatile("" :: "v"(g_mx), "v"(g_my), "v"(g_ca), "v"(g_cb), "v"(g_cc), "v"(g_op), "v"(g_r), "v"(g_g), "v"(g_b));
+            } else if (lane == 63) {
+                if constexpr (NT == 64) {   // single wave: plain read-modify-write is race free
+                    acc[0][j] += g_mx * ddelx_dx; acc[1][j] += g_my * ddely_dy;
+                    acc[2][j] += -0.5f * g_ca; acc[3][j] += -0.5f * g_cb; acc[4][j] += -0.5f * g_cc;
+                    acc[5][j] += g_op; acc[6][j] += g_r; acc[7][j] += g_g; acc[8][j] += g_b;
+                } else {
+                    atomicAdd(&acc[0][j], g_mx * ddelx_dx); atomicAdd(&acc[1][j], g_my * ddely_dy);
+                    atomicAdd(&acc[2][j], -0.5f * g_ca); atomicAdd(&acc[3][j], -0.5f * g_cb); atomicAdd(&acc[4][j], -0.5f * g_cc);
+                    atomicAdd(&acc[5][j], g_op); atomicAdd(&acc[6][j], g_r); atomicAdd(&acc[7][j], g_g); atomicAdd(&acc[8][j], g_b);
+                }
+            }
+        }
+        __syncthreads();
+        // commit: one lane per staged instance, 9 float atomics each, all lanes wide
+#pragma unroll
+        for (int r = 0; r < BATCH / NT; r++) {
+            const uint32_t slot = t + r * NT;
+            if (slot < cnt) {
+                const size_t gid = sid[slot];
+                const float v0 = acc[0][slot], v1 = acc[1][slot], v2 = acc[2][slot], v3 = acc[3][slot], v4 = acc[4][slot];
+                const float v5 = acc[5][slot], v6 = acc[6][slot], v7 = acc[7][slot], v8 = acc[8][slot];
+                const bool any = (v0 != 0.f) | (v1 != 0.f) | (v2 != 0.f) | (v3 != 0.f) | (v4 != 0.f) | (v5 != 0.f) | (v6 != 0.f) | (v7 != 0.f) | (v8 != 0.f);
+                if (any) {
+                    atomicAdd(&dL_dmean2D[3 * gid], v0); atomicAdd(&dL_dmean2D[3 * gid + 1], v1);
+                    atomicAdd(&dL_dconic[4 * gid], v2); atomicAdd(&dL_dconic[4 * gid + 1], v3); atomicAdd(&dL_dconic[4 * gid + 3], v4);
+                    atomicAdd(&dL_dopacity[gid], v5);
+                    atomicAdd(&dL_dcolors[3 * gid], v6); atomicAdd(&dL_dcolors[3 * gid + 1], v7); atomicAdd(&dL_dcolors[3 * gid + 2], v8);
+                }
+            }
+        }
+    }
+}
+
+// Backward blend with wave-level culling.  Same arithmetic and the same reduction / commit scheme as
+// blend_bwd_kernel; the difference is WHICH (strip, instance) pairs are evaluated at all: per staged
+// round of 64 instances every lane tests one instance against each of the wave's PPL pixel strips
+// (exact box minimum of the quadratic, strip_may_touch) and against the deepest list position that
+// strip still needs; the ballots are 64-bit SGPR masks, the blend loop walks their union with
+// s_ff1 and enters pixel slot k only if bit j of mask k is set -- a scalar branch, no VALU work for
+// untouched strips.
+template <int EXPMODE, int PPL>
+__global__ void __launch_bounds__(256 / PPL)
+blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+                      int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                      const float4* __restrict__ rec2, const float* __restrict__ bg,
+                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                      const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
+                      float* __restrict__ dL_dmean2D /*[P][3]*/, float* __restrict__ dL_dconic /*[P][4]*/,
+                      float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/)
+{
+#pragma clang fp contract(fast)
+    using Cfg = BlendCfg<PPL>;
+    constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
+    __shared__ float4 s0[BATCH];
+    __shared__ float4 s1[BATCH];
+    __shared__ float2 s2[BATCH];          // {blue, skip threshold}
+    __shared__ uint32_t sid[BATCH];
+    __shared__ float acc[9][BATCH];
+
+    const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    const uint32_t t = threadIdx.x;
+    const unsigned lane = lane_id(), wave = t >> 6;
+    const uint32_t px = tx * TILE_X + (t & 15u);
+    const float pxf = (float)px;
+    const uint2 range = ranges[tile];
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const uint32_t n_all = range.y - range.x;
+    const uint32_t tm = tile_max[tile];
+    const uint32_t n = tm < n_all ? tm : n_all;       // instances at list position >= n touch no pixel
+    const size_t plane = (size_t)W * H;
+    const float sx0 = (float)(tx * TILE_X), sx1 = sx0 + 15.0f;
+
+    float pyf[PPL], tfbg[PPL], T[PPL], last_alpha[PPL], sy0[PPL];
+    float ac0[PPL], ac1[PPL], ac2[PPL], lc0[PPL], lc1[PPL], lc2[PPL], dp0[PPL], dp1[PPL], dp2[PPL];
+    uint32_t last[PPL], strip_last[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const uint32_t py = ty * TILE_Y + (t >> 4) + k * Cfg::ROWSTEP;
+        pyf[k] = (float)py;
+        sy0[k] = (float)(ty * TILE_Y + wave * 4u + k * Cfg::ROWSTEP);
+        const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+        const size_t pid = (size_t)W * py + px;
+        const float Tf = inside ? final_T[pid] : 0.0f;
+        T[k] = Tf;
+        last[k] = inside ? n_contrib[pid] : 0u;
+        dp0[k] = inside ? dL_dpix[pid] : 0.f; dp1[k] = inside ? dL_dpix[plane + pid] : 0.f; dp2[k] = inside ? dL_dpix[2 * plane + pid] : 0.f;
+        tfbg[k] = -Tf * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
+        ac0[k] = ac1[k] = ac2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = 0.f;
+        uint32_t m = last[k];                            // deepest position the strip needs (wave-uniform)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+        strip_last[k] = __builtin_amdgcn_readfirstlane(m);
+    }
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    for (uint32_t base = 0; base < n; base += BATCH) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BATCH / NT; r++) {
+            const uint32_t slot = t + r * NT, i = base + slot;
+            if (i < n) {
+                const uint32_t g = point_list[range.x + (n - 1 - i)];
+                sid[slot] = g;
+                s0[slot] = rec0[g]; s1[slot] = rec1[g];
+                const float4 c = rec2[g];
+                s2[slot] = make_float2(c.x, c.z);
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) acc[q][slot] = 0.0f;
+        }
+        __syncthreads();
+        const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
+#pragma unroll 1
+        for (uint32_t r = 0; r < (uint32_t)BATCH / 64u; r++) {
+            if (r * 64u >= cnt) break;
+            const uint32_t slot = r * 64u + lane;
+            const uint32_t spos = n - 1 - (base + slot);      // list position of this lane's instance
+            uint64_t mk[PPL];
+            uint64_t uni = 0;
+            {
+                const bool valid = slot < cnt;
+                const float4 a = valid ? s0[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
+                const float czv = valid ? s1[slot].x : 1.f;
+                const float thr = valid ? s2[slot].y : 1.f;
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    const bool touch = valid && spos < strip_last[k] &&
+                                       strip_may_touch(a, czv, thr, sx0, sx1, sy0[k], sy0[k] + 3.0f);
+                    mk[k] = __ballot(touch);
+                    uni |= mk[k];
+                }
+            }
+            while (uni) {
+                const uint32_t jb = (uint32_t)__builtin_ctzll(uni);
+                uni &= uni - 1;
+                const uint32_t j = r * 64u + jb;
+                const uint32_t pos = n - 1 - (base + j);
+                const float4 a = s0[j];
+                const float4 b = s1[j];
+                const float2 c = s2[j];
+                const float dx = a.x - pxf;
+                const float xx = (a.z * dx) * dx;
+                const float xy = a.w * dx;
+                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+                bool contributed = false;
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    if (!((mk[k] >> jb) & 1ull)) continue;                 // scalar: strip k untouched
+                    const float dy = a.y - pyf[k];
+                    const float q = __builtin_fmaf(b.x * dy, dy, xx);
+                    const float power = __builtin_fmaf(-0.5f, q, -(xy * dy));
+                    if (!(pos < last[k]) || power > 0.0f || power < c.y) continue;
+                    const float G = gs_exp<EXPMODE>(power);
+                    float alpha = b.y * G;
+                    alpha = alpha < 0.99f ? alpha : 0.99f;
+                    if (alpha < 1.0f / 255.0f) continue;
+                    contributed = true;
+                    const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T[k] = T[k] * rcp1ma;
+                    const float dch = alpha * T[k];
+                    const float c0 = b.z, c1 = b.w, c2 = c.x;
+                    ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
+                    ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
+                    ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
+                    float dL_dalpha = (c0 - ac0[k]) * dp0[k] + (c1 - ac1[k]) * dp1[k] + (c2 - ac2[k]) * dp2[k];
+                    g_r += dch * dp0[k]; g_g += dch * dp1[k]; g_b += dch * dp2[k];
+                    dL_dalpha *= T[k];
+                    last_alpha[k] = alpha;
+                    dL_dalpha += tfbg[k] * rcp1ma;
+                    const float dL_dG = b.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    g_mx += dL_dG * (-gdx * a.z - gdy * a.w);
+                    g_my += dL_dG * (-gdy * b.x - gdx * a.w);
+                    g_ca += gdx * dx * dL_dG;
+                    g_cb += gdx * dy * dL_dG;
+                    g_cc += gdy * dy * dL_dG;
+                    g_op += G * dL_dalpha;
+                }
+                if (!__any(contributed)) continue;
+                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
+                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+                g_op = wave_sum_to_lane63(g_op);
+                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+                if (lane == 63) {
+                    if constexpr (NT == 64) {   // single wave: plain read-modify-write is race free
+                        acc[0][j] += g_mx * ddelx_dx; acc[1][j] += g_my * ddely_dy;
+                        acc[2][j] += -0.5f * g_ca; acc[3][j] += -0.5f * g_cb; acc[4][j] += -0.5f * g_cc;
+                        acc[5][j] += g_op; acc[6][j] += g_r; acc[7][j] += g_g; acc[8][j] += g_b;
+                    } else {
+                        atomicAdd(&acc[0][j], g_mx * ddelx_dx); atomicAdd(&acc[1][j], g_my * ddely_dy);
+                        atomicAdd(&acc[2][j], -0.5f * g_ca); atomicAdd(&acc[3][j], -0.5f * g_cb); atomicAdd(&acc[4][j], -0.5f * g_cc);
+                        atomicAdd(&acc[5][j], g_op); atomicAdd(&acc[6][j], g_r); atomicAdd(&acc[7][j], g_g); atomicAdd(&acc[8][j], g_b);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BATCH / NT; r++) {
+            const uint32_t slot = t + r * NT;
+            if (slot < cnt) {
+                const size_t gid = sid[slot];
+                const float v0 = acc[0][slot], v1 = acc[1][slot], v2 = acc[2][slot], v3 = acc[3][slot], v4 = acc[4][slot];
+                const float v5 = acc[5][slot], v6 = acc[6][slot], v7 = acc[7][slot], v8 = acc[8][slot];
+                const bool any = (v0 != 0.f) | (v1 != 0.f) | (v2 != 0.f) | (v3 != 0.f) | (v4 != 0.f) | (v5 != 0.f) | (v6 != 0.f) | (v7 != 0.f) | (v8 != 0.f);
+                if (any) {
+                    atomicAdd(&dL_dmean2D[3 * gid], v0); atomicAdd(&dL_dmean2D[3 * gid + 1], v1);
+                    atomicAdd(&dL_dconic[4 * gid], v2); atomicAdd(&dL_dconic[4 * gid + 1], v3); atomicAdd(&dL_dconic[4 * gid + 3], v4);
+                    atomicAdd(&dL_dopacity[gid], v5);
+                    atomicAdd(&dL_dcolors[3 * gid], v6); atomicAdd(&dL_dcolors[3 * gid + 1], v7); atomicAdd(&dL_dcolors[3 * gid + 2], v8);
+                }
             }
         }
     }

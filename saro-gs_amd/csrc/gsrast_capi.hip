@@ -25,7 +25,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_exp_mode{0}, g_profile{0}, g_debug_sync{0};
+std::atomic<int> g_exp_mode{0}, g_profile{0}, g_debug_sync{0}, g_ablate{0};
 
 int fail(int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -107,21 +107,29 @@ int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst
     return GSRAST_OK;
 }
 
-// Stable sort of n (key,value) pairs on `passes` 8-bit digits starting at bit 0.
-// Result ends in (kA,vA) if passes is even, else in (kB,vB).
-int radix_sort(uint32_t* kA, uint32_t* vA, uint32_t* kB, uint32_t* vB, uint32_t n, int passes,
+// Stable sort of n (key,value) pairs on the low `bits` key bits, in ceil(bits/8) passes of (nearly)
+// equal digit width (13 bits -> 7 + 6: narrower digits mean fewer bins per block, i.e. longer
+// contiguous runs in the scatter's write-out).  Result ends in (kA,vA) if the pass count is even,
+// else in (kB,vB).
+int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
+int radix_sort(uint32_t* kA, uint32_t* vA, uint32_t* kB, uint32_t* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nblk = (uint32_t)rs_blocks(n);
+    const int passes = radix_passes(bits);
+    int shift = 0;
     for (int p = 0; p < passes; p++) {
-        radix_hist_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, n, 8 * p, hist, nblk);
+        const int w = (bits - shift + (passes - p) - 1) / (passes - p);   // remaining bits spread evenly
+        const uint32_t mask = (1u << w) - 1u;
+        radix_hist_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, n, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
         int rc = scan_u32(hist, nullptr, 256u * nblk, hist, false, scan_tmp, nullptr, s);
         if (rc != GSRAST_OK) return rc;
-        radix_scatter_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, 8 * p, hist, nblk);
+        radix_scatter_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
+        shift += w;
     }
     return GSRAST_OK;
 }
@@ -179,20 +187,59 @@ export_keys_kernel(uint32_t R, const uint32_t* __restrict__ tile_sorted, const u
     if (point_list) point_list[i] = g;
 }
 
-template <int MODE>
-void launch_blend_fwd(uint32_t grid, hipStream_t s, const uint2* ranges, const uint32_t* plist, int W, int H, int gx,
-                      uint32_t T, const float4* r0, const float4* r1, const float4* r2, const float* bg, float* oc,
-                      float* od, float* fT, uint32_t* nc, uint32_t* tm)
+std::atomic<int> g_ppl_fwd{0}, g_ppl_bwd{0};   // pixels per lane of the blend kernels: 0 = auto, else 1 / 2 / 4
+std::atomic<int> g_cull{1};                    // wave-level strip culling in the blend kernels (default on)
+
+int pick_ppl(uint32_t ntiles, bool backward)
 {
-    blend_fwd_kernel<MODE><<<grid, 256, 0, s>>>(ranges, plist, W, H, gx, T, r0, r1, r2, bg, oc, od, fT, nc, tm);
+    const int forced = backward ? g_ppl_bwd.load() : g_ppl_fwd.load();
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    // Measured on MI355X (profiles/): the forward is fastest with one pixel per lane (finest skip /
+    // early-exit granularity, most waves in flight); the backward amortises its wave reductions and
+    // atomics over 4 pixels per lane once there are enough tiles to fill 1024 SIMDs with one wave each.
+    if (!backward) return 1;
+    return ntiles >= 4096 ? 4 : (ntiles >= 1536 ? 2 : 1);   // re-tuned in profiles/ (bwd culling variants)
+}
+
+struct BlendArgs {
+    const uint2* ranges; const uint32_t* plist; int W, H, gx; uint32_t T; const float4 *r0, *r1, *r2; const float* bg;
+    float *oc, *od, *fT; uint32_t *nc, *tm;                       // forward outputs (fT / nc / tm: inputs of backward)
+    const float* dpix; float *dm2, *dcon, *dop, *dcol;            // backward
+};
+template <int MODE, int PPL>
+void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
+{
+    blend_fwd_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm);
+}
+template <int MODE, int PPL, int ABL>
+void launch_bwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
+{
+    blend_bwd_kernel<MODE, PPL, ABL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol);
 }
 template <int MODE>
-void launch_blend_bwd(uint32_t grid, hipStream_t s, const uint2* ranges, const uint32_t* plist, int W, int H, int gx,
-                      uint32_t T, const float4* r0, const float4* r1, const float4* r2, const float* bg,
-                      const float* fT, const uint32_t* nc, const uint32_t* tm, const float* dpix, float* dm2,
-                      float* dcon, float* dop, float* dcol)
+void dispatch_fwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_bwd_kernel<MODE><<<grid, 256, 0, s>>>(ranges, plist, W, H, gx, T, r0, r1, r2, bg, fT, nc, tm, dpix, dm2, dcon, dop, dcol);
+    if (ppl == 4) launch_fwd<MODE, 4>(grid, s, a); else if (ppl == 2) launch_fwd<MODE, 2>(grid, s, a); else launch_fwd<MODE, 1>(grid, s, a);
+}
+template <int MODE, int PPL>
+void launch_bwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
+{
+    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol);
+}
+template <int MODE>
+void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
+{
+    if (ppl == 4) launch_bwd_cull<MODE, 4>(grid, s, a); else if (ppl == 2) launch_bwd_cull<MODE, 2>(grid, s, a); else launch_bwd_cull<MODE, 1>(grid, s, a);
+}
+template <int MODE>
+void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
+{
+    blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm);
+}
+template <int MODE>
+void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
+{
+    if (ppl == 4) launch_bwd<MODE, 4, 0>(grid, s, a); else if (ppl == 2) launch_bwd<MODE, 2, 0>(grid, s, a); else launch_bwd<MODE, 1, 0>(grid, s, a);
 }
 
 } // namespace
@@ -208,6 +255,14 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "exp_mode")) { if (value < 0 || value > 2) return GSRAST_E_ARG; g_exp_mode = value; return 0; }
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
+    if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
+        if (name[0] != 'b') g_ppl_fwd = value;
+        if (name[0] != 'f') g_ppl_bwd = value;
+        return 0;
+    }
     return GSRAST_E_ARG;
 }
 int gsrast_get_option(const char* name)
@@ -216,6 +271,9 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "exp_mode")) return g_exp_mode.load();
     if (!strcmp(name, "profile")) return g_profile.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
+    if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_ppl_fwd.load();
+    if (!strcmp(name, "bwd_pixels_per_lane")) return g_ppl_bwd.load();
+    if (!strcmp(name, "cull")) return g_cull.load();
     return GSRAST_E_ARG;
 }
 
@@ -322,7 +380,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     }
     {
         ProfScope ps(K_SORT_DEPTH, s);
-        int rc = radix_sort(kA, vA, kB, vB, (uint32_t)P, 4, hist, scan_tmp, s);
+        int rc = radix_sort(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A
@@ -356,7 +414,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         }
         {
             ProfScope ps(K_SORT_TILE, s);
-            int rc = radix_sort(tkA, tvA, tkB, tvB, R, tpasses, bhist, bscan, s);
+            int rc = radix_sort(tkA, tvA, tkB, tvB, R, tile_bits(T), bhist, bscan, s);
             if (rc != GSRAST_OK) return rc;
         }
         const uint32_t* tk_sorted = (tpasses & 1) ? tkB : tkA;
@@ -372,10 +430,15 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         const uint32_t grid = ((T + 7) / 8) * 8;
         float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
         uint32_t* tm = at<uint32_t>(img, IL.tile_max);
+        BlendArgs ba{};
+        ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
+        ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
+        const int ppl = pick_ppl(T, false);
+        const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
         switch (g_exp_mode.load()) {
-        case 0: launch_blend_fwd<0>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, out_color, out_depth, fT, nc, tm); break;
-        case 1: launch_blend_fwd<1>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, out_color, out_depth, fT, nc, tm); break;
-        default: launch_blend_fwd<2>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, out_color, out_depth, fT, nc, tm); break;
+        case 0: if (cull) launch_fwd_cull<0>(grid, s, ba); else dispatch_fwd<0>(ppl, grid, s, ba); break;
+        case 1: if (cull) launch_fwd_cull<1>(grid, s, ba); else dispatch_fwd<1>(ppl, grid, s, ba); break;
+        default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
         }
         GS_LAUNCHED("blend_fwd");
     }
@@ -418,10 +481,19 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         const uint2* ranges = at<uint2>(img, IL.ranges);
         const float* fT = at<float>(img, IL.final_T); const uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
         const uint32_t* tm = at<uint32_t>(img, IL.tile_max);
+        BlendArgs ba{};
+        ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
+        ba.bg = background; ba.fT = const_cast<float*>(fT); ba.nc = const_cast<uint32_t*>(nc); ba.tm = const_cast<uint32_t*>(tm);
+        ba.dpix = dL_dpix; ba.dm2 = dL_dmean2D; ba.dcon = dL_dconic; ba.dop = dL_dopacity; ba.dcol = dL_dcolor;
+        const int ppl = pick_ppl(T, true);
+        const bool cull = g_cull.load() != 0;
+        if (g_ablate.load() == 1) launch_bwd<0, 4, 1>(grid, s, ba);
+        else if (g_ablate.load() == 2) launch_bwd<0, 4, 2>(grid, s, ba);
+        else
         switch (g_exp_mode.load()) {
-        case 0: launch_blend_bwd<0>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, fT, nc, tm, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor); break;
-        case 1: launch_blend_bwd<1>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, fT, nc, tm, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor); break;
-        default: launch_blend_bwd<2>(grid, s, ranges, plist, W, H, cam.gx, T, rec0, rec1, rec2, background, fT, nc, tm, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor); break;
+        case 0: if (cull) dispatch_bwd_cull<0>(ppl, grid, s, ba); else dispatch_bwd<0>(ppl, grid, s, ba); break;
+        case 1: if (cull) dispatch_bwd_cull<1>(ppl, grid, s, ba); else dispatch_bwd<1>(ppl, grid, s, ba); break;
+        default: if (cull) dispatch_bwd_cull<2>(ppl, grid, s, ba); else dispatch_bwd<2>(ppl, grid, s, ba); break;
         }
         GS_LAUNCHED("blend_bwd");
     }

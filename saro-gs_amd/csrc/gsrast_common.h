@@ -97,12 +97,16 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     L.total = o + 256;
     return L;
 }
-// number of 8-bit passes needed to sort tile ids < T
+// key bits / radix passes needed to sort tile ids < T
+static inline int tile_bits(size_t T)
+{
+    int bits = 1;
+    while (((size_t)1 << bits) < T) bits++;
+    return bits;
+}
 static inline int tile_passes(size_t T)
 {
-    int bits = 0;
-    while (((size_t)1 << bits) < T) bits++;
-    int p = (bits + 7) / 8;
+    int p = (tile_bits(T) + 7) / 8;
     return p ? p : 1;
 }
 

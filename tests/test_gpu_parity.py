@@ -244,3 +244,27 @@ def test_golden_fixture(rast, gpu):
             ref = z["f64_" + k]
             err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
             assert (err <= ATOL + RTOL * np.abs(ref)).all(), (f, k, err.max())
+
+
+@pytest.mark.parametrize("cull", [0, 1])
+@pytest.mark.parametrize("ppl", [0, 1, 2, 4])
+def test_pixels_per_lane_variants(ppl, cull, orc, scenes, rast, gpu):
+    """The blend kernels exist in three work decompositions (1 / 2 / 4 pixels per lane = 4 / 2 / 1 waves
+    per tile; 0 = picked from the tile count), each with and without wave-level strip culling; every
+    combination must meet the same bars (culling must not change a single bit of the forward)."""
+    P, W, H = 6000, 200, 150
+    sc = scenes.synth(P, 71, scale_mul=0.8)
+    sc["bg"] = np.array([0.2, 0.1, 0.4], np.float32)
+    cam = scenes.camera(2, 5, W, H)
+    g = scenes.upstream_grad(H, W, 72)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    rast._C.set_option("pixels_per_lane", ppl)
+    rast._C.set_option("cull", cull)
+    try:
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    finally:
+        rast._C.set_option("pixels_per_lane", 0)
+        rast._C.set_option("cull", 1)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], strict=True)
