@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--ppl-fwd", type=int, default=0)
     ap.add_argument("--ppl-bwd", type=int, default=0)
     ap.add_argument("--no-cull", action="store_true", help="disable wave-level strip culling (A/B experiments)")
+    ap.add_argument("--no-lpt", action="store_true", help="disable heaviest-tile-first launch order (A/B experiments)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     return ap.parse_args()
 
@@ -178,6 +179,8 @@ def main():
         _C.set_option("bwd_pixels_per_lane", a.ppl_bwd)
     if a.no_cull:
         _C.set_option("cull", 0)
+    if a.no_lpt:
+        _C.set_option("lpt", 0)
 
     P, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)
@@ -229,7 +232,7 @@ def main():
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "R_eff": st["R_eff"], "visible": st["P_vis"],
                        "blended_pairs_fwd": st["pairs_fwd"]},
-            "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+            "roofline": {"kernel": "blend_bwd_cull_kernel", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "algorithmic_bytes_per_launch": bwd_bytes,
                          "avg_launch_ms": round(bwd_ms, 4),

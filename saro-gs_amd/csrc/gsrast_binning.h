@@ -111,6 +111,9 @@ scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__
 // A block owns RS_CHUNK consecutive elements; wave w owns a contiguous quarter, visited in
 // rounds of 64 (coalesced).  Ranks inside a round come from a ballot match, so equal digits keep
 // their input order (stability) and LDS counters see no conflicts.
+// Histogram: order does not matter here, so plain LDS atomics (per-wave private counters keep
+// contention inside a wave; a uniform digit costs at most 64 LDS cycles per round, still far below
+// the HBM time of the keys).
 __global__ void __launch_bounds__(RS_THREADS)
 radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t* __restrict__ block_hist, uint32_t nblk)
 {
@@ -118,15 +121,17 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     __syncthreads();
-    volatile uint32_t* wc = cnt[wave];
     const uint32_t wbase = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
-#pragma unroll 4
+    uint32_t key[RS_ITEMS];
+#pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
-        const bool valid = i < n;
-        const uint32_t d = valid ? ((keys[i] >> shift) & mask) : 0u;
-        const uint64_t m = wave_match8(d, valid);
-        if (valid && (m & lanemask_lt()) == 0) wc[d] = wc[d] + (uint32_t)__popcll(m);
+        key[r] = i < n ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < n) atomicAdd(&cnt[wave][(key[r] >> shift) & mask], 1u);
     }
     __syncthreads();
     const uint32_t t = threadIdx.x;
@@ -264,6 +269,44 @@ tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ tile_keys_sorted, ui
         if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
     }
     if (i == R - 1) ranges[cur].y = R;
+}
+
+// Launch order of the blend kernels: tiles sorted by descending work (bucketed counting sort,
+// one workgroup).  work(tile) = ranges[tile].y - ranges[tile].x for the forward, tile_max[tile] for the
+// backward.  A tile is processed by one wave(-group) from start to end, so without this the heaviest
+// tiles, wherever they fall in the grid, set the kernel's tail.
+constexpr int ORDER_BUCKETS = 64;
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(uint32_t T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max,
+                  uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t cnt[ORDER_BUCKETS];
+    __shared__ uint32_t start[ORDER_BUCKETS];
+    __shared__ uint32_t wmax;
+    if (threadIdx.x < ORDER_BUCKETS) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) wmax = 1;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+        const uint32_t w = tile_max ? tile_max[t] : (ranges[t].y - ranges[t].x);
+        m = w > m ? w : m;
+    }
+    atomicMax(&wmax, m);
+    __syncthreads();
+    const float scale = (float)(ORDER_BUCKETS - 1) / (float)wmax;
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+        const uint32_t w = tile_max ? tile_max[t] : (ranges[t].y - ranges[t].x);
+        const int b = ORDER_BUCKETS - 1 - (int)((float)w * scale);     // bucket 0 = heaviest
+        atomicAdd(&cnt[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t a = 0; for (int b = 0; b < ORDER_BUCKETS; b++) { start[b] = a; a += cnt[b]; } }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+        const uint32_t w = tile_max ? tile_max[t] : (ranges[t].y - ranges[t].x);
+        const int b = ORDER_BUCKETS - 1 - (int)((float)w * scale);
+        order[atomicAdd(&start[b], 1u)] = t;
+    }
 }
 
 } // namespace gsrast

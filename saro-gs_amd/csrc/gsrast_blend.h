@@ -59,7 +59,8 @@ __device__ __forceinline__ bool strip_may_touch(const float4 a, const float cz, 
 // Forward blend, 4 wave64 per tile, one pixel per lane, with wave-level culling (see above).
 template <int EXPMODE>
 __global__ void __launch_bounds__(256)
-blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const uint32_t* __restrict__ order, int W, int H,
                       int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                       const float4* __restrict__ rec2, const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
@@ -70,8 +71,8 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ float4 s2[256];
     __shared__ uint32_t s_max;
 
-    const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;   // heaviest tiles first
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
     const unsigned lane = lane_id(), wave = t >> 6;
@@ -484,7 +485,8 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
 // untouched strips.
 template <int EXPMODE, int PPL>
 __global__ void __launch_bounds__(256 / PPL)
-blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const uint32_t* __restrict__ order, int W, int H,
                       int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                       const float4* __restrict__ rec2, const float* __restrict__ bg,
                       const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -501,8 +503,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ uint32_t sid[BATCH];
     __shared__ float acc[9][BATCH];
 
-    const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;   // heaviest tiles first
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
     const unsigned lane = lane_id(), wave = t >> 6;

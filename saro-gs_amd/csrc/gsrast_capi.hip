@@ -188,7 +188,7 @@ export_keys_kernel(uint32_t R, const uint32_t* __restrict__ tile_sorted, const u
 }
 
 std::atomic<int> g_ppl_fwd{0}, g_ppl_bwd{0};   // pixels per lane of the blend kernels: 0 = auto, else 1 / 2 / 4
-std::atomic<int> g_cull{1};                    // wave-level strip culling in the blend kernels (default on)
+std::atomic<int> g_cull{1}, g_lpt{1};                    // wave-level strip culling in the blend kernels (default on)
 
 int pick_ppl(uint32_t ntiles, bool backward)
 {
@@ -202,7 +202,7 @@ int pick_ppl(uint32_t ntiles, bool backward)
 }
 
 struct BlendArgs {
-    const uint2* ranges; const uint32_t* plist; int W, H, gx; uint32_t T; const float4 *r0, *r1, *r2; const float* bg;
+    const uint2* ranges; const uint32_t* plist; const uint32_t* order; int W, H, gx; uint32_t T; const float4 *r0, *r1, *r2; const float* bg;
     float *oc, *od, *fT; uint32_t *nc, *tm;                       // forward outputs (fT / nc / tm: inputs of backward)
     const float* dpix; float *dm2, *dcon, *dop, *dcol;            // backward
 };
@@ -224,7 +224,7 @@ void dispatch_fwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
 template <int MODE, int PPL>
 void launch_bwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol);
+    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol);
 }
 template <int MODE>
 void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -234,7 +234,7 @@ void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a
 template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm);
+    blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -257,6 +257,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
         if (name[0] != 'b') g_ppl_fwd = value;
@@ -435,6 +436,12 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
         const int ppl = pick_ppl(T, false);
         const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
+        if (cull && g_lpt.load()) {
+            uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
+            tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, nullptr, ord);
+            GS_LAUNCHED("tile_order");
+            ba.order = ord;
+        }
         switch (g_exp_mode.load()) {
         case 0: if (cull) launch_fwd_cull<0>(grid, s, ba); else dispatch_fwd<0>(ppl, grid, s, ba); break;
         case 1: if (cull) launch_fwd_cull<1>(grid, s, ba); else dispatch_fwd<1>(ppl, grid, s, ba); break;
@@ -487,6 +494,12 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         ba.dpix = dL_dpix; ba.dm2 = dL_dmean2D; ba.dcon = dL_dconic; ba.dop = dL_dopacity; ba.dcol = dL_dcolor;
         const int ppl = pick_ppl(T, true);
         const bool cull = g_cull.load() != 0;
+        if (cull && g_lpt.load()) {
+            uint32_t* ord = at<uint32_t>(img, IL.order_bwd);
+            tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, tm, ord);
+            GS_LAUNCHED("tile_order");
+            ba.order = ord;
+        }
         if (g_ablate.load() == 1) launch_bwd<0, 4, 1>(grid, s, ba);
         else if (g_ablate.load() == 2) launch_bwd<0, 4, 2>(grid, s, ba);
         else

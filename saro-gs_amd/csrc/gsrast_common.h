@@ -39,8 +39,10 @@ struct BinLayout {
 // Image (per pixel / per tile), replaces ImageState (rasterizer_impl.h:47-54):
 //   final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_max u32[T] (deepest list position any
 //   pixel of the tile consumed -- bounds the backward traversal)
+//   order_fwd / order_bwd u32[T]: tiles sorted by descending work (longest-processing-time-first
+//   launch order for the blend kernels; a tile is one indivisible unit of work per wave(-group))
 struct ImgLayout {
-    size_t final_T, n_contrib, ranges, tile_max, total;
+    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, total;
 };
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
@@ -94,6 +96,7 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     size_t T = ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     if (!T) T = 1;
     L.final_T = take(N * 4); L.n_contrib = take(N * 4); L.ranges = take(T * 8); L.tile_max = take(T * 4);
+    L.order_fwd = take(T * 4); L.order_bwd = take(T * 4);
     L.total = o + 256;
     return L;
 }
