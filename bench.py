@@ -161,7 +161,9 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
-    dev = torch.device("cuda", local if world > 1 else 0)
+    # GSRAST_SINGLE_DEVICE=1: every rank on cuda:0 (only to exercise the N>1 path on a 1-GPU box, with gloo)
+    single = os.environ.get("GSRAST_SINGLE_DEVICE") == "1"
+    dev = torch.device("cuda", local if (world > 1 and not single) else 0)
     torch.cuda.set_device(dev)
     import diff_gaussian_rasterization_ch3 as rast
     import scenes

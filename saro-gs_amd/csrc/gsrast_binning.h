@@ -212,47 +212,50 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 // ------------------------------------------------------------------------------------------
 // Instance emission (reference duplicateWithKeys, rasterizer_impl.cu:70-111), in depth order.
 // order[j] = Gaussian at depth rank j; offsets = inclusive scan of tiles[order[.]].
-// Gaussians covering many tiles are expanded by the whole wave, small ones by their own lane.
-constexpr int EMIT_COOP_MIN = 48;
-
+// The 64 Gaussians of a wave own one contiguous output range; the wave walks that range 64 slots
+// at a time and every lane finds the Gaussian its slot belongs to (6-step binary search over the
+// wave's 64 segment starts in LDS), so the two output streams are written fully coalesced and a
+// Gaussian covering thousands of tiles costs the same per instance as one covering two.
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect, int gx,
                       uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ inst_vals)
 {
+    __shared__ uint32_t s_e[4][64], s_g[4][64], s_xy[4][64], s_w[4][64];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t g = 0, cnt = 0, off = 0, x0 = 0, y0 = 0, w = 1;
+    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t g = 0, cnt = 0, incl, xy = 0, w = 1;
     if (j < P) {
         g = order[j];
         cnt = tiles[g];
+        incl = offsets[j];
         if (cnt) {
-            off = j == 0 ? 0u : offsets[j - 1];
             const uint2 rc = rect[g];
-            x0 = rc.x & 0xFFFFu; y0 = rc.x >> 16;
-            w = (rc.y & 0xFFFFu) - x0;
+            xy = rc.x;                                  // x0 | y0 << 16
+            w = (rc.y & 0xFFFFu) - (rc.x & 0xFFFFu);
         }
+    } else {
+        incl = P > 0 ? offsets[P - 1] : 0u;
     }
-    // wave-cooperative expansion of the big ones
-    uint64_t big = __ballot(cnt >= (uint32_t)EMIT_COOP_MIN);
-    const unsigned lane = lane_id();
-    while (big) {
-        const int src = __builtin_ctzll(big);
-        big &= big - 1;
-        const uint32_t bg = __shfl(g, src, 64), bc = __shfl(cnt, src, 64), bo = __shfl(off, src, 64);
-        const uint32_t bx = __shfl(x0, src, 64), by = __shfl(y0, src, 64), bw = __shfl(w, src, 64);
-        for (uint32_t k = lane; k < bc; k += 64) {
-            const uint32_t yy = k / bw, xx = k - yy * bw;
-            tile_keys[bo + k] = (by + yy) * (uint32_t)gx + bx + xx;
-            inst_vals[bo + k] = bg;
-        }
-    }
-    if (cnt && cnt < (uint32_t)EMIT_COOP_MIN) {
-        uint32_t xx = 0, yy = 0;
-        for (uint32_t k = 0; k < cnt; k++) {
-            tile_keys[off + k] = (y0 + yy) * (uint32_t)gx + x0 + xx;
-            inst_vals[off + k] = g;
-            if (++xx == w) { xx = 0; yy++; }
-        }
+    const uint32_t e = incl - cnt;                      // exclusive start of this Gaussian's segment
+    const uint32_t wstart = __shfl(e, 0, 64);
+    const uint32_t wend = __shfl(incl, 63, 64);
+    s_e[wave][lane] = e - wstart; s_g[wave][lane] = g; s_xy[wave][lane] = xy; s_w[wave][lane] = w;
+    __syncthreads();
+    const uint32_t C = wend - wstart;
+    for (uint32_t o = lane; o < C; o += 64) {
+        uint32_t sidx = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (s_e[wave][sidx + step] <= o) sidx += step;   // largest s with start[s] <= o (sidx + step <= 63)
+        const uint32_t k = o - s_e[wave][sidx];
+        const uint32_t ww = s_w[wave][sidx], pxy = s_xy[wave][sidx];
+        uint32_t yy = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)ww));
+        if (yy * ww > k) yy--;
+        if ((yy + 1) * ww <= k) yy++;
+        const uint32_t xx = k - yy * ww;
+        tile_keys[wstart + o] = ((pxy >> 16) + yy) * (uint32_t)gx + (pxy & 0xFFFFu) + xx;
+        inst_vals[wstart + o] = s_g[wave][sidx];
     }
 }
 

@@ -373,7 +373,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
 
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
-        preprocess_fwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+        preprocess_fwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
             colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
             at<unsigned char>(geom, GL.clamped), tiles, rect, kA, vA);
@@ -513,7 +513,7 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
     {
         ProfScope ps(K_PREPROCESS_BWD, s);
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
-        preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+        preprocess_bwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, radii, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
             use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, dL_dmean2D, dL_dconic, dL_dcolor,
             dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);

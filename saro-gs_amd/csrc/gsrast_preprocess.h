@@ -167,9 +167,61 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float pos[3], const flo
     }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// SH coefficients are [P][M][3] AoS: one lane's block is M*12 bytes at a stride of M*12 bytes, the
+// worst case for per-lane loads.  The workgroup therefore moves its PP_THREADS consecutive blocks
+// with coalesced 16-byte loads into LDS (row stride M*3+1 floats: conflict-free for the per-lane
+// reads that follow), and the backward writes dL/dsh back the same way.
+constexpr int PP_THREADS = 128;
+constexpr int PP_SH_MAX = 48;                   // (3+1)^2 coefficients x 3 channels
+constexpr int PP_SH_STRIDE = PP_SH_MAX + 1;
+
+__device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int P, int M, int base, float* lds)
+{
+    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
+    const int row = M * 3;
+    const int nfl = ng * row;
+    const float* src = shs + (size_t)base * row;
+    if ((row & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int q = threadIdx.x; q * 4 < nfl; q += PP_THREADS) {
+            const float4 v = src4[q];
+            const int f = q * 4, g = f / row, c = f - g * row;
+            float* d = lds + g * PP_SH_STRIDE + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int f = threadIdx.x; f < nfl; f += PP_THREADS) {
+            const int g = f / row, c = f - g * row;
+            lds[g * PP_SH_STRIDE + c] = src[f];
+        }
+    }
+}
+__device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P, int M, int base, const float* lds)
+{
+    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
+    const int row = M * 3;
+    const int nfl = ng * row;
+    float* dst = dst_all + (size_t)base * row;
+    if ((row & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+        for (int q = threadIdx.x; q * 4 < nfl; q += PP_THREADS) {
+            const int f = q * 4, g = f / row, c = f - g * row;
+            const float* sp = lds + g * PP_SH_STRIDE + c;
+            dst4[q] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    } else {
+        for (int f = threadIdx.x; f < nfl; f += PP_THREADS) {
+            const int g = f / row, c = f - g * row;
+            dst[f] = lds[g * PP_SH_STRIDE + c];
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // K1 forward.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PP_THREADS)
 preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
@@ -179,8 +231,12 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, uint32_t* __restrict__ sort_key,
                       uint32_t* __restrict__ sort_val)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
+    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+    const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
+    if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
     if (i >= P) return;
+    const float* my_sh = staged ? sh_lds + threadIdx.x * PP_SH_STRIDE : shs + (size_t)i * M * 3;
     const Cam cam = load_cam(cam_args);
     int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
 
@@ -224,7 +280,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 float col[3];
                 unsigned cl = 0;
                 if (!colors_precomp) {
-                    sh_to_rgb(D, p, cam.campos, shs + (size_t)i * M * 3, col);
+                    sh_to_rgb(D, p, cam.campos, my_sh, col);
 #pragma unroll
                     for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
                 } else {
@@ -331,8 +387,8 @@ __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const f
 }
 
 // K6 + K7 fused.  Every output row is written exactly once (zeros for culled Gaussians), so the
-// caller does not have to zero-fill the five output arrays.
-__global__ void __launch_bounds__(256)
+// caller does not have to zero-fill the five output arrays.  dL/dsh leaves through LDS (coalesced).
+__global__ void __launch_bounds__(PP_THREADS)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
                       const float* __restrict__ shs, const unsigned char* __restrict__ clamped,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -342,23 +398,30 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drot)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
+    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
     const int ncoef = (D + 1) * (D + 1);
+    const bool staged = shs && M * 3 <= PP_SH_MAX;
+    float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
+    if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
     const Cam cam = load_cam(cam_args);
-    if (!(radii[i] > 0)) {
+    const bool live = i < P && radii[i] > 0;
+    if (i < P && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
-        if (shs) for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.0f;
+        if (shs) {
+            if (staged) { for (int k = 0; k < M * 3; k++) my_lds[k] = 0.0f; }
+            else { for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.0f; }
+        }
         if (scales) {
 #pragma unroll
             for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)i + k] = 0.0f;
             reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        return;
     }
+    if (live) {
     const float mean[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
     float c6[6];
 #pragma unroll
@@ -423,9 +486,18 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
     if (shs) {
         const float dcol[3] = { dL_dcolor[3 * (size_t)i], dL_dcolor[3 * (size_t)i + 1], dL_dcolor[3 * (size_t)i + 2] };
-        float* dsh = dL_dsh + (size_t)i * M * 3;
-        sh_backward(D, mean, cam.campos, shs + (size_t)i * M * 3, clamped[i], dcol, dmean, dsh);
-        for (int k = ncoef * 3; k < M * 3; k++) dsh[k] = 0.0f;
+        if (staged) {
+            // the lane's coefficients move LDS -> registers first: its LDS row is then reused for dL/dsh
+            float shv[PP_SH_MAX];
+#pragma unroll
+            for (int k = 0; k < PP_SH_MAX; k++) shv[k] = k < ncoef * 3 ? my_lds[k] : 0.0f;
+            sh_backward(D, mean, cam.campos, shv, clamped[i], dcol, dmean, my_lds);
+            for (int k = ncoef * 3; k < M * 3; k++) my_lds[k] = 0.0f;
+        } else {
+            float* dsh = dL_dsh + (size_t)i * M * 3;
+            sh_backward(D, mean, cam.campos, shs + (size_t)i * M * 3, clamped[i], dcol, dmean, dsh);
+            for (int k = ncoef * 3; k < M * 3; k++) dsh[k] = 0.0f;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = dmean[k];
@@ -466,6 +538,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #undef D_
         reinterpret_cast<float4*>(dL_drot)[i] = dq;
     }
+    } // live
+    if (staged) { __syncthreads(); stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds); }
 }
 
 } // namespace gsrast

@@ -29,7 +29,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GSRAST_DIST_BACKEND=gloo lets a 1-GPU box exercise the multi-rank code path (tests only)
+            backend = os.environ.get("GSRAST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local)
