@@ -76,6 +76,8 @@ class Workload:
         self.g = t(scenes.upstream_grad(H, W, 1))
         self.raster = rast.GaussianRasterizer(self.rs)
         self.dev = dev
+        import view_parallel
+        self.vp = view_parallel
 
     def step(self, bucket=None, world=1):
         L = self.leaves
@@ -85,9 +87,8 @@ class Workload:
                                           shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)
         if bucket is not None and world > 1:
-            bucket.pack()
-            bucket.allreduce_mean(world)
-            bucket.unpack()
+            # the backward wrote the leaf gradients straight into bucket.flat (zero-copy GradArena)
+            self.vp.allreduce_mean_inplace(bucket.flat, world)
         return radii
 
     def stats(self):
@@ -188,9 +189,10 @@ def main():
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)
     bucket = None
     if world > 1:
-        L = wl.leaves
-        bucket = vp.FlatGradBucket([L["means3D"], L["shs"], L["opacities"], L["scales"], L["rotations"], wl.means2D])
-        wl.step(None, 1)  # materialise .grad so the bucket has shapes
+        # one flat fp32 buffer holds every leaf gradient of the rasterizer (62 floats / Gaussian); the
+        # backward writes into it directly and the step ends with ONE in-place all-reduce (mean)
+        bucket = _C.GradArena(P, 16, dev)
+        _C.set_grad_arena(bucket)
 
     names = [_C.lib().gsrast_profile_kernel_name(k).decode() for k in range(_C.lib().gsrast_profile_kernel_count())]
     kid = {n: i for i, n in enumerate(names)}

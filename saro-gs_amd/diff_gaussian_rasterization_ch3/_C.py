@@ -111,6 +111,42 @@ def _require_gpu(t: torch.Tensor) -> torch.device:
     return t.device
 
 
+class GradArena:
+    """Optional zero-copy gradient bucket for the multi-GPU path (view_parallel.py).
+
+    When installed with ``set_grad_arena``, ``rasterize_gaussians_backward`` carves the leaf
+    gradients it returns (means3D, sh, opacities, scales, rotations, means2D) out of ONE flat fp32
+    buffer, in that order, so the cross-rank exchange is a single in-place all-reduce of ``flat`` with
+    no pack / unpack copies (the same idea as DDP's gradient-as-bucket-view).  Not part of the
+    reference's _C: without an arena the outputs are ordinary tensors, exactly as before."""
+
+    ORDER = (("means3D", 3), ("sh", None), ("opacity", 1), ("scales", 3), ("rotations", 4), ("means2D", 3))
+
+    def __init__(self, P: int, M: int, device: torch.device):
+        self.P, self.M = P, M
+        self.widths = {name: (M * 3 if w is None else w) for name, w in self.ORDER}
+        self.offsets, o = {}, 0
+        for name, _ in self.ORDER:
+            self.offsets[name] = o
+            o += P * self.widths[name]
+        self.flat = torch.zeros(o, dtype=torch.float32, device=device)
+
+    def take(self, name: str, shape, zero: bool) -> torch.Tensor:
+        n = self.P * self.widths[name]
+        v = self.flat[self.offsets[name]: self.offsets[name] + n].view(shape)   # a fresh view every call
+        if zero:
+            v.zero_()
+        return v
+
+
+_grad_arena: Optional[GradArena] = None
+
+
+def set_grad_arena(arena: Optional[GradArena]) -> None:
+    global _grad_arena
+    _grad_arena = arena
+
+
 class _Arena:
     """The three resizable state buffers of the reference (rasterize_points.cu:27-33, :71-78):
     each allocation callback creates one uint8 tensor that is later saved for backward."""
@@ -189,17 +225,26 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     opts = dict(dtype=torch.float32, device=dev)
     # accumulated with atomics -> zero-filled (44 B/Gaussian); everything else is written exactly
     # once by the fused per-Gaussian backward kernel, so no 300 B/Gaussian memset as in the reference
-    dL_dmeans2D = torch.zeros((P, 3), **opts)
-    dL_dconic = torch.zeros((P, 2, 2), **opts)
-    dL_dopacity = torch.zeros((P, 1), **opts)
-    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **opts)
     use_sh = sh.numel() != 0 and colors.numel() == 0
     use_sr = cov3D_precomp.numel() == 0
-    dL_dmeans3D = torch.empty((P, 3), **opts)
+    ar = _grad_arena
+    if ar is not None and not (ar.P == P and ar.M == M and use_sh and use_sr and ar.flat.device == dev):
+        ar = None                       # the arena only serves the SH + scale/rotation training path
+
+    def out(name, shape, zero):
+        if ar is not None and name in ar.offsets:
+            return ar.take(name, shape, zero)
+        return torch.zeros(shape, **opts) if zero else torch.empty(shape, **opts)
+
+    dL_dmeans2D = out("means2D", (P, 3), True)
+    dL_dconic = torch.zeros((P, 2, 2), **opts)
+    dL_dopacity = out("opacity", (P, 1), True)
+    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **opts)
+    dL_dmeans3D = out("means3D", (P, 3), False)
     dL_dcov3D = torch.empty((P, 6), **opts)
-    dL_dsh = torch.empty((P, M, 3), **opts) if use_sh else torch.zeros((P, M, 3), **opts)
-    dL_dscales = torch.empty((P, 3), **opts) if use_sr else torch.zeros((P, 3), **opts)
-    dL_drotations = torch.empty((P, 4), **opts) if use_sr else torch.zeros((P, 4), **opts)
+    dL_dsh = out("sh", (P, M, 3), not use_sh)
+    dL_dscales = out("scales", (P, 3), not use_sr)
+    dL_drotations = out("rotations", (P, 4), not use_sr)
     if P != 0:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream

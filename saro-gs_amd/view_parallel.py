@@ -87,6 +87,20 @@ class FlatGradBucket:
                 p.grad.copy_(v)
 
 
+def allreduce_mean_inplace(flat: torch.Tensor, batch: int) -> None:
+    """Mean over the batch of one flat gradient buffer, in place.  RCCL's AVG does the division inside
+    the collective (no extra pass over the buffer); gloo has no AVG, so SUM then scale."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if batch != 1:
+            flat.mul_(1.0 / batch)
+        return
+    if dist.get_backend() == "nccl" and batch == dist.get_world_size():
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / batch)
+
+
 def reduce_densification_stats(point_grad_norm: torch.Tensor, visible_count: torch.Tensor,
                                max_radii: torch.Tensor) -> None:
     """In-place cross-rank reduction of the densification statistics of train.py:282-292:

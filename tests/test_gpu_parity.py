@@ -268,3 +268,43 @@ def test_pixels_per_lane_variants(ppl, cull, orc, scenes, rast, gpu):
         rast._C.set_option("cull", 1)
     _check_forward_exact(o32, h)
     _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], strict=True)
+
+
+def test_grad_arena_zero_copy_bucket(scenes, rast, gpu):
+    """Multi-GPU path: with a GradArena installed the backward writes the leaf gradients straight into
+    one flat buffer (what view_parallel all-reduces in place).  Same numbers, and .grad aliases it."""
+    import torch
+    from conftest import settings_from
+    P, W, H = 3000, 128, 96
+    sc = scenes.synth(P, 81)
+    cam = scenes.camera(1, 4, W, H)
+    g = torch.as_tensor(scenes.upstream_grad(H, W, 82), device=gpu)
+    rs = settings_from(rast, cam, sc, gpu)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+
+    def run():
+        leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        color, _, _ = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                  shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        color.backward(g)
+        leaves["means2D"] = m2
+        return leaves
+
+    plain = run()
+    arena = rast._C.GradArena(P, 16, gpu)
+    rast._C.set_grad_arena(arena)
+    try:
+        bucketed = run()
+    finally:
+        rast._C.set_grad_arena(None)
+    assert arena.flat.numel() == P * 62
+    lo, hi = arena.flat.data_ptr(), arena.flat.data_ptr() + arena.flat.numel() * 4
+    for k in plain:
+        a, b = plain[k].grad, bucketed[k].grad
+        assert lo <= b.data_ptr() < hi, f"{k}.grad does not alias the arena (a copy was made)"
+        tol = 1e-5 + 1e-4 * a.abs()
+        assert ((a - b).abs() <= tol).all(), k      # two runs differ only by float-atomic ordering
+    # the arena really is the concatenation of the gradients
+    off = arena.offsets["sh"]
+    assert torch.equal(arena.flat[off: off + P * 48].view(P, 16, 3), bucketed["shs"].grad)

@@ -55,6 +55,10 @@ def _worker(rank, world, port, out_dir):
     radii = torch.from_numpy(o["radii"].astype(np.float32))
     vp.reduce_densification_stats(grad_norm, vis, radii)
     assert abs(vp.max_over_ranks(float(rank), torch.device("cpu")) - (world - 1)) < 1e-12
+    # the zero-copy path of bench.py: one in-place mean over a flat buffer
+    flat = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    vp.allreduce_mean_inplace(flat, world)
+    assert torch.allclose(flat, torch.arange(8, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
     vp.barrier()
     if rank == 0:
         np.savez(os.path.join(out_dir, "dist.npz"), grad_norm=grad_norm.numpy(), vis=vis.numpy(), radii=radii.numpy(),
