@@ -138,10 +138,34 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint
     block_hist[(size_t)t * nblk + blockIdx.x] = cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];
 }
 
+// One workgroup per digit: in-place exclusive scan of that digit's row of block counts, row total
+// out.  The scatter kernel adds the exclusive prefix over digit totals itself, so a radix pass is
+// three launches (histogram, row scan, scatter) instead of five.
+__global__ void __launch_bounds__(256)
+radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t* __restrict__ digit_total)
+{
+    uint32_t* row = block_hist + (size_t)blockIdx.x * nblk;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nblk; c0 += 256 * 8) {
+        const uint32_t base = c0 + threadIdx.x * 8;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = (base + k < nblk) ? row[base + k] : 0u; sum += v[k]; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(sum, &tot) + carry;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (base + k < nblk) row[base + k] = ex; ex += v[k]; }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
-                     const uint32_t* __restrict__ hist_scanned, uint32_t nblk)
+                     const uint32_t* __restrict__ hist_scanned /* per-digit exclusive row scans */,
+                     const uint32_t* __restrict__ digit_total, uint32_t nblk)
 {
     // Ranks -> block-local order in LDS -> coalesced write-out: after the exchange consecutive lanes
     // hold consecutive elements of the same digit, whose global destinations are consecutive too.
@@ -178,10 +202,11 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     {
         const uint32_t t = threadIdx.x;
         const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
-        uint32_t tot;
+        uint32_t tot, gtot;
         const uint32_t start = block_excl_scan(c0 + c1 + c2 + c3, &tot);
+        const uint32_t dbase = block_excl_scan(digit_total[t], &gtot);   // elements with a smaller digit, globally
         dstart[t] = start;
-        gbase[t] = hist_scanned[(size_t)t * nblk + blockIdx.x];
+        gbase[t] = dbase + hist_scanned[(size_t)t * nblk + blockIdx.x];
         cnt[0][t] = start; cnt[1][t] = start + c0; cnt[2][t] = start + c0 + c1; cnt[3][t] = start + c0 + c1 + c2;
     }
     __syncthreads();

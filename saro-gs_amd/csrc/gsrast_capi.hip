@@ -124,9 +124,9 @@ int radix_sort(uint32_t* kA, uint32_t* vA, uint32_t* kB, uint32_t* vB, uint32_t 
         const uint32_t mask = (1u << w) - 1u;
         radix_hist_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, n, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
-        int rc = scan_u32(hist, nullptr, 256u * nblk, hist, false, scan_tmp, nullptr, s);
-        if (rc != GSRAST_OK) return rc;
-        radix_scatter_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, nblk);
+        radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
+        GS_LAUNCHED("radix_rowscan");
+        radix_scatter_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
         shift += w;

@@ -160,15 +160,19 @@ __device__ __forceinline__ float dpp_add(float v)
     int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
     return v + __int_as_float(t);
 }
-// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.  Six fused v_add_f32_dpp.
+// The two broadcast steps run UNMASKED (row_mask 0xf): row r then adds row r-1's lane 15 (rows 1-3),
+// and rows 2-3 add lane 31 = r0+r1, so lane 63 = (r2+r3) + (r0+r1); the other lanes hold partial
+// sums nobody reads.  Unmasked, hipcc folds each step into one v_add_f32_dpp; with the textbook row
+// masks it emits v_mov 0 + v_mov_dpp + v_add (3 instructions) per step.
 __device__ __forceinline__ float wave_sum_to_lane63(float v)
 {
     v = dpp_add<0x111>(v);              // row_shr:1
     v = dpp_add<0x112>(v);              // row_shr:2
     v = dpp_add<0x114>(v);              // row_shr:4
     v = dpp_add<0x118>(v);              // row_shr:8   -> lane 15 of each row holds the row sum
-    v = dpp_add<0x142, 0xa>(v);         // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xc>(v);         // row_bcast:31 into rows 2,3 -> lane 63 = total
+    v = dpp_add<0x142>(v);              // row_bcast:15 -> lane 31 = r0+r1, lane 63 = r2+r3
+    v = dpp_add<0x143>(v);              // row_bcast:31 -> lane 63 = total
     return v;
 }
 
