@@ -114,8 +114,9 @@ scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__
 // Histogram: order does not matter here, so plain LDS atomics (per-wave private counters keep
 // contention inside a wave; a uniform digit costs at most 64 LDS cycles per round, still far below
 // the HBM time of the keys).
+template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t* __restrict__ block_hist, uint32_t nblk)
+radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t* __restrict__ block_hist, uint32_t nblk)
 {
     __shared__ uint32_t cnt[4][256];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
@@ -161,9 +162,10 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
+radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                     KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
                      const uint32_t* __restrict__ hist_scanned /* per-digit exclusive row scans */,
                      const uint32_t* __restrict__ digit_total, uint32_t nblk)
 {
@@ -172,7 +174,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t dstart[256];       // first block-local slot of each digit
     __shared__ uint32_t gbase[256];        // global destination of that slot
-    __shared__ uint32_t xk[RS_CHUNK];
+    __shared__ KeyT xk[RS_CHUNK];
     __shared__ uint32_t xv[RS_CHUNK];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
@@ -184,7 +186,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        key[r] = valid ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
         val[r] = valid ? vals_in[i] : 0u;
     }
 #pragma unroll
@@ -216,7 +218,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
         if (i < n) {
             const uint32_t d = (key[r] >> shift) & mask;
             const uint32_t slot = cnt[wave][d] + rk[r];
-            xk[slot] = key[r]; xv[slot] = val[r];
+            xk[slot] = (KeyT)key[r]; xv[slot] = val[r];
         }
     }
     __syncthreads();
@@ -225,10 +227,11 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t slot = r * RS_THREADS + threadIdx.x;
         if (slot < nvalid) {
-            const uint32_t k = xk[slot];
+            const KeyT kk = xk[slot];
+            const uint32_t k = (uint32_t)kk;
             const uint32_t d = (k >> shift) & mask;
             const uint32_t pos = gbase[d] + (slot - dstart[d]);
-            keys_out[pos] = k;
+            keys_out[pos] = kk;
             vals_out[pos] = xv[slot];
         }
     }
@@ -241,10 +244,11 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 // at a time and every lane finds the Gaussian its slot belongs to (6-step binary search over the
 // wave's 64 segment starts in LDS), so the two output streams are written fully coalesced and a
 // Gaussian covering thousands of tiles costs the same per instance as one covering two.
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect, int gx,
-                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ inst_vals)
+                      KeyT* __restrict__ tile_keys, uint32_t* __restrict__ inst_vals)
 {
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_xy[4][64], s_w[4][64];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,14 +283,15 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
         if (yy * ww > k) yy--;
         if ((yy + 1) * ww <= k) yy++;
         const uint32_t xx = k - yy * ww;
-        tile_keys[wstart + o] = ((pxy >> 16) + yy) * (uint32_t)gx + (pxy & 0xFFFFu) + xx;
+        tile_keys[wstart + o] = (KeyT)(((pxy >> 16) + yy) * (uint32_t)gx + (pxy & 0xFFFFu) + xx);
         inst_vals[wstart + o] = s_g[wave][sidx];
     }
 }
 
-// Tile ranges (reference identifyTileRanges, rasterizer_impl.cu:116-138) on 32-bit tile ids.
+// Tile ranges (reference identifyTileRanges, rasterizer_impl.cu:116-138) on 16- or 32-bit tile ids.
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ tile_keys_sorted, uint2* __restrict__ ranges)
+tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ tile_keys_sorted, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;

@@ -112,7 +112,8 @@ int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst
 // contiguous runs in the scatter's write-out).  Result ends in (kA,vA) if the pass count is even,
 // else in (kB,vB).
 int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
-int radix_sort(uint32_t* kA, uint32_t* vA, uint32_t* kB, uint32_t* vB, uint32_t n, int bits,
+template <typename KeyT>
+int radix_sort(KeyT* kA, uint32_t* vA, KeyT* kB, uint32_t* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s)
 {
     if (n == 0) return GSRAST_OK;
@@ -122,11 +123,11 @@ int radix_sort(uint32_t* kA, uint32_t* vA, uint32_t* kB, uint32_t* vB, uint32_t 
     for (int p = 0; p < passes; p++) {
         const int w = (bits - shift + (passes - p) - 1) / (passes - p);   // remaining bits spread evenly
         const uint32_t mask = (1u << w) - 1u;
-        radix_hist_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, n, shift, mask, hist, nblk);
+        radix_hist_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, n, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
         radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
         GS_LAUNCHED("radix_rowscan");
-        radix_scatter_kernel<<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk);
+        radix_scatter_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
         shift += w;
@@ -176,8 +177,9 @@ export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __r
     if (tiles) tiles[i] = tiles_in[i];
 }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
-export_keys_kernel(uint32_t R, const uint32_t* __restrict__ tile_sorted, const uint32_t* __restrict__ vals_sorted,
+export_keys_kernel(uint32_t R, const KeyT* __restrict__ tile_sorted, const uint32_t* __restrict__ vals_sorted,
                    const float* __restrict__ depths, uint64_t* keys, uint32_t* point_list)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,7 +383,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     }
     {
         ProfScope ps(K_SORT_DEPTH, s);
-        int rc = radix_sort(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s);
+        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A
@@ -407,22 +409,30 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
 
     uint2* ranges = at<uint2>(img, IL.ranges);
     GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s)); // reference rasterizer_impl.cu:311
+    // Tile ids fit 16 bits up to 65 536 tiles (4096 x 4096 pixels): the R-sized key streams are then
+    // half as wide (the key buffers are sized for 32-bit ids either way).
+    const bool k16 = T <= 65536u;
     if (R > 0) {
-        {
-            ProfScope ps(K_EMIT, s);
-            emit_instances_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, offsets, tiles, rect, cam.gx, tkA, tvA);
-            GS_LAUNCHED("emit_instances");
-        }
-        {
-            ProfScope ps(K_SORT_TILE, s);
-            int rc = radix_sort(tkA, tvA, tkB, tvB, R, tile_bits(T), bhist, bscan, s);
+        int rc = GSRAST_OK;
+        if (k16) {
+            uint16_t *hA = reinterpret_cast<uint16_t*>(tkA), *hB = reinterpret_cast<uint16_t*>(tkB);
+            { ProfScope ps(K_EMIT, s);
+              emit_instances_kernel<uint16_t><<<(P + 255) / 256, 256, 0, s>>>(P, order, offsets, tiles, rect, cam.gx, hA, tvA);
+              GS_LAUNCHED("emit_instances"); }
+            { ProfScope ps(K_SORT_TILE, s); rc = radix_sort<uint16_t>(hA, tvA, hB, tvB, R, tile_bits(T), bhist, bscan, s); }
             if (rc != GSRAST_OK) return rc;
-        }
-        const uint32_t* tk_sorted = (tpasses & 1) ? tkB : tkA;
-        {
-            ProfScope ps(K_RANGES, s);
-            tile_ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, tk_sorted, ranges);
-            GS_LAUNCHED("tile_ranges");
+            { ProfScope ps(K_RANGES, s);
+              tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, (tpasses & 1) ? hB : hA, ranges);
+              GS_LAUNCHED("tile_ranges"); }
+        } else {
+            { ProfScope ps(K_EMIT, s);
+              emit_instances_kernel<uint32_t><<<(P + 255) / 256, 256, 0, s>>>(P, order, offsets, tiles, rect, cam.gx, tkA, tvA);
+              GS_LAUNCHED("emit_instances"); }
+            { ProfScope ps(K_SORT_TILE, s); rc = radix_sort<uint32_t>(tkA, tvA, tkB, tvB, R, tile_bits(T), bhist, bscan, s); }
+            if (rc != GSRAST_OK) return rc;
+            { ProfScope ps(K_RANGES, s);
+              tile_ranges_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>(R, (tpasses & 1) ? tkB : tkA, ranges);
+              GS_LAUNCHED("tile_ranges"); }
         }
     }
     const uint32_t* plist = (tpasses & 1) ? tvB : tvA;
@@ -542,7 +552,10 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
         const int tpasses = tile_passes(T);
         const uint32_t* tk = (tpasses & 1) ? at<uint32_t>(binning_buffer, BL.keyB) : at<uint32_t>(binning_buffer, BL.keyA);
         const uint32_t* tv = (tpasses & 1) ? at<uint32_t>(binning_buffer, BL.valB) : at<uint32_t>(binning_buffer, BL.valA);
-        export_keys_kernel<<<(R + 255) / 256, 256, 0, s>>>((uint32_t)R, tk, tv, at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
+        if (T <= 65536u)
+            export_keys_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>((uint32_t)R, reinterpret_cast<const uint16_t*>(tk), tv, at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
+        else
+            export_keys_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>((uint32_t)R, tk, tv, at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
         GS_LAUNCHED("export_keys");
     }
     if (image_buffer) {
