@@ -1,0 +1,132 @@
+"""-m gpu: BASELINE.json's full-size configurations, checked through size-independent properties
+(the CPU oracle would need minutes here): sortedness and partition of the binning, bounds, determinism,
+invariance of the forward under every kernel variant, linearity of the backward in the upstream gradient."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import settings_from
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # BASELINE.json configs 2, 3, 5 (synthetic stand-ins of the named shapes)
+    ("cfg2_mutant_100k_800", 100_000, 800, 800),
+    ("cfg3_cook_spinach_1M_1352x1014", 1_000_000, 1352, 1014),
+    ("cfg5_stress_3M_1080p", 3_000_000, 1920, 1080),
+]
+
+
+def _inputs(scenes, rast, P, W, H, dev, seed=0):
+    sc = scenes.synth(P, seed)
+    cam = scenes.camera(0, 1, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    rs = settings_from(rast, cam, sc, dev)
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    return sc, cam, rs, ten
+
+
+def _forward_state(rast, rs, ten, P, W, H):
+    e = torch.empty(0)
+    R, color, radii, gb, bb, ib, depth = rast._C.rasterize_gaussians(
+        rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix,
+        rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, ten["shs"], rs.sh_degree, rs.campos, False)
+    st = rast._C.debug_export(P, R, W, H, gb, bb, ib)
+    return R, color, radii, depth, st
+
+
+@pytest.mark.parametrize("name,P,W,H", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_binning_and_image_properties(name, P, W, H, scenes, rast, gpu):
+    sc, cam, rs, ten = _inputs(scenes, rast, P, W, H, gpu)
+    R, color, radii, depth, st = _forward_state(rast, rs, ten, P, W, H)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    assert R == int(st["tiles_touched"].to(torch.int64).sum())
+    keys = st["keys_sorted"]                                   # (tile << 32) | depth bits, int64 view of uint64
+    assert bool((keys[1:] >= keys[:-1]).all()), "sorted keys must be non-decreasing"   # tile < 2^31: sign bit clear
+    tiles = keys >> 32
+    ranges = st["ranges"].to(torch.int64)
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == R and bool((lens >= 0).all())
+    nz = lens > 0
+    starts = ranges[nz, 0]
+    assert bool((tiles[starts] == torch.nonzero(nz).flatten()).all()), "a tile's range starts at its own key"
+    ends = ranges[nz, 1] - 1
+    assert bool((tiles[ends] == torch.nonzero(nz).flatten()).all())
+    # stable tie-break: equal keys keep ascending Gaussian index
+    pl = st["point_list"].to(torch.int64)
+    same = keys[1:] == keys[:-1]
+    assert bool((pl[1:][same] > pl[:-1][same]).all())
+    # low key bits are the depth's float bits of the listed Gaussian
+    dbits = st["depths"].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    assert bool(((keys & 0xFFFFFFFF) == dbits[pl]).all())
+    # per-pixel bounds
+    nc = st["n_contrib"].to(torch.int64)
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    tile_of_pixel = (torch.arange(H, device=gpu)[:, None] // 16) * gx + torch.arange(W, device=gpu)[None, :] // 16
+    assert bool((nc <= lens[tile_of_pixel]).all())
+    assert bool(torch.isfinite(color).all()) and float(color.min()) >= 0.0
+    fT = st["final_T"]
+    assert bool(((fT >= 0) & (fT <= 1)).all())
+    d = depth[0]
+    vis_depth = st["depths"][radii > 0]
+    assert bool(((d == 15.0) | ((d >= vis_depth.min()) & (d <= vis_depth.max()))).all()), "median depth is a listed depth or the default"
+    assert int((radii > 0).sum()) > 0.9 * P and T == ranges.shape[0]
+
+
+def test_forward_is_deterministic_and_variant_invariant(scenes, rast, gpu):
+    """1M Gaussians at 1080p: identical bits from two runs, with / without wave-level culling, with /
+    without heaviest-first launch order, and for 1 / 2 / 4 pixels per lane."""
+    P, W, H = 1_000_000, 1920, 1080
+    sc, cam, rs, ten = _inputs(scenes, rast, P, W, H, gpu)
+    _C = rast._C
+
+    def fwd():
+        R, color, radii, depth, st = _forward_state(rast, rs, ten, P, W, H)
+        return R, color.clone(), depth.clone(), st["n_contrib"].clone(), st["final_T"].clone()
+
+    base = fwd()
+    variants = [dict(), dict(cull=0), dict(lpt=0), dict(pixels_per_lane=1, cull=0), dict(pixels_per_lane=2, cull=0), dict(pixels_per_lane=4, cull=0)]
+    try:
+        for v in variants:
+            for k, val in v.items():
+                _C.set_option(k, val)
+            got = fwd()
+            assert got[0] == base[0]
+            for a, b in zip(got[1:], base[1:]):
+                assert torch.equal(a, b), f"forward differs under {v}"
+            for k in v:
+                _C.set_option(k, 1 if k in ("cull", "lpt") else 0)
+    finally:
+        _C.set_option("cull", 1); _C.set_option("lpt", 1); _C.set_option("pixels_per_lane", 0)
+
+
+@pytest.mark.parametrize("name,P,W,H", CONFIGS[:2], ids=[c[0] for c in CONFIGS[:2]])
+def test_backward_is_linear_in_the_upstream_gradient(name, P, W, H, scenes, rast, gpu):
+    """grad(a*g1 + b*g2) == a*grad(g1) + b*grad(g2) up to float-atomic ordering; depth gets no gradient;
+    culled Gaussians get exactly zero."""
+    sc, cam, rs, ten = _inputs(scenes, rast, P, W, H, gpu)
+    g1 = torch.as_tensor(scenes.upstream_grad(H, W, 1), device=gpu)
+    g2 = torch.as_tensor(scenes.upstream_grad(H, W, 2), device=gpu)
+
+    def grads(g):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in ten.items()}
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        color, radii, depth = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                          shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        assert not depth.requires_grad and radii.dtype == torch.int32
+        color.backward(g)
+        out = {k: v.grad for k, v in leaves.items()}
+        out["means2D"] = m2.grad
+        return out, radii
+
+    ga, radii = grads(g1)
+    gb, _ = grads(g2)
+    gc, _ = grads(2.0 * g1 - 0.5 * g2)
+    dead = radii == 0
+    for k in ga:
+        want = 2.0 * ga[k] - 0.5 * gb[k]
+        err = (gc[k] - want).abs()
+        assert bool((err <= 1e-6 + 1e-3 * want.abs()).all()), (k, float(err.max()))
+        assert bool(torch.isfinite(gc[k]).all())
+        assert not bool(gc[k][dead].any()), k
+    assert bool((ga["means2D"][:, 2] == 0).all())      # only .x/.y of the screen-space gradient are written
