@@ -308,3 +308,77 @@ def test_grad_arena_zero_copy_bucket(scenes, rast, gpu):
     # the arena really is the concatenation of the gradients
     off = arena.offsets["sh"]
     assert torch.equal(arena.flat[off: off + P * 48].view(P, 16, 3), bucketed["shs"].grad)
+
+
+@pytest.mark.parametrize("M,deg", [(1, 0), (4, 1), (9, 2), (16, 1), (25, 3)])
+def test_sh_row_lengths(M, deg, orc, scenes, rast, gpu):
+    """max_coeffs M other than 16 (M*3 floats per row: 3, 12, 27, 48, 75 -- aligned and unaligned rows,
+    staged through LDS up to 48 floats and read directly beyond), active degree below what M allows."""
+    P, W, H = 1500, 112, 80
+    sc = scenes.synth(P, 90 + M, sh_degree=deg)
+    rng = np.random.default_rng(M)
+    shs = np.zeros((P, M, 3), np.float32)
+    shs[:, 0] = rng.uniform(-1.7, 1.7, size=(P, 3))
+    shs[:, 1:] = rng.normal(0, 0.2, size=(P, M - 1, 3))
+    sc["shs"] = shs
+    cam = scenes.camera(1, 3, W, H)
+    g = scenes.upstream_grad(H, W, 5)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], strict=True)
+    ncoef = (deg + 1) ** 2
+    assert not h["dL_dsh"][:, ncoef:].any()          # coefficients above the active degree get zero gradient
+
+
+def test_scale_modifier_single_gaussian_and_views(orc, scenes, rast, gpu):
+    """scale_modifier != 1 (settings field the reference multiplies into the scales, forward.cu:122-124);
+    P = 1; non-contiguous input views (the binding makes them contiguous like the reference's .contiguous())."""
+    import torch
+    from conftest import settings_from
+    W, H = 80, 64
+    sc = scenes.synth(700, 95)
+    cam = scenes.camera(0, 1, W, H)
+    cam["scale_modifier"] = 0.6
+    g = scenes.upstream_grad(H, W, 6)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], strict=True)
+    # one Gaussian in the middle of the screen
+    one = {k: (v[:1].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (700,) else v) for k, v in sc.items()}
+    one["means3D"][:] = 0.0
+    cam1 = scenes.camera(0, 1, W, H)
+    o1 = orc.render(one, cam1, g)
+    h1 = run_hip(rast, one, cam1, gpu, dL_dcolor=g)
+    _check_forward_exact(o1, h1)
+    assert h1["R"] == o1["R"] > 0
+    # strided views of larger tensors
+    rs = settings_from(rast, cam1, sc, gpu)
+    big = torch.as_tensor(np.repeat(sc["means3D"], 2, axis=0), device=gpu)
+    means_view = big[::2]                                       # stride (6, 1): not contiguous
+    assert not means_view.is_contiguous()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    shs_view = torch.as_tensor(np.ascontiguousarray(sc["shs"].transpose(1, 0, 2)), device=gpu).permute(1, 0, 2)
+    assert not shs_view.is_contiguous()
+    color, radii, _ = rast.GaussianRasterizer(rs)(means3D=means_view, means2D=torch.zeros(700, 3, device=gpu), opacities=t(sc["opacities"]),
+                                                  shs=shs_view, scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    ref = orc.render(sc, cam1, None)
+    np.testing.assert_array_equal(bits(color.cpu().numpy()), bits(ref["out_color"]))
+
+
+def test_runs_on_a_side_stream(orc, scenes, rast, gpu):
+    """Kernels are enqueued on torch's CURRENT stream (the reference used the legacy default stream)."""
+    import torch
+    P, W, H = 2000, 96, 96
+    sc = scenes.synth(P, 97)
+    cam = scenes.camera(2, 6, W, H)
+    g = scenes.upstream_grad(H, W, 7)
+    o32 = orc.render(sc, cam, g)
+    s = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(s):
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    s.synchronize()
+    _check_forward_exact(o32, h)
