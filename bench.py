@@ -189,7 +189,7 @@ def main():
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)
     bucket = None
     if world > 1:
-        # one flat fp32 buffer holds every leaf gradient of the rasterizer (62 floats / Gaussian); the
+        # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the
         # backward writes into it directly and the step ends with ONE in-place all-reduce (mean)
         bucket = _C.GradArena(P, 16, dev)
         _C.set_grad_arena(bucket)
@@ -232,7 +232,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
-                                   + (" + RCCL all-reduce(mean) of 62 floats/Gaussian" if world > 1 else ""),
+                                   + (" + RCCL all-reduce(mean) of 59 floats/Gaussian" if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "R_eff": st["R_eff"], "visible": st["P_vis"],
                        "blended_pairs_fwd": st["pairs_fwd"]},

@@ -115,12 +115,14 @@ class GradArena:
     """Optional zero-copy gradient bucket for the multi-GPU path (view_parallel.py).
 
     When installed with ``set_grad_arena``, ``rasterize_gaussians_backward`` carves the leaf
-    gradients it returns (means3D, sh, opacities, scales, rotations, means2D) out of ONE flat fp32
-    buffer, in that order, so the cross-rank exchange is a single in-place all-reduce of ``flat`` with
-    no pack / unpack copies (the same idea as DDP's gradient-as-bucket-view).  Not part of the
-    reference's _C: without an arena the outputs are ordinary tensors, exactly as before."""
+    gradients it returns (means3D, sh, opacities, scales, rotations) out of ONE flat fp32 buffer, in
+    that order, so the cross-rank exchange is a single in-place all-reduce of ``flat`` with no pack /
+    unpack copies (the same idea as DDP's gradient-as-bucket-view).  The screen-space gradient
+    (means2D) is deliberately NOT in the bucket: the reference only ever uses its per-view norm
+    (train.py:212), which is reduced separately as a [P] statistic.  Not part of the reference's _C:
+    without an arena the outputs are ordinary tensors, exactly as before."""
 
-    ORDER = (("means3D", 3), ("sh", None), ("opacity", 1), ("scales", 3), ("rotations", 4), ("means2D", 3))
+    ORDER = (("means3D", 3), ("sh", None), ("opacity", 1), ("scales", 3), ("rotations", 4))
 
     def __init__(self, P: int, M: int, device: torch.device):
         self.P, self.M = P, M

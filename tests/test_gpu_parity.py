@@ -298,11 +298,12 @@ def test_grad_arena_zero_copy_bucket(scenes, rast, gpu):
         bucketed = run()
     finally:
         rast._C.set_grad_arena(None)
-    assert arena.flat.numel() == P * 62
+    assert arena.flat.numel() == P * 59
     lo, hi = arena.flat.data_ptr(), arena.flat.data_ptr() + arena.flat.numel() * 4
     for k in plain:
         a, b = plain[k].grad, bucketed[k].grad
-        assert lo <= b.data_ptr() < hi, f"{k}.grad does not alias the arena (a copy was made)"
+        if k != "means2D":      # the screen-space gradient stays a private tensor (only its norm is exchanged)
+            assert lo <= b.data_ptr() < hi, f"{k}.grad does not alias the arena (a copy was made)"
         tol = 1e-5 + 1e-4 * a.abs()
         assert ((a - b).abs() <= tol).all(), k      # two runs differ only by float-atomic ordering
     # the arena really is the concatenation of the gradients
