@@ -540,6 +540,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         strip_last[k] = __builtin_amdgcn_readfirstlane(m);
     }
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    // factor applied by lane l (< 8) when it commits value l: {mean.x, mean.y, conic a, b, c, opacity, r, g}
+    const float commit_scale = lane == 0 ? ddelx_dx : lane == 1 ? ddely_dy : (lane >= 2 && lane <= 4) ? -0.5f : 1.0f;
 
     for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
@@ -625,16 +627,23 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     g_op += G * dL_dalpha;
                 }
                 if (!__any(contributed)) continue;
-                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-                g_op = wave_sum_to_lane63(g_op);
-                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-                if (lane == 63) {
-                    if constexpr (NT == 64) {   // single wave: plain read-modify-write is race free
-                        acc[0][j] += g_mx * ddelx_dx; acc[1][j] += g_my * ddely_dy;
-                        acc[2][j] += -0.5f * g_ca; acc[3][j] += -0.5f * g_cb; acc[4][j] += -0.5f * g_cc;
-                        acc[5][j] += g_op; acc[6][j] += g_r; acc[7][j] += g_g; acc[8][j] += g_b;
-                    } else {
+                if constexpr (NT == 64) {
+                    // one wave per tile: eight of the nine sums through the transposing reduction (every
+                    // lane l ends with the total of value l & 7), the ninth through the DPP chain to lane
+                    // 63; lanes 0..7 and 63 then commit all nine with ONE LDS read-add-write.
+                    const float v8[8] = { g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g };
+                    const float tot = wave_sum8_transposed(v8, lane);
+                    const float tb = wave_sum_to_lane63(g_b);
+                    if (lane < 8u || lane == 63u) {
+                        const uint32_t q = lane < 8u ? lane : 8u;
+                        acc[q][j] += lane < 8u ? tot * commit_scale : tb;
+                    }
+                } else {
+                    g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
+                    g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+                    g_op = wave_sum_to_lane63(g_op);
+                    g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+                    if (lane == 63) {
                         atomicAdd(&acc[0][j], g_mx * ddelx_dx); atomicAdd(&acc[1][j], g_my * ddely_dy);
                         atomicAdd(&acc[2][j], -0.5f * g_ca); atomicAdd(&acc[3][j], -0.5f * g_cb); atomicAdd(&acc[4][j], -0.5f * g_cc);
                         atomicAdd(&acc[5][j], g_op); atomicAdd(&acc[6][j], g_r); atomicAdd(&acc[7][j], g_g); atomicAdd(&acc[8][j], g_b);

@@ -176,6 +176,43 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// Transposing ("reduce-scatter") wave sum of EIGHT values at once.  Step by step each lane keeps half
+// of its values and hands the other half to its partner, so the work halves every step:
+//   xor 1 (quad_perm) 8 -> 4 values, xor 2 (quad_perm) 4 -> 2, rotate 4 / rotate 8 inside the 16-lane
+//   row 2 -> 1, then the four rows are combined with two ds_bpermute exchanges (LDS crossbar, no VALU).
+// Afterwards EVERY lane l holds the wave-wide total of v[l & 7].  28 VALU instructions instead of the
+// 8 x 6 = 48 of eight independent DPP reductions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_pair_sum(float v)     // v + v[partner], full rows, no bound control needed
+{
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum8_transposed(const float (&v)[8], unsigned lane)
+{
+    const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
+    float w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float a = dpp_pair_sum<0xB1>(v[2 * i]);          // quad_perm [1,0,3,2]: lanes l, l^1
+        const float b = dpp_pair_sum<0xB1>(v[2 * i + 1]);
+        w[i] = b0 ? b : a;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float a = dpp_pair_sum<0x4E>(w[2 * i]);          // quad_perm [2,3,0,1]: lanes l, l^2
+        const float b = dpp_pair_sum<0x4E>(w[2 * i + 1]);
+        x[i] = b1 ? b : a;
+    }
+    const float a = dpp_pair_sum<0x124>(x[0]);                 // row_ror:4 (same l & 3 => same value kind)
+    const float b = dpp_pair_sum<0x124>(x[1]);
+    float y = b2 ? b : a;
+    y = dpp_pair_sum<0x128>(y);                                // row_ror:8 -> total of the 16-lane row
+    y += __shfl_xor(y, 16, 64);                                // rows 0+1, 2+3
+    y += __shfl_xor(y, 32, 64);                                // whole wave
+    return y;
+}
+
 // Lanes of the wave whose 8-bit digit equals mine (among `valid` lanes).
 __device__ __forceinline__ uint64_t wave_match8(uint32_t d, bool valid)
 {
