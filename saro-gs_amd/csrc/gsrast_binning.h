@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
                      const uint32_t* __restrict__ hist_scanned /* per-digit exclusive row scans */,
-                     const uint32_t* __restrict__ digit_total, uint32_t nblk)
+                     const uint32_t* __restrict__ digit_total, uint32_t nblk,
+                     const uint32_t* __restrict__ gather_src /* optional */, uint32_t* __restrict__ gather_dst)
 {
     // Ranks -> block-local order in LDS -> coalesced write-out: after the exchange consecutive lanes
     // hold consecutive elements of the same digit, whose global destinations are consecutive too.
@@ -232,7 +233,9 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restric
             const uint32_t d = (k >> shift) & mask;
             const uint32_t pos = gbase[d] + (slot - dstart[d]);
             keys_out[pos] = kk;
-            vals_out[pos] = xv[slot];
+            const uint32_t vv = xv[slot];
+            vals_out[pos] = vv;
+            if (gather_src) gather_dst[pos] = gather_src[vv];   // last depth pass: tiles_touched in depth order
         }
     }
 }

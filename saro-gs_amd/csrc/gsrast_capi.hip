@@ -114,7 +114,8 @@ int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst
 int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
 template <typename KeyT>
 int radix_sort(KeyT* kA, uint32_t* vA, KeyT* kB, uint32_t* vB, uint32_t n, int bits,
-               uint32_t* hist, uint32_t* scan_tmp, hipStream_t s)
+               uint32_t* hist, uint32_t* scan_tmp, hipStream_t s,
+               const uint32_t* gather_src = nullptr, uint32_t* gather_dst = nullptr)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nblk = (uint32_t)rs_blocks(n);
@@ -127,7 +128,9 @@ int radix_sort(KeyT* kA, uint32_t* vA, KeyT* kB, uint32_t* vB, uint32_t n, int b
         GS_LAUNCHED("radix_hist");
         radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
         GS_LAUNCHED("radix_rowscan");
-        radix_scatter_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk);
+        const bool last = p == passes - 1;
+        radix_scatter_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk,
+                                                               last ? gather_src : nullptr, last ? gather_dst : nullptr);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
         shift += w;
@@ -383,13 +386,14 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     }
     {
         ProfScope ps(K_SORT_DEPTH, s);
-        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s);
+        // the last pass also writes tiles_touched in depth order (into `offsets`, scanned in place below)
+        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, tiles, offsets);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A
     {
         ProfScope ps(K_SCAN_TILES, s);
-        int rc = scan_u32(tiles, order, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
+        int rc = scan_u32(offsets, nullptr, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
         if (rc != GSRAST_OK) return rc;
     }
     uint32_t num_rendered = 0;

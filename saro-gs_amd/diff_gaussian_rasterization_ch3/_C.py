@@ -238,10 +238,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             return ar.take(name, shape, zero)
         return torch.zeros(shape, **opts) if zero else torch.empty(shape, **opts)
 
-    dL_dmeans2D = out("means2D", (P, 3), True)
-    dL_dconic = torch.zeros((P, 2, 2), **opts)
-    dL_dopacity = out("opacity", (P, 1), True)
-    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **opts)
+    # the four atomically accumulated arrays share ONE zero-filled allocation (one fill kernel, 44 B/Gaussian)
+    if ar is None:
+        zbuf = torch.zeros(P * 11, **opts)
+        dL_dmeans2D = zbuf[: 3 * P].view(P, 3)
+        dL_dconic = zbuf[3 * P: 7 * P].view(P, 2, 2)
+        dL_dopacity = zbuf[7 * P: 8 * P].view(P, 1)
+        dL_dcolors = zbuf[8 * P: 11 * P].view(P, NUM_CHANNELS)
+    else:
+        zbuf = torch.zeros(P * 10, **opts)
+        dL_dmeans2D = zbuf[: 3 * P].view(P, 3)
+        dL_dconic = zbuf[3 * P: 7 * P].view(P, 2, 2)
+        dL_dcolors = zbuf[7 * P: 10 * P].view(P, NUM_CHANNELS)
+        dL_dopacity = out("opacity", (P, 1), True)
     dL_dmeans3D = out("means3D", (P, 3), False)
     dL_dcov3D = torch.empty((P, 6), **opts)
     dL_dsh = out("sh", (P, M, 3), not use_sh)
