@@ -121,7 +121,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const float4 b = s1[j];
                 const float power = gs_power(a.z, a.w, b.x, dx, dy);
                 if (!done && !(power > 0.0f) && !(power < c.z)) {
-                    float alpha = b.y * gs_exp<EXPMODE>(power);
+                    float alpha = b.y * gs_exp<EXPMODE, false>(power);
                     alpha = alpha < 0.99f ? alpha : 0.99f;
                     if (!(alpha < 1.0f / 255.0f)) {
                         const float test_T = T * (1.0f - alpha);
@@ -253,7 +253,7 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
 #pragma unroll
             for (int k = 0; k < PPL; k++) {
                 if (hit[k]) {   // one exec-masked region per pixel slot, straight-line inside (selects, no branches)
-                    float alpha = b.y * gs_exp<EXPMODE>(power[k]);
+                    float alpha = b.y * gs_exp<EXPMODE, true>(power[k]);
                     alpha = alpha < 0.99f ? alpha : 0.99f;
                     const bool ok = !(alpha < 1.0f / 255.0f);
                     const float test_T = T[k] * (1.0f - alpha);
@@ -405,7 +405,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
 #pragma unroll
             for (int k = 0; k < PPL; k++) {
                 if (!hit[k]) continue;
-                const float G = gs_exp<EXPMODE>(power[k]);
+                const float G = gs_exp<EXPMODE, true>(power[k]);
                 float alpha = b.y * G;
                 alpha = alpha < 0.99f ? alpha : 0.99f;
                 if (alpha < 1.0f / 255.0f) continue;
@@ -600,7 +600,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     const float q = __builtin_fmaf(b.x * dy, dy, xx);
                     const float power = __builtin_fmaf(-0.5f, q, -(xy * dy));
                     if (!(pos < last[k]) || power > 0.0f || power < c.y) continue;
-                    const float G = gs_exp<EXPMODE>(power);
+                    const float G = gs_exp<EXPMODE, true>(power);
                     float alpha = b.y * G;
                     alpha = alpha < 0.99f ? alpha : 0.99f;
                     if (alpha < 1.0f / 255.0f) continue;

@@ -290,7 +290,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const float op = opacities[i];
                 // Conservative pre-test for the blend kernels: power < thr  ==>  op*exp(power) < 1/255
                 // with a 2% margin, so skipping the exp for such pairs never changes a decision.
-                const float thr = op > 0.0f ? (logf(1.0f / (255.0f * op)) - 0.02f) : 1.0f;
+                // (clamped at -80 so that exp() is only ever evaluated on [-80, 0]: gs_exp<., BOUNDED>)
+                const float thr = op > 0.0f ? fmaxf(logf(1.0f / (255.0f * op)) - 0.02f, -80.0f) : 1.0f;
                 depths[i] = pv[2];
                 rec0[i] = make_float4(px, py, con0, con1);
                 rec1[i] = make_float4(con2, op, col[0], col[1]);
