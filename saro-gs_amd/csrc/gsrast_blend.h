@@ -496,12 +496,12 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 {
 #pragma clang fp contract(fast)
     using Cfg = BlendCfg<PPL>;
-    constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
+    constexpr int NT = Cfg::NT, BATCH = 128, NW = NT / 64;
     __shared__ float4 s0[BATCH];
     __shared__ float4 s1[BATCH];
     __shared__ float2 s2[BATCH];          // {blue, skip threshold}
     __shared__ uint32_t sid[BATCH];
-    __shared__ float acc[9][BATCH];
+    __shared__ float acc[NW][9][BATCH];   // one accumulator slice per wave: plain LDS read-add-write, no LDS atomics
 
     if (blockIdx.x >= ntiles) return;
     const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;   // heaviest tiles first
@@ -545,9 +545,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 
     for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < BATCH / NT; r++) {
-            const uint32_t slot = t + r * NT, i = base + slot;
+        for (uint32_t slot = t; slot < (uint32_t)BATCH; slot += NT) {
+            const uint32_t i = base + slot;
             if (i < n) {
                 const uint32_t g = point_list[range.x + (n - 1 - i)];
                 sid[slot] = g;
@@ -556,7 +555,9 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 s2[slot] = make_float2(c.x, c.z);
             }
 #pragma unroll
-            for (int q = 0; q < 9; q++) acc[q][slot] = 0.0f;
+            for (int w = 0; w < NW; w++)
+#pragma unroll
+                for (int q = 0; q < 9; q++) acc[w][q][slot] = 0.0f;
         }
         __syncthreads();
         const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
@@ -627,45 +628,36 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     g_op += G * dL_dalpha;
                 }
                 if (!__any(contributed)) continue;
-                if constexpr (NT == 64) {
-                    // one wave per tile: eight of the nine sums through the transposing reduction (every
-                    // lane l ends with the total of value l & 7), the ninth through the DPP chain to lane
-                    // 63; lanes 0..7 and 63 then commit all nine with ONE LDS read-add-write.
+                {
+                    // eight of the nine sums through the transposing reduction (every lane l ends with the
+                    // total of value l & 7), the ninth through the DPP chain to lane 63; lanes 0..7 and 63
+                    // then commit all nine into this wave's accumulator slice with ONE LDS read-add-write.
                     const float v8[8] = { g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g };
                     const float tot = wave_sum8_transposed(v8, lane);
                     const float tb = wave_sum_to_lane63(g_b);
                     if (lane < 8u || lane == 63u) {
                         const uint32_t q = lane < 8u ? lane : 8u;
-                        acc[q][j] += lane < 8u ? tot * commit_scale : tb;
-                    }
-                } else {
-                    g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-                    g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-                    g_op = wave_sum_to_lane63(g_op);
-                    g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-                    if (lane == 63) {
-                        atomicAdd(&acc[0][j], g_mx * ddelx_dx); atomicAdd(&acc[1][j], g_my * ddely_dy);
-                        atomicAdd(&acc[2][j], -0.5f * g_ca); atomicAdd(&acc[3][j], -0.5f * g_cb); atomicAdd(&acc[4][j], -0.5f * g_cc);
-                        atomicAdd(&acc[5][j], g_op); atomicAdd(&acc[6][j], g_r); atomicAdd(&acc[7][j], g_g); atomicAdd(&acc[8][j], g_b);
+                        acc[wave][q][j] += lane < 8u ? tot * commit_scale : tb;
                     }
                 }
             }
         }
         __syncthreads();
+        for (uint32_t slot = t; slot < cnt; slot += NT) {
+            const size_t gid = sid[slot];
+            float v[9];
 #pragma unroll
-        for (int r = 0; r < BATCH / NT; r++) {
-            const uint32_t slot = t + r * NT;
-            if (slot < cnt) {
-                const size_t gid = sid[slot];
-                const float v0 = acc[0][slot], v1 = acc[1][slot], v2 = acc[2][slot], v3 = acc[3][slot], v4 = acc[4][slot];
-                const float v5 = acc[5][slot], v6 = acc[6][slot], v7 = acc[7][slot], v8 = acc[8][slot];
-                const bool any = (v0 != 0.f) | (v1 != 0.f) | (v2 != 0.f) | (v3 != 0.f) | (v4 != 0.f) | (v5 != 0.f) | (v6 != 0.f) | (v7 != 0.f) | (v8 != 0.f);
-                if (any) {
-                    atomicAdd(&dL_dmean2D[3 * gid], v0); atomicAdd(&dL_dmean2D[3 * gid + 1], v1);
-                    atomicAdd(&dL_dconic[4 * gid], v2); atomicAdd(&dL_dconic[4 * gid + 1], v3); atomicAdd(&dL_dconic[4 * gid + 3], v4);
-                    atomicAdd(&dL_dopacity[gid], v5);
-                    atomicAdd(&dL_dcolors[3 * gid], v6); atomicAdd(&dL_dcolors[3 * gid + 1], v7); atomicAdd(&dL_dcolors[3 * gid + 2], v8);
-                }
+            for (int q = 0; q < 9; q++) {
+                v[q] = acc[0][q][slot];
+#pragma unroll
+                for (int w = 1; w < NW; w++) v[q] += acc[w][q][slot];
+            }
+            const bool any = (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f) | (v[4] != 0.f) | (v[5] != 0.f) | (v[6] != 0.f) | (v[7] != 0.f) | (v[8] != 0.f);
+            if (any) {
+                atomicAdd(&dL_dmean2D[3 * gid], v[0]); atomicAdd(&dL_dmean2D[3 * gid + 1], v[1]);
+                atomicAdd(&dL_dconic[4 * gid], v[2]); atomicAdd(&dL_dconic[4 * gid + 1], v[3]); atomicAdd(&dL_dconic[4 * gid + 3], v[4]);
+                atomicAdd(&dL_dopacity[gid], v[5]);
+                atomicAdd(&dL_dcolors[3 * gid], v[6]); atomicAdd(&dL_dcolors[3 * gid + 1], v[7]); atomicAdd(&dL_dcolors[3 * gid + 2], v[8]);
             }
         }
     }

@@ -199,11 +199,12 @@ int pick_ppl(uint32_t ntiles, bool backward)
 {
     const int forced = backward ? g_ppl_bwd.load() : g_ppl_fwd.load();
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    // Measured on MI355X (profiles/): the forward is fastest with one pixel per lane (finest skip /
-    // early-exit granularity, most waves in flight); the backward amortises its wave reductions and
-    // atomics over 4 pixels per lane once there are enough tiles to fill 1024 SIMDs with one wave each.
+    // Measured on MI355X (profiles/): the forward is fastest with one pixel per lane (finest cull /
+    // early-exit granularity, most waves in flight).  With per-wave accumulator slices the backward is
+    // within 2 % for 1, 2 and 4 pixels per lane at 1080p and above; fewer pixels per lane win for small
+    // images (more waves) and small Gaussians (finer culling), more pixels per lane win at 4K.
     if (!backward) return 1;
-    return ntiles >= 4096 ? 4 : (ntiles >= 1536 ? 2 : 1);   // re-tuned in profiles/ (bwd culling variants)
+    return ntiles >= 32768 ? 4 : (ntiles >= 8192 ? 2 : 1);
 }
 
 struct BlendArgs {
