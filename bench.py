@@ -116,9 +116,16 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
         workload.step(bucket, world)
     vp.barrier()
     torch.cuda.synchronize(dev)
+    trace = os.environ.get("BENCH_STEP_TRACE")
+    marks = []
     t0 = time.perf_counter()
     for _ in range(steps):
         workload.step(bucket, world)
+        if trace:
+            marks.append(time.perf_counter())
+    if trace:
+        d = np.diff(np.array([t0] + marks)) * 1e3
+        print("step host ms:", " ".join(f"{x:.2f}" for x in d), file=sys.stderr)
     torch.cuda.synchronize(dev)
     vp.barrier()
     torch.cuda.synchronize(dev)

@@ -35,7 +35,10 @@ extern "C" {
 
 /* Allocation callback: must return a device pointer to at least `bytes` bytes, 256-byte aligned,
  * that stays valid until the matching backward call has completed (the reference keeps the
- * buffers alive through ctx.save_for_backward).  Replaces rasterize_points.cu:27-33. */
+ * buffers alive through ctx.save_for_backward).  A callback may be invoked more than once per
+ * forward call (the binning buffer is first requested from an estimate, then again if the estimate
+ * was too small); the LAST pointer returned is the buffer in use, earlier ones may be released.
+ * Replaces rasterize_points.cu:27-33. */
 typedef void* (*gsrast_alloc_fn)(void* ctx, size_t bytes);
 
 /* Forward pass.  Returns num_rendered (number of (Gaussian, tile) instances, >= 0) or a negative

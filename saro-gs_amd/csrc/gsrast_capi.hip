@@ -14,6 +14,8 @@
 #include "gsrast_blend.h"
 
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -138,6 +140,33 @@ int radix_sort(KeyT* kA, uint32_t* vA, KeyT* kB, uint32_t* vB, uint32_t n, int b
     return GSRAST_OK;
 }
 
+// Low-latency readback of one device word: async copy into pinned host memory, then spin on an event
+// (hipStreamSynchronize may sleep; the GPU is idle while we wait, so every microsecond counts).
+struct Readback {
+    uint32_t* pinned = nullptr; hipEvent_t ev = nullptr;
+    ~Readback() { if (pinned) (void)hipHostFree(pinned); if (ev) (void)hipEventDestroy(ev); }
+};
+thread_local Readback t_readback;
+int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out)
+{
+    Readback& rb = t_readback;
+    if (!rb.pinned) {
+        GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocDefault));
+        GS_HIP(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+    }
+    GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipEventRecord(rb.ev, s));
+    hipError_t e;
+    while ((e = hipEventQuery(rb.ev)) == hipErrorNotReady) { }
+    if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "read_u32", e);
+    *out = *rb.pinned;
+    return GSRAST_OK;
+}
+// Instances of the previous forward call: the binning buffer is requested for 1.25x that many BEFORE
+// the host waits for the real count, so the (Python) allocation callback runs while the GPU is still
+// busy with preprocess / depth sort instead of in the idle gap after the readback.
+std::atomic<uint32_t> g_R_hint{0};
+
 CamArgs make_cam(const float* view, const float* proj, const float* campos, float tanx, float tany,
                  float scale_mod, int W, int H)
 {
@@ -180,16 +209,17 @@ export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __r
     if (tiles) tiles[i] = tiles_in[i];
 }
 
-template <typename KeyT>
+// one workgroup per tile: the 64-bit keys of the reference, rebuilt from the tile's range
 __global__ void __launch_bounds__(256)
-export_keys_kernel(uint32_t R, const KeyT* __restrict__ tile_sorted, const uint32_t* __restrict__ vals_sorted,
+export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals_sorted,
                    const float* __restrict__ depths, uint64_t* keys, uint32_t* point_list)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t g = vals_sorted[i];
-    if (keys) keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(depths[g]);
-    if (point_list) point_list[i] = g;
+    const uint2 r = ranges[blockIdx.x];
+    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) {
+        const uint32_t g = vals_sorted[i];
+        if (keys) keys[i] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__float_as_uint(depths[g]);
+        if (point_list) point_list[i] = g;
+    }
 }
 
 std::atomic<int> g_ppl_fwd{0}, g_ppl_bwd{0};   // pixels per lane of the blend kernels: 0 = auto, else 1 / 2 / 4
@@ -397,23 +427,42 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         int rc = scan_u32(offsets, nullptr, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
         if (rc != GSRAST_OK) return rc;
     }
-    uint32_t num_rendered = 0;
-    GS_HIP(hipMemcpyAsync(&num_rendered, scalars, sizeof(num_rendered), hipMemcpyDeviceToHost, s));
-    GS_HIP(hipStreamSynchronize(s));
-    if (num_rendered > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
-    const uint32_t R = num_rendered;
-
-    const BinLayout BL = bin_layout((size_t)R);
-    char* bin = (char*)binning_alloc(binning_ctx, BL.total);
-    if (!bin) return fail(GSRAST_E_ALLOC, "forward: binning allocation failed");
-    uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
-    uint32_t *tvA = at<uint32_t>(bin, BL.valA), *tvB = at<uint32_t>(bin, BL.valB);
-    uint32_t* bhist = at<uint32_t>(bin, BL.hist);
-    uint32_t* bscan = at<uint32_t>(bin, BL.scan_tmp);
-    const int tpasses = tile_passes(T);
-
+    // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
     GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s)); // reference rasterizer_impl.cu:311
+    const int tpasses = tile_passes(T);
+    uint32_t cap = 0;
+    char* bin = nullptr;
+    static const bool trace = getenv("GSRAST_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    if (const uint32_t hint = g_R_hint.load()) {
+        const uint64_t want = (uint64_t)hint + hint / 4 + 4096;
+        cap = want > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)want;
+        bin = (char*)binning_alloc(binning_ctx, bin_layout((size_t)cap).total);
+        if (!bin) cap = 0;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    uint32_t num_rendered = 0;
+    { int rc = read_u32(scalars, s, &num_rendered); if (rc != GSRAST_OK) return rc; }
+    auto t2 = std::chrono::steady_clock::now();
+    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u\n",
+                       std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, num_rendered);
+    if (num_rendered > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
+    const uint32_t R = num_rendered;
+    g_R_hint = R;
+    if (!bin || R > cap) {      // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
+        cap = R;
+        bin = (char*)binning_alloc(binning_ctx, bin_layout((size_t)cap).total);
+        if (!bin) return fail(GSRAST_E_ALLOC, "forward: binning allocation failed");
+    }
+    // The layout inside the buffer follows its CAPACITY; the sorted Gaussian ids always end in the array
+    // at offset 0 (valA), whatever the capacity and the pass count, which is all the backward needs.
+    const BinLayout BL = bin_layout((size_t)cap);
+    uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
+    uint32_t *tvA = at<uint32_t>(bin, BL.valA), *tvB = at<uint32_t>(bin, BL.valB);
+    if (tpasses & 1) { std::swap(tkA, tkB); std::swap(tvA, tvB); }   // odd pass count: start in B, finish in A
+    uint32_t* bhist = at<uint32_t>(bin, BL.hist);
+    uint32_t* bscan = at<uint32_t>(bin, BL.scan_tmp);
     // Tile ids fit 16 bits up to 65 536 tiles (4096 x 4096 pixels): the R-sized key streams are then
     // half as wide (the key buffers are sized for 32-bit ids either way).
     const bool k16 = T <= 65536u;
@@ -427,7 +476,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             { ProfScope ps(K_SORT_TILE, s); rc = radix_sort<uint16_t>(hA, tvA, hB, tvB, R, tile_bits(T), bhist, bscan, s); }
             if (rc != GSRAST_OK) return rc;
             { ProfScope ps(K_RANGES, s);
-              tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, (tpasses & 1) ? hB : hA, ranges);
+              tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, reinterpret_cast<const uint16_t*>(at<uint32_t>(bin, BL.keyA)), ranges);
               GS_LAUNCHED("tile_ranges"); }
         } else {
             { ProfScope ps(K_EMIT, s);
@@ -436,11 +485,11 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             { ProfScope ps(K_SORT_TILE, s); rc = radix_sort<uint32_t>(tkA, tvA, tkB, tvB, R, tile_bits(T), bhist, bscan, s); }
             if (rc != GSRAST_OK) return rc;
             { ProfScope ps(K_RANGES, s);
-              tile_ranges_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>(R, (tpasses & 1) ? tkB : tkA, ranges);
+              tile_ranges_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>(R, at<uint32_t>(bin, BL.keyA), ranges);
               GS_LAUNCHED("tile_ranges"); }
         }
     }
-    const uint32_t* plist = (tpasses & 1) ? tvB : tvA;
+    const uint32_t* plist = at<uint32_t>(bin, BL.valA);
     {
         ProfScope ps(K_BLEND_FWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;
@@ -490,11 +539,9 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
     const CamArgs cam = make_cam(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, W, H);
     const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
     const GeomLayout GL = geom_layout((size_t)P);
-    const BinLayout BL = bin_layout((size_t)R);
     const ImgLayout IL = img_layout((size_t)W, (size_t)H);
-    const int tpasses = tile_passes(T);
     char* geom = geom_buffer; char* bin = binning_buffer; char* img = image_buffer;
-    const uint32_t* plist = bin ? ((tpasses & 1) ? at<uint32_t>(bin, BL.valB) : at<uint32_t>(bin, BL.valA)) : nullptr;
+    const uint32_t* plist = bin ? at<uint32_t>(bin, 0) : nullptr;     // BinLayout: point_list lives at offset 0
     const float4* rec0 = at<float4>(geom, GL.rec0); const float4* rec1 = at<float4>(geom, GL.rec1); const float4* rec2 = at<float4>(geom, GL.rec2);
 
     if (R > 0) {
@@ -545,7 +592,6 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
     hipStream_t s = (hipStream_t)stream;
     if (P <= 0 || !geom_buffer) return fail(GSRAST_E_ARG, "debug_export: bad arguments");
     const GeomLayout GL = geom_layout((size_t)P);
-    const BinLayout BL = bin_layout((size_t)(R > 0 ? R : 0));
     const ImgLayout IL = img_layout((size_t)width, (size_t)height);
     const uint32_t T = (uint32_t)((width + TILE_X - 1) / TILE_X) * (uint32_t)((height + TILE_Y - 1) / TILE_Y);
     export_geom_kernel<<<(P + 255) / 256, 256, 0, s>>>(
@@ -553,14 +599,9 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
         at<float4>(geom_buffer, GL.rec2), at<float>(geom_buffer, GL.cov3D), at<unsigned char>(geom_buffer, GL.clamped),
         at<uint32_t>(geom_buffer, GL.tiles), depths, means2D, cov3D, conic_opacity, rgb, clamped, tiles_touched);
     GS_LAUNCHED("export_geom");
-    if (R > 0 && binning_buffer && (keys_sorted || point_list)) {
-        const int tpasses = tile_passes(T);
-        const uint32_t* tk = (tpasses & 1) ? at<uint32_t>(binning_buffer, BL.keyB) : at<uint32_t>(binning_buffer, BL.keyA);
-        const uint32_t* tv = (tpasses & 1) ? at<uint32_t>(binning_buffer, BL.valB) : at<uint32_t>(binning_buffer, BL.valA);
-        if (T <= 65536u)
-            export_keys_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>((uint32_t)R, reinterpret_cast<const uint16_t*>(tk), tv, at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
-        else
-            export_keys_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>((uint32_t)R, tk, tv, at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
+    if (R > 0 && binning_buffer && image_buffer && (keys_sorted || point_list)) {
+        export_keys_kernel<<<T, 256, 0, s>>>(at<uint2>(image_buffer, IL.ranges), at<uint32_t>(binning_buffer, 0),
+                                             at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
         GS_LAUNCHED("export_keys");
     }
     if (image_buffer) {

@@ -31,8 +31,9 @@ struct GeomLayout {
         hist, scan_tmp, scalars, total;
 };
 // Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
-//   keyA/B u32[R] x2  tile id ping-pong    valA/B u32[R] x2  Gaussian id ping-pong
-//   hist u32[256*nblk(R)], scan_tmp
+//   valA/B u32[C] x2  Gaussian id ping-pong (valA at offset 0 = the final point_list)
+//   keyA/B u32[C] x2  tile id ping-pong (16-bit ids up to 65 536 tiles), hist u32[256*nblk(C)], scan_tmp
+//   C = capacity >= R the buffer was requested for (1.25 x the previous call's R, or R itself)
 struct BinLayout {
     size_t keyA, keyB, valA, valB, hist, scan_tmp, total;
 };
@@ -81,7 +82,9 @@ static inline BinLayout bin_layout(size_t R)
     BinLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     size_t Rp = R ? R : 1;
-    L.keyA = take(Rp * 4); L.keyB = take(Rp * 4); L.valA = take(Rp * 4); L.valB = take(Rp * 4);
+    // valA first: the sorted Gaussian ids (point_list) always end at offset 0, so the backward needs
+    // neither the instance count nor the capacity the buffer was sized for
+    L.valA = take(Rp * 4); L.valB = take(Rp * 4); L.keyA = take(Rp * 4); L.keyB = take(Rp * 4);
     size_t hist_n = 256 * rs_blocks(Rp);
     L.hist = take(hist_n * 4);
     L.scan_tmp = take(scan_tmp_elems(hist_n) * 4);
