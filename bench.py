@@ -216,6 +216,36 @@ def main():
     _C.set_option("profile", 0)
 
     st = wl.stats()
+    # ---- per-stage device times (all stages bracketed with events; separate, untimed pass) ----
+    per_kernel = None
+    if world == 1:
+        _C.profile_reset()
+        _C.set_option("profile", -1)
+        for _ in range(10):
+            wl.step(None, 1)
+        torch.cuda.synchronize(dev)
+        pk = _C.profile_read()
+        _C.set_option("profile", 0)
+        C = (deg + 1) ** 2
+        Pv, R, Re, N, T = st["P_vis"], st["R"], st["R_eff"], st["N"], st["T"]
+        passes_t = 2 if T > 256 else 1
+        alg = {   # algorithmic HBM bytes per launch of THIS build's stages
+            "preprocess_fwd": P * (44 + 12 * C) + Pv * 64 + P * 8,
+            "sort_depth": P * 20 * 4,
+            "scan_tiles": P * 12,
+            "emit_instances": P * 24 + R * 6,
+            "sort_tile": R * 14 * passes_t,
+            "tile_ranges": R * 2 + T * 8,
+            "blend_fwd": Re * 44 + N * 24,
+            "blend_bwd": N * 20 + Re * 76,
+            "preprocess_bwd": P * (24 * C + 173),
+        }
+        per_kernel = {}
+        for name, nbytes in alg.items():
+            ms = pk[name][0] / max(pk[name][1], 1)
+            per_kernel[name] = {"ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+                                "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                                "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
     result = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
@@ -251,6 +281,7 @@ def main():
                          "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None},
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
+            "per_stage": per_kernel,
         }
 
     # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----

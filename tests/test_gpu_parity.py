@@ -383,3 +383,17 @@ def test_runs_on_a_side_stream(orc, scenes, rast, gpu):
         h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
     s.synchronize()
     _check_forward_exact(o32, h)
+
+
+@pytest.mark.parametrize("W,H", [(16, 16), (1, 1), (17, 5), (300, 8)])
+def test_degenerate_image_sizes(W, H, orc, scenes, rast, gpu):
+    """One tile, one pixel, a partial tile, a one-tile-high strip."""
+    P = 300
+    sc = scenes.synth(P, 111, scale_mul=0.5)
+    cam = scenes.camera(0, 1, W, H)
+    g = scenes.upstream_grad(H, W, 3)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
