@@ -161,6 +161,51 @@ def cpu_baseline(scenes, P, W, H, deg, budget_s):
                        f"the full workload was predicted at {predict:.0f} s > budget")
 
 
+def loss_row(dev, H, W):
+    """"Next" row: fused L1 + D-SSIM loss fwd+bwd at the bench resolution, next to the
+    reference's own formulation (five depthwise conv2d + autograd) run through PyTorch on the same GPU."""
+    import math
+    import torch.nn.functional as F
+    import fused_loss
+    torch.manual_seed(0)
+    y = torch.rand(3, H, W, device=dev)
+    x = (y + 0.05 * torch.randn(3, H, W, device=dev)).clamp(0, 1).requires_grad_(True)
+
+    def fused():
+        x.grad = None
+        fused_loss.l1_dssim_loss(x, y, 0.2).backward()
+
+    g = torch.tensor([math.exp(-(i - 5) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)], device=dev)
+    g = g / g.sum()
+    w = (g[:, None] @ g[None, :]).expand(3, 1, 11, 11).contiguous()
+
+    def eager():
+        x.grad = None
+        conv = lambda a: F.conv2d(a[None], w, padding=5, groups=3)[0]  # noqa: E731
+        mu1, mu2 = conv(x), conv(y)
+        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+        sm = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+        (0.8 * (x - y).abs().mean() + 0.2 * (1 - sm.mean())).backward()
+
+    def t(fn, n=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    ms_f, ms_e = t(fused), t(eager)
+    nbytes = 3 * H * W * 4 * (2 + 3 + 3 + 2 + 1)       # fwd: 2 images in, 3 maps out; bwd: 3 maps + 2 images in, grad out
+    return {"fused_l1_dssim_fwd_bwd": {"ms": round(ms_f, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+                                       "GBps": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
+                                       "hbm_frac": round(nbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "pytorch_conv2d_autograd_same_gpu_ms": round(ms_e, 4),
+                                       "speedup_vs_pytorch": round(ms_e / ms_f, 2), "shape": [3, H, W]}}
+
+
 def main():
     a = parse()
     import view_parallel as vp
@@ -298,6 +343,11 @@ def main():
             sweep[str(p)] = {"views_per_s": round(a.sweep_steps / d, 3), "ms_per_step": round(d / a.sweep_steps * 1e3, 4)}
         result["sweep_1080p"] = sweep
 
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            result["next_rows"] = loss_row(dev, H, W)
+        except Exception as e:
+            result["next_rows"] = {"fused_l1_dssim_fwd_bwd": {"error": str(e)}}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -144,6 +144,19 @@ int gsrast_profile_collect(void);
 int gsrast_profile_read(int kernel_id, double* total_ms, long long* launches);
 void gsrast_profile_reset(void);
 
+/* ---- "next" row of the scope table: the photometric loss right after the rasterizer ----
+ * loss = (1 - lambda_dssim) * mean|img - gt| + lambda_dssim * (1 - mean(SSIM_map(img, gt)))
+ * Replaces the pair l1_loss / ssim of the reference's utils/loss_utils.py:18-19, :38-68 as combined in
+ * helper_train.py:50-53 (5 depthwise 11x11 convolutions forward, autograd through them backward) by one fused
+ * forward and one fused backward kernel.  img, gt: [C][H][W] planar fp32 in HBM.
+ * forward : out3 (device, 3 floats) = {loss, l1, ssim}; scratch keeps three derivative maps for the backward.
+ * backward: dL_dimg [C][H][W] = dL_dloss * d loss / d img  (dL_dloss: device scalar, NULL means 1). */
+size_t gsrast_loss_scratch_bytes(int C, int H, int W);
+int gsrast_loss_forward(int C, int H, int W, const float* img, const float* gt, float lambda_dssim,
+                        float* out3, char* scratch, void* stream);
+int gsrast_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda_dssim,
+                         const float* dL_dloss, const char* scratch, float* dL_dimg, void* stream);
+
 const char* gsrast_last_error(void);
 int gsrast_abi_version(void);
 

@@ -12,11 +12,13 @@
 #include "gsrast_preprocess.h"
 #include "gsrast_binning.h"
 #include "gsrast_blend.h"
+#include "gsrast_loss.h"
 
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -46,10 +48,10 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 // ---- per-kernel device timing (option "profile") -------------------------------------------
 enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
-                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_COUNT };
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COUNT };
 const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
                                             "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
-                                            "preprocess_bwd", "mark_visible" };
+                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd" };
 struct Pending { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<Pending> g_pending;
@@ -610,6 +612,58 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
         if (final_T) GS_HIP(hipMemcpyAsync(final_T, image_buffer + IL.final_T, N * 4, hipMemcpyDeviceToDevice, s));
         if (n_contrib) GS_HIP(hipMemcpyAsync(n_contrib, image_buffer + IL.n_contrib, N * 4, hipMemcpyDeviceToDevice, s));
     }
+    return GSRAST_OK;
+}
+
+// ---- fused L1 + D-SSIM loss (gsrast_loss.h) ---------------------------------------------------
+namespace {
+LossWin make_window()
+{   // utils/loss_utils.py:25-27: exp() in double, stored as fp32, normalised in fp32
+    LossWin w; float sum = 0.f;
+    for (int i = 0; i < LW; i++) { w.w[i] = (float)exp(-(double)((i - LW / 2) * (i - LW / 2)) / (2.0 * 1.5 * 1.5)); sum += w.w[i]; }
+    for (int i = 0; i < LW; i++) w.w[i] = w.w[i] / sum;
+    return w;
+}
+struct LossLayout { size_t d_mu, d_e11, d_e12, partial, total; int nblk; };
+LossLayout loss_layout(int C, int H, int W)
+{
+    LossLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    const size_t n = (size_t)C * H * W;
+    L.nblk = C * ((W + LT - 1) / LT) * ((H + LT - 1) / LT);
+    L.d_mu = take(n * 4); L.d_e11 = take(n * 4); L.d_e12 = take(n * 4); L.partial = take((size_t)L.nblk * 8);
+    L.total = o + 256;
+    return L;
+}
+} // namespace
+
+size_t gsrast_loss_scratch_bytes(int C, int H, int W) { return (C > 0 && H > 0 && W > 0) ? loss_layout(C, H, W).total : 256; }
+
+int gsrast_loss_forward(int C, int H, int W, const float* img, const float* gt, float lambda_dssim, float* out3,
+                        char* scratch, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !out3 || !scratch) return fail(GSRAST_E_ARG, "loss_forward: bad argument");
+    const LossLayout L = loss_layout(C, H, W);
+    ProfScope ps(K_LOSS_FWD, s);
+    loss_fwd_kernel<<<L.nblk, 256, 0, s>>>(C, H, W, img, gt, make_window(), at<float>(scratch, L.d_mu), at<float>(scratch, L.d_e11),
+                                           at<float>(scratch, L.d_e12), at<float2>(scratch, L.partial));
+    GS_LAUNCHED("loss_fwd");
+    loss_reduce_kernel<<<1, 256, 0, s>>>(at<float2>(scratch, L.partial), L.nblk, 1.0f / ((float)C * (float)H * (float)W), lambda_dssim, out3);
+    GS_LAUNCHED("loss_reduce");
+    return GSRAST_OK;
+}
+
+int gsrast_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda_dssim, const float* dL_dloss,
+                         const char* scratch, float* dL_dimg, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dL_dimg || !scratch) return fail(GSRAST_E_ARG, "loss_backward: bad argument");
+    const LossLayout L = loss_layout(C, H, W);
+    ProfScope ps(K_LOSS_BWD, s);
+    loss_bwd_kernel<<<L.nblk, 256, 0, s>>>(C, H, W, img, gt, make_window(), at<float>(scratch, L.d_mu), at<float>(scratch, L.d_e11),
+                                           at<float>(scratch, L.d_e12), lambda_dssim, 1.0f / ((float)C * (float)H * (float)W), dL_dloss, dL_dimg);
+    GS_LAUNCHED("loss_bwd");
     return GSRAST_OK;
 }
 

@@ -31,7 +31,7 @@ EXPORTS = (
     "gsrast_binning_bytes", "gsrast_image_bytes", "gsrast_debug_export", "gsrast_set_option",
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
-    "gsrast_abi_version",
+    "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
 )
 
 
@@ -74,6 +74,12 @@ def lib() -> C.CDLL:
     L.gsrast_profile_read.restype = ci
     L.gsrast_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.gsrast_profile_reset.restype = None
+    L.gsrast_loss_scratch_bytes.restype = C.c_size_t
+    L.gsrast_loss_scratch_bytes.argtypes = [ci, ci, ci]
+    L.gsrast_loss_forward.restype = ci
+    L.gsrast_loss_forward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp]
+    L.gsrast_loss_backward.restype = ci
+    L.gsrast_loss_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
     if L.gsrast_abi_version() != 1:

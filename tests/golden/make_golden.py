@@ -104,3 +104,19 @@ if __name__ == "__main__":
     else:
         print("no /root/reference here: keeping the committed ref_python_vectors.npz")
     oracle_scenes()
+
+
+def loss_vectors():
+    """loss_vectors.npz: one image pair + the loss oracle's (loss, l1, ssim) -- drift guard for oracle/loss_oracle.py.
+    (utils/loss_utils.py of the reference imports torchmetrics, which this image lacks, so it cannot be imported.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_loss
+    from oracle import loss_oracle
+    img, gt = test_loss._images(3, 48, 64, 9)
+    out = np.array(loss_oracle.l1_dssim(img, gt, 0.2))
+    np.savez_compressed(os.path.join(HERE, "loss_vectors.npz"), img=img, gt=gt, lambda_dssim=np.float64(0.2), loss_l1_ssim=out)
+    print("wrote loss_vectors.npz", out)
+
+
+if __name__ == "__main__":
+    loss_vectors()
