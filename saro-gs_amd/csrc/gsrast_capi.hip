@@ -148,12 +148,20 @@ struct Readback {
     uint32_t* pinned = nullptr; hipEvent_t ev = nullptr;
     ~Readback() { if (pinned) (void)hipHostFree(pinned); if (ev) (void)hipEventDestroy(ev); }
 };
-thread_local Readback t_readback;
+constexpr int kMaxDevices = 32;
+thread_local Readback t_readback[kMaxDevices];     // one per (host thread, device): events belong to a device
 int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out)
 {
-    Readback& rb = t_readback;
+    int device = 0;
+    GS_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) {     // exotic topology: plain blocking copy
+        GS_HIP(hipMemcpyAsync(out, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GS_HIP(hipStreamSynchronize(s));
+        return GSRAST_OK;
+    }
+    Readback& rb = t_readback[device];
     if (!rb.pinned) {
-        GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocDefault));
+        GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable));
         GS_HIP(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
     }
     GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
