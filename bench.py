@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--ppl-bwd", type=int, default=0)
     ap.add_argument("--no-cull", action="store_true", help="disable wave-level strip culling (A/B experiments)")
     ap.add_argument("--no-lpt", action="store_true", help="disable heaviest-tile-first launch order (A/B experiments)")
+    ap.add_argument("--binning", type=int, default=None, help="0 run-compressed binning (default), 1 instance-level two-pass sort")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     return ap.parse_args()
 
@@ -236,6 +237,8 @@ def main():
         _C.set_option("cull", 0)
     if a.no_lpt:
         _C.set_option("lpt", 0)
+    if a.binning is not None:
+        _C.set_option("binning", a.binning)
 
     P, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)

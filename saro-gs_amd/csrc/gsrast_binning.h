@@ -47,16 +47,24 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total)
     return base + inc - v;
 }
 
+// value i of the scanned sequence: src[idx[i]] (gather), src[i], or -- when `runs` is set -- the height
+// field (.y >> 16) of the i-th column run
+__device__ __forceinline__ uint32_t scan_load(const uint32_t* src, const uint32_t* idx, const uint2* runs, uint32_t i)
+{
+    if (runs) return runs[i].y >> 16;
+    return idx ? src[idx[i]] : src[i];
+}
+
 __global__ void __launch_bounds__(256)
-scan_block_sums_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n,
-                       uint32_t* __restrict__ sums)
+scan_block_sums_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, const uint2* __restrict__ runs,
+                       uint32_t n, uint32_t* __restrict__ sums)
 {
     const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * 16;
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         uint32_t i = base + k;
-        if (i < n) s += idx ? src[idx[i]] : src[i];
+        if (i < n) s += scan_load(src, idx, runs, i);
     }
     uint32_t tot;
     block_excl_scan(s, &tot);
@@ -83,8 +91,8 @@ scan_single_block_kernel(uint32_t* __restrict__ data, uint32_t m)
 }
 
 __global__ void __launch_bounds__(256)
-scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n,
-                  const uint32_t* __restrict__ sums_scanned /* exclusive, may be null for 1 block */,
+scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, const uint2* __restrict__ runs,
+                  uint32_t n, const uint32_t* __restrict__ sums_scanned /* exclusive, may be null for 1 block */,
                   uint32_t* __restrict__ dst, int inclusive, uint32_t* __restrict__ total_out)
 {
     const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * 16;
@@ -92,7 +100,7 @@ scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         uint32_t i = base + k;
-        v[k] = (i < n) ? (idx ? src[idx[i]] : src[i]) : 0u;
+        v[k] = (i < n) ? scan_load(src, idx, runs, i) : 0u;
         s += v[k];
     }
     uint32_t tot;
@@ -162,13 +170,14 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
-template <typename KeyT>
+template <typename KeyT, typename ValT>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                     KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
+radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
+                     KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
                      const uint32_t* __restrict__ hist_scanned /* per-digit exclusive row scans */,
                      const uint32_t* __restrict__ digit_total, uint32_t nblk,
-                     const uint32_t* __restrict__ gather_src /* optional */, uint32_t* __restrict__ gather_dst)
+                     const uint2* __restrict__ gather_rect /* optional, last depth pass only */,
+                     uint32_t* __restrict__ gather_tiles, uint32_t* __restrict__ gather_width)
 {
     // Ranks -> block-local order in LDS -> coalesced write-out: after the exchange consecutive lanes
     // hold consecutive elements of the same digit, whose global destinations are consecutive too.
@@ -176,26 +185,28 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restric
     __shared__ uint32_t dstart[256];       // first block-local slot of each digit
     __shared__ uint32_t gbase[256];        // global destination of that slot
     __shared__ KeyT xk[RS_CHUNK];
-    __shared__ uint32_t xv[RS_CHUNK];
+    __shared__ ValT xv[RS_CHUNK];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     __syncthreads();
     volatile uint32_t* wc = cnt[wave];
     const uint32_t wbase = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], rk[RS_ITEMS];
+    const int nbits = 32 - __builtin_clz(mask);          // digit width of this pass (mask = 2^w - 1)
+    uint32_t key[RS_ITEMS], rk[RS_ITEMS];
+    ValT val[RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[i] : 0u;
+        val[r] = valid ? vals_in[i] : ValT{};
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = (key[r] >> shift) & mask;
-        const uint64_t m = wave_match8(d, valid);
+        const uint64_t m = wave_match8(d, valid, nbits);
         const uint32_t prev = wc[d];
         const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
         if (valid && below == 0) wc[d] = prev + (uint32_t)__popcll(m);
@@ -233,9 +244,16 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restric
             const uint32_t d = (k >> shift) & mask;
             const uint32_t pos = gbase[d] + (slot - dstart[d]);
             keys_out[pos] = kk;
-            const uint32_t vv = xv[slot];
+            const ValT vv = xv[slot];
             vals_out[pos] = vv;
-            if (gather_src) gather_dst[pos] = gather_src[vv];   // last depth pass: tiles_touched in depth order
+            if constexpr (sizeof(ValT) == 4) {
+                if (gather_rect) {   // last depth pass: tile count and rectangle width of each Gaussian, in depth order
+                    const uint2 rc = gather_rect[vv];
+                    const uint32_t w = (rc.y & 0xFFFFu) - (rc.x & 0xFFFFu), h = (rc.y >> 16) - (rc.x >> 16);
+                    gather_tiles[pos] = w * h;
+                    gather_width[pos] = w;
+                }
+            }
         }
     }
 }
@@ -305,6 +323,206 @@ tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ tile_keys_sorted, uint2*
         if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
     }
     if (i == R - 1) ranges[cur].y = R;
+}
+
+// ==========================================================================================
+// Run-compressed binning (default when the image has <= 256 tile rows).
+//
+// Sorting by tile id = sorting by (row y, column x).  LSD order: x first, then y.  The x pass does not
+// need instances at all: a Gaussian's tile rectangle is w "column runs" (x, y0, h), so the first pass
+// sorts Q' = sum(w) compact runs (about R/5 of them) instead of R = sum(w*h) instances.  The second pass
+// sorts by y; its input is the virtual instance sequence obtained by expanding the x-sorted runs in
+// order, which the scatter kernel generates on the fly, and its histogram is computed from the runs
+// with a difference array.  Every instance is therefore written exactly ONCE (Gaussian id + tile id,
+// 6 bytes) instead of being emitted and carried through two full radix passes (36 bytes of traffic).
+// Stability of both passes keeps the depth order, so point_list and the tile ranges are again
+// bit-identical to the reference's single 64-bit-key sort.
+constexpr int RUNS_PER_BLOCK = 512;
+
+// Column runs of the depth-ordered Gaussians: run k of Gaussian g covers column x0+k, rows [y0, y0+h).
+// key = x (16 bit), payload = {g, y0 | h << 16}.  Balanced and coalesced like emit_instances_kernel.
+__global__ void __launch_bounds__(256)
+emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ woffsets /* incl. scan of widths */,
+                        const uint2* __restrict__ rect, uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals)
+{
+    __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t g = 0, w = 0, incl, x0 = 0, yh = 0;
+    if (j < P) {
+        g = order[j];
+        incl = woffsets[j];
+        const uint2 rc = rect[g];
+        x0 = rc.x & 0xFFFFu;
+        w = (rc.y & 0xFFFFu) - x0;
+        yh = (rc.x >> 16) | (((rc.y >> 16) - (rc.x >> 16)) << 16);
+    } else {
+        incl = P > 0 ? woffsets[P - 1] : 0u;
+    }
+    const uint32_t e = incl - w;
+    const uint32_t wstart = __shfl(e, 0, 64);
+    const uint32_t wend = __shfl(incl, 63, 64);
+    s_e[wave][lane] = e - wstart; s_g[wave][lane] = g; s_x0[wave][lane] = x0; s_yh[wave][lane] = yh;
+    __syncthreads();
+    const uint32_t C = wend - wstart;
+    for (uint32_t o = lane; o < C; o += 64) {
+        uint32_t sidx = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (s_e[wave][sidx + step] <= o) sidx += step;
+        const uint32_t k = o - s_e[wave][sidx];
+        run_keys[wstart + o] = (uint16_t)(s_x0[wave][sidx] + k);
+        run_vals[wstart + o] = make_uint2(s_g[wave][sidx], s_yh[wave][sidx]);
+    }
+}
+
+// Per-block histogram over tile rows of the instances of RUNS_PER_BLOCK consecutive (x-sorted) runs:
+// +1 at y0, -1 at y0+h in an LDS difference array, prefix sum, one column of the digit-major table.
+__global__ void __launch_bounds__(256)
+run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, uint32_t* __restrict__ block_hist, uint32_t nblk)
+{
+    __shared__ int diff[257];
+    for (int k = threadIdx.x; k < 257; k += 256) diff[k] = 0;
+    __syncthreads();
+    const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)RUNS_PER_BLOCK; k += 256) {
+        const uint32_t r = r0 + k;
+        if (r < Q) {
+            const uint32_t yh = run_vals[r].y;
+            const uint32_t y0 = yh & 0xFFFFu, h = yh >> 16;
+            atomicAdd(&diff[y0], 1);
+            atomicAdd(&diff[y0 + h], -1);
+        }
+    }
+    __syncthreads();
+    const uint32_t mine = (uint32_t)diff[threadIdx.x];
+    uint32_t tot;
+    const uint32_t incl = block_excl_scan(mine, &tot) + mine;      // wrap-around arithmetic of the signed deltas is exact
+    block_hist[(size_t)threadIdx.x * nblk + blockIdx.x] = incl;
+}
+
+// Second (final) pass: instances of the block's runs, generated in order, ranked by tile row with the
+// same ballot-match / LDS-exchange scheme as radix_scatter_kernel, written once.
+// The run an instance belongs to is found without searching: every run sets ONE bit (at its first
+// instance) in a per-sub-batch LDS bitmap, and "number of run starts at or before slot i" is a word
+// prefix count plus a popcount of the slot's word.
+__global__ void __launch_bounds__(RS_THREADS)
+run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, const uint2* __restrict__ run_vals,
+                        uint32_t Q, int gx, int ybits, const uint32_t* __restrict__ hist_scanned,
+                        const uint32_t* __restrict__ digit_total, uint32_t nblk,
+                        uint32_t* __restrict__ point_list, uint16_t* __restrict__ tile_keys)
+{
+    __shared__ uint32_t s_start[RUNS_PER_BLOCK + 1]; // block-local first instance of every run (+ total at the end)
+    __shared__ uint2 s_val[RUNS_PER_BLOCK];
+    __shared__ uint16_t s_x[RUNS_PER_BLOCK];
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t dstart[256], gbase[256], running[256];
+    __shared__ unsigned long long bits[RS_CHUNK / 64];
+    __shared__ uint32_t wpre[RS_CHUNK / 64];         // run starts before each bitmap word (relative to the sub-batch)
+    __shared__ uint32_t xk[RS_CHUNK];                // y | tile << 16
+    __shared__ uint32_t xv[RS_CHUNK];
+    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t t = threadIdx.x;
+    const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
+    const uint32_t nruns = (Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK;
+    {   // stage the runs; exclusive prefix of their heights = first instance of each run (2 runs per lane)
+        const uint32_t k0 = 2 * t, k1 = 2 * t + 1;
+        uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
+        if (k0 < nruns) { v0 = run_vals[r0 + k0]; s_x[k0] = run_keys[r0 + k0]; }
+        if (k1 < nruns) { v1 = run_vals[r0 + k1]; s_x[k1] = run_keys[r0 + k1]; }
+        s_val[k0] = v0; s_val[k1] = v1;
+        const uint32_t h0 = v0.y >> 16, h1 = v1.y >> 16;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(h0 + h1, &tot);
+        s_start[k0] = ex; s_start[k1] = ex + h0;
+        if (t == 0) s_start[RUNS_PER_BLOCK] = tot;
+        uint32_t gtot;
+        const uint32_t dbase = block_excl_scan(digit_total[t], &gtot);   // instances in lower tile rows, globally
+        running[t] = dbase + hist_scanned[(size_t)t * nblk + blockIdx.x];
+    }
+    __syncthreads();
+    const uint32_t ninst = s_start[RUNS_PER_BLOCK];
+    volatile uint32_t* wc = cnt[wave];
+    uint32_t first_run = 0;                           // runs starting before the current sub-batch (uniform)
+    for (uint32_t sb = 0; sb < ninst; sb += RS_CHUNK) {
+        for (int k = t; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
+        if (t < RS_CHUNK / 64) bits[t] = 0ull;
+        __syncthreads();
+        const uint32_t nsub = (ninst - sb) < (uint32_t)RS_CHUNK ? (ninst - sb) : (uint32_t)RS_CHUNK;
+        for (uint32_t k = t; k < nruns; k += RS_THREADS) {
+            const uint32_t st = s_start[k];
+            if (st >= sb && st < sb + RS_CHUNK && (s_val[k].y >> 16) != 0u)
+                atomicOr(&bits[(st - sb) >> 6], 1ull << ((st - sb) & 63u));
+        }
+        __syncthreads();
+        if (t < 64) {   // wave 0: exclusive prefix of the words' popcounts
+            const uint32_t pc = (uint32_t)__popcll(bits[t]);
+            wpre[t] = wave_incl_scan(pc) - pc;
+        }
+        __syncthreads();
+        // a short sub-batch is split evenly over the four waves: share = slots per wave (multiple of 64)
+        const uint32_t share = ((nsub + 255u) >> 8) << 6;
+        uint32_t key[RS_ITEMS], val[RS_ITEMS], rk[RS_ITEMS];     // key = y | tile << 16
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            if ((uint32_t)r * 64u >= share) break;
+            const uint32_t ls = wave * share + r * 64 + lane;               // slot inside the sub-batch (= instance order)
+            const bool valid = ls < nsub;
+            uint32_t y = 0, tile = 0, g = 0;
+            if (valid) {
+                const uint32_t wd = ls >> 6;
+                // runs that start at or before this slot, minus one = index of the run covering it
+                const uint32_t upto = wpre[wd] + (uint32_t)__popcll(bits[wd] & (~0ull >> (63u - (ls & 63u))));
+                const uint32_t k = first_run + upto - 1u;
+                const uint2 v = s_val[k];
+                y = (v.y & 0xFFFFu) + (sb + ls - s_start[k]);
+                tile = y * (uint32_t)gx + s_x[k];
+                g = v.x;
+            }
+            key[r] = y | (tile << 16); val[r] = g;
+            const uint64_t m = wave_match8(y, valid, ybits);
+            const uint32_t prev = wc[y];
+            const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
+            if (valid && below == 0) wc[y] = prev + (uint32_t)__popcll(m);
+            rk[r] = prev + below;
+        }
+        first_run += wpre[RS_CHUNK / 64 - 1] + (uint32_t)__popcll(bits[RS_CHUNK / 64 - 1]);
+        __syncthreads();
+        {
+            const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+            uint32_t tot;
+            const uint32_t start = block_excl_scan(c0 + c1 + c2 + c3, &tot);
+            dstart[t] = start;
+            gbase[t] = running[t];
+            running[t] += c0 + c1 + c2 + c3;
+            cnt[0][t] = start; cnt[1][t] = start + c0; cnt[2][t] = start + c0 + c1; cnt[3][t] = start + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            if ((uint32_t)r * 64u >= share) break;
+            const uint32_t ls = wave * share + r * 64 + lane;
+            if (ls < nsub) {
+                const uint32_t slot = cnt[wave][key[r] & 0xFFFFu] + rk[r];
+                xk[slot] = key[r]; xv[slot] = val[r];
+            }
+        }
+        __syncthreads();
+        // write-out: slot order = (row, instance order)
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const uint32_t slot = r * RS_THREADS + t;
+            if ((uint32_t)r * RS_THREADS >= nsub) break;
+            if (slot < nsub) {
+                const uint32_t kk = xk[slot];
+                const uint32_t y = kk & 0xFFFFu;
+                const uint32_t pos = gbase[y] + (slot - dstart[y]);
+                point_list[pos] = xv[slot];
+                tile_keys[pos] = (uint16_t)(kk >> 16);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Launch order of the blend kernels: tiles sorted by descending work (bucketed counting sort,

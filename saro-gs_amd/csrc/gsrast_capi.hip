@@ -93,20 +93,20 @@ int post_launch(const char* what, hipStream_t s)
 // ---- scan / sort drivers --------------------------------------------------------------------
 // dst[i] = scan of (idx ? src[idx[i]] : src[i]); two levels (single-block scan of block sums).
 int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst, bool inclusive,
-             uint32_t* tmp, uint32_t* total_out, hipStream_t s)
+             uint32_t* tmp, uint32_t* total_out, hipStream_t s, const uint2* runs = nullptr)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nb = (n + SC_CHUNK - 1) / SC_CHUNK;
     if (nb == 1) {
-        scan_apply_kernel<<<1, 256, 0, s>>>(src, idx, n, nullptr, dst, inclusive ? 1 : 0, total_out);
+        scan_apply_kernel<<<1, 256, 0, s>>>(src, idx, runs, n, nullptr, dst, inclusive ? 1 : 0, total_out);
         GS_LAUNCHED("scan_apply");
         return GSRAST_OK;
     }
-    scan_block_sums_kernel<<<nb, 256, 0, s>>>(src, idx, n, tmp);
+    scan_block_sums_kernel<<<nb, 256, 0, s>>>(src, idx, runs, n, tmp);
     GS_LAUNCHED("scan_block_sums");
     scan_single_block_kernel<<<1, 256, 0, s>>>(tmp, nb);
     GS_LAUNCHED("scan_single_block");
-    scan_apply_kernel<<<nb, 256, 0, s>>>(src, idx, n, tmp, dst, inclusive ? 1 : 0, total_out);
+    scan_apply_kernel<<<nb, 256, 0, s>>>(src, idx, runs, n, tmp, dst, inclusive ? 1 : 0, total_out);
     GS_LAUNCHED("scan_apply");
     return GSRAST_OK;
 }
@@ -116,10 +116,10 @@ int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst
 // contiguous runs in the scatter's write-out).  Result ends in (kA,vA) if the pass count is even,
 // else in (kB,vB).
 int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
-template <typename KeyT>
-int radix_sort(KeyT* kA, uint32_t* vA, KeyT* kB, uint32_t* vB, uint32_t n, int bits,
+template <typename KeyT, typename ValT = uint32_t>
+int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s,
-               const uint32_t* gather_src = nullptr, uint32_t* gather_dst = nullptr)
+               const uint2* gather_rect = nullptr, uint32_t* gather_tiles = nullptr, uint32_t* gather_width = nullptr)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nblk = (uint32_t)rs_blocks(n);
@@ -133,8 +133,8 @@ int radix_sort(KeyT* kA, uint32_t* vA, KeyT* kB, uint32_t* vB, uint32_t n, int b
         radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
         GS_LAUNCHED("radix_rowscan");
         const bool last = p == passes - 1;
-        radix_scatter_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk,
-                                                               last ? gather_src : nullptr, last ? gather_dst : nullptr);
+        radix_scatter_kernel<KeyT, ValT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk,
+                                                                     last ? gather_rect : nullptr, gather_tiles, gather_width);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
         shift += w;
@@ -150,12 +150,12 @@ struct Readback {
 };
 constexpr int kMaxDevices = 32;
 thread_local Readback t_readback[kMaxDevices];     // one per (host thread, device): events belong to a device
-int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out)
+int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 {
     int device = 0;
     GS_HIP(hipGetDevice(&device));
     if (device < 0 || device >= kMaxDevices) {     // exotic topology: plain blocking copy
-        GS_HIP(hipMemcpyAsync(out, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GS_HIP(hipMemcpyAsync(out, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
         GS_HIP(hipStreamSynchronize(s));
         return GSRAST_OK;
     }
@@ -164,18 +164,19 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out)
         GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable));
         GS_HIP(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
     }
-    GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
     GS_HIP(hipEventRecord(rb.ev, s));
     hipError_t e;
     while ((e = hipEventQuery(rb.ev)) == hipErrorNotReady) { }
     if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "read_u32", e);
-    *out = *rb.pinned;
+    for (int k = 0; k < nwords; k++) out[k] = rb.pinned[k];
     return GSRAST_OK;
 }
 // Instances of the previous forward call: the binning buffer is requested for 1.25x that many BEFORE
 // the host waits for the real count, so the (Python) allocation callback runs while the GPU is still
 // busy with preprocess / depth sort instead of in the idle gap after the readback.
-std::atomic<uint32_t> g_R_hint{0};
+std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0};
+std::atomic<int> g_binning{0};     // 0 = run-compressed binning when the image allows it, 1 = always the instance-level two-pass sort
 
 CamArgs make_cam(const float* view, const float* proj, const float* campos, float tanx, float tany,
                  float scale_mod, int W, int H)
@@ -303,6 +304,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_binning = value; return 0; }
     if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
@@ -321,6 +323,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_ppl_fwd.load();
     if (!strcmp(name, "bwd_pixels_per_lane")) return g_ppl_bwd.load();
     if (!strcmp(name, "cull")) return g_cull.load();
+    if (!strcmp(name, "binning")) return g_binning.load();
     return GSRAST_E_ARG;
 }
 
@@ -413,6 +416,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     uint32_t *kA = at<uint32_t>(geom, GL.keyA), *kB = at<uint32_t>(geom, GL.keyB);
     uint32_t *vA = at<uint32_t>(geom, GL.valA), *vB = at<uint32_t>(geom, GL.valB);
     uint32_t* offsets = at<uint32_t>(geom, GL.offsets);
+    uint32_t* woffsets = at<uint32_t>(geom, GL.woffsets);
     uint32_t* hist = at<uint32_t>(geom, GL.hist);
     uint32_t* scan_tmp = at<uint32_t>(geom, GL.scan_tmp);
     uint32_t* scalars = at<uint32_t>(geom, GL.scalars);
@@ -427,8 +431,8 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     }
     {
         ProfScope ps(K_SORT_DEPTH, s);
-        // the last pass also writes tiles_touched in depth order (into `offsets`, scanned in place below)
-        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, tiles, offsets);
+        // the last pass also writes tile counts and rectangle widths in depth order (scanned in place below)
+        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, offsets, woffsets);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A
@@ -436,47 +440,82 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         ProfScope ps(K_SCAN_TILES, s);
         int rc = scan_u32(offsets, nullptr, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
         if (rc != GSRAST_OK) return rc;
+        rc = scan_u32(woffsets, nullptr, (uint32_t)P, woffsets, true, scan_tmp, scalars + 1, s);   // column runs
+        if (rc != GSRAST_OK) return rc;
     }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
     GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s)); // reference rasterizer_impl.cu:311
     const int tpasses = tile_passes(T);
-    uint32_t cap = 0;
+    // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
+    const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
+    auto bin_bytes = [&](uint32_t capR, uint32_t capQ) {
+        return runbin ? runbin_layout((size_t)capR, (size_t)capQ).total : bin_layout((size_t)capR).total;
+    };
+    auto grow = [](uint32_t v) { const uint64_t w = (uint64_t)v + v / 4 + 4096; return w > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)w; };
+    uint32_t cap = 0, capQ = 0;
     char* bin = nullptr;
     static const bool trace = getenv("GSRAST_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     if (const uint32_t hint = g_R_hint.load()) {
-        const uint64_t want = (uint64_t)hint + hint / 4 + 4096;
-        cap = want > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)want;
-        bin = (char*)binning_alloc(binning_ctx, bin_layout((size_t)cap).total);
-        if (!bin) cap = 0;
+        cap = grow(hint); capQ = grow(g_Q_hint.load());
+        bin = (char*)binning_alloc(binning_ctx, bin_bytes(cap, capQ));
+        if (!bin) cap = capQ = 0;
     }
     auto t1 = std::chrono::steady_clock::now();
-    uint32_t num_rendered = 0;
-    { int rc = read_u32(scalars, s, &num_rendered); if (rc != GSRAST_OK) return rc; }
+    uint32_t counts[2] = { 0, 0 };      // {instances R, column runs Q}
+    { int rc = read_u32(scalars, s, counts, 2); if (rc != GSRAST_OK) return rc; }
     auto t2 = std::chrono::steady_clock::now();
-    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u\n",
-                       std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, num_rendered);
-    if (num_rendered > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
-    const uint32_t R = num_rendered;
-    g_R_hint = R;
-    if (!bin || R > cap) {      // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
-        cap = R;
-        bin = (char*)binning_alloc(binning_ctx, bin_layout((size_t)cap).total);
+    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u\n",
+                       std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, counts[0], counts[1]);
+    if (counts[0] > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
+    const uint32_t R = counts[0], Q = counts[1];
+    g_R_hint = R; g_Q_hint = Q;
+    if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
+        cap = R; capQ = Q;
+        bin = (char*)binning_alloc(binning_ctx, bin_bytes(cap, capQ));
         if (!bin) return fail(GSRAST_E_ALLOC, "forward: binning allocation failed");
     }
-    // The layout inside the buffer follows its CAPACITY; the sorted Gaussian ids always end in the array
-    // at offset 0 (valA), whatever the capacity and the pass count, which is all the backward needs.
-    const BinLayout BL = bin_layout((size_t)cap);
-    uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
-    uint32_t *tvA = at<uint32_t>(bin, BL.valA), *tvB = at<uint32_t>(bin, BL.valB);
-    if (tpasses & 1) { std::swap(tkA, tkB); std::swap(tvA, tvB); }   // odd pass count: start in B, finish in A
-    uint32_t* bhist = at<uint32_t>(bin, BL.hist);
-    uint32_t* bscan = at<uint32_t>(bin, BL.scan_tmp);
-    // Tile ids fit 16 bits up to 65 536 tiles (4096 x 4096 pixels): the R-sized key streams are then
-    // half as wide (the key buffers are sized for 32-bit ids either way).
-    const bool k16 = T <= 65536u;
-    if (R > 0) {
+    // The layout inside the buffer follows its CAPACITY; the sorted Gaussian ids (point_list) always end in the
+    // array at offset 0, whatever the capacity, the pass count and the binning scheme -- all the backward needs.
+    const uint32_t* plist = at<uint32_t>(bin, 0);
+    if (R > 0 && runbin) {
+        const RunBinLayout RL = runbin_layout((size_t)cap, (size_t)capQ);
+        uint16_t *rkA = at<uint16_t>(bin, RL.rkeyA), *rkB = at<uint16_t>(bin, RL.rkeyB);
+        uint2 *rvA = at<uint2>(bin, RL.rvalA), *rvB = at<uint2>(bin, RL.rvalB);
+        uint32_t* hist_x = at<uint32_t>(bin, RL.hist_x);
+        uint32_t* hist_y = at<uint32_t>(bin, RL.hist_y);
+        uint32_t* rscan = at<uint32_t>(bin, RL.scan_tmp);
+        uint16_t* tkeys = at<uint16_t>(bin, RL.tile_keys);
+        uint32_t* plist_w = at<uint32_t>(bin, RL.point_list);
+        const int xbits = tile_bits((size_t)cam.gx);
+        {   ProfScope ps(K_EMIT, s);
+            emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, rect, rkA, rvA);
+            GS_LAUNCHED("emit_column_runs"); }
+        {   ProfScope ps(K_SORT_TILE, s);
+            int rc = radix_sort<uint16_t, uint2>(rkA, rvA, rkB, rvB, Q, xbits, hist_x, rscan, s);      // runs by column
+            if (rc != GSRAST_OK) return rc;
+            if (radix_passes(xbits) & 1) { std::swap(rkA, rkB); std::swap(rvA, rvB); }                   // sorted runs now in (rkA, rvA)
+            const uint32_t nblk = (Q + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
+            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, Q, hist_y, nblk);
+            GS_LAUNCHED("run_hist_rows");
+            radix_rowscan_kernel<<<256, 256, 0, s>>>(hist_y, nblk, rscan);
+            GS_LAUNCHED("radix_rowscan");
+            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rkA, rvA, Q, cam.gx, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, tkeys);
+            GS_LAUNCHED("run_scatter_rows"); }
+        {   ProfScope ps(K_RANGES, s);
+            tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, tkeys, ranges);
+            GS_LAUNCHED("tile_ranges"); }
+    } else if (R > 0) {
+        const BinLayout BL = bin_layout((size_t)cap);
+        uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
+        uint32_t *tvA = at<uint32_t>(bin, BL.valA), *tvB = at<uint32_t>(bin, BL.valB);
+        if (tpasses & 1) { std::swap(tkA, tkB); std::swap(tvA, tvB); }   // odd pass count: start in B, finish in A
+        uint32_t* bhist = at<uint32_t>(bin, BL.hist);
+        uint32_t* bscan = at<uint32_t>(bin, BL.scan_tmp);
+        // Tile ids fit 16 bits up to 65 536 tiles (4096 x 4096 pixels): the R-sized key streams are then
+        // half as wide (the key buffers are sized for 32-bit ids either way).
+        const bool k16 = T <= 65536u;
         int rc = GSRAST_OK;
         if (k16) {
             uint16_t *hA = reinterpret_cast<uint16_t*>(tkA), *hB = reinterpret_cast<uint16_t*>(tkB);
@@ -499,7 +538,6 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
               GS_LAUNCHED("tile_ranges"); }
         }
     }
-    const uint32_t* plist = at<uint32_t>(bin, BL.valA);
     {
         ProfScope ps(K_BLEND_FWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;

@@ -27,7 +27,7 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
 //   scalars  u32[64]     [0] = num_rendered
 struct GeomLayout {
-    size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, keyA, keyB, valA, valB, offsets,
+    size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, keyA, keyB, valA, valB, offsets, woffsets,
         hist, scan_tmp, scalars, total;
 };
 // Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
@@ -68,7 +68,7 @@ static inline GeomLayout geom_layout(size_t P)
     L.depths = take(Pp * 4); L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16);
     L.cov3D = take(Pp * 24); L.clamped = take(Pp); L.tiles = take(Pp * 4); L.rect = take(Pp * 8);
     L.keyA = take(Pp * 4); L.keyB = take(Pp * 4); L.valA = take(Pp * 4); L.valB = take(Pp * 4);
-    L.offsets = take(Pp * 4);
+    L.offsets = take(Pp * 4); L.woffsets = take(Pp * 4);
     size_t hist_n = 256 * rs_blocks(Pp);
     L.hist = take(hist_n * 4);
     size_t st = scan_tmp_elems(hist_n) > scan_tmp_elems(Pp) ? scan_tmp_elems(hist_n) : scan_tmp_elems(Pp);
@@ -91,6 +91,27 @@ static inline BinLayout bin_layout(size_t R)
     L.total = o + 256;
     return L;
 }
+// Run-compressed binning (gsrast_binning.h): capR = instance capacity, capQ = column-run capacity.
+//   point_list u32[capR] (offset 0), tile_keys u16[capR], run key / value ping-pong u16[capQ] x2 / uint2[capQ] x2,
+//   histogram of the x pass (256 x blocks(capQ)), of the row pass (256 x capQ/512), scan partials
+struct RunBinLayout {
+    size_t point_list, tile_keys, rkeyA, rkeyB, rvalA, rvalB, hist_x, hist_y, scan_tmp, total;
+};
+static inline RunBinLayout runbin_layout(size_t capR, size_t capQ)
+{
+    RunBinLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    if (!capR) capR = 1;
+    if (!capQ) capQ = 1;
+    L.point_list = take(capR * 4); L.tile_keys = take(capR * 2);
+    L.rkeyA = take(capQ * 2); L.rkeyB = take(capQ * 2); L.rvalA = take(capQ * 8); L.rvalB = take(capQ * 8);
+    L.hist_x = take(256 * rs_blocks(capQ) * 4);
+    L.hist_y = take(256 * ((capQ + 511) / 512) * 4);
+    L.scan_tmp = take((scan_tmp_elems(capQ) + 512) * 4);
+    L.total = o + 256;
+    return L;
+}
+
 static inline ImgLayout img_layout(size_t W, size_t H)
 {
     ImgLayout L; size_t o = 0;
@@ -221,12 +242,12 @@ __device__ __forceinline__ float wave_sum8_transposed(const float (&v)[8], unsig
     return y;
 }
 
-// Lanes of the wave whose 8-bit digit equals mine (among `valid` lanes).
-__device__ __forceinline__ uint64_t wave_match8(uint32_t d, bool valid)
+// Lanes of the wave whose digit equals mine (among `valid` lanes); only the low `nbits` (wave-uniform,
+// <= 8) bits of the digit can differ, so only those are balloted.
+__device__ __forceinline__ uint64_t wave_match8(uint32_t d, bool valid, int nbits = 8)
 {
     uint64_t m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < nbits; b++) {
         bool bit = (d >> b) & 1u;
         uint64_t bal = __ballot(bit);
         m &= bit ? bal : ~bal;

@@ -82,10 +82,10 @@ def test_forward_is_deterministic_and_variant_invariant(scenes, rast, gpu):
 
     def fwd():
         R, color, radii, depth, st = _forward_state(rast, rs, ten, P, W, H)
-        return R, color.clone(), depth.clone(), st["n_contrib"].clone(), st["final_T"].clone()
+        return R, color.clone(), depth.clone(), st["n_contrib"].clone(), st["final_T"].clone(), st["point_list"].clone(), st["ranges"].clone()
 
     base = fwd()
-    variants = [dict(), dict(cull=0), dict(lpt=0), dict(pixels_per_lane=1, cull=0), dict(pixels_per_lane=2, cull=0), dict(pixels_per_lane=4, cull=0)]
+    variants = [dict(), dict(binning=1), dict(cull=0), dict(lpt=0), dict(pixels_per_lane=1, cull=0), dict(pixels_per_lane=2, cull=0), dict(pixels_per_lane=4, cull=0)]
     try:
         for v in variants:
             for k, val in v.items():
@@ -97,7 +97,7 @@ def test_forward_is_deterministic_and_variant_invariant(scenes, rast, gpu):
             for k in v:
                 _C.set_option(k, 1 if k in ("cull", "lpt") else 0)
     finally:
-        _C.set_option("cull", 1); _C.set_option("lpt", 1); _C.set_option("pixels_per_lane", 0)
+        _C.set_option("cull", 1); _C.set_option("lpt", 1); _C.set_option("pixels_per_lane", 0); _C.set_option("binning", 0)
 
 
 @pytest.mark.parametrize("name,P,W,H", CONFIGS[:2], ids=[c[0] for c in CONFIGS[:2]])

@@ -246,6 +246,27 @@ def test_golden_fixture(rast, gpu):
             assert (err <= ATOL + RTOL * np.abs(ref)).all(), (f, k, err.max())
 
 
+@pytest.mark.parametrize("binning", [0, 1])
+@pytest.mark.parametrize("name,P,W,H,scale_mul", [("small", 3000, 200, 150, 0.8), ("big_gaussians", 800, 320, 240, 4.0),
+                                                    ("tall", 2000, 48, 400, 1.0), ("wide", 2000, 400, 48, 1.0)])
+def test_binning_schemes(name, P, W, H, scale_mul, binning, orc, scenes, rast, gpu):
+    """Both binning schemes -- 0: column runs sorted by x, then one instance-level pass by tile row that expands the
+    runs on the fly (default); 1: instance-level two-pass radix sort on tile ids -- must produce the reference's
+    point_list and ranges bit for bit."""
+    sc = scenes.synth(P, 77, scale_mul=scale_mul)
+    cam = scenes.camera(1, 4, W, H)
+    g = scenes.upstream_grad(H, W, 78)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    rast._C.set_option("binning", binning)
+    try:
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+    finally:
+        rast._C.set_option("binning", 0)
+    _check_forward_exact(o32, h)
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], strict=True)
+
+
 @pytest.mark.parametrize("cull", [0, 1])
 @pytest.mark.parametrize("ppl", [0, 1, 2, 4])
 def test_pixels_per_lane_variants(ppl, cull, orc, scenes, rast, gpu):
