@@ -337,8 +337,6 @@ tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ tile_keys_sorted, uint2*
 // 6 bytes) instead of being emitted and carried through two full radix passes (36 bytes of traffic).
 // Stability of both passes keeps the depth order, so point_list and the tile ranges are again
 // bit-identical to the reference's single 64-bit-key sort.
-constexpr int RUNS_PER_BLOCK = 512;
-
 // Column runs of the depth-ordered Gaussians: run k of Gaussian g covers column x0+k, rows [y0, y0+h).
 // key = x (16 bit), payload = {g, y0 | h << 16}.  Balanced and coalesced like emit_instances_kernel.
 __global__ void __launch_bounds__(256)
@@ -417,24 +415,29 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
     __shared__ uint16_t s_x[RUNS_PER_BLOCK];
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t dstart[256], gbase[256], running[256];
-    __shared__ unsigned long long bits[RS_CHUNK / 64];
-    __shared__ uint32_t wpre[RS_CHUNK / 64];         // run starts before each bitmap word (relative to the sub-batch)
-    __shared__ uint32_t xk[RS_CHUNK];                // y | tile << 16
-    __shared__ uint32_t xv[RS_CHUNK];
+    __shared__ unsigned long long bits[RUN_CHUNK / 64];
+    __shared__ uint32_t wpre[RUN_CHUNK / 64];         // run starts before each bitmap word (relative to the sub-batch)
+    __shared__ uint32_t xk[RUN_CHUNK];                // y | tile << 16
+    __shared__ uint32_t xv[RUN_CHUNK];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t t = threadIdx.x;
     const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
     const uint32_t nruns = (Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK;
-    {   // stage the runs; exclusive prefix of their heights = first instance of each run (2 runs per lane)
-        const uint32_t k0 = 2 * t, k1 = 2 * t + 1;
-        uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
-        if (k0 < nruns) { v0 = run_vals[r0 + k0]; s_x[k0] = run_keys[r0 + k0]; }
-        if (k1 < nruns) { v1 = run_vals[r0 + k1]; s_x[k1] = run_keys[r0 + k1]; }
-        s_val[k0] = v0; s_val[k1] = v1;
-        const uint32_t h0 = v0.y >> 16, h1 = v1.y >> 16;
+    {   // stage the runs; exclusive prefix of their heights = first instance of each run (RPT consecutive runs per lane)
+        constexpr int RPT = RUNS_PER_BLOCK / RS_THREADS;
+        uint32_t hh[RPT], hsum = 0;
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            const uint32_t k = RPT * t + j;
+            uint2 v = make_uint2(0u, 0u);
+            if (k < nruns) { v = run_vals[r0 + k]; s_x[k] = run_keys[r0 + k]; }
+            s_val[k] = v;
+            hh[j] = v.y >> 16; hsum += hh[j];
+        }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan(h0 + h1, &tot);
-        s_start[k0] = ex; s_start[k1] = ex + h0;
+        uint32_t ex = block_excl_scan(hsum, &tot);
+#pragma unroll
+        for (int j = 0; j < RPT; j++) { s_start[RPT * t + j] = ex; ex += hh[j]; }
         if (t == 0) s_start[RUNS_PER_BLOCK] = tot;
         uint32_t gtot;
         const uint32_t dbase = block_excl_scan(digit_total[t], &gtot);   // instances in lower tile rows, globally
@@ -444,27 +447,28 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
     const uint32_t ninst = s_start[RUNS_PER_BLOCK];
     volatile uint32_t* wc = cnt[wave];
     uint32_t first_run = 0;                           // runs starting before the current sub-batch (uniform)
-    for (uint32_t sb = 0; sb < ninst; sb += RS_CHUNK) {
+    for (uint32_t sb = 0; sb < ninst; sb += RUN_CHUNK) {
         for (int k = t; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
-        if (t < RS_CHUNK / 64) bits[t] = 0ull;
+        if (t < RUN_CHUNK / 64) bits[t] = 0ull;
         __syncthreads();
-        const uint32_t nsub = (ninst - sb) < (uint32_t)RS_CHUNK ? (ninst - sb) : (uint32_t)RS_CHUNK;
+        const uint32_t nsub = (ninst - sb) < (uint32_t)RUN_CHUNK ? (ninst - sb) : (uint32_t)RUN_CHUNK;
         for (uint32_t k = t; k < nruns; k += RS_THREADS) {
             const uint32_t st = s_start[k];
-            if (st >= sb && st < sb + RS_CHUNK && (s_val[k].y >> 16) != 0u)
+            if (st >= sb && st < sb + RUN_CHUNK && (s_val[k].y >> 16) != 0u)
                 atomicOr(&bits[(st - sb) >> 6], 1ull << ((st - sb) & 63u));
         }
         __syncthreads();
         if (t < 64) {   // wave 0: exclusive prefix of the words' popcounts
-            const uint32_t pc = (uint32_t)__popcll(bits[t]);
-            wpre[t] = wave_incl_scan(pc) - pc;
+            const uint32_t pc = t < RUN_CHUNK / 64 ? (uint32_t)__popcll(bits[t]) : 0u;
+            const uint32_t in = wave_incl_scan(pc);
+            if (t < RUN_CHUNK / 64) wpre[t] = in - pc;
         }
         __syncthreads();
         // a short sub-batch is split evenly over the four waves: share = slots per wave (multiple of 64)
         const uint32_t share = ((nsub + 255u) >> 8) << 6;
-        uint32_t key[RS_ITEMS], val[RS_ITEMS], rk[RS_ITEMS];     // key = y | tile << 16
+        uint32_t key[RUN_ITEMS], val[RUN_ITEMS], rk[RUN_ITEMS];     // key = y | tile << 16
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++) {
+        for (int r = 0; r < RUN_ITEMS; r++) {
             if ((uint32_t)r * 64u >= share) break;
             const uint32_t ls = wave * share + r * 64 + lane;               // slot inside the sub-batch (= instance order)
             const bool valid = ls < nsub;
@@ -486,7 +490,7 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
             if (valid && below == 0) wc[y] = prev + (uint32_t)__popcll(m);
             rk[r] = prev + below;
         }
-        first_run += wpre[RS_CHUNK / 64 - 1] + (uint32_t)__popcll(bits[RS_CHUNK / 64 - 1]);
+        first_run += wpre[RUN_CHUNK / 64 - 1] + (uint32_t)__popcll(bits[RUN_CHUNK / 64 - 1]);
         __syncthreads();
         {
             const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
@@ -499,7 +503,7 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++) {
+        for (int r = 0; r < RUN_ITEMS; r++) {
             if ((uint32_t)r * 64u >= share) break;
             const uint32_t ls = wave * share + r * 64 + lane;
             if (ls < nsub) {
@@ -510,7 +514,7 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
         __syncthreads();
         // write-out: slot order = (row, instance order)
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++) {
+        for (int r = 0; r < RUN_ITEMS; r++) {
             const uint32_t slot = r * RS_THREADS + t;
             if ((uint32_t)r * RS_THREADS >= nsub) break;
             if (slot < nsub) {
