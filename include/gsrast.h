@@ -132,7 +132,13 @@ int gsrast_debug_export(int P, int R, int width, int height,
 /* Options: "exp_mode" 0 = fixed-sequence exp (bit-reproducible vs the CPU oracle), 1 = libm-grade
  * expf, 2 = hardware v_exp_f32;  "profile" = bit mask of kernel ids (gsrast_profile_kernel_name) whose launches are bracketed
  * with HIP events on the launch stream, -1 = all, 0 = off;
- * "debug_sync" 0/1 = synchronise + check errors after every launch.  Returns 0 or GSRAST_E_ARG. */
+ * "debug_sync" 0/1 = synchronise + check errors after every launch;
+ * "binning" 0 = run-compressed binning (default), 1 = instance-level two-pass radix sort;
+ * "tile_clip" 1 (default) = with "binning" 0, a Gaussian is listed only in the tiles its alpha >= 1/255 ellipse can
+ * reach instead of every tile of its 3-sigma square (outputs bit-identical, the internal lists get shorter;
+ * num_rendered keeps the reference's meaning), 0 = the reference's literal lists;
+ * "cull" / "lpt" 0/1 = wave-level strip culling / heaviest-tile-first launch order in the blend kernels;
+ * "pixels_per_lane" (+ "fwd_" / "bwd_" prefixed) 0 = auto, 1 / 2 / 4.  Returns 0 or GSRAST_E_ARG. */
 int gsrast_set_option(const char* name, int value);
 int gsrast_get_option(const char* name);
 

@@ -312,9 +312,11 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
 // Tile ranges (reference identifyTileRanges, rasterizer_impl.cu:116-138) on 16- or 32-bit tile ids.
 template <typename KeyT>
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ tile_keys_sorted, uint2* __restrict__ ranges)
+tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ R_dev /* optional: the list may be shorter than the launch */,
+                   const KeyT* __restrict__ tile_keys_sorted, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R_dev) R = *R_dev;
     if (i >= R) return;
     const uint32_t cur = tile_keys_sorted[i];
     if (i == 0) ranges[cur].x = 0;
@@ -339,21 +341,83 @@ tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ tile_keys_sorted, uint2*
 // bit-identical to the reference's single 64-bit-key sort.
 // Column runs of the depth-ordered Gaussians: run k of Gaussian g covers column x0+k, rows [y0, y0+h).
 // key = x (16 bit), payload = {g, y0 | h << 16}.  Balanced and coalesced like emit_instances_kernel.
+//
+// Exact row clipping (CULL).  The reference bins a Gaussian into every tile of the bounding square of its
+// 3-sigma circle (forward.cu:232-236, auxiliary.h:46-58); the blend then skips it at every pixel whose
+// alpha is below 1/255 (forward.cu:372-374).  A tile in which EVERY pixel takes that skip changes nothing:
+// not the colour, not T, not the contributor bookkeeping the backward uses (skipped entries are skipped
+// again).  The pixels that do not skip lie inside the ellipse  q(d) = 0.5(a dx^2 + c dy^2) + b dx dy <= t,
+// t = -skip_threshold; for a tile column (dx in [dx0, dx1]) the rows that can intersect it form ONE
+// interval (a convex set cut by a strip), whose ends are either the ellipse's own top / bottom or its
+// crossing with the strip's nearer edge (a root of the quadratic in dy at that dx; a negative
+// discriminant means the ellipse does not reach the column).  The interval is evaluated in fp64 on the fp32 coefficients
+// (so it is the exact set for the quadratic the blend evaluates, no cancellation even for needle-shaped
+// Gaussians), t is raised by a bound on the blend kernel's own fp32 rounding of the power
+// (1e-6 * (|a| + |b|) DX^2 + (|c| + |b|) DY^2, three roundings of terms that size), and the pixel
+// interval is widened by 1e-3 pixel.  Runs whose interval is empty keep their slot with h = 0.
+// Output bits are identical with and without clipping (tests/test_gpu_parity.py::test_tile_clipping_*);
+// only the internal lists get shorter (on the bench scene 2x).
+// sqrt of a double to ~1e-14 relative from the fp32 hardware sqrt / rcp and one Newton step in fp64
+// (v_sqrt_f64 costs an order of magnitude more; 1e-14 * 4096 pixels is far inside the 1e-3 pixel slack)
+__device__ __forceinline__ double sqrt_newton(double x)
+{
+    const float xf = (float)x;
+    if (!(xf > 1e-30f) || !(xf < 1e30f)) return sqrt(x);
+    const float s0f = __builtin_sqrtf(xf);
+    const double s0 = (double)s0f;
+    return __builtin_fma(__builtin_fma(-s0, s0, x), 0.5 * (double)__builtin_amdgcn_rcpf(s0f), s0);
+}
+
 __global__ void __launch_bounds__(256)
 emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ woffsets /* incl. scan of widths */,
-                        const uint2* __restrict__ rect, uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals)
+                        const float4* __restrict__ binrec, int W, int H, int cull,
+                        uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals)
 {
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
+    // per-Gaussian ellipse terms (fp64): det, 2tc, b, 1/c, dy_max, dx_top;  mode 0 = keep the column, 1 = clip, 2 = empty
+    __shared__ double s_det[4][64], s_t2c[4][64], s_b[4][64], s_invc[4][64], s_dymax[4][64], s_dxtop[4][64];
+    __shared__ float s_mx[4][64], s_my[4][64];
+    __shared__ uint32_t s_mode[4][64];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t g = 0, w = 0, incl, x0 = 0, yh = 0;
     if (j < P) {
         g = order[j];
         incl = woffsets[j];
-        const uint2 rc = rect[g];
+        const uint32_t prev = j > 0 ? woffsets[j - 1] : 0u;
+        w = incl - prev;                         // culled Gaussians (sorted last, width 0) never touch binrec
+        uint2 rc = make_uint2(0u, 0u);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (w != 0u) {
+            r0 = binrec[2 * (size_t)g]; r1 = binrec[2 * (size_t)g + 1];
+            rc = make_uint2(__float_as_uint(r1.z), __float_as_uint(r1.w));
+        }
         x0 = rc.x & 0xFFFFu;
-        w = (rc.y & 0xFFFFu) - x0;
         yh = (rc.x >> 16) | (((rc.y >> 16) - (rc.x >> 16)) << 16);
+        if (cull && w != 0u) {
+            const float cz = r1.x;
+            const float thr = r1.y;
+            const float mx = r0.x, my = r0.y, A = r0.z, B = r0.w;
+            // largest |dx|, |dy| any pixel of the rectangle can see
+            const float DX = fmaxf(fabsf(mx - 16.0f * (float)x0), fabsf(16.0f * (float)(rc.y & 0xFFFFu) - mx));
+            const float DY = fmaxf(fabsf(my - 16.0f * (float)(rc.x >> 16)), fabsf(16.0f * (float)(rc.y >> 16) - my));
+            const float M = (fabsf(A) + fabsf(B)) * DX * DX + (fabsf(cz) + fabsf(B)) * DY * DY;
+            const double t = (double)(-thr + 1e-6f * M);       // thr > 0 (opacity < 1/255): t < 0, nothing survives
+            const double a = (double)A, b = (double)B, c = (double)cz;
+            const double det = a * c - b * b;
+            uint32_t mode = 1;
+            if (!(t >= 0.0)) mode = 2;                                              // also NaN
+            else if (!(det > 0.0 && a > 0.0 && c > 0.0)) mode = 0;
+            double dy_max = 0.0, dx_top = 0.0;
+            if (mode == 1) {
+                dy_max = sqrt(2.0 * t * a / det);
+                dx_top = -b * dy_max / a;                       // where the ellipse reaches dy = +dy_max
+                if (!(dy_max < 1e30)) mode = 0;
+            }
+            s_det[wave][lane] = det; s_t2c[wave][lane] = 2.0 * t * c; s_b[wave][lane] = b; s_invc[wave][lane] = 1.0 / c;
+            s_dymax[wave][lane] = dy_max; s_dxtop[wave][lane] = dx_top;
+            s_mx[wave][lane] = mx; s_my[wave][lane] = my; s_mode[wave][lane] = mode;
+        }
     } else {
         incl = P > 0 ? woffsets[P - 1] : 0u;
     }
@@ -369,8 +433,33 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         for (int step = 32; step >= 1; step >>= 1)
             if (s_e[wave][sidx + step] <= o) sidx += step;
         const uint32_t k = o - s_e[wave][sidx];
-        run_keys[wstart + o] = (uint16_t)(s_x0[wave][sidx] + k);
-        run_vals[wstart + o] = make_uint2(s_g[wave][sidx], s_yh[wave][sidx]);
+        const uint32_t x = s_x0[wave][sidx] + k;
+        uint32_t yhv = s_yh[wave][sidx];
+        const uint32_t mode = cull ? s_mode[wave][sidx] : 0u;
+        if (mode == 2u) yhv &= 0xFFFFu;
+        else if (mode == 1u) {
+            uint32_t y0 = yhv & 0xFFFFu, h = yhv >> 16;
+            const double det = s_det[wave][sidx], t2c = s_t2c[wave][sidx], b = s_b[wave][sidx], invc = s_invc[wave][sidx];
+            const double dy_max = s_dymax[wave][sidx], dx_top = s_dxtop[wave][sidx];
+            const double mx = (double)s_mx[wave][sidx], my = (double)s_my[wave][sidx];
+            const int px1 = min((int)x * 16 + 15, W - 1);
+            const double dx0 = mx - (double)px1, dx1 = mx - (double)((int)x * 16);   // dx = mean - pixel
+            double hi = dy_max, lo = -dy_max;
+            bool empty = false;
+            {   const double dxc = fmin(fmax(dx_top, dx0), dx1);
+                if (dxc != dx_top) { const double disc = __builtin_fma(-det * dxc, dxc, t2c); empty |= disc < 0.0; hi = (sqrt_newton(fmax(disc, 0.0)) - b * dxc) * invc; } }
+            {   const double dxc = fmin(fmax(-dx_top, dx0), dx1);
+                if (dxc != -dx_top) { const double disc = __builtin_fma(-det * dxc, dxc, t2c); empty |= disc < 0.0; lo = (-sqrt_newton(fmax(disc, 0.0)) - b * dxc) * invc; } }
+            // pixel rows p with my - p in [lo, hi]
+            const double plo = ceil(my - hi - 1e-3), phi = floor(my + 1e-3 - lo);
+            const int tlo = max((int)y0, (int)fmax(plo, 0.0) >> 4);
+            const int thi = min((int)(y0 + h) - 1, (int)fmin(phi, (double)(H - 1)) >> 4);
+            if (empty || phi < 0.0 || plo > (double)(H - 1) || thi < tlo) h = 0;
+            else { y0 = (uint32_t)tlo; h = (uint32_t)(thi - tlo + 1); }
+            yhv = y0 | (h << 16);
+        }
+        run_keys[wstart + o] = (uint16_t)x;
+        run_vals[wstart + o] = make_uint2(s_g[wave][sidx], yhv);
     }
 }
 
@@ -408,11 +497,13 @@ __global__ void __launch_bounds__(RS_THREADS)
 run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, const uint2* __restrict__ run_vals,
                         uint32_t Q, int gx, int ybits, const uint32_t* __restrict__ hist_scanned,
                         const uint32_t* __restrict__ digit_total, uint32_t nblk,
-                        uint32_t* __restrict__ point_list, uint16_t* __restrict__ tile_keys)
+                        uint32_t* __restrict__ point_list, uint16_t* __restrict__ tile_keys,
+                        uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */)
 {
     __shared__ uint32_t s_start[RUNS_PER_BLOCK + 1]; // block-local first instance of every run (+ total at the end)
     __shared__ uint2 s_val[RUNS_PER_BLOCK];
     __shared__ uint16_t s_x[RUNS_PER_BLOCK];
+    __shared__ uint32_t s_nruns;
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t dstart[256], gbase[256], running[256];
     __shared__ unsigned long long bits[RUN_CHUNK / 64];
@@ -422,29 +513,37 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t t = threadIdx.x;
     const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
-    const uint32_t nruns = (Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK;
-    {   // stage the runs; exclusive prefix of their heights = first instance of each run (RPT consecutive runs per lane)
-        constexpr int RPT = RUNS_PER_BLOCK / RS_THREADS;
-        uint32_t hh[RPT], hsum = 0;
+    const uint32_t nslots = (Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK;
+    uint32_t nruns;                                   // non-empty runs of this block (row clipping leaves h = 0 slots)
+    {   // stage the non-empty runs, compacted; exclusive prefix of their heights = first instance of each run
+        constexpr int RPT = RUNS_PER_BLOCK / RS_THREADS;     // consecutive runs per lane
+        static_assert(RUNS_PER_BLOCK <= 1024, "packed scan: 20 bits of instances, 11 bits of runs");
+        uint2 v[RPT]; uint16_t xx[RPT];
+        uint32_t packed = 0;                          // heights in the low 20 bits (<= 1024 * 256), non-empty count above
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
             const uint32_t k = RPT * t + j;
-            uint2 v = make_uint2(0u, 0u);
-            if (k < nruns) { v = run_vals[r0 + k]; s_x[k] = run_keys[r0 + k]; }
-            s_val[k] = v;
-            hh[j] = v.y >> 16; hsum += hh[j];
+            v[j] = make_uint2(0u, 0u); xx[j] = 0;
+            if (k < nslots) { v[j] = run_vals[r0 + k]; xx[j] = run_keys[r0 + k]; }
+            const uint32_t h = v[j].y >> 16;
+            packed += h + (h ? (1u << 20) : 0u);
         }
         uint32_t tot;
-        uint32_t ex = block_excl_scan(hsum, &tot);
+        uint32_t ex = block_excl_scan(packed, &tot);
 #pragma unroll
-        for (int j = 0; j < RPT; j++) { s_start[RPT * t + j] = ex; ex += hh[j]; }
-        if (t == 0) s_start[RUNS_PER_BLOCK] = tot;
+        for (int j = 0; j < RPT; j++) {
+            const uint32_t h = v[j].y >> 16;
+            if (h) { const uint32_t k = ex >> 20; s_val[k] = v[j]; s_x[k] = xx[j]; s_start[k] = ex & 0xFFFFFu; ex += h + (1u << 20); }
+        }
+        if (t == 0) { s_start[RUNS_PER_BLOCK] = tot & 0xFFFFFu; s_nruns = tot >> 20; }
         uint32_t gtot;
         const uint32_t dbase = block_excl_scan(digit_total[t], &gtot);   // instances in lower tile rows, globally
+        if (blockIdx.x == 0 && t == 0) *total_out = gtot;
         running[t] = dbase + hist_scanned[(size_t)t * nblk + blockIdx.x];
     }
     __syncthreads();
     const uint32_t ninst = s_start[RUNS_PER_BLOCK];
+    nruns = s_nruns;
     volatile uint32_t* wc = cnt[wave];
     uint32_t first_run = 0;                           // runs starting before the current sub-batch (uniform)
     for (uint32_t sb = 0; sb < ninst; sb += RUN_CHUNK) {
@@ -454,7 +553,7 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
         const uint32_t nsub = (ninst - sb) < (uint32_t)RUN_CHUNK ? (ninst - sb) : (uint32_t)RUN_CHUNK;
         for (uint32_t k = t; k < nruns; k += RS_THREADS) {
             const uint32_t st = s_start[k];
-            if (st >= sb && st < sb + RUN_CHUNK && (s_val[k].y >> 16) != 0u)
+            if (st >= sb && st < sb + RUN_CHUNK)
                 atomicOr(&bits[(st - sb) >> 6], 1ull << ((st - sb) & 63u));
         }
         __syncthreads();

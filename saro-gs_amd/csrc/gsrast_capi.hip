@@ -176,6 +176,7 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // the host waits for the real count, so the (Python) allocation callback runs while the GPU is still
 // busy with preprocess / depth sort instead of in the idle gap after the readback.
 std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0};
+std::atomic<int> g_tile_clip{1};   // run-compressed binning only: drop the tiles of a Gaussian's rectangle its alpha >= 1/255 ellipse cannot reach
 std::atomic<int> g_binning{0};     // 0 = run-compressed binning when the image allows it, 1 = always the instance-level two-pass sort
 
 CamArgs make_cam(const float* view, const float* proj, const float* campos, float tanx, float tany,
@@ -305,6 +306,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
     if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_binning = value; return 0; }
+    if (!strcmp(name, "tile_clip")) { g_tile_clip = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
@@ -324,6 +326,8 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "bwd_pixels_per_lane")) return g_ppl_bwd.load();
     if (!strcmp(name, "cull")) return g_cull.load();
     if (!strcmp(name, "binning")) return g_binning.load();
+    if (!strcmp(name, "tile_clip")) return g_tile_clip.load();
+    if (!strcmp(name, "lpt")) return g_lpt.load();
     return GSRAST_E_ARG;
 }
 
@@ -426,7 +430,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         preprocess_fwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
             colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
-            at<unsigned char>(geom, GL.clamped), tiles, rect, kA, vA);
+            at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA);
         GS_LAUNCHED("preprocess_fwd");
     }
     {
@@ -490,7 +494,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         uint32_t* plist_w = at<uint32_t>(bin, RL.point_list);
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
-            emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, rect, rkA, rvA);
+            emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H, g_tile_clip.load(), rkA, rvA);
             GS_LAUNCHED("emit_column_runs"); }
         {   ProfScope ps(K_SORT_TILE, s);
             int rc = radix_sort<uint16_t, uint2>(rkA, rvA, rkB, rvB, Q, xbits, hist_x, rscan, s);      // runs by column
@@ -501,10 +505,10 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             GS_LAUNCHED("run_hist_rows");
             radix_rowscan_kernel<<<256, 256, 0, s>>>(hist_y, nblk, rscan);
             GS_LAUNCHED("radix_rowscan");
-            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rkA, rvA, Q, cam.gx, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, tkeys);
+            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rkA, rvA, Q, cam.gx, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, tkeys, scalars + 2);
             GS_LAUNCHED("run_scatter_rows"); }
         {   ProfScope ps(K_RANGES, s);
-            tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, tkeys, ranges);
+            tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, scalars + 2, tkeys, ranges);
             GS_LAUNCHED("tile_ranges"); }
     } else if (R > 0) {
         const BinLayout BL = bin_layout((size_t)cap);
@@ -525,7 +529,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             { ProfScope ps(K_SORT_TILE, s); rc = radix_sort<uint16_t>(hA, tvA, hB, tvB, R, tile_bits(T), bhist, bscan, s); }
             if (rc != GSRAST_OK) return rc;
             { ProfScope ps(K_RANGES, s);
-              tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, reinterpret_cast<const uint16_t*>(at<uint32_t>(bin, BL.keyA)), ranges);
+              tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, nullptr, reinterpret_cast<const uint16_t*>(at<uint32_t>(bin, BL.keyA)), ranges);
               GS_LAUNCHED("tile_ranges"); }
         } else {
             { ProfScope ps(K_EMIT, s);
@@ -534,7 +538,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             { ProfScope ps(K_SORT_TILE, s); rc = radix_sort<uint32_t>(tkA, tvA, tkB, tvB, R, tile_bits(T), bhist, bscan, s); }
             if (rc != GSRAST_OK) return rc;
             { ProfScope ps(K_RANGES, s);
-              tile_ranges_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>(R, at<uint32_t>(bin, BL.keyA), ranges);
+              tile_ranges_kernel<uint32_t><<<(R + 255) / 256, 256, 0, s>>>(R, nullptr, at<uint32_t>(bin, BL.keyA), ranges);
               GS_LAUNCHED("tile_ranges"); }
         }
     }

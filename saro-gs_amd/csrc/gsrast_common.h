@@ -22,12 +22,14 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   clamped  u8[P]       bit c set <=> colour channel c was clamped at 0
 //   tiles    u32[P]      tiles touched
 //   rect     uint2[P]    {min.x | min.y<<16, max.x | max.y<<16} tile rectangle
+//   binrec   float4[2P]  {x, y, conic.x, conic.y} {conic.z, skip_threshold, rect.x bits, rect.y bits}: one 32-byte gather per
+//                        Gaussian for the column-run emission (only written for visible Gaussians, only read for those)
 //   keyA/B   u32[P] x2   depth-sort ping-pong keys        valA/B u32[P] x2   ping-pong values
 //   offsets  u32[P]      inclusive scan of tiles[] in depth order
 //   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
 //   scalars  u32[64]     [0] = num_rendered
 struct GeomLayout {
-    size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, keyA, keyB, valA, valB, offsets, woffsets,
+    size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
         hist, scan_tmp, scalars, total;
 };
 // Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
@@ -66,7 +68,7 @@ static inline GeomLayout geom_layout(size_t P)
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     size_t Pp = P ? P : 1;
     L.depths = take(Pp * 4); L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16);
-    L.cov3D = take(Pp * 24); L.clamped = take(Pp); L.tiles = take(Pp * 4); L.rect = take(Pp * 8);
+    L.cov3D = take(Pp * 24); L.clamped = take(Pp); L.tiles = take(Pp * 4); L.rect = take(Pp * 8); L.binrec = take(Pp * 32);
     L.keyA = take(Pp * 4); L.keyB = take(Pp * 4); L.valA = take(Pp * 4); L.valB = take(Pp * 4);
     L.offsets = take(Pp * 4); L.woffsets = take(Pp * 4);
     size_t hist_n = 256 * rs_blocks(Pp);

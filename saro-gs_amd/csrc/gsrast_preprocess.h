@@ -228,8 +228,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ colors_precomp, CamArgs cam_args, int* __restrict__ radii,
                       float* __restrict__ depths, float4* __restrict__ rec0, float4* __restrict__ rec1,
                       float4* __restrict__ rec2, float* __restrict__ cov3D, unsigned char* __restrict__ clamped,
-                      uint32_t* __restrict__ tiles, uint2* __restrict__ rect, uint32_t* __restrict__ sort_key,
-                      uint32_t* __restrict__ sort_val)
+                      uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
+                      uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
@@ -300,6 +300,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 rad_out = rad; ntiles = (uint32_t)area;
                 key = __float_as_uint(pv[2]);
                 rc = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
+                // everything the binning needs about this Gaussian in ONE 32-byte record (it is gathered in depth order)
+                binrec[2 * (size_t)i] = make_float4(px, py, con0, con1);
+                binrec[2 * (size_t)i + 1] = make_float4(con2, thr, __uint_as_float(rc.x), __uint_as_float(rc.y));
             }
         }
     }

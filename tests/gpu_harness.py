@@ -6,9 +6,22 @@ import torch
 from conftest import settings_from
 
 
-def run_hip(rast, scene, cam, device, dL_dcolor=None, colors_precomp=None, cov3D_precomp=None, exp_mode=0):
+def run_hip(rast, scene, cam, device, dL_dcolor=None, colors_precomp=None, cov3D_precomp=None, exp_mode=0,
+            tile_clip=0):
+    """tile_clip=0: the reference's literal tile lists (every tile of the 3-sigma square), so keys / point_list /
+    ranges / n_contrib can be compared entry by entry.  tile_clip=1 is the product default (lists without the tiles the
+    alpha >= 1/255 ellipse cannot reach): same outputs, shorter lists -- see check_clipped_lists."""
     _C = rast._C
     _C.set_option("exp_mode", exp_mode)
+    _C.set_option("tile_clip", tile_clip)
+    try:
+        return _run_hip(rast, scene, cam, device, dL_dcolor, colors_precomp, cov3D_precomp)
+    finally:
+        _C.set_option("tile_clip", 1)
+
+
+def _run_hip(rast, scene, cam, device, dL_dcolor, colors_precomp, cov3D_precomp):
+    _C = rast._C
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)  # noqa: E731
     rs = settings_from(rast, cam, scene, device)
     P = scene["means3D"].shape[0]
@@ -71,3 +84,32 @@ def run_hip(rast, scene, cam, device, dL_dcolor=None, colors_precomp=None, cov3D
 def bits(a):
     a = np.ascontiguousarray(a)
     return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def check_clipped_lists(o, h, W, H):
+    """Lists built with tile_clip=1 (h) against the reference's literal lists (o, oracle):
+    every tile's list is an ordered subsequence of the reference's, and every pixel's last contributor
+    (the entry n_contrib points at) is the same Gaussian."""
+    gx = (W + 15) // 16
+    ro, rh = o["ranges"].reshape(-1, 2).astype(np.int64), h["ranges"].reshape(-1, 2).astype(np.int64)
+    po, ph = o["point_list"], h["point_list"]
+    total = int((rh[:, 1] - rh[:, 0]).sum())
+    assert total <= o["R"]
+    for t in range(ro.shape[0]):
+        lo, lh = po[ro[t, 0]:ro[t, 1]], ph[rh[t, 0]:rh[t, 1]]
+        assert len(lh) <= len(lo)
+        if len(lh) == 0:
+            continue
+        # ordered subsequence: positions of lh's entries in lo must be strictly increasing (ids are unique per tile)
+        pos = {int(g): i for i, g in enumerate(lo)}
+        idx = np.array([pos.get(int(g), -1) for g in lh])
+        assert (idx >= 0).all() and (np.diff(idx) > 0).all(), f"tile {t}: clipped list is not a subsequence"
+    nco, nch = o["n_contrib"].reshape(H, W).astype(np.int64), h["n_contrib"].reshape(H, W).astype(np.int64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    tile = (ys // 16) * gx + xs // 16
+    assert ((nco > 0) == (nch > 0)).all()
+    m = nco > 0
+    last_o = po[(ro[tile, 0] + nco - 1)[m]]
+    last_h = ph[(rh[tile, 0] + nch - 1)[m]]
+    np.testing.assert_array_equal(last_o, last_h)
+    return total

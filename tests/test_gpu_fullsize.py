@@ -35,13 +35,21 @@ def _forward_state(rast, rs, ten, P, W, H):
     return R, color, radii, depth, st
 
 
+@pytest.mark.parametrize("clip", [0, 1], ids=["literal_lists", "clipped_lists"])
 @pytest.mark.parametrize("name,P,W,H", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_binning_and_image_properties(name, P, W, H, scenes, rast, gpu):
+def test_binning_and_image_properties(name, P, W, H, clip, scenes, rast, gpu):
     sc, cam, rs, ten = _inputs(scenes, rast, P, W, H, gpu)
-    R, color, radii, depth, st = _forward_state(rast, rs, ten, P, W, H)
+    rast._C.set_option("tile_clip", clip)
+    try:
+        R, color, radii, depth, st = _forward_state(rast, rs, ten, P, W, H)
+    finally:
+        rast._C.set_option("tile_clip", 1)
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    assert R == int(st["tiles_touched"].to(torch.int64).sum())
-    keys = st["keys_sorted"]                                   # (tile << 32) | depth bits, int64 view of uint64
+    assert R == int(st["tiles_touched"].to(torch.int64).sum())     # num_rendered keeps the reference's meaning
+    R_ref = R
+    R = int((st["ranges"].to(torch.int64)[:, 1] - st["ranges"].to(torch.int64)[:, 0]).sum())   # entries actually listed
+    assert (R == R_ref) if clip == 0 else (0 < R < R_ref)
+    keys = st["keys_sorted"][:R]                               # (tile << 32) | depth bits, int64 view of uint64
     assert bool((keys[1:] >= keys[:-1]).all()), "sorted keys must be non-decreasing"   # tile < 2^31: sign bit clear
     tiles = keys >> 32
     ranges = st["ranges"].to(torch.int64)
@@ -53,7 +61,7 @@ def test_binning_and_image_properties(name, P, W, H, scenes, rast, gpu):
     ends = ranges[nz, 1] - 1
     assert bool((tiles[ends] == torch.nonzero(nz).flatten()).all())
     # stable tie-break: equal keys keep ascending Gaussian index
-    pl = st["point_list"].to(torch.int64)
+    pl = st["point_list"][:R].to(torch.int64)
     same = keys[1:] == keys[:-1]
     assert bool((pl[1:][same] > pl[:-1][same]).all())
     # low key bits are the depth's float bits of the listed Gaussian
@@ -75,7 +83,9 @@ def test_binning_and_image_properties(name, P, W, H, scenes, rast, gpu):
 
 def test_forward_is_deterministic_and_variant_invariant(scenes, rast, gpu):
     """1M Gaussians at 1080p: identical bits from two runs, with / without wave-level culling, with /
-    without heaviest-first launch order, and for 1 / 2 / 4 pixels per lane."""
+    without heaviest-first launch order, for 1 / 2 / 4 pixels per lane and both binning schemes (all on the
+    reference's literal lists, tile_clip=0); the default row-clipped lists (tile_clip=1) must give the same
+    colour / depth / transmittance bits."""
     P, W, H = 1_000_000, 1920, 1080
     sc, cam, rs, ten = _inputs(scenes, rast, P, W, H, gpu)
     _C = rast._C
@@ -84,7 +94,12 @@ def test_forward_is_deterministic_and_variant_invariant(scenes, rast, gpu):
         R, color, radii, depth, st = _forward_state(rast, rs, ten, P, W, H)
         return R, color.clone(), depth.clone(), st["n_contrib"].clone(), st["final_T"].clone(), st["point_list"].clone(), st["ranges"].clone()
 
+    clipped = fwd()          # product default
+    _C.set_option("tile_clip", 0)
     base = fwd()
+    assert clipped[0] == base[0]
+    for i in (1, 2, 4):
+        assert torch.equal(clipped[i], base[i]), "row-clipped lists changed an output bit"
     variants = [dict(), dict(binning=1), dict(cull=0), dict(lpt=0), dict(pixels_per_lane=1, cull=0), dict(pixels_per_lane=2, cull=0), dict(pixels_per_lane=4, cull=0)]
     try:
         for v in variants:
@@ -98,6 +113,7 @@ def test_forward_is_deterministic_and_variant_invariant(scenes, rast, gpu):
                 _C.set_option(k, 1 if k in ("cull", "lpt") else 0)
     finally:
         _C.set_option("cull", 1); _C.set_option("lpt", 1); _C.set_option("pixels_per_lane", 0); _C.set_option("binning", 0)
+        _C.set_option("tile_clip", 1)
 
 
 @pytest.mark.parametrize("name,P,W,H", CONFIGS[:2], ids=[c[0] for c in CONFIGS[:2]])
