@@ -89,10 +89,15 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dm = 15.0f;
     uint32_t last = 0;
-    bool done = !inside;
+    // A finished pixel (T would drop below 1e-4, forward.cu:377-381) moves to x = FAR: its power becomes ~ -1e30 x conic
+    // (finite: conic entries are <= 1/0.3), so it fails the skip test like any far pixel and needs no flag in the loop.
+    // The set of live lanes is a 64-bit scalar, updated from the ballot of the (rare) terminations only.
+    constexpr float FAR = 1.0e15f;
+    float pxa = inside ? pxf : FAR;
+    uint64_t alive = __ballot(inside);
 
     for (uint32_t base = 0; base < n; base += 256) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(alive == 0ull)) break;
         const uint32_t i = base + t;
         if (i < n) {
             const uint32_t g = point_list[range.x + i];
@@ -100,7 +105,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         }
         __syncthreads();
         const uint32_t cnt = (n - base) < 256u ? (n - base) : 256u;
-        if (!__any(!done)) continue;                        // whole wave saturated: only helps staging
+        if (alive == 0ull) continue;                        // whole wave saturated: only helps staging
 #pragma unroll 1
         for (uint32_t r = 0; r < 4; r++) {
             const uint32_t slot = r * 64 + lane;
@@ -117,28 +122,32 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 mask &= mask - 1;
                 const float4 a = s0[j];
                 const float4 c = s2[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float dx = a.x - pxa, dy = a.y - pyf;
                 const float4 b = s1[j];
                 const float power = gs_power(a.z, a.w, b.x, dx, dy);
-                if (!done && !(power > 0.0f) && !(power < c.z)) {
-                    float alpha = b.y * gs_exp<EXPMODE, false>(power);
+                bool term = false;
+                // ONE divergent region; inside it the reference's nested tests (forward.cu:368-381) are selects
+                if (power <= 0.0f && power >= c.z) {
+                    float alpha = b.y * gs_exp<EXPMODE, true>(power);      // c.z >= -80: the bounded exp is exact here
                     alpha = alpha < 0.99f ? alpha : 0.99f;
-                    if (!(alpha < 1.0f / 255.0f)) {
-                        const float test_T = T * (1.0f - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const float w = alpha * T;
-                            C0 = __builtin_fmaf(b.z, w, C0);
-                            C1 = __builtin_fmaf(b.w, w, C1);
-                            C2 = __builtin_fmaf(c.x, w, C2);
-                            if (T > 0.5f && test_T < 0.5f) Dm = c.y;
-                            T = test_T;
-                            last = base + j + 1;
-                        }
-                    }
+                    const float test_T = T * (1.0f - alpha);
+                    const bool contrib = !(alpha < 1.0f / 255.0f);
+                    term = contrib && test_T < 0.0001f;
+                    const bool upd = contrib && !term;
+                    const float w = upd ? alpha * T : 0.0f;                // fma(colour, 0, C) == C exactly
+                    C0 = __builtin_fmaf(b.z, w, C0);
+                    C1 = __builtin_fmaf(b.w, w, C1);
+                    C2 = __builtin_fmaf(c.x, w, C2);
+                    Dm = (upd && T > 0.5f && test_T < 0.5f) ? c.y : Dm;
+                    T = upd ? test_T : T;
+                    last = upd ? base + j + 1 : last;
+                    pxa = term ? FAR : pxa;
                 }
-                if (!__any(!done)) { mask = 0; r = 4; }    // wave saturated
+                const uint64_t tm = __ballot(term);
+                if (tm) {
+                    alive &= ~tm;
+                    if (alive == 0ull) { mask = 0; r = 4; }                // wave saturated
+                }
             }
         }
     }
