@@ -601,53 +601,63 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const float dx = a.x - pxf;
                 const float xx = (a.z * dx) * dx;
                 const float xy = a.w * dx;
-                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+                // Per pixel slot, the divergent part produces only three numbers (zero when the pair does not
+                // contribute): dch = alpha * T, dLa = dL/dalpha, Gk = G.  The nine per-instance partials are
+                // products of those and are formed afterwards by ALL lanes, so no lane needs nine zero-initialised
+                // registers per branch level and the exec mask is manipulated once per level instead of per output.
+                float dch[PPL], dLa[PPL], Gk[PPL];
                 bool contributed = false;
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {
+                    dch[k] = 0.f; dLa[k] = 0.f; Gk[k] = 0.f;
                     if (!((mk[k] >> jb) & 1ull)) continue;                 // scalar: strip k untouched
                     const float dy = a.y - pyf[k];
                     const float q = __builtin_fmaf(b.x * dy, dy, xx);
                     const float power = __builtin_fmaf(-0.5f, q, -(xy * dy));
-                    if (!(pos < last[k]) || power > 0.0f || power < c.y) continue;
-                    const float G = gs_exp<EXPMODE, true>(power);
-                    float alpha = b.y * G;
-                    alpha = alpha < 0.99f ? alpha : 0.99f;
-                    if (alpha < 1.0f / 255.0f) continue;
-                    contributed = true;
-                    const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T[k] = T[k] * rcp1ma;
-                    const float dch = alpha * T[k];
-                    const float c0 = b.z, c1 = b.w, c2 = c.x;
-                    ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
-                    ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
-                    ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
-                    float dL_dalpha = (c0 - ac0[k]) * dp0[k] + (c1 - ac1[k]) * dp1[k] + (c2 - ac2[k]) * dp2[k];
-                    g_r += dch * dp0[k]; g_g += dch * dp1[k]; g_b += dch * dp2[k];
-                    dL_dalpha *= T[k];
-                    last_alpha[k] = alpha;
-                    dL_dalpha += tfbg[k] * rcp1ma;
-                    const float dL_dG = b.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
+                    if (pos < last[k] && power <= 0.0f && power >= c.y) {
+                        const float G = gs_exp<EXPMODE, true>(power);
+                        float alpha = b.y * G;
+                        alpha = alpha < 0.99f ? alpha : 0.99f;
+                        if (!(alpha < 1.0f / 255.0f)) {
+                            contributed = true;
+                            const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                            T[k] = T[k] * rcp1ma;
+                            const float c0 = b.z, c1 = b.w, c2 = c.x;
+                            ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
+                            ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
+                            ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
+                            float dL_dalpha = (c0 - ac0[k]) * dp0[k] + (c1 - ac1[k]) * dp1[k] + (c2 - ac2[k]) * dp2[k];
+                            dL_dalpha *= T[k];
+                            last_alpha[k] = alpha;
+                            dL_dalpha += tfbg[k] * rcp1ma;
+                            dch[k] = alpha * T[k]; dLa[k] = dL_dalpha; Gk[k] = G;
+                        }
+                    }
+                }
+                if (!__any(contributed)) continue;
+                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    if (PPL > 1 && !((mk[k] >> jb) & 1ull)) continue;      // scalar
+                    const float dy = a.y - pyf[k];
+                    g_r += dch[k] * dp0[k]; g_g += dch[k] * dp1[k]; g_b += dch[k] * dp2[k];
+                    const float dL_dG = b.y * dLa[k];
+                    const float gdx = Gk[k] * dx, gdy = Gk[k] * dy;
                     g_mx += dL_dG * (-gdx * a.z - gdy * a.w);
                     g_my += dL_dG * (-gdy * b.x - gdx * a.w);
                     g_ca += gdx * dx * dL_dG;
                     g_cb += gdx * dy * dL_dG;
                     g_cc += gdy * dy * dL_dG;
-                    g_op += G * dL_dalpha;
+                    g_op += Gk[k] * dLa[k];
                 }
-                if (!__any(contributed)) continue;
                 {
                     // eight of the nine sums through the transposing reduction (every lane l ends with the
-                    // total of value l & 7), the ninth through the DPP chain to lane 63; lanes 0..7 and 63
-                    // then commit all nine into this wave's accumulator slice with ONE LDS read-add-write.
+                    // total of value l & 7), the ninth through the DPP chain to lane 63, read back as a scalar;
+                    // lanes 0..8 then commit all nine into this wave's accumulator slice with ONE LDS read-add-write.
                     const float v8[8] = { g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g };
                     const float tot = wave_sum8_transposed(v8, lane);
-                    const float tb = wave_sum_to_lane63(g_b);
-                    if (lane < 8u || lane == 63u) {
-                        const uint32_t q = lane < 8u ? lane : 8u;
-                        acc[wave][q][j] += lane < 8u ? tot * commit_scale : tb;
-                    }
+                    const float tb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(g_b)), 63));
+                    if (lane < 9u) acc[wave][lane][j] += (lane < 8u ? tot : tb) * commit_scale;
                 }
             }
         }
