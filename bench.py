@@ -112,6 +112,9 @@ class Workload:
                     pairs_fwd=int(nc.sum().item()), T=gx * gy, N=self.W * self.H)
 
 
+HOST_STEPS = {}     # per-step host enqueue times of the last timed() call: a stall of the host shows up here
+
+
 def timed(workload, steps, warmup, bucket, world, vp, dev):
     for _ in range(warmup):
         workload.step(bucket, world)
@@ -122,10 +125,11 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     t0 = time.perf_counter()
     for _ in range(steps):
         workload.step(bucket, world)
-        if trace:
-            marks.append(time.perf_counter())
-    if trace:
-        d = np.diff(np.array([t0] + marks)) * 1e3
+        marks.append(time.perf_counter())        # host-side enqueue time of each step (diagnostic only)
+    d = np.diff(np.array([t0] + marks)) * 1e3
+    HOST_STEPS.clear()
+    HOST_STEPS.update(median=round(float(np.median(d)), 4), max=round(float(d.max()), 4), argmax=int(d.argmax()))
+    if trace or d.max() > 20.0 * max(float(np.median(d)), 0.05):
         print("step host ms:", " ".join(f"{x:.2f}" for x in d), file=sys.stderr)
     torch.cuda.synchronize(dev)
     vp.barrier()
@@ -330,6 +334,7 @@ def main():
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,
+            "host_step_ms": dict(HOST_STEPS),
         }
 
     # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----

@@ -488,27 +488,85 @@ run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, uint32_t* _
     block_hist[(size_t)threadIdx.x * nblk + blockIdx.x] = incl;
 }
 
+// Tile ranges without reading the sorted list back (and without a tile id stream next to it):
+// tile (x, y) starts at  [instances in rows < y] + [instances in row y from runs of columns < x].
+// Runs are sorted by column, so "runs of columns < x" is a prefix [0, F(x)) of the run array: whole
+// blocks of it are in the scanned row histogram, the partial block is counted here.  One workgroup per
+// tile column, one lane per tile row.  Empty tiles keep {0, 0} as in the reference
+// (rasterizer_impl.cu:311 + identifyTileRanges :116-138).
+__device__ __forceinline__ uint32_t first_run_of_column(const uint16_t* __restrict__ run_keys, uint32_t Q, uint32_t x)
+{
+    uint32_t lo = 0, hi = Q;                                   // first index whose key >= x; 256-ary search, block-wide
+    while (hi > lo) {
+        const uint32_t step = (hi - lo + 255u) / 256u;
+        const uint32_t idx = lo + threadIdx.x * step;
+        const bool below = idx < hi && (uint32_t)run_keys[idx] < x;
+        const uint32_t c = (uint32_t)__syncthreads_count(below);   // samples are monotone: the first c are below
+        if (c == 0) { hi = lo; break; }
+        const uint32_t nlo = lo + (c - 1u) * step + 1u;
+        const uint32_t nhi = lo + c * step;
+        lo = nlo; hi = nhi < hi ? nhi : hi;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t row_instances_before_run(const uint2* __restrict__ run_vals, uint32_t Q, uint32_t F,
+                                                              const uint32_t* __restrict__ hist_scanned, uint32_t nblk,
+                                                              uint32_t row_total, int* diff /* LDS [257] */)
+{
+    if (F >= Q) return row_total;                              // uniform
+    const uint32_t b0 = F / RUNS_PER_BLOCK, r0 = b0 * RUNS_PER_BLOCK;
+    __syncthreads();
+    for (int k = threadIdx.x; k < 257; k += 256) diff[k] = 0;
+    __syncthreads();
+    for (uint32_t r = r0 + threadIdx.x; r < F; r += 256) {
+        const uint32_t yh = run_vals[r].y;
+        atomicAdd(&diff[yh & 0xFFFFu], 1);
+        atomicAdd(&diff[(yh & 0xFFFFu) + (yh >> 16)], -1);
+    }
+    __syncthreads();
+    const uint32_t mine = (uint32_t)diff[threadIdx.x];
+    uint32_t tot;
+    const uint32_t incl = block_excl_scan(mine, &tot) + mine;
+    return hist_scanned[(size_t)threadIdx.x * nblk + b0] + incl;
+}
+__global__ void __launch_bounds__(256)
+tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q,
+                             int gx, int gy, const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ digit_total,
+                             uint32_t nblk, uint2* __restrict__ ranges)
+{
+    __shared__ int diff[257];
+    const uint32_t x = blockIdx.x, y = threadIdx.x;
+    const uint32_t row_total = digit_total[y];
+    uint32_t all;
+    const uint32_t row_base = block_excl_scan(row_total, &all);
+    const uint32_t F0 = first_run_of_column(run_keys, Q, x);
+    const uint32_t F1 = first_run_of_column(run_keys, Q, x + 1u);
+    const uint32_t before0 = row_instances_before_run(run_vals, Q, F0, hist_scanned, nblk, row_total, diff);
+    const uint32_t before1 = row_instances_before_run(run_vals, Q, F1, hist_scanned, nblk, row_total, diff);
+    if (y < (uint32_t)gy && before1 > before0)
+        ranges[y * (uint32_t)gx + x] = make_uint2(row_base + before0, row_base + before1);
+}
+
 // Second (final) pass: instances of the block's runs, generated in order, ranked by tile row with the
 // same ballot-match / LDS-exchange scheme as radix_scatter_kernel, written once.
 // The run an instance belongs to is found without searching: every run sets ONE bit (at its first
 // instance) in a per-sub-batch LDS bitmap, and "number of run starts at or before slot i" is a word
 // prefix count plus a popcount of the slot's word.
 __global__ void __launch_bounds__(RS_THREADS)
-run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, const uint2* __restrict__ run_vals,
-                        uint32_t Q, int gx, int ybits, const uint32_t* __restrict__ hist_scanned,
+run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column */,
+                        uint32_t Q, int ybits, const uint32_t* __restrict__ hist_scanned,
                         const uint32_t* __restrict__ digit_total, uint32_t nblk,
-                        uint32_t* __restrict__ point_list, uint16_t* __restrict__ tile_keys,
+                        uint32_t* __restrict__ point_list,
                         uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */)
 {
     __shared__ uint32_t s_start[RUNS_PER_BLOCK + 1]; // block-local first instance of every run (+ total at the end)
     __shared__ uint2 s_val[RUNS_PER_BLOCK];
-    __shared__ uint16_t s_x[RUNS_PER_BLOCK];
     __shared__ uint32_t s_nruns;
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t dstart[256], gbase[256], running[256];
     __shared__ unsigned long long bits[RUN_CHUNK / 64];
     __shared__ uint32_t wpre[RUN_CHUNK / 64];         // run starts before each bitmap word (relative to the sub-batch)
-    __shared__ uint32_t xk[RUN_CHUNK];                // y | tile << 16
+    __shared__ uint8_t xk[RUN_CHUNK];                 // tile row
     __shared__ uint32_t xv[RUN_CHUNK];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t t = threadIdx.x;
@@ -518,13 +576,13 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
     {   // stage the non-empty runs, compacted; exclusive prefix of their heights = first instance of each run
         constexpr int RPT = RUNS_PER_BLOCK / RS_THREADS;     // consecutive runs per lane
         static_assert(RUNS_PER_BLOCK <= 1024, "packed scan: 20 bits of instances, 11 bits of runs");
-        uint2 v[RPT]; uint16_t xx[RPT];
+        uint2 v[RPT];
         uint32_t packed = 0;                          // heights in the low 20 bits (<= 1024 * 256), non-empty count above
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
             const uint32_t k = RPT * t + j;
-            v[j] = make_uint2(0u, 0u); xx[j] = 0;
-            if (k < nslots) { v[j] = run_vals[r0 + k]; xx[j] = run_keys[r0 + k]; }
+            v[j] = make_uint2(0u, 0u);
+            if (k < nslots) v[j] = run_vals[r0 + k];
             const uint32_t h = v[j].y >> 16;
             packed += h + (h ? (1u << 20) : 0u);
         }
@@ -533,7 +591,7 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
             const uint32_t h = v[j].y >> 16;
-            if (h) { const uint32_t k = ex >> 20; s_val[k] = v[j]; s_x[k] = xx[j]; s_start[k] = ex & 0xFFFFFu; ex += h + (1u << 20); }
+            if (h) { const uint32_t k = ex >> 20; s_val[k] = v[j]; s_start[k] = ex & 0xFFFFFu; ex += h + (1u << 20); }
         }
         if (t == 0) { s_start[RUNS_PER_BLOCK] = tot & 0xFFFFFu; s_nruns = tot >> 20; }
         uint32_t gtot;
@@ -565,13 +623,13 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
         __syncthreads();
         // a short sub-batch is split evenly over the four waves: share = slots per wave (multiple of 64)
         const uint32_t share = ((nsub + 255u) >> 8) << 6;
-        uint32_t key[RUN_ITEMS], val[RUN_ITEMS], rk[RUN_ITEMS];     // key = y | tile << 16
+        uint32_t key[RUN_ITEMS], val[RUN_ITEMS], rk[RUN_ITEMS];     // key = tile row
 #pragma unroll
         for (int r = 0; r < RUN_ITEMS; r++) {
             if ((uint32_t)r * 64u >= share) break;
             const uint32_t ls = wave * share + r * 64 + lane;               // slot inside the sub-batch (= instance order)
             const bool valid = ls < nsub;
-            uint32_t y = 0, tile = 0, g = 0;
+            uint32_t y = 0, g = 0;
             if (valid) {
                 const uint32_t wd = ls >> 6;
                 // runs that start at or before this slot, minus one = index of the run covering it
@@ -579,10 +637,9 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
                 const uint32_t k = first_run + upto - 1u;
                 const uint2 v = s_val[k];
                 y = (v.y & 0xFFFFu) + (sb + ls - s_start[k]);
-                tile = y * (uint32_t)gx + s_x[k];
                 g = v.x;
             }
-            key[r] = y | (tile << 16); val[r] = g;
+            key[r] = y; val[r] = g;
             const uint64_t m = wave_match8(y, valid, ybits);
             const uint32_t prev = wc[y];
             const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
@@ -606,8 +663,8 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
             if ((uint32_t)r * 64u >= share) break;
             const uint32_t ls = wave * share + r * 64 + lane;
             if (ls < nsub) {
-                const uint32_t slot = cnt[wave][key[r] & 0xFFFFu] + rk[r];
-                xk[slot] = key[r]; xv[slot] = val[r];
+                const uint32_t slot = cnt[wave][key[r]] + rk[r];
+                xk[slot] = (uint8_t)key[r]; xv[slot] = val[r];
             }
         }
         __syncthreads();
@@ -617,11 +674,8 @@ run_scatter_rows_kernel(const uint16_t* __restrict__ run_keys /* x, sorted */, c
             const uint32_t slot = r * RS_THREADS + t;
             if ((uint32_t)r * RS_THREADS >= nsub) break;
             if (slot < nsub) {
-                const uint32_t kk = xk[slot];
-                const uint32_t y = kk & 0xFFFFu;
-                const uint32_t pos = gbase[y] + (slot - dstart[y]);
-                point_list[pos] = xv[slot];
-                tile_keys[pos] = (uint16_t)(kk >> 16);
+                const uint32_t y = xk[slot];
+                point_list[gbase[y] + (slot - dstart[y])] = xv[slot];
             }
         }
         __syncthreads();

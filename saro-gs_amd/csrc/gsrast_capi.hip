@@ -490,7 +490,6 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         uint32_t* hist_x = at<uint32_t>(bin, RL.hist_x);
         uint32_t* hist_y = at<uint32_t>(bin, RL.hist_y);
         uint32_t* rscan = at<uint32_t>(bin, RL.scan_tmp);
-        uint16_t* tkeys = at<uint16_t>(bin, RL.tile_keys);
         uint32_t* plist_w = at<uint32_t>(bin, RL.point_list);
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
@@ -505,10 +504,10 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             GS_LAUNCHED("run_hist_rows");
             radix_rowscan_kernel<<<256, 256, 0, s>>>(hist_y, nblk, rscan);
             GS_LAUNCHED("radix_rowscan");
-            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rkA, rvA, Q, cam.gx, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, tkeys, scalars + 2);
+            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, Q, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, scalars + 2);
             GS_LAUNCHED("run_scatter_rows"); }
         {   ProfScope ps(K_RANGES, s);
-            tile_ranges_kernel<uint16_t><<<(R + 255) / 256, 256, 0, s>>>(R, scalars + 2, tkeys, ranges);
+            tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, Q, cam.gx, cam.gy, hist_y, rscan, (Q + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK, ranges);
             GS_LAUNCHED("tile_ranges"); }
     } else if (R > 0) {
         const BinLayout BL = bin_layout((size_t)cap);

@@ -94,7 +94,7 @@ static inline BinLayout bin_layout(size_t R)
     return L;
 }
 // Run-compressed binning (gsrast_binning.h): capR = instance capacity, capQ = column-run capacity.
-//   point_list u32[capR] (offset 0), tile_keys u16[capR], run key / value ping-pong u16[capQ] x2 / uint2[capQ] x2,
+//   point_list u32[capR] (offset 0), run key / value ping-pong u16[capQ] x2 / uint2[capQ] x2,
 //   histogram of the x pass (256 x blocks(capQ)), of the row pass (256 x capQ/RUNS_PER_BLOCK), scan partials
 #ifndef GSRAST_RUNS_PER_BLOCK
 #define GSRAST_RUNS_PER_BLOCK 512
@@ -106,7 +106,7 @@ constexpr int RUNS_PER_BLOCK = GSRAST_RUNS_PER_BLOCK;  // runs per workgroup of 
 constexpr int RUN_ITEMS = GSRAST_RUN_ITEMS;            // instances per lane per sub-batch of the row pass
 constexpr int RUN_CHUNK = RUN_ITEMS * 256;
 struct RunBinLayout {
-    size_t point_list, tile_keys, rkeyA, rkeyB, rvalA, rvalB, hist_x, hist_y, scan_tmp, total;
+    size_t point_list, rkeyA, rkeyB, rvalA, rvalB, hist_x, hist_y, scan_tmp, total;
 };
 static inline RunBinLayout runbin_layout(size_t capR, size_t capQ)
 {
@@ -114,7 +114,7 @@ static inline RunBinLayout runbin_layout(size_t capR, size_t capQ)
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     if (!capR) capR = 1;
     if (!capQ) capQ = 1;
-    L.point_list = take(capR * 4); L.tile_keys = take(capR * 2);
+    L.point_list = take(capR * 4);
     L.rkeyA = take(capQ * 2); L.rkeyB = take(capQ * 2); L.rvalA = take(capQ * 8); L.rvalB = take(capQ * 8);
     L.hist_x = take(256 * rs_blocks(capQ) * 4);
     L.hist_y = take(256 * ((capQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK) * 4);
