@@ -1,0 +1,24 @@
+"""Dev helper: runs one fwd+bwd of the bench workload with the counter build (gpurun_variants/lib_counters.so)."""
+import ctypes, os, shutil, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = os.path.join(root, "saro-gs_amd", "diff_gaussian_rasterization_ch3", "libgsrast_hip.so")
+shutil.copy(lib, "/tmp/orig.so"); shutil.copy(os.path.join(root, "gpurun_variants", "lib_counters.so"), lib)
+try:
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "saro-gs_amd"))
+    import torch, bench
+    import diff_gaussian_rasterization_ch3 as rast
+    import scenes
+    from diff_gaussian_rasterization_ch3 import _C
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, 1, torch.device("cuda:0"))
+    L = _C.lib()
+    out = (ctypes.c_ulonglong * 8)()
+    wl.step(None, 1); torch.cuda.synchronize()
+    L.gsrast_debug_counters(out, 1)
+    wl.step(None, 1); torch.cuda.synchronize()
+    L.gsrast_debug_counters(out, 1)
+    v = list(out)
+    print("fwd: survivor iterations %d, with a lane in range %d, with a contribution %d, contributing lanes %d (%.1f / iteration)" % (v[0], v[1], v[3], v[2], v[2] / max(v[1], 1)))
+    print("bwd: survivor iterations %d, with a contribution %d, contributing lanes %d (%.1f / contributing iteration)" % (v[4], v[5], v[6], v[6] / max(v[5], 1)))
+finally:
+    shutil.copy("/tmp/orig.so", lib)
