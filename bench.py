@@ -92,8 +92,7 @@ class Workload:
             self.vp.allreduce_mean_inplace(bucket.flat, world)
         return radii
 
-    def stats(self):
-        """Measured R, R_eff, P_vis for the algorithmic-bytes formulas (one untimed forward)."""
+    def _forward_state(self):
         _C = self.rast._C
         L = self.leaves
         e = torch.empty(0)
@@ -108,8 +107,26 @@ class Workload:
         pad = torch.zeros((gy * 16, gx * 16), dtype=torch.int64, device=nc.device)
         pad[: self.H, : self.W] = nc
         tile_max = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
+        rg = st["ranges"].to(torch.int64)
         return dict(R=int(R), R_eff=int(tile_max.sum().item()), P_vis=int((radii > 0).sum().item()),
-                    pairs_fwd=int(nc.sum().item()), T=gx * gy, N=self.W * self.H)
+                    pairs=int(nc.sum().item()), listed=int((rg[:, 1] - rg[:, 0]).sum().item()))
+
+    def stats(self):
+        """Measured R, R_eff, P_vis for the algorithmic-bytes formulas of SURVEY.md 8(d) (untimed forwards).
+        R and R_eff are defined on the REFERENCE's tile lists (every tile of the 3-sigma square), so they are measured
+        with tile_clip=0; the product default lists fewer instances (tile_clip=1): R_listed / R_eff_listed / Q."""
+        _C = self.rast._C
+        clip = _C.get_option("tile_clip")
+        _C.set_option("tile_clip", 0)
+        try:
+            ref = self._forward_state()
+        finally:
+            _C.set_option("tile_clip", clip)
+        cur = self._forward_state()
+        gy, gx = (self.H + 15) // 16, (self.W + 15) // 16
+        return dict(R=ref["R"], R_eff=ref["R_eff"], P_vis=ref["P_vis"], pairs_fwd=ref["pairs"], T=gx * gy,
+                    N=self.W * self.H, R_listed=cur["listed"], R_eff_listed=cur["R_eff"], pairs_listed=cur["pairs"],
+                    Q=int(_C.get_option("last_runs")))
 
 
 HOST_STEPS = {}     # per-step host enqueue times of the last timed() call: a stall of the host shows up here
@@ -256,8 +273,8 @@ def main():
     names = [_C.lib().gsrast_profile_kernel_name(k).decode() for k in range(_C.lib().gsrast_profile_kernel_count())]
     kid = {n: i for i, n in enumerate(names)}
     _C.profile_reset()
-    # only the two blend kernels are bracketed with events inside the timed region (4 records/step)
-    _C.set_option("profile", (1 << kid["blend_bwd"]) | (1 << kid["blend_fwd"]))
+    # only the roofline kernel is bracketed with events inside the timed region (2 records/step, ~5 us of GPU idle each)
+    _C.set_option("profile", 1 << kid["blend_bwd"])
     # warm-up happens inside timed(); reset the event totals after it by timing warm-up separately
     for _ in range(a.warmup):
         wl.step(bucket, world)
@@ -280,14 +297,17 @@ def main():
         _C.set_option("profile", 0)
         C = (deg + 1) ** 2
         Pv, R, Re, N, T = st["P_vis"], st["R"], st["R_eff"], st["N"], st["T"]
+        Rl, Q = st["R_listed"], st["Q"]
         passes_t = 2 if T > 256 else 1
+        run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
         alg = {   # algorithmic HBM bytes per launch of THIS build's stages
-            "preprocess_fwd": P * (44 + 12 * C) + Pv * 64 + P * 8,
+            "preprocess_fwd": P * (44 + 12 * C) + Pv * 96 + P * 8,
             "sort_depth": P * 20 * 4,
-            "scan_tiles": P * 12,
-            "emit_instances": P * 24 + R * 6,
-            "sort_tile": R * 14 * passes_t,
-            "tile_ranges": R * 2 + T * 8,
+            "scan_tiles": P * 12 if run_binning else P * 24,
+            # run-compressed: Q column runs of 10 B emitted, sorted by column (one pass), expanded once into Rl instances
+            "emit_instances": (P * 40 + Q * 10) if run_binning else (P * 24 + R * 6),
+            "sort_tile": (Q * 22 + Q * 16 + Rl * 4) if run_binning else R * 14 * passes_t,
+            "tile_ranges": T * 8 if run_binning else R * 2 + T * 8,
             "blend_fwd": Re * 44 + N * 24,
             "blend_bwd": N * 20 + Re * 76,
             "preprocess_bwd": P * (24 * C + 173),
@@ -303,7 +323,7 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt
         bwd_ms = prof["blend_bwd"][0] / max(prof["blend_bwd"][1], 1)
-        fwd_ms = prof["blend_fwd"][0] / max(prof["blend_fwd"][1], 1)
+        fwd_ms = pk["blend_fwd"][0] / max(pk["blend_fwd"][1], 1) if per_kernel else 0.0   # separate all-stages pass
         # K5 = N*20 + R_eff*40 + R_eff*36 bytes per launch
         bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
         fwd_bytes = st["R_eff"] * 44 + st["N"] * 24
@@ -323,7 +343,8 @@ def main():
             "config": {"workload": f"stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
                                    + (" + RCCL all-reduce(mean) of 59 floats/Gaussian" if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
-                       "views_per_step": world, "instances_R": st["R"], "R_eff": st["R_eff"], "visible": st["P_vis"],
+                       "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
+                       "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],
                        "blended_pairs_fwd": st["pairs_fwd"]},
             "roofline": {"kernel": "blend_bwd_cull_kernel", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

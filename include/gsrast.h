@@ -138,7 +138,9 @@ int gsrast_debug_export(int P, int R, int width, int height,
  * reach instead of every tile of its 3-sigma square (outputs bit-identical, the internal lists get shorter;
  * num_rendered keeps the reference's meaning), 0 = the reference's literal lists;
  * "cull" / "lpt" 0/1 = wave-level strip culling / heaviest-tile-first launch order in the blend kernels;
- * "pixels_per_lane" (+ "fwd_" / "bwd_" prefixed) 0 = auto, 1 / 2 / 4.  Returns 0 or GSRAST_E_ARG. */
+ * "pixels_per_lane" (+ "fwd_" / "bwd_" prefixed) 0 = auto, 1 / 2 / 4.  Returns 0 or GSRAST_E_ARG.
+ * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
+ * last forward call of the process. */
 int gsrast_set_option(const char* name, int value);
 int gsrast_get_option(const char* name);
 

@@ -57,24 +57,40 @@ __device__ __forceinline__ uint32_t scan_load(const uint32_t* src, const uint32_
 
 __global__ void __launch_bounds__(256)
 scan_block_sums_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, const uint2* __restrict__ runs,
-                       uint32_t n, uint32_t* __restrict__ sums)
+                       uint32_t n, uint32_t* __restrict__ sums,
+                       const uint32_t* __restrict__ aux /* optional: a second array that is only summed */,
+                       uint32_t* __restrict__ aux_sums)
 {
     const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * 16;
-    uint32_t s = 0;
+    uint32_t s = 0, s2 = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         uint32_t i = base + k;
-        if (i < n) s += scan_load(src, idx, runs, i);
+        if (i < n) { s += scan_load(src, idx, runs, i); if (aux) s2 += aux[i]; }
     }
     uint32_t tot;
     block_excl_scan(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+    if (aux) {      // a block's sum fits 32 bits (4096 entries of at most 2^16 tiles); the grand total is 64-bit
+        block_excl_scan(s2, &tot);
+        if (threadIdx.x == 0) aux_sums[blockIdx.x] = tot;
+    }
 }
 
 // single block: in-place exclusive scan of m values (loops in chunks of 4096 with a carry)
 __global__ void __launch_bounds__(256)
-scan_single_block_kernel(uint32_t* __restrict__ data, uint32_t m)
+scan_single_block_kernel(uint32_t* __restrict__ data, uint32_t m, const uint32_t* __restrict__ aux_sums,
+                         uint32_t* __restrict__ aux_total_lo, uint32_t* __restrict__ aux_total_hi)
 {
+    if (aux_sums) {
+        __shared__ unsigned long long part[256];
+        unsigned long long a = 0;
+        for (uint32_t i = threadIdx.x; i < m; i += 256) a += aux_sums[i];
+        part[threadIdx.x] = a;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st]; __syncthreads(); }
+        if (threadIdx.x == 0) { *aux_total_lo = (uint32_t)part[0]; *aux_total_hi = (uint32_t)(part[0] >> 32); }
+    }
     uint32_t carry = 0;
     for (uint32_t c0 = 0; c0 < m; c0 += SC_CHUNK) {
         const uint32_t base = c0 + threadIdx.x * 16;
@@ -250,7 +266,7 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
                 if (gather_rect) {   // last depth pass: tile count and rectangle width of each Gaussian, in depth order
                     const uint2 rc = gather_rect[vv];
                     const uint32_t w = (rc.y & 0xFFFFu) - (rc.x & 0xFFFFu), h = (rc.y >> 16) - (rc.x >> 16);
-                    gather_tiles[pos] = w * h;
+                    if (gather_tiles) gather_tiles[pos] = w * h;
                     gather_width[pos] = w;
                 }
             }
@@ -492,7 +508,7 @@ run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, uint32_t* _
 // tile (x, y) starts at  [instances in rows < y] + [instances in row y from runs of columns < x].
 // Runs are sorted by column, so "runs of columns < x" is a prefix [0, F(x)) of the run array: whole
 // blocks of it are in the scanned row histogram, the partial block is counted here.  One workgroup per
-// tile column, one lane per tile row.  Empty tiles keep {0, 0} as in the reference
+// tile column, one lane per tile row.  Empty tiles get {0, 0} as in the reference
 // (rasterizer_impl.cu:311 + identifyTileRanges :116-138).
 __device__ __forceinline__ uint32_t first_run_of_column(const uint16_t* __restrict__ run_keys, uint32_t Q, uint32_t x)
 {
@@ -543,8 +559,8 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
     const uint32_t F1 = first_run_of_column(run_keys, Q, x + 1u);
     const uint32_t before0 = row_instances_before_run(run_vals, Q, F0, hist_scanned, nblk, row_total, diff);
     const uint32_t before1 = row_instances_before_run(run_vals, Q, F1, hist_scanned, nblk, row_total, diff);
-    if (y < (uint32_t)gy && before1 > before0)
-        ranges[y * (uint32_t)gx + x] = make_uint2(row_base + before0, row_base + before1);
+    if (y < (uint32_t)gy)
+        ranges[y * (uint32_t)gx + x] = before1 > before0 ? make_uint2(row_base + before0, row_base + before1) : make_uint2(0u, 0u);
 }
 
 // Second (final) pass: instances of the block's runs, generated in order, ranked by tile row with the

@@ -92,19 +92,21 @@ int post_launch(const char* what, hipStream_t s)
 
 // ---- scan / sort drivers --------------------------------------------------------------------
 // dst[i] = scan of (idx ? src[idx[i]] : src[i]); two levels (single-block scan of block sums).
+// `aux` (optional, n entries): only summed; its 64-bit total goes to aux_lo / aux_hi.
 int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst, bool inclusive,
-             uint32_t* tmp, uint32_t* total_out, hipStream_t s, const uint2* runs = nullptr)
+             uint32_t* tmp, uint32_t* total_out, hipStream_t s, const uint2* runs = nullptr,
+             const uint32_t* aux = nullptr, uint32_t* aux_lo = nullptr, uint32_t* aux_hi = nullptr)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nb = (n + SC_CHUNK - 1) / SC_CHUNK;
-    if (nb == 1) {
+    if (nb == 1 && !aux) {
         scan_apply_kernel<<<1, 256, 0, s>>>(src, idx, runs, n, nullptr, dst, inclusive ? 1 : 0, total_out);
         GS_LAUNCHED("scan_apply");
         return GSRAST_OK;
     }
-    scan_block_sums_kernel<<<nb, 256, 0, s>>>(src, idx, runs, n, tmp);
+    scan_block_sums_kernel<<<nb, 256, 0, s>>>(src, idx, runs, n, tmp, aux, tmp + nb);
     GS_LAUNCHED("scan_block_sums");
-    scan_single_block_kernel<<<1, 256, 0, s>>>(tmp, nb);
+    scan_single_block_kernel<<<1, 256, 0, s>>>(tmp, nb, aux ? tmp + nb : nullptr, aux_lo, aux_hi);
     GS_LAUNCHED("scan_single_block");
     scan_apply_kernel<<<nb, 256, 0, s>>>(src, idx, runs, n, tmp, dst, inclusive ? 1 : 0, total_out);
     GS_LAUNCHED("scan_apply");
@@ -327,6 +329,8 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "cull")) return g_cull.load();
     if (!strcmp(name, "binning")) return g_binning.load();
     if (!strcmp(name, "tile_clip")) return g_tile_clip.load();
+    if (!strcmp(name, "last_instances")) return (int)g_R_hint.load();   // num_rendered / column runs of the last forward call
+    if (!strcmp(name, "last_runs")) return (int)g_Q_hint.load();
     if (!strcmp(name, "lpt")) return g_lpt.load();
     return GSRAST_E_ARG;
 }
@@ -433,26 +437,32 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA);
         GS_LAUNCHED("preprocess_fwd");
     }
+    // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
+    const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
     {
         ProfScope ps(K_SORT_DEPTH, s);
-        // the last pass also writes tile counts and rectangle widths in depth order (scanned in place below)
-        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, offsets, woffsets);
+        // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
+        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A
     {
         ProfScope ps(K_SCAN_TILES, s);
-        int rc = scan_u32(offsets, nullptr, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
-        if (rc != GSRAST_OK) return rc;
-        rc = scan_u32(woffsets, nullptr, (uint32_t)P, woffsets, true, scan_tmp, scalars + 1, s);   // column runs
+        int rc;
+        if (runbin) {   // only the widths are scanned (-> run offsets, Q); num_rendered is just the sum of the tile counts
+            rc = scan_u32(woffsets, nullptr, (uint32_t)P, woffsets, true, scan_tmp, scalars + 1, s, nullptr, tiles, scalars, scalars + 3);
+        } else {
+            rc = scan_u32(offsets, nullptr, (uint32_t)P, offsets, true, scan_tmp, scalars, s);
+            if (rc != GSRAST_OK) return rc;
+            rc = scan_u32(woffsets, nullptr, (uint32_t)P, woffsets, true, scan_tmp, scalars + 1, s);   // column runs
+        }
         if (rc != GSRAST_OK) return rc;
     }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
-    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s)); // reference rasterizer_impl.cu:311
+    // reference rasterizer_impl.cu:311 (the run-compressed path writes every tile's range itself, empty ones included)
+    if (!runbin) GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s));
     const int tpasses = tile_passes(T);
-    // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
-    const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
     auto bin_bytes = [&](uint32_t capR, uint32_t capQ) {
         return runbin ? runbin_layout((size_t)capR, (size_t)capQ).total : bin_layout((size_t)capR).total;
     };
@@ -467,8 +477,9 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         if (!bin) cap = capQ = 0;
     }
     auto t1 = std::chrono::steady_clock::now();
-    uint32_t counts[2] = { 0, 0 };      // {instances R, column runs Q}
-    { int rc = read_u32(scalars, s, counts, 2); if (rc != GSRAST_OK) return rc; }
+    uint32_t counts[4] = { 0, 0, 0, 0 };      // {instances R (low word), column runs Q, -, R (high word, run-compressed path)}
+    { int rc = read_u32(scalars, s, counts, 4); if (rc != GSRAST_OK) return rc; }
+    if (runbin && counts[3] != 0) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     auto t2 = std::chrono::steady_clock::now();
     if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u\n",
                        std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, counts[0], counts[1]);
@@ -483,7 +494,8 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     // The layout inside the buffer follows its CAPACITY; the sorted Gaussian ids (point_list) always end in the
     // array at offset 0, whatever the capacity, the pass count and the binning scheme -- all the backward needs.
     const uint32_t* plist = at<uint32_t>(bin, 0);
-    if (R > 0 && runbin) {
+    if (runbin && (R == 0 || Q == 0)) GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s));
+    if (R > 0 && Q > 0 && runbin) {
         const RunBinLayout RL = runbin_layout((size_t)cap, (size_t)capQ);
         uint16_t *rkA = at<uint16_t>(bin, RL.rkeyA), *rkB = at<uint16_t>(bin, RL.rkeyB);
         uint2 *rvA = at<uint2>(bin, RL.rvalA), *rvB = at<uint2>(bin, RL.rvalB);
@@ -509,7 +521,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         {   ProfScope ps(K_RANGES, s);
             tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, Q, cam.gx, cam.gy, hist_y, rscan, (Q + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK, ranges);
             GS_LAUNCHED("tile_ranges"); }
-    } else if (R > 0) {
+    } else if (R > 0 && !runbin) {
         const BinLayout BL = bin_layout((size_t)cap);
         uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
         uint32_t *tvA = at<uint32_t>(bin, BL.valA), *tvB = at<uint32_t>(bin, BL.valB);

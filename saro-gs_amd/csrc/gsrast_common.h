@@ -58,7 +58,7 @@ static inline size_t rs_blocks(size_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK;
 static inline size_t scan_tmp_elems(size_t n)
 { // partial sums for a multi-level scan of n elements
     size_t tot = 0;
-    while (n > SC_CHUNK) { n = (n + SC_CHUNK - 1) / SC_CHUNK; tot += align256(n * 4) / 4; }
+    while (n > SC_CHUNK) { n = (n + SC_CHUNK - 1) / SC_CHUNK; tot += 2 * (align256(n * 4) / 4); }   // x2: room for the sums of an auxiliary array
     return tot + 64;
 }
 
