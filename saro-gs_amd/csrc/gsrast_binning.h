@@ -130,6 +130,16 @@ scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__
     if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total_out = ex;
 }
 
+// Element count of a launch that was sized for a CAPACITY before the host knew the real count: the grid and the
+// histogram stride follow the capacity `n`, the kernel works on min(*n_dev, n) elements (blocks past the end find an
+// empty chunk and contribute zeros).  n_dev == nullptr: `n` is exact.
+__device__ __forceinline__ uint32_t dev_count(uint32_t n, const uint32_t* __restrict__ n_dev)
+{
+    if (!n_dev) return n;
+    const uint32_t m = *n_dev;
+    return m < n ? m : n;
+}
+
 // ------------------------------------------------------------------------------------------
 // Stable LSD radix sort pass on (u32 key, u32 value) pairs, 8-bit digit.
 // A block owns RS_CHUNK consecutive elements; wave w owns a contiguous quarter, visited in
@@ -140,9 +150,11 @@ scan_apply_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__
 // the HBM time of the keys).
 template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t* __restrict__ block_hist, uint32_t nblk)
+radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+                  uint32_t* __restrict__ block_hist, uint32_t nblk)
 {
     __shared__ uint32_t cnt[4][256];
+    n = dev_count(n, n_dev);
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     __syncthreads();
@@ -189,12 +201,14 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
 template <typename KeyT, typename ValT>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
-                     KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask,
+                     KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev,
+                     int shift, uint32_t mask,
                      const uint32_t* __restrict__ hist_scanned /* per-digit exclusive row scans */,
                      const uint32_t* __restrict__ digit_total, uint32_t nblk,
                      const uint2* __restrict__ gather_rect /* optional, last depth pass only */,
                      uint32_t* __restrict__ gather_tiles, uint32_t* __restrict__ gather_width)
 {
+    n = dev_count(n, n_dev);
     // Ranks -> block-local order in LDS -> coalesced write-out: after the exchange consecutive lanes
     // hold consecutive elements of the same digit, whose global destinations are consecutive too.
     __shared__ uint32_t cnt[4][256];
@@ -250,7 +264,8 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
         }
     }
     __syncthreads();
-    const uint32_t nvalid = (n - blockIdx.x * RS_CHUNK) < (uint32_t)RS_CHUNK ? (n - blockIdx.x * RS_CHUNK) : (uint32_t)RS_CHUNK;
+    const uint32_t b0 = blockIdx.x * RS_CHUNK;      // may lie past n in a capacity-sized launch
+    const uint32_t nvalid = b0 >= n ? 0u : ((n - b0) < (uint32_t)RS_CHUNK ? (n - b0) : (uint32_t)RS_CHUNK);
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t slot = r * RS_THREADS + threadIdx.x;
@@ -386,7 +401,7 @@ __device__ __forceinline__ double sqrt_newton(double x)
 
 __global__ void __launch_bounds__(256)
 emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ woffsets /* incl. scan of widths */,
-                        const float4* __restrict__ binrec, int W, int H, int cull,
+                        const float4* __restrict__ binrec, int W, int H, int cull, uint32_t capQ,
                         uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals)
 {
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
@@ -442,7 +457,8 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
     const uint32_t wend = __shfl(incl, 63, 64);
     s_e[wave][lane] = e - wstart; s_g[wave][lane] = g; s_x0[wave][lane] = x0; s_yh[wave][lane] = yh;
     __syncthreads();
-    const uint32_t C = wend - wstart;
+    // capQ: the buffers may have been sized before the host knew Q (speculative launch); nothing is written past them
+    const uint32_t C = wstart >= capQ ? 0u : ((wend < capQ ? wend : capQ) - wstart);
     for (uint32_t o = lane; o < C; o += 64) {
         uint32_t sidx = 0;
 #pragma unroll
@@ -482,9 +498,11 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
 // Per-block histogram over tile rows of the instances of RUNS_PER_BLOCK consecutive (x-sorted) runs:
 // +1 at y0, -1 at y0+h in an LDS difference array, prefix sum, one column of the digit-major table.
 __global__ void __launch_bounds__(256)
-run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, uint32_t* __restrict__ block_hist, uint32_t nblk)
+run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, const uint32_t* __restrict__ Q_dev,
+                     uint32_t* __restrict__ block_hist, uint32_t nblk)
 {
     __shared__ int diff[257];
+    Q = dev_count(Q, Q_dev);
     for (int k = threadIdx.x; k < 257; k += 256) diff[k] = 0;
     __syncthreads();
     const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
@@ -547,11 +565,20 @@ __device__ __forceinline__ uint32_t row_instances_before_run(const uint2* __rest
 }
 __global__ void __launch_bounds__(256)
 tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q,
-                             int gx, int gy, const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ digit_total,
-                             uint32_t nblk, uint2* __restrict__ ranges)
+                             const uint32_t* __restrict__ counts_dev /* optional {R lo, Q, -, R hi}: speculative launch */,
+                             uint32_t capR, int gx, int gy, const uint32_t* __restrict__ hist_scanned,
+                             const uint32_t* __restrict__ digit_total, uint32_t nblk, uint2* __restrict__ ranges)
 {
     __shared__ int diff[257];
     const uint32_t x = blockIdx.x, y = threadIdx.x;
+    if (counts_dev) {
+        // The launch was sized for capacities (Q = capQ).  If the real counts do not fit, the lists are truncated:
+        // publish empty ranges (the blend kernels then touch nothing) -- the host sees the same counts and redoes the
+        // binning with exact sizes.
+        const bool overflow = counts_dev[1] > Q || counts_dev[3] != 0u || counts_dev[0] > capR;
+        if (overflow) { if (y < (uint32_t)gy) ranges[y * (uint32_t)gx + x] = make_uint2(0u, 0u); return; }
+        Q = counts_dev[1];
+    }
     const uint32_t row_total = digit_total[y];
     uint32_t all;
     const uint32_t row_base = block_excl_scan(row_total, &all);
@@ -570,7 +597,7 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
 // prefix count plus a popcount of the slot's word.
 __global__ void __launch_bounds__(RS_THREADS)
 run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column */,
-                        uint32_t Q, int ybits, const uint32_t* __restrict__ hist_scanned,
+                        uint32_t Q, const uint32_t* __restrict__ Q_dev, uint32_t capR, int ybits, const uint32_t* __restrict__ hist_scanned,
                         const uint32_t* __restrict__ digit_total, uint32_t nblk,
                         uint32_t* __restrict__ point_list,
                         uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */)
@@ -587,7 +614,9 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t t = threadIdx.x;
     const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
-    const uint32_t nslots = (Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK;
+    Q = dev_count(Q, Q_dev);
+    if (r0 >= Q && blockIdx.x != 0) return;                    // block past the end of a capacity-sized launch (uniform)
+    const uint32_t nslots = r0 >= Q ? 0u : ((Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK);
     uint32_t nruns;                                   // non-empty runs of this block (row clipping leaves h = 0 slots)
     {   // stage the non-empty runs, compacted; exclusive prefix of their heights = first instance of each run
         constexpr int RPT = RUNS_PER_BLOCK / RS_THREADS;     // consecutive runs per lane
@@ -691,7 +720,8 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
             if ((uint32_t)r * RS_THREADS >= nsub) break;
             if (slot < nsub) {
                 const uint32_t y = xk[slot];
-                point_list[gbase[y] + (slot - dstart[y])] = xv[slot];
+                const uint32_t pos = gbase[y] + (slot - dstart[y]);
+                if (pos < capR) point_list[pos] = xv[slot];        // capR: see tile_ranges_from_runs_kernel
             }
         }
         __syncthreads();

@@ -121,7 +121,8 @@ int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
 template <typename KeyT, typename ValT = uint32_t>
 int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s,
-               const uint2* gather_rect = nullptr, uint32_t* gather_tiles = nullptr, uint32_t* gather_width = nullptr)
+               const uint2* gather_rect = nullptr, uint32_t* gather_tiles = nullptr, uint32_t* gather_width = nullptr,
+               const uint32_t* n_dev = nullptr /* n is a capacity, the real count is on the device (dev_count) */)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nblk = (uint32_t)rs_blocks(n);
@@ -130,12 +131,12 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
     for (int p = 0; p < passes; p++) {
         const int w = (bits - shift + (passes - p) - 1) / (passes - p);   // remaining bits spread evenly (7+6 == 6+7 measured)
         const uint32_t mask = (1u << w) - 1u;
-        radix_hist_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, n, shift, mask, hist, nblk);
+        radix_hist_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
         radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
         GS_LAUNCHED("radix_rowscan");
         const bool last = p == passes - 1;
-        radix_scatter_kernel<KeyT, ValT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, shift, mask, hist, scan_tmp, nblk,
+        radix_scatter_kernel<KeyT, ValT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist, scan_tmp, nblk,
                                                                      last ? gather_rect : nullptr, gather_tiles, gather_width);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
@@ -152,15 +153,14 @@ struct Readback {
 };
 constexpr int kMaxDevices = 32;
 thread_local Readback t_readback[kMaxDevices];     // one per (host thread, device): events belong to a device
-int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
+// begin: enqueue the copy + event; finish: spin until it landed.  Work enqueued between the two runs on the GPU while
+// the host waits (speculative launch in gsrast_forward).
+int read_u32_begin(const uint32_t* dev, hipStream_t s, int nwords, Readback** handle)
 {
     int device = 0;
+    *handle = nullptr;
     GS_HIP(hipGetDevice(&device));
-    if (device < 0 || device >= kMaxDevices) {     // exotic topology: plain blocking copy
-        GS_HIP(hipMemcpyAsync(out, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
-        GS_HIP(hipStreamSynchronize(s));
-        return GSRAST_OK;
-    }
+    if (device < 0 || device >= kMaxDevices) return GSRAST_OK;      // exotic topology: finish() does a blocking copy
     Readback& rb = t_readback[device];
     if (!rb.pinned) {
         GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable));
@@ -168,16 +168,34 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
     }
     GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
     GS_HIP(hipEventRecord(rb.ev, s));
-    hipError_t e;
-    while ((e = hipEventQuery(rb.ev)) == hipErrorNotReady) { }
-    if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "read_u32", e);
-    for (int k = 0; k < nwords; k++) out[k] = rb.pinned[k];
+    *handle = &rb;
     return GSRAST_OK;
+}
+int read_u32_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords)
+{
+    if (!rb) {
+        GS_HIP(hipMemcpyAsync(out, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
+        GS_HIP(hipStreamSynchronize(s));
+        return GSRAST_OK;
+    }
+    hipError_t e;
+    while ((e = hipEventQuery(rb->ev)) == hipErrorNotReady) { }
+    if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "read_u32", e);
+    for (int k = 0; k < nwords; k++) out[k] = rb->pinned[k];
+    return GSRAST_OK;
+}
+int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
+{
+    Readback* rb = nullptr;
+    int rc = read_u32_begin(dev, s, nwords, &rb);
+    if (rc != GSRAST_OK) return rc;
+    return read_u32_finish(rb, dev, s, out, nwords);
 }
 // Instances of the previous forward call: the binning buffer is requested for 1.25x that many BEFORE
 // the host waits for the real count, so the (Python) allocation callback runs while the GPU is still
 // busy with preprocess / depth sort instead of in the idle gap after the readback.
-std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0};
+std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0}, g_last_R{0}, g_last_Q{0};
+std::atomic<int> g_speculative{1};  // enqueue binning + blend before the host has read R / Q back (run-compressed path)
 std::atomic<int> g_tile_clip{1};   // run-compressed binning only: drop the tiles of a Gaussian's rectangle its alpha >= 1/255 ellipse cannot reach
 std::atomic<int> g_binning{0};     // 0 = run-compressed binning when the image allows it, 1 = always the instance-level two-pass sort
 
@@ -309,6 +327,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
     if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_binning = value; return 0; }
     if (!strcmp(name, "tile_clip")) { g_tile_clip = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "speculative")) { g_speculative = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
@@ -329,8 +348,9 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "cull")) return g_cull.load();
     if (!strcmp(name, "binning")) return g_binning.load();
     if (!strcmp(name, "tile_clip")) return g_tile_clip.load();
-    if (!strcmp(name, "last_instances")) return (int)g_R_hint.load();   // num_rendered / column runs of the last forward call
-    if (!strcmp(name, "last_runs")) return (int)g_Q_hint.load();
+    if (!strcmp(name, "last_instances")) return (int)g_last_R.load();   // num_rendered / column runs of the last forward call
+    if (!strcmp(name, "last_runs")) return (int)g_last_Q.load();
+    if (!strcmp(name, "speculative")) return g_speculative.load();
     if (!strcmp(name, "lpt")) return g_lpt.load();
     return GSRAST_E_ARG;
 }
@@ -477,15 +497,91 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         if (!bin) cap = capQ = 0;
     }
     auto t1 = std::chrono::steady_clock::now();
+
+    // ---- the rest of the forward as two re-launchable pieces ----
+    // run-compressed binning; nQ / capR are either exact counts (counts_dev == nullptr) or capacities with the real
+    // counts read on the device (speculative launch: grids and histogram strides follow the capacities)
+    auto launch_run_binning = [&](char* binb, uint32_t capR_, uint32_t capQ_, uint32_t nQ, const uint32_t* counts_dev) -> int {
+        const RunBinLayout RL = runbin_layout((size_t)capR_, (size_t)capQ_);
+        uint16_t *rkA = at<uint16_t>(binb, RL.rkeyA), *rkB = at<uint16_t>(binb, RL.rkeyB);
+        uint2 *rvA = at<uint2>(binb, RL.rvalA), *rvB = at<uint2>(binb, RL.rvalB);
+        uint32_t* hist_x = at<uint32_t>(binb, RL.hist_x);
+        uint32_t* hist_y = at<uint32_t>(binb, RL.hist_y);
+        uint32_t* rscan = at<uint32_t>(binb, RL.scan_tmp);
+        uint32_t* plist_w = at<uint32_t>(binb, RL.point_list);
+        const uint32_t* Q_dev = counts_dev ? counts_dev + 1 : nullptr;
+        const int xbits = tile_bits((size_t)cam.gx);
+        {   ProfScope ps(K_EMIT, s);
+            emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
+                                                                   g_tile_clip.load(), capQ_, rkA, rvA);
+            GS_LAUNCHED("emit_column_runs"); }
+        const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
+        {   ProfScope ps(K_SORT_TILE, s);
+            int rc = radix_sort<uint16_t, uint2>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev);   // runs by column
+            if (rc != GSRAST_OK) return rc;
+            if (radix_passes(xbits) & 1) { std::swap(rkA, rkB); std::swap(rvA, rvB); }                   // sorted runs now in (rkA, rvA)
+            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, nQ, Q_dev, hist_y, nblk);
+            GS_LAUNCHED("run_hist_rows");
+            radix_rowscan_kernel<<<256, 256, 0, s>>>(hist_y, nblk, rscan);
+            GS_LAUNCHED("radix_rowscan");
+            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, scalars + 2);
+            GS_LAUNCHED("run_scatter_rows"); }
+        {   ProfScope ps(K_RANGES, s);
+            tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges);
+            GS_LAUNCHED("tile_ranges"); }
+        return GSRAST_OK;
+    };
+    auto launch_blend = [&](const uint32_t* plist) -> int {
+        ProfScope ps(K_BLEND_FWD, s);
+        const uint32_t grid = ((T + 7) / 8) * 8;
+        float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
+        uint32_t* tm = at<uint32_t>(img, IL.tile_max);
+        BlendArgs ba{};
+        ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
+        ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
+        const int ppl = pick_ppl(T, false);
+        const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
+        if (cull && g_lpt.load()) {
+            uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
+            tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, nullptr, ord);
+            GS_LAUNCHED("tile_order");
+            ba.order = ord;
+        }
+        switch (g_exp_mode.load()) {
+        case 0: if (cull) launch_fwd_cull<0>(grid, s, ba); else dispatch_fwd<0>(ppl, grid, s, ba); break;
+        case 1: if (cull) launch_fwd_cull<1>(grid, s, ba); else dispatch_fwd<1>(ppl, grid, s, ba); break;
+        default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
+        }
+        GS_LAUNCHED("blend_fwd");
+        return GSRAST_OK;
+    };
+
     uint32_t counts[4] = { 0, 0, 0, 0 };      // {instances R (low word), column runs Q, -, R (high word, run-compressed path)}
-    { int rc = read_u32(scalars, s, counts, 4); if (rc != GSRAST_OK) return rc; }
+    Readback* rb = nullptr;
+    { int rc = read_u32_begin(scalars, s, 4, &rb); if (rc != GSRAST_OK) return rc; }
+    // Speculative launch: with a buffer sized from the previous call, binning and blend are enqueued BEFORE the host knows
+    // R and Q (the kernels read the counts on the device), so the GPU never idles on the read-back.  If the counts turn
+    // out not to fit, the device published empty ranges and the two pieces are simply launched again with exact sizes.
+    const bool speculative = runbin && bin != nullptr && g_speculative.load() != 0;
+    if (speculative) {
+        int rc = launch_run_binning(bin, cap, capQ, capQ, scalars);
+        if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0));
+        if (rc != GSRAST_OK) return rc;
+    }
+    { int rc = read_u32_finish(rb, scalars, s, counts, 4); if (rc != GSRAST_OK) return rc; }
     if (runbin && counts[3] != 0) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     auto t2 = std::chrono::steady_clock::now();
-    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u\n",
-                       std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, counts[0], counts[1]);
+    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u%s\n",
+                       std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, counts[0], counts[1],
+                       speculative ? " (speculative)" : "");
     if (counts[0] > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     const uint32_t R = counts[0], Q = counts[1];
-    g_R_hint = R; g_Q_hint = Q;
+    // capacity hints decay slowly: consecutive calls render different views, a buffer sized for the largest recent one
+    // keeps the speculative launch valid
+    { const uint32_t hr = g_R_hint.load(), hq = g_Q_hint.load();
+      g_R_hint = R > hr - hr / 16 ? R : hr - hr / 16; g_Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
+    g_last_R = R; g_last_Q = Q;
+    if (speculative && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
         cap = R; capQ = Q;
         bin = (char*)binning_alloc(binning_ctx, bin_bytes(cap, capQ));
@@ -496,31 +592,8 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     const uint32_t* plist = at<uint32_t>(bin, 0);
     if (runbin && (R == 0 || Q == 0)) GS_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s));
     if (R > 0 && Q > 0 && runbin) {
-        const RunBinLayout RL = runbin_layout((size_t)cap, (size_t)capQ);
-        uint16_t *rkA = at<uint16_t>(bin, RL.rkeyA), *rkB = at<uint16_t>(bin, RL.rkeyB);
-        uint2 *rvA = at<uint2>(bin, RL.rvalA), *rvB = at<uint2>(bin, RL.rvalB);
-        uint32_t* hist_x = at<uint32_t>(bin, RL.hist_x);
-        uint32_t* hist_y = at<uint32_t>(bin, RL.hist_y);
-        uint32_t* rscan = at<uint32_t>(bin, RL.scan_tmp);
-        uint32_t* plist_w = at<uint32_t>(bin, RL.point_list);
-        const int xbits = tile_bits((size_t)cam.gx);
-        {   ProfScope ps(K_EMIT, s);
-            emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H, g_tile_clip.load(), rkA, rvA);
-            GS_LAUNCHED("emit_column_runs"); }
-        {   ProfScope ps(K_SORT_TILE, s);
-            int rc = radix_sort<uint16_t, uint2>(rkA, rvA, rkB, rvB, Q, xbits, hist_x, rscan, s);      // runs by column
-            if (rc != GSRAST_OK) return rc;
-            if (radix_passes(xbits) & 1) { std::swap(rkA, rkB); std::swap(rvA, rvB); }                   // sorted runs now in (rkA, rvA)
-            const uint32_t nblk = (Q + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
-            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, Q, hist_y, nblk);
-            GS_LAUNCHED("run_hist_rows");
-            radix_rowscan_kernel<<<256, 256, 0, s>>>(hist_y, nblk, rscan);
-            GS_LAUNCHED("radix_rowscan");
-            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, Q, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, scalars + 2);
-            GS_LAUNCHED("run_scatter_rows"); }
-        {   ProfScope ps(K_RANGES, s);
-            tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, Q, cam.gx, cam.gy, hist_y, rscan, (Q + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK, ranges);
-            GS_LAUNCHED("tile_ranges"); }
+        int rc = launch_run_binning(bin, cap, capQ, Q, nullptr);
+        if (rc != GSRAST_OK) return rc;
     } else if (R > 0 && !runbin) {
         const BinLayout BL = bin_layout((size_t)cap);
         uint32_t *tkA = at<uint32_t>(bin, BL.keyA), *tkB = at<uint32_t>(bin, BL.keyB);
@@ -553,29 +626,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
               GS_LAUNCHED("tile_ranges"); }
         }
     }
-    {
-        ProfScope ps(K_BLEND_FWD, s);
-        const uint32_t grid = ((T + 7) / 8) * 8;
-        float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
-        uint32_t* tm = at<uint32_t>(img, IL.tile_max);
-        BlendArgs ba{};
-        ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
-        ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
-        const int ppl = pick_ppl(T, false);
-        const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
-        if (cull && g_lpt.load()) {
-            uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
-            tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, nullptr, ord);
-            GS_LAUNCHED("tile_order");
-            ba.order = ord;
-        }
-        switch (g_exp_mode.load()) {
-        case 0: if (cull) launch_fwd_cull<0>(grid, s, ba); else dispatch_fwd<0>(ppl, grid, s, ba); break;
-        case 1: if (cull) launch_fwd_cull<1>(grid, s, ba); else dispatch_fwd<1>(ppl, grid, s, ba); break;
-        default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
-        }
-        GS_LAUNCHED("blend_fwd");
-    }
+    { int rc = launch_blend(plist); if (rc != GSRAST_OK) return rc; }
     return (int)R;
 }
 
