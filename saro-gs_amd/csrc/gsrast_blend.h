@@ -568,7 +568,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     }
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     // factor applied by lane l (< 8) when it commits value l: {mean.x, mean.y, conic a, b, c, opacity, r, g}
-    const float commit_scale = lane == 0 ? ddelx_dx : lane == 1 ? ddely_dy : (lane >= 2 && lane <= 4) ? -0.5f : 1.0f;
+    const float commit_scale = lane == 0 ? -ddelx_dx : lane == 1 ? -ddely_dy : (lane >= 2 && lane <= 4) ? -0.5f : 1.0f;
 
     for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
@@ -615,7 +615,10 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const uint32_t pos = n - 1 - (base + j);
                 const float4 a = s0[j];
                 const float4 b = s1[j];
-                const float2 c = s2[j];
+                float2 c = s2[j];
+                // keep the blue channel's LDS read up here with the others: sunk into the contributing branch (where it is
+                // first used) its latency is exposed on every iteration (measured: +8 % kernel time)
+                asm volatile("" : "+v"(c.x));
                 const float dx = a.x - pxf;
                 const float xx = (a.z * dx) * dx;
                 const float xy = a.w * dx;
@@ -640,13 +643,16 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                             contributed = true;
                             const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
                             T[k] = T[k] * rcp1ma;
+                            // (folding the current pair into ac right after use -- ac += alpha (c - ac), no last_alpha /
+                            // last_color state -- is 7 VALU shorter but measured 4 % SLOWER: it makes ac wait for this
+                            // iteration's exp; here everything ac needs is known when the iteration starts)
                             const float c0 = b.z, c1 = b.w, c2 = c.x;
                             ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
                             ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
                             ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
                             float dL_dalpha = (c0 - ac0[k]) * dp0[k] + (c1 - ac1[k]) * dp1[k] + (c2 - ac2[k]) * dp2[k];
-                            dL_dalpha *= T[k];
                             last_alpha[k] = alpha;
+                            dL_dalpha *= T[k];
                             dL_dalpha += tfbg[k] * rcp1ma;
                             dch[k] = alpha * T[k]; dLa[k] = dL_dalpha; Gk[k] = G;
                         }
@@ -660,15 +666,17 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 for (int k = 0; k < PPL; k++) {
                     if (PPL > 1 && !((mk[k] >> jb) & 1ull)) continue;      // scalar
                     const float dy = a.y - pyf[k];
-                    g_r += dch[k] * dp0[k]; g_g += dch[k] * dp1[k]; g_b += dch[k] * dp2[k];
                     const float dL_dG = b.y * dLa[k];
-                    const float gdx = Gk[k] * dx, gdy = Gk[k] * dy;
-                    g_mx += dL_dG * (-gdx * a.z - gdy * a.w);
-                    g_my += dL_dG * (-gdy * b.x - gdx * a.w);
-                    g_ca += gdx * dx * dL_dG;
-                    g_cb += gdx * dy * dL_dG;
-                    g_cc += gdy * dy * dL_dG;
-                    g_op += Gk[k] * dLa[k];
+                    const float gx_ = Gk[k] * dx * dL_dG, gy_ = Gk[k] * dy * dL_dG;      // dL/dpower * d(-power)/d(...)
+                    const float t_r = dch[k] * dp0[k], t_g = dch[k] * dp1[k], t_b = dch[k] * dp2[k];
+                    const float t_mx = gx_ * a.z + gy_ * a.w;                            // sign folded into commit_scale
+                    const float t_my = gy_ * b.x + gx_ * a.w;
+                    const float t_ca = gx_ * dx, t_cb = gx_ * dy, t_cc = gy_ * dy, t_op = Gk[k] * dLa[k];
+                    if (PPL == 1) {     // plain assignment: "0 + x" is not foldable under IEEE signed-zero rules
+                        g_r = t_r; g_g = t_g; g_b = t_b; g_mx = t_mx; g_my = t_my; g_ca = t_ca; g_cb = t_cb; g_cc = t_cc; g_op = t_op;
+                    } else {
+                        g_r += t_r; g_g += t_g; g_b += t_b; g_mx += t_mx; g_my += t_my; g_ca += t_ca; g_cb += t_cb; g_cc += t_cc; g_op += t_op;
+                    }
                 }
                 {
                     // eight of the nine sums through the transposing reduction (every lane l ends with the
