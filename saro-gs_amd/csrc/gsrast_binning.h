@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t dev_count(uint32_t n, const uint32_t* __rest
 // Histogram: order does not matter here, so plain LDS atomics (per-wave private counters keep
 // contention inside a wave; a uniform digit costs at most 64 LDS cycles per round, still far below
 // the HBM time of the keys).
-template <typename KeyT>
+template <typename KeyT, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
                   uint32_t* __restrict__ block_hist, uint32_t nblk)
@@ -158,15 +158,15 @@ radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __r
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     __syncthreads();
-    const uint32_t wbase = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
-    uint32_t key[RS_ITEMS];
+    const uint32_t wbase = blockIdx.x * (RS_THREADS * ITEMS) + wave * ((RS_THREADS * ITEMS) / 4);
+    uint32_t key[ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         key[r] = i < n ? keys[i] : 0u;
     }
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) atomicAdd(&cnt[wave][(key[r] >> shift) & mask], 1u);
     }
@@ -198,7 +198,7 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
-template <typename KeyT, typename ValT>
+template <typename KeyT, typename ValT, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev,
@@ -214,25 +214,25 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t dstart[256];       // first block-local slot of each digit
     __shared__ uint32_t gbase[256];        // global destination of that slot
-    __shared__ KeyT xk[RS_CHUNK];
-    __shared__ ValT xv[RS_CHUNK];
+    __shared__ KeyT xk[(RS_THREADS * ITEMS)];
+    __shared__ ValT xv[(RS_THREADS * ITEMS)];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     __syncthreads();
     volatile uint32_t* wc = cnt[wave];
-    const uint32_t wbase = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
+    const uint32_t wbase = blockIdx.x * (RS_THREADS * ITEMS) + wave * ((RS_THREADS * ITEMS) / 4);
     const int nbits = 32 - __builtin_clz(mask);          // digit width of this pass (mask = 2^w - 1)
-    uint32_t key[RS_ITEMS], rk[RS_ITEMS];
-    ValT val[RS_ITEMS];
+    uint32_t key[ITEMS], rk[ITEMS];
+    ValT val[ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
         val[r] = valid ? vals_in[i] : ValT{};
     }
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = (key[r] >> shift) & mask;
@@ -255,7 +255,7 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
             const uint32_t d = (key[r] >> shift) & mask;
@@ -264,10 +264,10 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
         }
     }
     __syncthreads();
-    const uint32_t b0 = blockIdx.x * RS_CHUNK;      // may lie past n in a capacity-sized launch
-    const uint32_t nvalid = b0 >= n ? 0u : ((n - b0) < (uint32_t)RS_CHUNK ? (n - b0) : (uint32_t)RS_CHUNK);
+    const uint32_t b0 = blockIdx.x * (RS_THREADS * ITEMS);      // may lie past n in a capacity-sized launch
+    const uint32_t nvalid = b0 >= n ? 0u : ((n - b0) < (uint32_t)(RS_THREADS * ITEMS) ? (n - b0) : (uint32_t)(RS_THREADS * ITEMS));
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t slot = r * RS_THREADS + threadIdx.x;
         if (slot < nvalid) {
             const KeyT kk = xk[slot];

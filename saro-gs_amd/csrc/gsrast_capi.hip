@@ -118,25 +118,28 @@ int scan_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst
 // contiguous runs in the scatter's write-out).  Result ends in (kA,vA) if the pass count is even,
 // else in (kB,vB).
 int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
-template <typename KeyT, typename ValT = uint32_t>
+// ITEMS = elements per lane: a workgroup sorts 256 * ITEMS consecutive elements.  The R-sized sort wants 16 (long
+// contiguous runs in the write-out); the P- and Q-sized ones have too few elements to fill 256 CUs with 4096-element
+// chunks (1 M Gaussians = 245 workgroups) and run faster with smaller ones.
+template <typename KeyT, typename ValT = uint32_t, int ITEMS = RS_ITEMS>
 int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s,
                const uint2* gather_rect = nullptr, uint32_t* gather_tiles = nullptr, uint32_t* gather_width = nullptr,
                const uint32_t* n_dev = nullptr /* n is a capacity, the real count is on the device (dev_count) */)
 {
     if (n == 0) return GSRAST_OK;
-    const uint32_t nblk = (uint32_t)rs_blocks(n);
+    const uint32_t nblk = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
     const int passes = radix_passes(bits);
     int shift = 0;
     for (int p = 0; p < passes; p++) {
         const int w = (bits - shift + (passes - p) - 1) / (passes - p);   // remaining bits spread evenly (7+6 == 6+7 measured)
         const uint32_t mask = (1u << w) - 1u;
-        radix_hist_kernel<KeyT><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk);
+        radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
         radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
         GS_LAUNCHED("radix_rowscan");
         const bool last = p == passes - 1;
-        radix_scatter_kernel<KeyT, ValT><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist, scan_tmp, nblk,
+        radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist, scan_tmp, nblk,
                                                                      last ? gather_rect : nullptr, gather_tiles, gather_width);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
@@ -462,7 +465,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     {
         ProfScope ps(K_SORT_DEPTH, s);
         // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
-        int rc = radix_sort<uint32_t>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets);
+        int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A
@@ -517,7 +520,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             GS_LAUNCHED("emit_column_runs"); }
         const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
         {   ProfScope ps(K_SORT_TILE, s);
-            int rc = radix_sort<uint16_t, uint2>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev);   // runs by column
+            int rc = radix_sort<uint16_t, uint2, GSRAST_RUN_SORT_ITEMS>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev);   // runs by column
             if (rc != GSRAST_OK) return rc;
             if (radix_passes(xbits) & 1) { std::swap(rkA, rkB); std::swap(rvA, rvB); }                   // sorted runs now in (rkA, rvA)
             run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, nQ, Q_dev, hist_y, nblk);
