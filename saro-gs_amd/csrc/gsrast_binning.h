@@ -172,7 +172,7 @@ radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __r
     }
     __syncthreads();
     const uint32_t t = threadIdx.x;
-    block_hist[(size_t)t * nblk + blockIdx.x] = cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];
+    if (t <= mask) block_hist[(size_t)t * nblk + blockIdx.x] = cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];   // rows past the digit range are never read
 }
 
 // One workgroup per digit: in-place exclusive scan of that digit's row of block counts, row total
@@ -248,9 +248,10 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
         const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
         uint32_t tot, gtot;
         const uint32_t start = block_excl_scan(c0 + c1 + c2 + c3, &tot);
-        const uint32_t dbase = block_excl_scan(digit_total[t], &gtot);   // elements with a smaller digit, globally
+        const bool used = t <= mask;                                      // the row scan ran for mask + 1 digits only
+        const uint32_t dbase = block_excl_scan(used ? digit_total[t] : 0u, &gtot);   // elements with a smaller digit, globally
         dstart[t] = start;
-        gbase[t] = dbase + hist_scanned[(size_t)t * nblk + blockIdx.x];
+        gbase[t] = dbase + (used ? hist_scanned[(size_t)t * nblk + blockIdx.x] : 0u);
         cnt[0][t] = start; cnt[1][t] = start + c0; cnt[2][t] = start + c0 + c1; cnt[3][t] = start + c0 + c1 + c2;
     }
     __syncthreads();
@@ -499,7 +500,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
 // +1 at y0, -1 at y0+h in an LDS difference array, prefix sum, one column of the digit-major table.
 __global__ void __launch_bounds__(256)
 run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, const uint32_t* __restrict__ Q_dev,
-                     uint32_t* __restrict__ block_hist, uint32_t nblk)
+                     uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t nrows /* tile rows: only these table rows exist */)
 {
     __shared__ int diff[257];
     Q = dev_count(Q, Q_dev);
@@ -519,7 +520,7 @@ run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, const uint3
     const uint32_t mine = (uint32_t)diff[threadIdx.x];
     uint32_t tot;
     const uint32_t incl = block_excl_scan(mine, &tot) + mine;      // wrap-around arithmetic of the signed deltas is exact
-    block_hist[(size_t)threadIdx.x * nblk + blockIdx.x] = incl;
+    if (threadIdx.x < nrows) block_hist[(size_t)threadIdx.x * nblk + blockIdx.x] = incl;
 }
 
 // Tile ranges without reading the sorted list back (and without a tile id stream next to it):
@@ -545,7 +546,7 @@ __device__ __forceinline__ uint32_t first_run_of_column(const uint16_t* __restri
 }
 __device__ __forceinline__ uint32_t row_instances_before_run(const uint2* __restrict__ run_vals, uint32_t Q, uint32_t F,
                                                               const uint32_t* __restrict__ hist_scanned, uint32_t nblk,
-                                                              uint32_t row_total, int* diff /* LDS [257] */)
+                                                              uint32_t nrows, uint32_t row_total, int* diff /* LDS [257] */)
 {
     if (F >= Q) return row_total;                              // uniform
     const uint32_t b0 = F / RUNS_PER_BLOCK, r0 = b0 * RUNS_PER_BLOCK;
@@ -561,7 +562,7 @@ __device__ __forceinline__ uint32_t row_instances_before_run(const uint2* __rest
     const uint32_t mine = (uint32_t)diff[threadIdx.x];
     uint32_t tot;
     const uint32_t incl = block_excl_scan(mine, &tot) + mine;
-    return hist_scanned[(size_t)threadIdx.x * nblk + b0] + incl;
+    return (threadIdx.x < nrows ? hist_scanned[(size_t)threadIdx.x * nblk + b0] : 0u) + incl;
 }
 __global__ void __launch_bounds__(256)
 tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q,
@@ -579,13 +580,14 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
         if (overflow) { if (y < (uint32_t)gy) ranges[y * (uint32_t)gx + x] = make_uint2(0u, 0u); return; }
         Q = counts_dev[1];
     }
-    const uint32_t row_total = digit_total[y];
+    const uint32_t nrows = (uint32_t)gy;
+    const uint32_t row_total = y < nrows ? digit_total[y] : 0u;
     uint32_t all;
     const uint32_t row_base = block_excl_scan(row_total, &all);
     const uint32_t F0 = first_run_of_column(run_keys, Q, x);
     const uint32_t F1 = first_run_of_column(run_keys, Q, x + 1u);
-    const uint32_t before0 = row_instances_before_run(run_vals, Q, F0, hist_scanned, nblk, row_total, diff);
-    const uint32_t before1 = row_instances_before_run(run_vals, Q, F1, hist_scanned, nblk, row_total, diff);
+    const uint32_t before0 = row_instances_before_run(run_vals, Q, F0, hist_scanned, nblk, nrows, row_total, diff);
+    const uint32_t before1 = row_instances_before_run(run_vals, Q, F1, hist_scanned, nblk, nrows, row_total, diff);
     if (y < (uint32_t)gy)
         ranges[y * (uint32_t)gx + x] = before1 > before0 ? make_uint2(row_base + before0, row_base + before1) : make_uint2(0u, 0u);
 }
@@ -597,7 +599,7 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
 // prefix count plus a popcount of the slot's word.
 __global__ void __launch_bounds__(RS_THREADS)
 run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column */,
-                        uint32_t Q, const uint32_t* __restrict__ Q_dev, uint32_t capR, int ybits, const uint32_t* __restrict__ hist_scanned,
+                        uint32_t Q, const uint32_t* __restrict__ Q_dev, uint32_t capR, int ybits, uint32_t nrows, const uint32_t* __restrict__ hist_scanned,
                         const uint32_t* __restrict__ digit_total, uint32_t nblk,
                         uint32_t* __restrict__ point_list,
                         uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */)
@@ -640,9 +642,9 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
         }
         if (t == 0) { s_start[RUNS_PER_BLOCK] = tot & 0xFFFFFu; s_nruns = tot >> 20; }
         uint32_t gtot;
-        const uint32_t dbase = block_excl_scan(digit_total[t], &gtot);   // instances in lower tile rows, globally
+        const uint32_t dbase = block_excl_scan(t < nrows ? digit_total[t] : 0u, &gtot);   // instances in lower tile rows, globally
         if (blockIdx.x == 0 && t == 0) *total_out = gtot;
-        running[t] = dbase + hist_scanned[(size_t)t * nblk + blockIdx.x];
+        running[t] = dbase + (t < nrows ? hist_scanned[(size_t)t * nblk + blockIdx.x] : 0u);
     }
     __syncthreads();
     const uint32_t ninst = s_start[RUNS_PER_BLOCK];

@@ -136,7 +136,7 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
         const uint32_t mask = (1u << w) - 1u;
         radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
-        radix_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblk, scan_tmp);
+        radix_rowscan_kernel<<<mask + 1, 256, 0, s>>>(hist, nblk, scan_tmp);     // one workgroup per digit value in use
         GS_LAUNCHED("radix_rowscan");
         const bool last = p == passes - 1;
         radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist, scan_tmp, nblk,
@@ -523,11 +523,11 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             int rc = radix_sort<uint16_t, uint2, GSRAST_RUN_SORT_ITEMS>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev);   // runs by column
             if (rc != GSRAST_OK) return rc;
             if (radix_passes(xbits) & 1) { std::swap(rkA, rkB); std::swap(rvA, rvB); }                   // sorted runs now in (rkA, rvA)
-            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, nQ, Q_dev, hist_y, nblk);
+            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, nQ, Q_dev, hist_y, nblk, (uint32_t)cam.gy);
             GS_LAUNCHED("run_hist_rows");
-            radix_rowscan_kernel<<<256, 256, 0, s>>>(hist_y, nblk, rscan);
+            radix_rowscan_kernel<<<cam.gy, 256, 0, s>>>(hist_y, nblk, rscan);     // one workgroup per tile row
             GS_LAUNCHED("radix_rowscan");
-            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), hist_y, rscan, nblk, plist_w, scalars + 2);
+            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), (uint32_t)cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2);
             GS_LAUNCHED("run_scatter_rows"); }
         {   ProfScope ps(K_RANGES, s);
             tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges);
