@@ -452,16 +452,17 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     uint32_t* scan_tmp = at<uint32_t>(geom, GL.scan_tmp);
     uint32_t* scalars = at<uint32_t>(geom, GL.scalars);
 
+    // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
+    const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
         preprocess_fwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
             colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
-            at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA);
+            at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
+            (runbin && g_tile_clip.load()) ? 1 : 0);
         GS_LAUNCHED("preprocess_fwd");
     }
-    // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
-    const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
     {
         ProfScope ps(K_SORT_DEPTH, s);
         // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order

@@ -232,7 +232,8 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ depths, float4* __restrict__ rec0, float4* __restrict__ rec1,
                       float4* __restrict__ rec2, float* __restrict__ cov3D, unsigned char* __restrict__ clamped,
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
-                      uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val)
+                      uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val,
+                      int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
@@ -302,6 +303,33 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 clamped[i] = (unsigned char)cl;
                 rad_out = rad; ntiles = (uint32_t)area;
                 key = __float_as_uint(pv[2]);
+                if (clip_rect) {
+                    // Bounding box of the ellipse the alpha >= 1/255 pixels lie in (same construction and margins as the
+                    // per-column clipping in emit_column_runs_kernel, gsrast_binning.h): whole tile columns / rows of the
+                    // 3-sigma square that it cannot reach produce no column runs at all.  tiles[] (-> num_rendered) keeps
+                    // the reference's count.
+                    const float DX = fmaxf(fabsf(px - 16.0f * (float)rmin[0]), fabsf(16.0f * (float)rmax[0] - px));
+                    const float DY = fmaxf(fabsf(py - 16.0f * (float)rmin[1]), fabsf(16.0f * (float)rmax[1] - py));
+                    const float Mb = (fabsf(con0) + fabsf(con1)) * DX * DX + (fabsf(con2) + fabsf(con1)) * DY * DY;
+                    const double t = (double)(-thr + 1e-6f * Mb);
+                    const double a = (double)con0, b = (double)con1, c = (double)con2;
+                    const double dd = a * c - b * b;
+                    if (!(t >= 0.0)) { rmax[0] = rmin[0]; rmax[1] = rmin[1]; }
+                    else if (dd > 0.0 && a > 0.0 && c > 0.0) {
+                        const double ex[2] = { sqrt(2.0 * t * c / dd), sqrt(2.0 * t * a / dd) };   // half extents in x, y
+                        const double ctr[2] = { (double)px, (double)py };
+                        const int lim[2] = { cam.W - 1, cam.H - 1 };
+#pragma unroll
+                        for (int ax = 0; ax < 2; ax++) {
+                            if (!(ex[ax] < 1e30)) continue;
+                            const double plo = ceil(ctr[ax] - ex[ax] - 1e-3), phi = floor(ctr[ax] + ex[ax] + 1e-3);
+                            const int tlo = max(rmin[ax], (int)fmax(plo, 0.0) >> 4);
+                            const int thi = min(rmax[ax] - 1, (int)fmin(phi, (double)lim[ax]) >> 4);
+                            if (phi < 0.0 || plo > (double)lim[ax] || thi < tlo) { rmax[0] = rmin[0]; rmax[1] = rmin[1]; }
+                            else { rmin[ax] = tlo; rmax[ax] = thi + 1; }
+                        }
+                    }
+                }
                 rc = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
                 // everything the binning needs about this Gaussian in ONE 32-byte record (it is gathered in depth order)
                 binrec[2 * (size_t)i] = make_float4(px, py, con0, con1);
