@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--exchange", choices=("factors", "allreduce"), default="factors",
+                    help="multi-GPU gradient exchange: 'factors' = all-reduce 11 + all-gather 3 floats/Gaussian (default), "
+                         "'allreduce' = all-reduce all 59 floats/Gaussian")
     ap.add_argument("--exp-mode", type=int, default=None, help="0 fixed-sequence (default), 1 ocml, 2 v_exp_f32")
     ap.add_argument("--sweep", type=str, default="100000,300000,1000000,3000000",
                     help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
@@ -88,8 +91,11 @@ class Workload:
                                           shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)
         if bucket is not None and world > 1:
-            # the backward wrote the leaf gradients straight into bucket.flat (zero-copy GradArena)
-            self.vp.allreduce_mean_inplace(bucket.flat, world)
+            # the backward wrote the leaf gradients straight into the bucket (zero-copy GradArena)
+            if getattr(bucket, "sh_factors", False):
+                self.vp.exchange_gradients(bucket, L["means3D"].detach(), world)     # all-reduce 11 + all-gather 3 floats/Gaussian
+            else:
+                self.vp.allreduce_mean_inplace(bucket.flat, world)                    # all-reduce 59 floats/Gaussian
         return radii
 
     def _forward_state(self):
@@ -265,9 +271,11 @@ def main():
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)
     bucket = None
     if world > 1:
-        # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the
-        # backward writes into it directly and the step ends with ONE in-place all-reduce (mean)
-        bucket = _C.GradArena(P, 16, dev)
+        # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the backward writes
+        # into it directly.  Default exchange: all-reduce of the 11 dense floats + all-gather of the 3-float factor of
+        # dL/dsh, recombined locally (view_parallel.exchange_gradients); --exchange allreduce: ONE in-place all-reduce
+        # of all 59 floats.  Both give the batch-mean gradient of set_batch_gradient (saro_gaussian.py:266-276).
+        bucket = _C.GradArena(P, 16, dev, sh_factors=(a.exchange == "factors"), world=world)
         _C.set_grad_arena(bucket)
 
     names = [_C.lib().gsrast_profile_kernel_name(k).decode() for k in range(_C.lib().gsrast_profile_kernel_count())]
@@ -341,7 +349,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
-                                   + (" + RCCL all-reduce(mean) of 59 floats/Gaussian" if world > 1 else ""),
+                                   + ((" + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
+                                       if a.exchange == "factors" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
                        "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],

@@ -116,6 +116,16 @@ size_t gsrast_geometry_bytes(int P);
 size_t gsrast_binning_bytes(int num_rendered, int width, int height);
 size_t gsrast_image_bytes(int width, int height);
 
+/* Multi-GPU gradient exchange (no counterpart in the reference, which is single-GPU and sums the per-view gradients of a
+ * batch in place, scene/saro_gaussian.py:226-247, :266-276).  Row k of a view's dL/dsh is w_k(view direction) * g, where
+ * g[3] is that view's clamp-masked colour gradient of the Gaussian: instead of all-reducing 16 x 3 products per Gaussian,
+ * ranks all-gather the 3 numbers and every rank recombines.  With gsrast_set_option("sh_grad_factors", 1),
+ * gsrast_backward writes g into dL_dsh, which is then a [P][3] array.  gsrast_sh_grad_combine evaluates
+ *     dL_dsh[i][k][c] = scale * sum_{r < N} w_k(normalize(means3D[i] - campos_r)) * g_r[i][c]
+ * chunks = N records of chunk_stride floats: [3P floats g_r | 3 floats campos_r | padding].  All device pointers. */
+int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
+                           float scale, float* dL_dsh /*[P][M][3]*/, void* stream);
+
 /* Parity-test helper: copies internal state out in the reference's array layout
  * (GeometryState / BinningState / ImageState members, rasterizer_impl.h:30-65).  Any output
  * pointer may be NULL.  All pointers are device pointers.  keys_sorted is rebuilt as

@@ -199,6 +199,7 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // busy with preprocess / depth sort instead of in the idle gap after the readback.
 std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0}, g_last_R{0}, g_last_Q{0};
 std::atomic<int> g_speculative{1};  // enqueue binning + blend before the host has read R / Q back (run-compressed path)
+std::atomic<int> g_sh_grad_factors{0};   // gsrast_backward writes the [P][3] factor of dL/dsh instead of dL/dsh (multi-GPU exchange)
 std::atomic<int> g_tile_clip{1};   // run-compressed binning only: drop the tiles of a Gaussian's rectangle its alpha >= 1/255 ellipse cannot reach
 std::atomic<int> g_binning{0};     // 0 = run-compressed binning when the image allows it, 1 = always the instance-level two-pass sort
 
@@ -330,6 +331,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
     if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_binning = value; return 0; }
     if (!strcmp(name, "tile_clip")) { g_tile_clip = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "sh_grad_factors")) { g_sh_grad_factors = value ? 1 : 0; return 0; }
     if (!strcmp(name, "speculative")) { g_speculative = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -351,6 +353,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "cull")) return g_cull.load();
     if (!strcmp(name, "binning")) return g_binning.load();
     if (!strcmp(name, "tile_clip")) return g_tile_clip.load();
+    if (!strcmp(name, "sh_grad_factors")) return g_sh_grad_factors.load();
     if (!strcmp(name, "last_instances")) return (int)g_last_R.load();   // num_rendered / column runs of the last forward call
     if (!strcmp(name, "last_runs")) return (int)g_last_Q.load();
     if (!strcmp(name, "speculative")) return g_speculative.load();
@@ -634,6 +637,18 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     return (int)R;
 }
 
+int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
+                           float scale, float* dL_dsh, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || N < 1 || M < 1 || D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail(GSRAST_E_ARG, "sh_grad_combine: bad sizes");
+    if (P == 0) return GSRAST_OK;
+    if (!means3D || !chunks || !dL_dsh || chunk_stride < (size_t)3 * P + 3) return fail(GSRAST_E_ARG, "sh_grad_combine: NULL or short buffer");
+    sh_grad_combine_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(P, D, M, N, means3D, chunks, chunk_stride, scale, dL_dsh);
+    GS_LAUNCHED("sh_grad_combine");
+    return GSRAST_OK;
+}
+
 int gsrast_backward(int P, int D, int M, int R, const float* background, int width, int height,
                     const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                     float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -696,7 +711,7 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         preprocess_bwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, radii, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
             use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, dL_dmean2D, dL_dconic, dL_dcolor,
-            dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, (use_sh && g_sh_grad_factors.load()) ? 1 : 0);
         GS_LAUNCHED("preprocess_bwd");
     }
     return GSRAST_OK;

@@ -358,9 +358,13 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 
 // -------------------------------------------------------------------------------------------
 // SH backward: writes dL_dsh rows [0,(deg+1)^2) and ADDS the view-direction term to dmean.
+// FACTORS: dL/dsh is not written at all.  Row k of it is w_k(view direction) * g, with g = the clamp-masked colour
+// gradient: a rank-1 outer product of 16 weights that any rank can recompute from the camera position and 3 numbers.
+// The multi-GPU exchange moves g (returned in g_out) instead of the 48 products (gsrast_sh_grad_combine).
+template <bool FACTORS = false>
 __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const float campos[3],
                                             const float* __restrict__ sh, unsigned cl, const float dcol[3],
-                                            float dmean[3], float* __restrict__ dsh)
+                                            float dmean[3], float* __restrict__ dsh, float* g_out = nullptr)
 {
     const float o0 = pos[0] - campos[0], o1 = pos[1] - campos[1], o2 = pos[2] - campos[2];
     const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
@@ -368,9 +372,10 @@ __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const f
     float g[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) g[c] = dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f);
+    if (FACTORS) { g_out[0] = g[0]; g_out[1] = g[1]; g_out[2] = g[2]; }
     float dx[3] = { 0, 0, 0 }, dy[3] = { 0, 0, 0 }, dz[3] = { 0, 0, 0 };
 #define SHV(k, c) sh[(k) * 3 + (c)]
-#define PUT(k, w) { const float w_ = (w); dsh[(k) * 3 + 0] = w_ * g[0]; dsh[(k) * 3 + 1] = w_ * g[1]; dsh[(k) * 3 + 2] = w_ * g[2]; }
+#define PUT(k, w) { if (!FACTORS) { const float w_ = (w); dsh[(k) * 3 + 0] = w_ * g[0]; dsh[(k) * 3 + 1] = w_ * g[1]; dsh[(k) * 3 + 2] = w_ * g[2]; } }
     PUT(0, kSH0);
     if (deg > 0) {
         PUT(1, -kSH1 * y); PUT(2, kSH1 * z); PUT(3, -kSH1 * x);
@@ -431,7 +436,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic,
                       const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-                      float* __restrict__ dL_drot)
+                      float* __restrict__ dL_drot,
+                      int sh_factors /* dL_dsh is [P][3]: receives the factor g of every Gaussian instead of the rows */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
@@ -447,7 +453,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
         if (shs) {
-            if (staged) { for (int k = 0; k < M * 3; k++) my_lds[k] = 0.0f; }
+            if (sh_factors) { for (int k = 0; k < 3; k++) dL_dsh[3 * (size_t)i + k] = 0.0f; }
+            else if (staged) { for (int k = 0; k < M * 3; k++) my_lds[k] = 0.0f; }
             else { for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.0f; }
         }
         if (scales) {
@@ -521,7 +528,12 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
     if (shs) {
         const float dcol[3] = { dL_dcolor[3 * (size_t)i], dL_dcolor[3 * (size_t)i + 1], dL_dcolor[3 * (size_t)i + 2] };
-        if (staged) {
+        if (sh_factors) {
+            float gf[3];
+            sh_backward<true>(D, mean, cam.campos, staged ? my_lds : shs + (size_t)i * M * 3, clamped[i], dcol, dmean, nullptr, gf);
+#pragma unroll
+            for (int k = 0; k < 3; k++) dL_dsh[3 * (size_t)i + k] = gf[k];
+        } else if (staged) {
             // the lane's coefficients move LDS -> registers first: its LDS row is then reused for dL/dsh
             float shv[PP_SH_MAX];
 #pragma unroll
@@ -574,7 +586,62 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         reinterpret_cast<float4*>(dL_drot)[i] = dq;
     }
     } // live
-    if (staged) { __syncthreads(); stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds); }
+    if (staged && !sh_factors) { __syncthreads(); stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds); }
+}
+
+// dL/dsh of a batch of N views from the N per-view factors (see sh_backward<FACTORS>):
+//   dL_dsh[i][k][c] = scale * sum_r w_k(dir(means3D[i] - campos_r)) * g_r[i][c],   r in rank order.
+// chunks: N records of `stride` floats: [3P floats g | 3 floats campos | padding].  With N = 1, scale = 1 the result is
+// bit-identical to what preprocess_bwd_kernel writes itself (0 + w*g).
+__global__ void __launch_bounds__(PP_THREADS)
+sh_grad_combine_kernel(int P, int D, int M, int N, const float* __restrict__ means3D, const float* __restrict__ chunks,
+                       size_t stride, float scale, float* __restrict__ dL_dsh)
+{
+    __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
+    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+    const bool staged = M * 3 <= PP_SH_MAX;
+    float acc[PP_SH_MAX];
+#pragma unroll
+    for (int k = 0; k < PP_SH_MAX; k++) acc[k] = 0.0f;
+    if (i < P) {
+        const float pos[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+        for (int r = 0; r < N; r++) {
+            const float* ch = chunks + (size_t)r * stride;
+            const float o0 = pos[0] - ch[3 * (size_t)P], o1 = pos[1] - ch[3 * (size_t)P + 1], o2 = pos[2] - ch[3 * (size_t)P + 2];
+            const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+            const float x = o0 / len, y = o1 / len, z = o2 / len;
+            const float g[3] = { ch[3 * (size_t)i], ch[3 * (size_t)i + 1], ch[3 * (size_t)i + 2] };
+#define ACC(k, w) { const float w_ = (w); acc[(k) * 3 + 0] += w_ * g[0]; acc[(k) * 3 + 1] += w_ * g[1]; acc[(k) * 3 + 2] += w_ * g[2]; }
+            ACC(0, kSH0);
+            if (D > 0) {
+                ACC(1, -kSH1 * y); ACC(2, kSH1 * z); ACC(3, -kSH1 * x);
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    ACC(4, kSH2[0] * xy); ACC(5, kSH2[1] * yz); ACC(6, kSH2[2] * (2.0f * zz - xx - yy));
+                    ACC(7, kSH2[3] * xz); ACC(8, kSH2[4] * (xx - yy));
+                    if (D > 2) {
+                        ACC(9, kSH3[0] * y * (3.0f * xx - yy)); ACC(10, kSH3[1] * xy * z);
+                        ACC(11, kSH3[2] * y * (4.0f * zz - xx - yy));
+                        ACC(12, kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
+                        ACC(13, kSH3[4] * x * (4.0f * zz - xx - yy)); ACC(14, kSH3[5] * z * (xx - yy));
+                        ACC(15, kSH3[6] * x * (xx - 3.0f * yy));
+                    }
+                }
+            }
+#undef ACC
+        }
+    }
+    if (staged) {
+        float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
+        if (i < P) {
+#pragma unroll
+            for (int k = 0; k < PP_SH_MAX; k++) if (k < M * 3) my_lds[k] = N == 1 && scale == 1.0f ? acc[k] : acc[k] * scale;
+        }
+        __syncthreads();
+        stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
+    } else if (i < P) {
+        for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = k < PP_SH_MAX ? acc[k] * scale : 0.0f;
+    }
 }
 
 } // namespace gsrast

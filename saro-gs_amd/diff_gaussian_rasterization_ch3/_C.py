@@ -32,6 +32,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
+    "gsrast_sh_grad_combine",
 )
 
 
@@ -80,6 +81,8 @@ def lib() -> C.CDLL:
     L.gsrast_loss_forward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp]
     L.gsrast_loss_backward.restype = ci
     L.gsrast_loss_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
+    L.gsrast_sh_grad_combine.restype = ci
+    L.gsrast_sh_grad_combine.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, cf, vp, vp]
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
     if L.gsrast_abi_version() != 1:
@@ -129,15 +132,26 @@ class GradArena:
     without an arena the outputs are ordinary tensors, exactly as before."""
 
     ORDER = (("means3D", 3), ("sh", None), ("opacity", 1), ("scales", 3), ("rotations", 4))
+    # sh_factors=True: the dense part first (one contiguous all-reduce), dL/dsh last -- it is not exchanged at all: the
+    # backward writes the per-view FACTOR g[P,3] of dL/dsh (include/gsrast.h, gsrast_sh_grad_combine) into `factor`,
+    # ranks all-gather the factors (+ their camera positions) and every rank recombines dL/dsh locally.
+    ORDER_FACTORS = (("means3D", 3), ("opacity", 1), ("scales", 3), ("rotations", 4), ("sh", None))
 
-    def __init__(self, P: int, M: int, device: torch.device):
-        self.P, self.M = P, M
-        self.widths = {name: (M * 3 if w is None else w) for name, w in self.ORDER}
+    def __init__(self, P: int, M: int, device: torch.device, sh_factors: bool = False, world: int = 1):
+        self.P, self.M, self.sh_factors, self.world = P, M, bool(sh_factors), int(world)
+        order = self.ORDER_FACTORS if sh_factors else self.ORDER
+        self.widths = {name: (M * 3 if w is None else w) for name, w in order}
         self.offsets, o = {}, 0
-        for name, _ in self.ORDER:
+        for name, _ in order:
             self.offsets[name] = o
             o += P * self.widths[name]
         self.flat = torch.zeros(o, dtype=torch.float32, device=device)
+        if sh_factors:
+            self.dense = self.flat[: self.offsets["sh"]]                      # 11 floats / Gaussian: the all-reduced part
+            self.chunk = ((3 * P + 3 + 3) // 4) * 4                            # [3P g | 3 campos | pad], 16-byte multiple
+            self.factor = torch.zeros(self.chunk, dtype=torch.float32, device=device)
+            self.gathered = torch.zeros(self.world * self.chunk, dtype=torch.float32, device=device)
+        self.last_degree = 0
 
     def take(self, name: str, shape, zero: bool) -> torch.Tensor:
         n = self.P * self.widths[name]
@@ -260,22 +274,52 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dmeans3D = out("means3D", (P, 3), False)
     dL_dcov3D = torch.empty((P, 6), **opts)
     dL_dsh = out("sh", (P, M, 3), not use_sh)
+    factors = ar is not None and ar.sh_factors
+    if factors:
+        # dL_dsh (a view of the arena) is returned to autograd as usual but only becomes valid after
+        # sh_grad_combine(); the kernel writes this view's factor g[P,3] (+ the camera position behind it)
+        ar.factor[3 * P: 3 * P + 3].copy_(campos.reshape(-1)[:3])
+        ar.last_degree = int(degree)
     dL_dscales = out("scales", (P, 3), not use_sr)
     dL_drotations = out("rotations", (P, 4), not use_sr)
     if P != 0:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.gsrast_backward(
-                P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
-                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
-                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(),
-                dL_drotations.data_ptr(), stream)
+            sh_out = ar.factor.data_ptr() if factors else _ptr(dL_dsh)
+            if factors:
+                L.gsrast_set_option(b"sh_grad_factors", 1)
+            try:
+                rc = L.gsrast_backward(
+                    P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                    _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
+                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
+                    dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                    dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), sh_out, dL_dscales.data_ptr(),
+                    dL_drotations.data_ptr(), stream)
+            finally:
+                if factors:
+                    L.gsrast_set_option(b"sh_grad_factors", 0)
         if rc != 0:
             raise _err(rc, "gsrast_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Tensor, n_views: int, scale: float) -> torch.Tensor:
+    """dL/dsh of `n_views` views from their factors (include/gsrast.h: gsrast_sh_grad_combine), written into the
+    arena's dL/dsh region (the tensor autograd already handed out as shs.grad)."""
+    L = lib()
+    P, M = arena.P, arena.M
+    out = arena.take("sh", (P, M, 3), False)
+    if P == 0:
+        return out
+    dev = means3D.device
+    with torch.cuda.device(dev):
+        rc = L.gsrast_sh_grad_combine(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
+                                      arena.chunk, float(scale), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_sh_grad_combine")
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

@@ -1,0 +1,36 @@
+"""-m gpu: the N > 1 code path on a 1-GPU box -- two ranks (torch.distributed.run, gloo) share cuda:0.
+RCCL itself needs one GPU per rank, so the collective library differs from the 8-GPU run; everything else (arena
+layout, factor exchange, the HIP combine kernel, bench.py's multi-rank flow) is the code the driver launches."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torchrun(script_args, port):
+    env = dict(os.environ, GSRAST_DIST_BACKEND="gloo", GSRAST_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_factor_exchange_equals_plain_allreduce():
+    out = _torchrun([os.path.join("tests", "mr_exchange_check.py")], 29541)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("EXCHANGE_CHECK")]
+    assert len(lines) == 2 and all("same_on_all_ranks True" in l for l in lines), lines
+
+
+@pytest.mark.parametrize("exchange", ["factors", "allreduce"])
+def test_bench_two_ranks(exchange):
+    out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "100000", "--exchange", exchange,
+                     "--sweep", "", "--no-cpu-baseline"], 29542 if exchange == "factors" else 29543)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["views_per_step"] == 2 and d["value"] > 0 and d["scaling"] == "weak"

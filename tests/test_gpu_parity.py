@@ -369,6 +369,61 @@ def test_grad_arena_zero_copy_bucket(scenes, rast, gpu):
     assert torch.equal(arena.flat[off: off + P * 48].view(P, 16, 3), bucketed["shs"].grad)
 
 
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_gradient_factor_exchange(deg, scenes, rast, gpu):
+    """Multi-GPU exchange of dL/dsh by its rank-1 factor (view_parallel.exchange_gradients, gsrast_sh_grad_combine):
+    the batch mean of V views' dL/dsh recombined from V x 3 floats per Gaussian must equal the mean of the V dL/dsh
+    tensors the plain backward writes (here the V views run in one process; the collective is a copy)."""
+    import torch
+    from conftest import settings_from
+    import view_parallel
+    P, W, H, V = 4000, 160, 120, 3
+    sc = scenes.synth(P, 101, sh_degree=deg)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    g = t(scenes.upstream_grad(H, W, 102))
+    _C = rast._C
+
+    def run(k):
+        cam = scenes.camera(k, V, W, H)
+        rs = settings_from(rast, cam, sc, gpu)
+        leaves = {n: t(sc[n]).requires_grad_(True) for n in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        color, _, _ = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                  shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        color.backward(g)
+        return leaves
+
+    plain = [run(k) for k in range(V)]
+    want = {n: sum(p[n].grad for p in plain) / V for n in plain[0]}
+
+    # one "rank" per view: every backward leaves its factor chunk; the all-gather is emulated by stacking the chunks
+    arena = _C.GradArena(P, 16, gpu, sh_factors=True, world=1)
+    _C.set_grad_arena(arena)
+    try:
+        chunks, dense = [], torch.zeros_like(arena.dense)
+        for k in range(V):
+            lv = run(k)
+            chunks.append(arena.factor.clone())
+            dense += arena.dense
+            if k == 0:      # single view through the public entry point: shs.grad (a view of the arena) gets filled
+                view_parallel.exchange_gradients(arena, lv["means3D"].detach(), 1)
+                a, b = plain[0]["shs"].grad, lv["shs"].grad
+                assert ((a - b).abs() <= 1e-6 + 1e-4 * a.abs()).all()      # two runs: float-atomic order upstream
+        got_sh = _C.sh_grad_combine(arena, lv["means3D"].detach(), torch.cat(chunks), V, 1.0 / V).clone()
+    finally:
+        _C.set_grad_arena(None)
+    a = want["shs"]
+    assert ((a - got_sh).abs() <= 1e-6 + 1e-4 * a.abs()).all(), float((a - got_sh).abs().max())
+    assert not got_sh[:, (deg + 1) ** 2:, :].any()
+    # the dense part is the concatenation means3D | opacity | scales | rotations
+    dense /= V
+    o = 0
+    for n, w in (("means3D", 3), ("opacities", 1), ("scales", 3), ("rotations", 4)):
+        a, b = want[n].reshape(-1), dense[o: o + P * w]
+        assert ((a - b).abs() <= 1e-5 + 1e-4 * a.abs()).all(), n
+        o += P * w
+
+
 @pytest.mark.parametrize("M,deg", [(1, 0), (4, 1), (9, 2), (16, 1), (25, 3)])
 def test_sh_row_lengths(M, deg, orc, scenes, rast, gpu):
     """max_coeffs M other than 16 (M*3 floats per row: 3, 12, 27, 48, 75 -- aligned and unaligned rows,
