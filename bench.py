@@ -149,15 +149,18 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     for _ in range(steps):
         workload.step(bucket, world)
         marks.append(time.perf_counter())        # host-side enqueue time of each step (diagnostic only)
-    d = np.diff(np.array([t0] + marks)) * 1e3
-    HOST_STEPS.clear()
-    HOST_STEPS.update(median=round(float(np.median(d)), 4), max=round(float(d.max()), 4), argmax=int(d.argmax()))
-    if trace or d.max() > 20.0 * max(float(np.median(d)), 0.05):
-        print("step host ms:", " ".join(f"{x:.2f}" for x in d), file=sys.stderr)
+    t_loop = time.perf_counter()
     torch.cuda.synchronize(dev)
+    t_sync = time.perf_counter()
     vp.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    d = np.diff(np.array([t0] + marks)) * 1e3          # diagnostics, outside the timed window
+    HOST_STEPS.clear()
+    HOST_STEPS.update(median=round(float(np.median(d)), 4), max=round(float(d.max()), 4), argmax=int(d.argmax()),
+                      drain_ms=round((t_sync - t_loop) * 1e3, 4), loop_ms=round((t_loop - t0) * 1e3, 4))
+    if trace or d.max() > 20.0 * max(float(np.median(d)), 0.05):
+        print("step host ms:", " ".join(f"{x:.2f}" for x in d), file=sys.stderr)
     return vp.max_over_ranks(dt, dev)
 
 
