@@ -568,18 +568,25 @@ __global__ void __launch_bounds__(256)
 tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q,
                              const uint32_t* __restrict__ counts_dev /* optional {R lo, Q, -, R hi}: speculative launch */,
                              uint32_t capR, int gx, int gy, const uint32_t* __restrict__ hist_scanned,
-                             const uint32_t* __restrict__ digit_total, uint32_t nblk, uint2* __restrict__ ranges)
+                             const uint32_t* __restrict__ digit_total, uint32_t nblk, uint2* __restrict__ ranges,
+                             uint32_t* __restrict__ bucket_cnt /* forward launch order: [64] counts (zeroed), or null */,
+                             uint16_t* __restrict__ bucket_list /* [64][T] */)
 {
     __shared__ int diff[257];
+    __shared__ uint32_t lcnt[WORK_BUCKETS], lbase[WORK_BUCKETS];
     const uint32_t x = blockIdx.x, y = threadIdx.x;
+    bool overflow = false;
     if (counts_dev) {
         // The launch was sized for capacities (Q = capQ).  If the real counts do not fit, the lists are truncated:
         // publish empty ranges (the blend kernels then touch nothing) -- the host sees the same counts and redoes the
         // binning with exact sizes.
-        const bool overflow = counts_dev[1] > Q || counts_dev[3] != 0u || counts_dev[0] > capR;
-        if (overflow) { if (y < (uint32_t)gy) ranges[y * (uint32_t)gx + x] = make_uint2(0u, 0u); return; }
-        Q = counts_dev[1];
+        overflow = counts_dev[1] > Q || counts_dev[3] != 0u || counts_dev[0] > capR;      // uniform
+        if (!overflow) Q = counts_dev[1];
     }
+    uint32_t work = 0;
+    if (overflow) {
+        if (y < (uint32_t)gy) ranges[y * (uint32_t)gx + x] = make_uint2(0u, 0u);
+    } else {
     const uint32_t nrows = (uint32_t)gy;
     const uint32_t row_total = y < nrows ? digit_total[y] : 0u;
     uint32_t all;
@@ -590,6 +597,20 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
     const uint32_t before1 = row_instances_before_run(run_vals, Q, F1, hist_scanned, nblk, nrows, row_total, diff);
     if (y < (uint32_t)gy)
         ranges[y * (uint32_t)gx + x] = before1 > before0 ? make_uint2(row_base + before0, row_base + before1) : make_uint2(0u, 0u);
+    work = before1 > before0 ? before1 - before0 : 0u;
+    }
+    if (bucket_cnt) {
+        // forward launch order: append this column's tiles to the work buckets (one global atomic per bucket and column)
+        if (y < (uint32_t)WORK_BUCKETS) lcnt[y] = 0;
+        __syncthreads();
+        const uint32_t b = work_bucket(work);
+        uint32_t slot = 0;
+        if (y < (uint32_t)gy) slot = atomicAdd(&lcnt[b], 1u);
+        __syncthreads();
+        if (y < (uint32_t)WORK_BUCKETS) lbase[y] = lcnt[y] ? atomicAdd(&bucket_cnt[y], lcnt[y]) : 0u;
+        __syncthreads();
+        if (y < (uint32_t)gy) bucket_list[(size_t)b * ((size_t)gx * gy) + lbase[b] + slot] = (uint16_t)(y * (uint32_t)gx + x);
+    }
 }
 
 // Second (final) pass: instances of the block's runs, generated in order, ranked by tile row with the

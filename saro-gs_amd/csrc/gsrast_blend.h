@@ -34,6 +34,29 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles)
     return t;   // may be >= ntiles for the padded grid; caller checks
 }
 
+// Launch order without a sorting kernel: workgroup b takes entry b of the concatenation of the 64 work buckets
+// (gsrast_common.h: ImgLayout::bucket_cnt / bucket_list).  Every thread of the workgroup calls this.
+__device__ __forceinline__ uint32_t tile_from_buckets(const uint32_t* __restrict__ cnt, const uint16_t* __restrict__ list,
+                                                      uint32_t T, uint32_t b, uint32_t* s_tile)
+{
+    if (threadIdx.x < (unsigned)WORK_BUCKETS) {
+        const uint32_t c = cnt[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (threadIdx.x >= (unsigned)d) incl += o; }
+        const uint32_t excl = incl - c;
+        if (b >= excl && b < incl) *s_tile = list[(size_t)threadIdx.x * T + (b - excl)];
+    }
+    __syncthreads();
+    return *s_tile;
+}
+// ... and the producer side for the backward order: one append per tile, by the forward blend
+__device__ __forceinline__ void bucket_append(uint32_t* __restrict__ cnt, uint16_t* __restrict__ list, uint32_t T, uint32_t tile, uint32_t work)
+{
+    const uint32_t b = work_bucket(work);
+    list[(size_t)b * T + atomicAdd(&cnt[b], 1u)] = (uint16_t)tile;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-level culling of a staged batch against the wave's pixel strip.
 // Lane l takes instance (round*64 + l) of the batch and computes the EXACT minimum over the strip's
@@ -71,7 +94,9 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                       const float4* __restrict__ rec2, const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
-                      uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max)
+                      uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
+                      uint32_t* __restrict__ bucket_cnt /* [2][64] or null */, uint16_t* __restrict__ bucket_list /* [2][64][T] */,
+                      int order_from_buckets)
 {
 #ifndef GSRAST_FWD_BATCH
 #define GSRAST_FWD_BATCH 256
@@ -81,9 +106,12 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ float4 s1[FB];
     __shared__ float4 s2[FB];
     __shared__ uint32_t s_max;
+    __shared__ uint32_t s_tile;
 
     if (blockIdx.x >= ntiles) return;
-    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;   // heaviest tiles first
+    // heaviest tiles first
+    const uint32_t tile = order_from_buckets ? tile_from_buckets(bucket_cnt, bucket_list, ntiles, blockIdx.x, &s_tile)
+                                             : (order ? order[blockIdx.x] : blockIdx.x);
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
     const unsigned lane = lane_id(), wave = t >> 6;
@@ -185,7 +213,11 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __syncthreads();
     if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
-    if (t == 0) tile_max[tile] = s_max;
+    if (t == 0) {
+        tile_max[tile] = s_max;
+        // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
+        if (bucket_cnt) bucket_append(bucket_cnt + WORK_BUCKETS, bucket_list + (size_t)WORK_BUCKETS * ntiles, ntiles, tile, s_max);
+    }
 }
 
 // PPL = pixels per lane.  A tile is 256 pixels; a workgroup has NT = 256/PPL lanes (4/PPL wave64).
@@ -207,7 +239,8 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                  int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                  const float4* __restrict__ rec2, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
-                 uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max)
+                 uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
+                 uint32_t* __restrict__ bucket_cnt /* [2][64] or null */, uint16_t* __restrict__ bucket_list /* [2][64][T] */)
 {
     using Cfg = BlendCfg<PPL>;
     constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
@@ -325,7 +358,11 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     __syncthreads();
     if (lane_id() == 0) atomicMax(&s_max, m);
     __syncthreads();
-    if (t == 0) tile_max[tile] = s_max;
+    if (t == 0) {
+        tile_max[tile] = s_max;
+        // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
+        if (bucket_cnt) bucket_append(bucket_cnt + WORK_BUCKETS, bucket_list + (size_t)WORK_BUCKETS * ntiles, ntiles, tile, s_max);
+    }
 }
 
 // Backward.  Per (pixel, instance) contribution -> 9 partial derivatives.  A lane first adds up its
@@ -522,7 +559,9 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                       const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
                       float* __restrict__ dL_dmean2D /*[P][3]*/, float* __restrict__ dL_dconic /*[P][4]*/,
-                      float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/)
+                      float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/,
+                      const uint32_t* __restrict__ bucket_cnt /* [2][64]: launch order from the [1] lists, or null */,
+                      const uint16_t* __restrict__ bucket_list)
 {
 #pragma clang fp contract(fast)
     using Cfg = BlendCfg<PPL>;
@@ -536,8 +575,11 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ uint32_t sid[BATCH];
     __shared__ float acc[NW][9][BATCH];   // one accumulator slice per wave: plain LDS read-add-write, no LDS atomics
 
+    __shared__ uint32_t s_tile;
     if (blockIdx.x >= ntiles) return;
-    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;   // heaviest tiles first
+    // heaviest tiles first
+    const uint32_t tile = bucket_cnt ? tile_from_buckets(bucket_cnt + WORK_BUCKETS, bucket_list + (size_t)WORK_BUCKETS * ntiles, ntiles, blockIdx.x, &s_tile)
+                                     : (order ? order[blockIdx.x] : blockIdx.x);
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
     const unsigned lane = lane_id(), wave = t >> 6;

@@ -274,6 +274,7 @@ int pick_ppl(uint32_t ntiles, bool backward)
 }
 
 struct BlendArgs {
+    uint32_t* bcnt = nullptr; uint16_t* blist = nullptr; int from_buckets = 0;   // launch order from the work buckets (ImgLayout)
     const uint2* ranges; const uint32_t* plist; const uint32_t* order; int W, H, gx; uint32_t T; const float4 *r0, *r1, *r2; const float* bg;
     float *oc, *od, *fT; uint32_t *nc, *tm;                       // forward outputs (fT / nc / tm: inputs of backward)
     const float* dpix; float *dm2, *dcon, *dop, *dcol;            // backward
@@ -281,7 +282,7 @@ struct BlendArgs {
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_fwd_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm);
+    blend_fwd_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm, a.bcnt, a.blist);
 }
 template <int MODE, int PPL, int ABL>
 void launch_bwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -296,7 +297,8 @@ void dispatch_fwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
 template <int MODE, int PPL>
 void launch_bwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol);
+    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol,
+                                                                 a.from_buckets ? a.bcnt : nullptr, a.blist);
 }
 template <int MODE>
 void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -306,7 +308,8 @@ void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a
 template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm);
+    blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
+                                                     a.bcnt, a.blist, a.from_buckets);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -457,13 +460,14 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
 
     // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
     const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
+    const bool buckets_ok = T <= BUCKET_MAX_TILES;      // launch order of the blend kernels from work buckets (u16 tile ids)
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
         preprocess_fwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
             colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
             at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
-            (runbin && g_tile_clip.load()) ? 1 : 0);
+            (runbin && g_tile_clip.load()) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt));
         GS_LAUNCHED("preprocess_fwd");
     }
     {
@@ -534,11 +538,12 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), (uint32_t)cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2);
             GS_LAUNCHED("run_scatter_rows"); }
         {   ProfScope ps(K_RANGES, s);
-            tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges);
+            tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges,
+                                                                buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list));
             GS_LAUNCHED("tile_ranges"); }
         return GSRAST_OK;
     };
-    auto launch_blend = [&](const uint32_t* plist) -> int {
+    auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built) -> int {
         ProfScope ps(K_BLEND_FWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;
         float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
@@ -548,11 +553,15 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
         const int ppl = pick_ppl(T, false);
         const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
+        if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && g_lpt.load()) {
-            uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
-            tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, nullptr, ord);
-            GS_LAUNCHED("tile_order");
-            ba.order = ord;
+            if (buckets_ok && fwd_lists_built) ba.from_buckets = 1;      // the tile-range kernel already bucketed the tiles
+            else {
+                uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
+                tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, nullptr, ord);
+                GS_LAUNCHED("tile_order");
+                ba.order = ord;
+            }
         }
         switch (g_exp_mode.load()) {
         case 0: if (cull) launch_fwd_cull<0>(grid, s, ba); else dispatch_fwd<0>(ppl, grid, s, ba); break;
@@ -572,7 +581,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     const bool speculative = runbin && bin != nullptr && g_speculative.load() != 0;
     if (speculative) {
         int rc = launch_run_binning(bin, cap, capQ, capQ, scalars);
-        if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0));
+        if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true);
         if (rc != GSRAST_OK) return rc;
     }
     { int rc = read_u32_finish(rb, scalars, s, counts, 4); if (rc != GSRAST_OK) return rc; }
@@ -589,6 +598,8 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
       g_R_hint = R > hr - hr / 16 ? R : hr - hr / 16; g_Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
     g_last_R = R; g_last_Q = Q;
     if (speculative && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
+    if (speculative)    // redo: the truncated pass already appended every tile to the work buckets once
+        GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, 2 * WORK_BUCKETS * sizeof(uint32_t), s));
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
         cap = R; capQ = Q;
         bin = (char*)binning_alloc(binning_ctx, bin_bytes(cap, capQ));
@@ -633,7 +644,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
               GS_LAUNCHED("tile_ranges"); }
         }
     }
-    { int rc = launch_blend(plist); if (rc != GSRAST_OK) return rc; }
+    { int rc = launch_blend(plist, runbin && R > 0 && Q > 0); if (rc != GSRAST_OK) return rc; }
     return (int)R;
 }
 
@@ -690,10 +701,15 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         const int ppl = pick_ppl(T, true);
         const bool cull = g_cull.load() != 0;
         if (cull && g_lpt.load()) {
-            uint32_t* ord = at<uint32_t>(img, IL.order_bwd);
-            tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, tm, ord);
-            GS_LAUNCHED("tile_order");
-            ba.order = ord;
+            if (T <= BUCKET_MAX_TILES) {      // the forward blend appended every tile to the backward work buckets
+                ba.bcnt = const_cast<uint32_t*>(at<uint32_t>(img, IL.bucket_cnt)); ba.blist = const_cast<uint16_t*>(at<uint16_t>(img, IL.bucket_list));
+                ba.from_buckets = 1;
+            } else {
+                uint32_t* ord = at<uint32_t>(img, IL.order_bwd);
+                tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, tm, ord);
+                GS_LAUNCHED("tile_order");
+                ba.order = ord;
+            }
         }
         if (g_ablate.load() == 1) launch_bwd<0, 4, 1>(grid, s, ba);
         else if (g_ablate.load() == 2) launch_bwd<0, 4, 2>(grid, s, ba);

@@ -44,9 +44,15 @@ struct BinLayout {
 //   pixel of the tile consumed -- bounds the backward traversal)
 //   order_fwd / order_bwd u32[T]: tiles sorted by descending work (longest-processing-time-first
 //   launch order for the blend kernels; a tile is one indivisible unit of work per wave(-group))
+//   bucket_cnt u32[2][64], bucket_list u16[2][64][T] (T <= 65535): the same launch order without a sorting kernel --
+//   tiles are appended to one of 64 work buckets (half-octaves of the work estimate) by the kernel that produces the
+//   estimate (tile ranges -> forward order, forward blend's deepest consumed entry -> backward order); block b of a blend
+//   kernel finds its tile from the prefix sums of the 64 counts.  [0] = forward, [1] = backward.
 struct ImgLayout {
-    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, total;
+    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, bucket_cnt, bucket_list, total;
 };
+constexpr int WORK_BUCKETS = 64;
+constexpr size_t BUCKET_MAX_TILES = 65535;     // tile ids are stored as u16
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
 constexpr int RS_ITEMS = 16;        // keys per lane (32 measured slower: profiles/)
@@ -139,6 +145,8 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     if (!T) T = 1;
     L.final_T = take(N * 4); L.n_contrib = take(N * 4); L.ranges = take(T * 8); L.tile_max = take(T * 4);
     L.order_fwd = take(T * 4); L.order_bwd = take(T * 4);
+    L.bucket_cnt = take(2 * WORK_BUCKETS * 4);
+    L.bucket_list = take(T <= BUCKET_MAX_TILES ? 2 * WORK_BUCKETS * T * 2 : 0);
     L.total = o + 256;
     return L;
 }
@@ -159,6 +167,14 @@ static inline int tile_passes(size_t T)
 // Device helpers
 #if defined(__HIPCC__)
 
+// work estimate -> bucket, 0 = heaviest: two buckets per octave, bucket 63 = no work at all
+__device__ __forceinline__ uint32_t work_bucket(uint32_t w)
+{
+    if (w == 0u) return WORK_BUCKETS - 1;
+    const int e = 31 - __builtin_clz(w);
+    const uint32_t key = 2u * (uint32_t)e + (e >= 1 ? ((w >> (e - 1)) & 1u) : 0u);      // 0 .. 63
+    return key >= (uint32_t)WORK_BUCKETS - 2u ? 0u : (uint32_t)WORK_BUCKETS - 2u - key;
+}
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // exp(): three interchangeable implementations (option "exp_mode").

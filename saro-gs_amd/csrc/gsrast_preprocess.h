@@ -233,8 +233,10 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float4* __restrict__ rec2, float* __restrict__ cov3D, unsigned char* __restrict__ clamped,
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
                       uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val,
-                      int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */)
+                      int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */,
+                      uint32_t* __restrict__ bucket_cnt /* [2][64] work-bucket counters of this call: zeroed here */)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 2 * WORK_BUCKETS) bucket_cnt[threadIdx.x] = 0u;
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
     const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
