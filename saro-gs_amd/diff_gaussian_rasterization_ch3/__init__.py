@@ -67,6 +67,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buf, bin_buf, img_buf)
         ctx.mark_non_differentiable(radii, depth)
+        ctx.set_materialize_grads(False)     # no zero-filled [1,H,W] / [P] gradients for the two outputs nothing flows through
         return color, radii, depth
 
     @staticmethod
@@ -74,6 +75,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geom_buf, bin_buf, img_buf) = ctx.saved_tensors
+        if grad_out_color is None:      # cannot happen through autograd (radii / depth carry no gradient), kept for safety
+            grad_out_color = torch.zeros((_C.NUM_CHANNELS, rs.image_height, rs.image_width), device=means3D.device)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
