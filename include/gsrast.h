@@ -149,8 +149,11 @@ int gsrast_debug_export(int P, int R, int width, int height,
  * num_rendered keeps the reference's meaning), 0 = the reference's literal lists;
  * "cull" / "lpt" 0/1 = wave-level strip culling / heaviest-tile-first launch order in the blend kernels;
  * "pixels_per_lane" (+ "fwd_" / "bwd_" prefixed) 0 = auto, 1 / 2 / 4.  Returns 0 or GSRAST_E_ARG.
+ * "speculative" 1 (default) = binning + forward blend are enqueued before the host has read num_rendered back, against
+ * a capacity remembered from earlier calls (repeated with exact sizes if it did not fit), 0 = wait first;
+ * "sh_grad_factors" see gsrast_sh_grad_combine.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
- * last forward call of the process. */
+ * last forward call of the process, "redo_count" (speculative launches that had to be repeated). */
 int gsrast_set_option(const char* name, int value);
 int gsrast_get_option(const char* name);
 

@@ -198,6 +198,7 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // the host waits for the real count, so the (Python) allocation callback runs while the GPU is still
 // busy with preprocess / depth sort instead of in the idle gap after the readback.
 std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0}, g_last_R{0}, g_last_Q{0};
+std::atomic<int> g_redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
 std::atomic<int> g_speculative{1};  // enqueue binning + blend before the host has read R / Q back (run-compressed path)
 std::atomic<int> g_sh_grad_factors{0};   // gsrast_backward writes the [P][3] factor of dL/dsh instead of dL/dsh (multi-GPU exchange)
 std::atomic<int> g_tile_clip{1};   // run-compressed binning only: drop the tiles of a Gaussian's rectangle its alpha >= 1/255 ellipse cannot reach
@@ -360,6 +361,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "last_instances")) return (int)g_last_R.load();   // num_rendered / column runs of the last forward call
     if (!strcmp(name, "last_runs")) return (int)g_last_Q.load();
     if (!strcmp(name, "speculative")) return g_speculative.load();
+    if (!strcmp(name, "redo_count")) return g_redo_count.load();
     if (!strcmp(name, "lpt")) return g_lpt.load();
     return GSRAST_E_ARG;
 }
@@ -598,6 +600,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
       g_R_hint = R > hr - hr / 16 ? R : hr - hr / 16; g_Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
     g_last_R = R; g_last_Q = Q;
     if (speculative && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
+    if (speculative) g_redo_count++;
     if (speculative)    // redo: the truncated pass already appended every tile to the work buckets once
         GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, 2 * WORK_BUCKETS * sizeof(uint32_t), s));
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)

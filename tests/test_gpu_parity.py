@@ -369,6 +369,32 @@ def test_grad_arena_zero_copy_bucket(scenes, rast, gpu):
     assert torch.equal(arena.flat[off: off + P * 48].view(P, 16, 3), bucketed["shs"].grad)
 
 
+@pytest.mark.parametrize("speculative", [1, 0])
+def test_speculative_launch_overflow_and_shrink(speculative, orc, scenes, rast, gpu):
+    """The forward enqueues binning + blend against a capacity remembered from earlier calls, before it knows R and Q.
+    A scene 60x larger than the previous one does not fit (the launch is repeated with exact sizes), a much smaller one
+    runs inside an oversized capacity; both must be exact, as must the non-speculative path."""
+    _C = rast._C
+    _C.set_option("speculative", speculative)
+    try:
+        seq = [(300, 64, 48, 1.0), (20000, 320, 240, 1.0), (500, 96, 64, 0.5), (20000, 320, 240, 1.0)]
+        redo0 = _C.get_option("redo_count")
+        for n, (P, W, H, sm) in enumerate(seq):
+            sc = scenes.synth(P, 111 + n, scale_mul=sm)
+            cam = scenes.camera(n, 4, W, H)
+            g = scenes.upstream_grad(H, W, 112)
+            o32 = orc.render(sc, cam, g)
+            o64 = orc.render(sc, cam, g, f64=True)
+            for clip in (0, 1):
+                h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=clip)
+                _check_forward_exact(o32, h, clipped=bool(clip))
+                _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], strict=True)
+        redone = _C.get_option("redo_count") - redo0
+        assert (redone >= 1) if speculative else (redone == 0)
+    finally:
+        _C.set_option("speculative", 1)
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_sh_gradient_factor_exchange(deg, scenes, rast, gpu):
     """Multi-GPU exchange of dL/dsh by its rank-1 factor (view_parallel.exchange_gradients, gsrast_sh_grad_combine):
