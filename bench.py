@@ -237,6 +237,56 @@ def loss_row(dev, H, W):
                                        "speedup_vs_pytorch": round(ms_e / ms_f, 2), "shape": [3, H, W]}}
 
 
+def epilogue_row(dev, P):
+    """"Next" row: fused activation / deformation epilogue fwd+bwd for P Gaussians (all
+    residuals present = the dynamic stage), next to the reference's own formulation run through PyTorch."""
+    import torch.nn.functional as F
+    import fused_epilogue
+    torch.manual_seed(0)
+    M = 16
+    r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    raw = dict(xyz=r(P, 3), motion_res=0.05 * r(P, 3), rotation=r(P, 4), rot_res=0.1 * r(P, 7), scaling=r(P, 3) - 3.0,
+               opacity=2.0 * r(P, 1), trbf=torch.rand(P, 1, device=dev), f_dc=r(P, 1, 3), f_rest=0.1 * r(P, M - 1, 3),
+               shs_res=0.05 * r(P, M, 3))
+    raw = {k: v.requires_grad_(True) for k, v in raw.items()}
+    ups = [r(P, 3), r(P, 4), r(P, 3), r(P, 1), r(P, M, 3)]
+
+    def fused():
+        for v in raw.values():
+            v.grad = None
+        outs = fused_epilogue.activate_gaussians(raw["xyz"], raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"],
+                                                 motion_residual=raw["motion_res"], rot_residual=raw["rot_res"],
+                                                 trbfoutput=raw["trbf"], shs_residual=raw["shs_res"])
+        torch.autograd.backward(outs, ups)
+
+    def eager():      # scene/saro_gaussian.py:807-847
+        for v in raw.values():
+            v.grad = None
+        motion = raw["xyz"] + raw["motion_res"]
+        rot = F.normalize(raw["rotation"] + raw["rot_res"][:, :4])
+        scale = torch.exp(raw["scaling"] + raw["rot_res"][:, 4:])
+        opa = torch.sigmoid(raw["opacity"]) * raw["trbf"]
+        shs = torch.cat((raw["f_dc"], raw["f_rest"]), dim=1) + raw["shs_res"]
+        torch.autograd.backward((motion, rot, scale, opa, shs), ups)
+
+    def t(fn, n=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    ms_f, ms_e = t(fused), t(eager)
+    # forward: 12+12+16+28+12+4+4 in, 12+16+12+4 out (small), 12+180+192 in, 192 out (SH); backward: ~16+28+12+4+4+16+12+4 in, 16+12+28+4+4 out
+    nbytes = P * (88 + 44 + 384 + 192 + 96 + 64)
+    return {"ms": round(ms_f, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
+            "hbm_frac": round(nbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "pytorch_eager_same_gpu_ms": round(ms_e, 4),
+            "speedup_vs_pytorch": round(ms_e / ms_f, 2), "gaussians": P, "sh_coefficients": M}
+
+
 def main():
     a = parse()
     import view_parallel as vp
@@ -389,6 +439,10 @@ def main():
             result["next_rows"] = loss_row(dev, H, W)
         except Exception as e:
             result["next_rows"] = {"fused_l1_dssim_fwd_bwd": {"error": str(e)}}
+        try:
+            result["next_rows"]["fused_activation_epilogue_fwd_bwd"] = epilogue_row(dev, P)
+        except Exception as e:
+            result["next_rows"]["fused_activation_epilogue_fwd_bwd"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -178,6 +178,23 @@ int gsrast_loss_forward(int C, int H, int W, const float* img, const float* gt, 
 int gsrast_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda_dssim,
                          const float* dL_dloss, const char* scratch, float* dL_dimg, void* stream);
 
+/* ---- "next" row, rank 3: the activation / deformation epilogue that produces the rasterizer's inputs ----
+ * Replaces the tail of get_deformation, scene/saro_gaussian.py:807-847 with the activations of :39-47:
+ *   motion = xyz + motion_res;  rot = normalize(rotation + rot_res[:, :4]);  scale = exp(scaling + rot_res[:, 4:]);
+ *   opacity = sigmoid(opacity_logit) * trbf;  shs = cat(features_dc [P][1][3], features_rest [P][M-1][3]) + shs_res [P][M][3]
+ * motion_res, rot_res ([P][7]), trbf and shs_res may each be NULL (static stage: plain activations).
+ * backward: upstream d_rot [P][4], d_scale [P][3], d_opacity [P] (NULL = zero) -> d_rotation [P][4], d_scaling [P][3],
+ * d_rot_res [P][7] (NULL ok), d_opacity_logit [P], d_trbf [P] (NULL ok).  The other gradients need no kernel:
+ * d_xyz = d_motion_res = d_motion; d_features_dc / d_features_rest are slices of d_shs, d_shs_res = d_shs. */
+int gsrast_activate_forward(int P, int M, const float* xyz, const float* motion_res, const float* rotation,
+                            const float* rot_res, const float* scaling, const float* opacity_logit, const float* trbf,
+                            const float* features_dc, const float* features_rest, const float* shs_res,
+                            float* motion, float* rot, float* scale, float* opacity, float* shs, void* stream);
+int gsrast_activate_backward(int P, const float* rotation, const float* rot_res, const float* scale, const float* opacity_logit,
+                             const float* trbf, const float* d_rot, const float* d_scale, const float* d_opacity,
+                             float* d_rotation, float* d_scaling, float* d_rot_res, float* d_opacity_logit, float* d_trbf,
+                             void* stream);
+
 const char* gsrast_last_error(void);
 int gsrast_abi_version(void);
 

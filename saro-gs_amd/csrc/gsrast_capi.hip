@@ -13,6 +13,7 @@
 #include "gsrast_binning.h"
 #include "gsrast_blend.h"
 #include "gsrast_loss.h"
+#include "gsrast_epilogue.h"
 
 #include <atomic>
 #include <chrono>
@@ -649,6 +650,47 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     }
     { int rc = launch_blend(plist, runbin && R > 0 && Q > 0); if (rc != GSRAST_OK) return rc; }
     return (int)R;
+}
+
+int gsrast_activate_forward(int P, int M, const float* xyz, const float* motion_res, const float* rotation,
+                            const float* rot_res, const float* scaling, const float* opacity_logit, const float* trbf,
+                            const float* features_dc, const float* features_rest, const float* shs_res,
+                            float* motion, float* rot, float* scale, float* opacity, float* shs, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || M < 1) return fail(GSRAST_E_ARG, "activate_forward: bad sizes");
+    if (P == 0) return GSRAST_OK;
+    if (!xyz || !rotation || !scaling || !opacity_logit || !features_dc || (M > 1 && !features_rest) ||
+        !motion || !rot || !scale || !opacity || !shs) return fail(GSRAST_E_ARG, "activate_forward: NULL required pointer");
+    epilogue_small_fwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, motion_res, rotation, rot_res, scaling, opacity_logit, trbf,
+                                                             motion, rot, scale, opacity);
+    GS_LAUNCHED("epilogue_small_fwd");
+    const int row = 3 * M;
+    const size_t n = (size_t)P * row;
+    if ((row & 3) == 0 && (((uintptr_t)shs | (uintptr_t)shs_res) & 15) == 0) {
+        const size_t nq = n / 4;
+        epilogue_sh_fwd_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, s>>>(nq, row, features_dc, features_rest, shs_res, shs);
+    } else {
+        epilogue_sh_fwd_scalar_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, row, features_dc, features_rest, shs_res, shs);
+    }
+    GS_LAUNCHED("epilogue_sh_fwd");
+    return GSRAST_OK;
+}
+
+int gsrast_activate_backward(int P, const float* rotation, const float* rot_res, const float* scale, const float* opacity_logit,
+                             const float* trbf, const float* d_rot, const float* d_scale, const float* d_opacity,
+                             float* d_rotation, float* d_scaling, float* d_rot_res, float* d_opacity_logit, float* d_trbf,
+                             void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0) return fail(GSRAST_E_ARG, "activate_backward: bad sizes");
+    if (P == 0) return GSRAST_OK;
+    if (!rotation || !scale || !opacity_logit || !d_rotation || !d_scaling || !d_opacity_logit)
+        return fail(GSRAST_E_ARG, "activate_backward: NULL required pointer");
+    epilogue_small_bwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, rotation, rot_res, scale, opacity_logit, trbf, d_rot, d_scale, d_opacity,
+                                                             d_rotation, d_scaling, d_rot_res, d_opacity_logit, d_trbf);
+    GS_LAUNCHED("epilogue_small_bwd");
+    return GSRAST_OK;
 }
 
 int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,

@@ -32,7 +32,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine",
+    "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward",
 )
 
 
@@ -83,6 +83,10 @@ def lib() -> C.CDLL:
     L.gsrast_loss_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
     L.gsrast_sh_grad_combine.restype = ci
     L.gsrast_sh_grad_combine.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, cf, vp, vp]
+    L.gsrast_activate_forward.restype = ci
+    L.gsrast_activate_forward.argtypes = [ci, ci] + [vp] * 16
+    L.gsrast_activate_backward.restype = ci
+    L.gsrast_activate_backward.argtypes = [ci] + [vp] * 14
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
     if L.gsrast_abi_version() != 1:
