@@ -151,10 +151,9 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
 
 // Low-latency readback of one device word: async copy into pinned host memory, then spin on an event
 // (hipStreamSynchronize may sleep; the GPU is idle while we wait, so every microsecond counts).
-struct Readback {
-    uint32_t* pinned = nullptr; hipEvent_t ev = nullptr;
-    ~Readback() { if (pinned) (void)hipHostFree(pinned); if (ev) (void)hipEventDestroy(ev); }
-};
+struct Readback {     // 64 pinned bytes + one event per (host thread, device); deliberately never freed: the destructor of a
+    uint32_t* pinned = nullptr; hipEvent_t ev = nullptr;   // thread_local would call into the HIP runtime at thread / process exit,
+};                                                         // possibly after the runtime itself has been torn down
 constexpr int kMaxDevices = 32;
 thread_local Readback t_readback[kMaxDevices];     // one per (host thread, device): events belong to a device
 // begin: enqueue the copy + event; finish: spin until it landed.  Work enqueued between the two runs on the GPU while

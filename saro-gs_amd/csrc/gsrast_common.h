@@ -72,7 +72,10 @@ static inline size_t scan_tmp_elems(size_t n)
 { // partial sums for a multi-level scan of n elements
     size_t tot = 0;
     while (n > SC_CHUNK) { n = (n + SC_CHUNK - 1) / SC_CHUNK; tot += 2 * (align256(n * 4) / 4); }   // x2: room for the sums of an auxiliary array
-    return tot + 64;
+    // the same scratch also receives the 256 digit totals of a radix pass (radix_rowscan_kernel): never fewer than 512 words.
+    // (It used to be tot + 64: for n <= 4096 the digit totals ran 768 bytes past it -- over `scalars` and the end of the
+    // buffer, usually into the allocator's padding, occasionally into an unmapped page.)
+    return tot + 512;
 }
 
 static inline GeomLayout geom_layout(size_t P)
