@@ -369,6 +369,52 @@ def test_grad_arena_zero_copy_bucket(scenes, rast, gpu):
     assert torch.equal(arena.flat[off: off + P * 48].view(P, 16, 3), bucketed["shs"].grad)
 
 
+def test_state_buffers_are_not_overrun(scenes, rast, gpu, monkeypatch):
+    """Canary test: every state buffer the library asks for is allocated with a 4 KB tail of 0xA5; after forward +
+    backward the tails must be intact (a write past the end of a buffer usually lands in the allocator's padding and
+    goes unnoticed).  Sizes chosen to hit the small-input corners (P = 1, P <= 4096, tiny images, capacity-sized
+    speculative launches after a big scene) and both binning schemes."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    PAD = 4096
+    made = []
+
+    def _make(self, slot):
+        def alloc(_ctx, nbytes):
+            buf = torch.empty(int(nbytes) + PAD, dtype=torch.uint8, device=self.device)
+            buf[int(nbytes):] = 0xA5
+            made.append((slot, int(nbytes), buf))
+            self.buffers[slot] = buf
+            return buf.data_ptr()
+        return alloc
+
+    monkeypatch.setattr(_C._Arena, "_make", _make)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    seq = [(1, 64, 48), (7, 16, 16), (300, 97, 83), (5000, 320, 240), (1, 48, 32), (40, 640, 16), (4097, 128, 96), (2, 17, 5)]
+    try:
+        for binning in (0, 1):
+            _C.set_option("binning", binning)
+            for n, (P, W, H) in enumerate(seq):
+                sc = scenes.synth(P, 131 + n)
+                if P <= 2:
+                    sc["means3D"][:] = 0.0
+                cam = scenes.camera(n, 5, W, H)
+                rs = settings_from(rast, cam, sc, gpu)
+                leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+                m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+                made.clear()
+                color, _, _ = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                          shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+                color.backward(t(scenes.upstream_grad(H, W, 132)))
+                torch.cuda.synchronize()
+                assert len(made) >= 3
+                for slot, nbytes, buf in made:
+                    assert bool((buf[nbytes:] == 0xA5).all()), f"state buffer {slot} overrun (P={P}, {W}x{H}, binning={binning}, {nbytes} B)"
+    finally:
+        _C.set_option("binning", 0)
+
+
 @pytest.mark.parametrize("speculative", [1, 0])
 def test_speculative_launch_overflow_and_shrink(speculative, orc, scenes, rast, gpu):
     """The forward enqueues binning + blend against a capacity remembered from earlier calls, before it knows R and Q.
