@@ -74,7 +74,9 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
  * On entry dL_dmean2D [P][3], dL_dconic [P][4], dL_dopacity [P] and dL_dcolor [P][3] must be
  * zero (they are accumulated with atomics, like the reference); dL_dmean3D [P][3],
  * dL_dcov3D [P][6], dL_dsh [P][M][3], dL_dscale [P][3], dL_drot [P][4] are fully overwritten
- * (zeros for culled Gaussians), so they need not be initialised.  Returns 0 or GSRAST_E_*. */
+ * (zeros for culled Gaussians), so they need not be initialised.  dL_dcov3D may be NULL when scales / rotations
+ * are given (it is then an intermediate nobody reads; the reference computes and returns it regardless).
+ * Returns 0 or GSRAST_E_*. */
 int gsrast_backward(int P, int D, int M, int R,
                     const float* background,
                     int width, int height,

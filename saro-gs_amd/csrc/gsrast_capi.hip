@@ -718,7 +718,8 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
     if (P == 0) return GSRAST_OK;
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail(GSRAST_E_ARG, "backward: NULL state buffer");
     if (!means3D || !radii || !viewmatrix || !projmatrix || !dL_dpix || !background) return fail(GSRAST_E_ARG, "backward: NULL required input");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D) return fail(GSRAST_E_ARG, "backward: NULL gradient output");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D) return fail(GSRAST_E_ARG, "backward: NULL gradient output");
+    if (cov3D_precomp && !dL_dcov3D) return fail(GSRAST_E_ARG, "backward: cov3D_precomp path needs dL_dcov3D");
     const bool use_sh = shs && !colors_precomp;
     const bool use_sr = !cov3D_precomp;
     if (use_sh && (!dL_dsh || !campos)) return fail(GSRAST_E_ARG, "backward: SH path needs dL_dsh and campos");

@@ -452,8 +452,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     if (i < P && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = 0.0f;
+        if (dL_dcov3D) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+            for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+        }
         if (shs) {
             if (sh_factors) { for (int k = 0; k < 3; k++) dL_dsh[3 * (size_t)i + k] = 0.0f; }
             else if (staged) { for (int k = 0; k < M * 3; k++) my_lds[k] = 0.0f; }
@@ -467,9 +469,20 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     }
     if (live) {
     const float mean[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    // 3D covariance: recomputed from scale / rotation when those are the inputs (bit-identical to what the forward
+    // stored -- same function, same operands -- and 24 B / Gaussian less to read), else the caller's cov3D_precomp
     float c6[6];
+    float s[3] = { 0.f, 0.f, 0.f }, q[4] = { 0.f, 0.f, 0.f, 0.f };
+    M3 Mm;
+    if (scales) {
+        s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
+        const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
+        q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+        cov3d_from_scale_rot(s, cam.scale_mod, q, c6, Mm);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 6; k++) c6[k] = cov3D[6 * (size_t)i + k];
+        for (int k = 0; k < 6; k++) c6[k] = cov3D[6 * (size_t)i + k];
+    }
     Cov2D cv;
     cov2d_eval(mean, cam, c6, cv);
     const float xgm = (cv.txtz < -cv.limx || cv.txtz > cv.limx) ? 0.0f : 1.0f;
@@ -496,8 +509,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
         for (int k = 0; k < 6; k++) dcov[k] = 0.0f;
     }
+    if (dL_dcov3D) {     // only a caller that passed cov3D_precomp wants it: with scales / rotations it is an intermediate
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    }
     float dT[2][3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -551,11 +566,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = dmean[k];
     if (scales) {
-        const float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
-        const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
-        const float q[4] = { qv.x, qv.y, qv.z, qv.w };
-        float c6b[6]; M3 Mm, R;
-        cov3d_from_scale_rot(s, cam.scale_mod, q, c6b, Mm);
+        M3 R;
         quat_to_R(q, R);
         const float sm[3] = { cam.scale_mod * s[0], cam.scale_mod * s[1], cam.scale_mod * s[2] };
         M3 dSig, M2, dM;

@@ -276,7 +276,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dcolors = zbuf[7 * P: 10 * P].view(P, NUM_CHANNELS)
         dL_dopacity = out("opacity", (P, 1), True)
     dL_dmeans3D = out("means3D", (P, 3), False)
-    dL_dcov3D = torch.empty((P, 6), **opts)
+    # with scales / rotations dL_dcov3D is an intermediate nobody reads (the autograd node returns None for the absent
+    # cov3D_precomp input): not computed, not written -- the binding returns an empty tensor in its place
+    dL_dcov3D = torch.empty((0, 6) if use_sr else (P, 6), **opts)
     dL_dsh = out("sh", (P, M, 3), not use_sh)
     factors = ar is not None and ar.sh_factors
     if factors:
@@ -299,7 +301,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
                     _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
                     dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                    dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), sh_out, dL_dscales.data_ptr(),
+                    dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
                     dL_drotations.data_ptr(), stream)
             finally:
                 if factors:
