@@ -287,6 +287,39 @@ def epilogue_row(dev, P):
             "speedup_vs_pytorch": round(ms_e / ms_f, 2), "gaussians": P, "sh_coefficients": M}
 
 
+def adam_row(dev, P):
+    """"Next" row (third item): one Adam step of the seven per-Gaussian groups (60 floats per
+    Gaussian) with per-row learning rates in one launch, next to torch.optim.Adam(fused=True) with scalar rates
+    (torch's fused Adam has no per-row rate; the reference passes a [P,1] tensor as 'lr', saro_gaussian.py:345-398)."""
+    import fused_adam
+    torch.manual_seed(0)
+    shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (15, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,), "temporal_pos": (1,)}
+    mk = lambda: {k: torch.randn((P,) + s, device=dev).requires_grad_(True) for k, s in shapes.items()}  # noqa: E731
+    pa, pb = mk(), mk()
+    inv = 1.0 + torch.rand(P, 1, device=dev)
+    mine = fused_adam.GaussianAdam([{"params": [pa[k]], "lr": 1e-3 * inv if k != "f_rest" else 1e-4, "name": k} for k in shapes], eps=1e-15)
+    ref = torch.optim.Adam([{"params": [pb[k]], "lr": 1e-3, "name": k} for k in shapes], lr=0.0, eps=1e-15, fused=True)
+    for d in (pa, pb):
+        for v in d.values():
+            v.grad = torch.randn_like(v)
+
+    def t(fn, n=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    ms_f, ms_e = t(mine.step), t(ref.step)
+    nbytes = P * 60 * 28 + P * 4 * 6
+    return {"ms": round(ms_f, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
+            "hbm_frac": round(nbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "torch_fused_adam_scalar_lr_same_gpu_ms": round(ms_e, 4),
+            "speedup_vs_pytorch": round(ms_e / ms_f, 2), "gaussians": P, "floats_per_gaussian": 60}
+
+
 def main():
     a = parse()
     import view_parallel as vp
@@ -443,6 +476,10 @@ def main():
             result["next_rows"]["fused_activation_epilogue_fwd_bwd"] = epilogue_row(dev, P)
         except Exception as e:
             result["next_rows"]["fused_activation_epilogue_fwd_bwd"] = {"error": str(e)}
+        try:
+            result["next_rows"]["per_row_lr_adam_step"] = adam_row(dev, P)
+        except Exception as e:
+            result["next_rows"]["per_row_lr_adam_step"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:

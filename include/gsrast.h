@@ -197,6 +197,20 @@ int gsrast_activate_backward(int P, const float* rotation, const float* rot_res,
                              float* d_rotation, float* d_scaling, float* d_rot_res, float* d_opacity_logit, float* d_trbf,
                              void* stream);
 
+/* ---- "next" row, rank 4 (third item): Adam step of the per-Gaussian parameter groups with a PER-ROW learning rate ----
+ * Replaces torch.optim.Adam(l, lr=0.0, eps=1e-15, fused=True) for the groups of scene/saro_gaussian.py:306-323 whose
+ * 'lr' update_learning_rate (:345-398) sets to lr * inv_intergral, a [P,1] tensor.  One launch for up to 8 groups:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr_i / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * with lr_i = lr * (lr_rows ? lr_rows[row] : 1).  All tensors fp32, contiguous [rows][width], device pointers. */
+typedef struct gsrast_adam_group {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    const float* lr_rows;   /* [rows] or NULL */
+    float lr;
+    int rows, width;
+} gsrast_adam_group;
+int gsrast_adam_step(int n_groups, const gsrast_adam_group* groups /* host array */, double beta1, double beta2, double eps,
+                     int step /* 1-based */, void* stream);   /* betas in fp64: (1 - 0.999f) would be off by 1.3e-5 relative */
+
 const char* gsrast_last_error(void);
 int gsrast_abi_version(void);
 

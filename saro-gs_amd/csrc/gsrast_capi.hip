@@ -14,6 +14,7 @@
 #include "gsrast_blend.h"
 #include "gsrast_loss.h"
 #include "gsrast_epilogue.h"
+#include "gsrast_adam.h"
 
 #include <atomic>
 #include <chrono>
@@ -689,6 +690,36 @@ int gsrast_activate_backward(int P, const float* rotation, const float* rot_res,
     epilogue_small_bwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, rotation, rot_res, scale, opacity_logit, trbf, d_rot, d_scale, d_opacity,
                                                              d_rotation, d_scaling, d_rot_res, d_opacity_logit, d_trbf);
     GS_LAUNCHED("epilogue_small_bwd");
+    return GSRAST_OK;
+}
+
+int gsrast_adam_step(int n_groups, const gsrast_adam_group* groups, double beta1, double beta2, double eps, int step, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || (n_groups > 0 && !groups) || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        return fail(GSRAST_E_ARG, "adam_step: bad arguments (at most 8 groups, step >= 1, betas in [0, 1))");
+    AdamArgs a{};
+    unsigned long long blocks = 0;
+    for (int k = 0; k < n_groups; k++) {
+        const gsrast_adam_group& g = groups[k];
+        if (g.rows < 0 || g.width < 1) return fail(GSRAST_E_ARG, "adam_step: bad group shape");
+        const unsigned long long n = (unsigned long long)g.rows * (unsigned long long)g.width;
+        if (n && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq)) return fail(GSRAST_E_ARG, "adam_step: NULL tensor");
+        AdamGroup& o = a.grp[a.n_groups];
+        if (n == 0) continue;
+        o.p = g.param; o.g = g.grad; o.m = g.exp_avg; o.v = g.exp_avg_sq; o.lr_rows = g.lr_rows; o.lr = g.lr; o.width = (unsigned)g.width;
+        o.n = n; o.first_block = blocks; o.n_blocks = (n + ADAM_THREADS * ADAM_PER_THREAD - 1) / (ADAM_THREADS * ADAM_PER_THREAD);
+        blocks += o.n_blocks;
+        a.n_groups++;
+    }
+    if (blocks == 0) return GSRAST_OK;
+    if (blocks > 0x7FFFFFFFull) return fail(GSRAST_E_OVERFLOW, "adam_step: too many elements for one launch");
+    a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)eps;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);      // as torch: the subtraction in fp64, one rounding
+    a.inv_bc1 = (float)(1.0 / (1.0 - std::pow(beta1, (double)step)));
+    a.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(1.0 - std::pow(beta2, (double)step)));
+    adam_step_kernel<<<(unsigned)blocks, ADAM_THREADS, 0, s>>>(a);
+    GS_LAUNCHED("adam_step");
     return GSRAST_OK;
 }
 

@@ -32,8 +32,14 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward",
+    "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
 )
+
+
+class AdamGroupStruct(C.Structure):
+    """gsrast_adam_group (include/gsrast.h)."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("lr_rows", C.c_void_p), ("lr", C.c_float), ("rows", C.c_int), ("width", C.c_int)]
 
 
 def lib() -> C.CDLL:
@@ -87,6 +93,8 @@ def lib() -> C.CDLL:
     L.gsrast_activate_forward.argtypes = [ci, ci] + [vp] * 16
     L.gsrast_activate_backward.restype = ci
     L.gsrast_activate_backward.argtypes = [ci] + [vp] * 14
+    L.gsrast_adam_step.restype = ci
+    L.gsrast_adam_step.argtypes = [ci, C.POINTER(AdamGroupStruct), C.c_double, C.c_double, C.c_double, ci, vp]
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
     if L.gsrast_abi_version() != 1:
