@@ -320,6 +320,76 @@ def adam_row(dev, P):
             "speedup_vs_pytorch": round(ms_e / ms_f, 2), "gaussians": P, "floats_per_gaussian": 60}
 
 
+def iteration_row(rast, scenes, dev, P, W, H, deg):
+    """A whole static-stage training iteration (train.py:190-250 with one view): raw parameters -> activation epilogue ->
+    rasterizer -> L1 + D-SSIM -> backward -> Adam, (a) with this repository's fused pieces around the rasterizer,
+    (b) with the reference's PyTorch formulation of those pieces around the SAME rasterizer."""
+    import math
+    import torch.nn.functional as F
+    import fused_adam
+    import fused_epilogue
+    import fused_loss
+    sc = scenes.synth(P, 0, sh_degree=deg)
+    cam = scenes.camera(0, 1, W, H)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
+    rs = rast.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]), scale_modifier=1.0,
+        viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
+    raster = rast.GaussianRasterizer(rs)
+
+    def raw():
+        d = dict(xyz=t(sc["means3D"]), rotation=t(sc["rotations"]), scaling=torch.log(t(sc["scales"])),
+                 opacity=torch.logit(t(sc["opacities"]).clamp(1e-4, 1 - 1e-4)), f_dc=t(sc["shs"][:, :1]), f_rest=t(sc["shs"][:, 1:]))
+        return {k: v.requires_grad_(True) for k, v in d.items()}
+
+    gt = torch.rand(3, H, W, device=dev)
+    ra, rb = raw(), raw()
+    inv = torch.ones(P, 1, device=dev)
+    lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
+    opt_a = fused_adam.GaussianAdam([{"params": [ra[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in ra], eps=1e-15)
+    opt_b = torch.optim.Adam([{"params": [rb[k]], "lr": lr[k], "name": k} for k in rb], lr=0.0, eps=1e-15, fused=True)
+    g = torch.tensor([math.exp(-(i - 5) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)], device=dev)
+    g = g / g.sum()
+    w = (g[:, None] @ g[None, :]).expand(3, 1, 11, 11).contiguous()
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+
+    def fused():
+        motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(ra["xyz"], ra["rotation"], ra["scaling"], ra["opacity"], ra["f_dc"], ra["f_rest"])
+        color, _, _ = raster(means3D=motion, means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
+        loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
+        opt_a.zero_grad(); m2.grad = None
+        loss.backward()
+        opt_a.step()
+
+    def eager():
+        rot, scale, opa = F.normalize(rb["rotation"]), torch.exp(rb["scaling"]), torch.sigmoid(rb["opacity"])
+        shs = torch.cat((rb["f_dc"], rb["f_rest"]), dim=1)
+        x, _, _ = raster(means3D=rb["xyz"], means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
+        conv = lambda a_: F.conv2d(a_[None], w, padding=5, groups=3)[0]  # noqa: E731
+        mu1, mu2 = conv(x), conv(gt)
+        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(gt * gt) - mu2 * mu2, conv(x * gt) - mu1 * mu2
+        sm = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+        loss = 0.8 * (x - gt).abs().mean() + 0.2 * (1 - sm.mean())
+        opt_b.zero_grad(); m2.grad = None
+        loss.backward()
+        opt_b.step()
+
+    def tm(fn, n=20):
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    ms_f, ms_e = tm(fused), tm(eager)
+    return {"ms": round(ms_f, 4), "iterations_per_s": round(1e3 / ms_f, 1), "pytorch_pieces_around_same_rasterizer_ms": round(ms_e, 4),
+            "speedup": round(ms_e / ms_f, 2), "gaussians": P, "image": [H, W],
+            "pieces": "activate_gaussians -> GaussianRasterizer -> l1_dssim_loss -> backward -> GaussianAdam.step"}
+
+
 def main():
     a = parse()
     import view_parallel as vp
@@ -480,6 +550,10 @@ def main():
             result["next_rows"]["per_row_lr_adam_step"] = adam_row(dev, P)
         except Exception as e:
             result["next_rows"]["per_row_lr_adam_step"] = {"error": str(e)}
+        try:
+            result["next_rows"]["static_stage_training_iteration"] = iteration_row(rast, scenes, dev, P, W, H, deg)
+        except Exception as e:
+            result["next_rows"]["static_stage_training_iteration"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:
