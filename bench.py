@@ -145,6 +145,7 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     torch.cuda.synchronize(dev)
     trace = os.environ.get("BENCH_STEP_TRACE")
     marks = []
+    mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         workload.step(bucket, world)
@@ -158,7 +159,8 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     d = np.diff(np.array([t0] + marks)) * 1e3          # diagnostics, outside the timed window
     HOST_STEPS.clear()
     HOST_STEPS.update(median=round(float(np.median(d)), 4), max=round(float(d.max()), 4), argmax=int(d.argmax()),
-                      drain_ms=round((t_sync - t_loop) * 1e3, 4), loop_ms=round((t_loop - t0) * 1e3, 4))
+                      drain_ms=round((t_sync - t_loop) * 1e3, 4), loop_ms=round((t_loop - t0) * 1e3, 4),
+                      device_mallocs=int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0))
     if trace or d.max() > 20.0 * max(float(np.median(d)), 0.05):
         print("step host ms:", " ".join(f"{x:.2f}" for x in d), file=sys.stderr)
     return vp.max_over_ranks(dt, dev)

@@ -204,6 +204,14 @@ class _Arena:
         b = self.buffers[slot]
         return b if b is not None else torch.empty(0, dtype=torch.uint8, device=self.device)
 
+    def close(self) -> None:
+        """Drop the callbacks and the buffer references.  The callbacks are closures over `self`, so the arena sits in
+        a reference cycle: without this the three state buffers (hundreds of MB) stay alive until Python's CYCLIC
+        collector happens to run, the caching allocator sees them freed at irregular times and occasionally has to
+        hipMalloc fresh blocks in the middle of a training loop (a ~250 ms stall)."""
+        self.callbacks = None
+        self.buffers = [None, None, None]
+
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
@@ -227,17 +235,20 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     arena = _Arena(dev)
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        rendered = L.gsrast_forward(
-            arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
-            P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
-            _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-            _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-            out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii), stream)
-    if rendered < 0:
-        raise _err(rendered, "gsrast_forward")
-    return rendered, out_color, radii, arena.tensor(0), arena.tensor(1), arena.tensor(2), out_depth
+    try:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rendered = L.gsrast_forward(
+                arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
+                P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii), stream)
+        if rendered < 0:
+            raise _err(rendered, "gsrast_forward")
+        return rendered, out_color, radii, arena.tensor(0), arena.tensor(1), arena.tensor(2), out_depth
+    finally:
+        arena.close()       # break the arena <-> callback cycle now, not whenever the cyclic GC runs
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,

@@ -69,3 +69,23 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle", text, flags=re.M), f
+
+
+def test_state_arena_is_freed_by_refcounting_not_by_the_cyclic_gc():
+    """The allocation callbacks are closures over the arena: close() must break that cycle, otherwise the three state
+    buffers (hundreds of MB on the GPU) live until the cyclic collector happens to run."""
+    import gc
+    import weakref
+    import torch
+    from diff_gaussian_rasterization_ch3 import _C
+    gc.disable()
+    try:
+        arena = _C._Arena(torch.device("cpu"))
+        ptr = arena.callbacks[1](None, 1024)                 # what libgsrast does: ask for 1 KiB of binning state
+        assert ptr and arena.tensor(1).numel() == 1024
+        buf_ref, arena_ref = weakref.ref(arena.tensor(1)), weakref.ref(arena)
+        arena.close()
+        del arena
+        assert arena_ref() is None and buf_ref() is None     # gone without gc.collect()
+    finally:
+        gc.enable()

@@ -8,4 +8,4 @@ if not line:
     print("FAILED", args, out.stderr[-2000:]); sys.exit(1)
 d = json.loads(line[-1])
 ps = {k: round(v["ms"], 3) if isinstance(v, dict) and "ms" in v else v for k, v in d.get("per_stage", {}).items()}
-print(" ".join(args), "| views/s", d["value"], "ms/step", d["ms_per_step"], ps or d["kernels_ms"])
+print(" ".join(args), "| views/s", d["value"], "ms/step", d["ms_per_step"], ps or d["kernels_ms"], d.get("host_step_ms"))
