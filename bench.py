@@ -494,11 +494,18 @@ def main():
         bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
         fwd_bytes = st["R_eff"] * 44 + st["N"] * 24
         achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                vi = pj.get("valu_wave_insts_per_launch")
+                if vi and bwd_ms > 0:
+                    # a wave64 VALU instruction occupies its SIMD16 for 4 cycles; 1024 SIMDs at 2.4 GHz
+                    valu = {"wave_insts_per_launch": vi, "issue_slot_frac": round(vi * 4.0 / (1024 * 2.4e9 * bwd_ms * 1e-3), 3),
+                            "note": "fraction of the chip's VALU issue slots the kernel's VALU instructions need in its measured "
+                                    "duration (SQ_INSTS_VALU from profiles/, 4 cycles each, 1024 SIMDs, 2.4 GHz): the binding resource"}
             except Exception:
                 traffic = None
         result = {
@@ -518,7 +525,8 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": bwd_bytes,
                          "avg_launch_ms": round(bwd_ms, 4),
                          "note": "VALU/atomic-bound kernel: see DESIGN.md; pair-evaluations/s is the telling rate",
-                         "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None},
+                         "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
+                         "valu": valu},
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,
