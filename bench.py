@@ -173,22 +173,28 @@ def cpu_baseline(scenes, P, W, H, deg, budget_s):
     orc.set_exp_mode(0)
     cores = os.cpu_count() or 1
 
-    def run(p, w, h):
+    def run(p, w, h, min_s=0.0, max_views=1):
+        """mean seconds per view over enough views (of the same scene, other cameras) to fill ~min_s of CPU work"""
         sc = scenes.synth(p, 0, sh_degree=deg)
-        cam = scenes.camera(0, 1, w, h)
         g = scenes.upstream_grad(h, w, 1)
-        t0 = time.perf_counter()
-        orc.render(sc, cam, g)
-        return time.perf_counter() - t0
+        total, n = 0.0, 0
+        while n < max_views and (n == 0 or total < min_s):
+            cam = scenes.camera(n, max_views, w, h)
+            t0 = time.perf_counter()
+            orc.render(sc, cam, g)
+            total += time.perf_counter() - t0
+            n += 1
+        return total / n, n, total
 
     run(2000, 128, 96)                      # page in the library / spin up the OpenMP pool
-    t_small = run(10_000, 400, 400)         # BASELINE config 1
+    t_small, _, _ = run(10_000, 400, 400)   # BASELINE config 1
     # pixel-work scales with the image area; use config 1 to predict the full view
     predict = t_small * (W * H) / (400 * 400) * 1.5
     if predict <= budget_s:
-        t = run(P, W, H)
+        # a bounded sample of the same workload: whole views until ~12 s of CPU work (at most 8 views)
+        t, n, total = run(P, W, H, min_s=min(12.0, budget_s), max_views=8)
         return dict(value=1.0 / t, unit="views/s", cores=cores, kind="port",
-                    sample=f"1 view fwd+bwd of the same workload (P={P}, {W}x{H}, SH{deg}), {t:.2f} s")
+                    sample=f"{n} view(s) fwd+bwd of the same workload (P={P}, {W}x{H}, SH{deg}), {total:.1f} s of CPU work")
     return dict(value=1.0 / t_small, unit="views/s", cores=cores, kind="port",
                 sample=f"1 view fwd+bwd of BASELINE config 1 (P=10000, 400x400, SH{deg}), {t_small:.2f} s; "
                        f"the full workload was predicted at {predict:.0f} s > budget")
