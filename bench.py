@@ -398,6 +398,32 @@ def iteration_row(rast, scenes, dev, P, W, H, deg):
             "pieces": "activate_gaussians -> GaussianRasterizer -> l1_dssim_loss -> backward -> GaussianAdam.step"}
 
 
+def knn_row(dev, P):
+    """"Next" row (second item): simple_knn.distCUDA2 for P points (the reference's random-init
+    cube, dataset_readers.py:526), next to an exact k-d tree 3-NN on all host cores (scipy cKDTree, fp64)."""
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-1.3, 1.3, size=(P, 3)).astype(np.float32)
+    x = torch.from_numpy(pts).to(dev)
+    for _ in range(2):
+        distCUDA2(x)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        out = distCUDA2(x)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / n * 1e3
+    t0 = time.perf_counter()
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4, workers=-1)
+    cpu_s = time.perf_counter() - t0
+    want = (np.sort(d ** 2, axis=1)[:, 1:]).sum(1) / 3.0
+    err = float(np.abs(out.cpu().numpy().astype(np.float64) - want).max() / want.max())
+    return {"ms": round(ms, 3), "points": P, "scipy_ckdtree_all_cores_s": round(cpu_s, 3), "cores": os.cpu_count(),
+            "max_abs_err_rel_to_max": err}
+
+
 def main():
     a = parse()
     import view_parallel as vp
@@ -566,6 +592,10 @@ def main():
             result["next_rows"]["per_row_lr_adam_step"] = adam_row(dev, P)
         except Exception as e:
             result["next_rows"]["per_row_lr_adam_step"] = {"error": str(e)}
+        try:
+            result["next_rows"]["knn3_mean_dist2"] = knn_row(dev, P)
+        except Exception as e:
+            result["next_rows"]["knn3_mean_dist2"] = {"error": str(e)}
         try:
             result["next_rows"]["static_stage_training_iteration"] = iteration_row(rast, scenes, dev, P, W, H, deg)
         except Exception as e:

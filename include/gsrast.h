@@ -211,6 +211,14 @@ typedef struct gsrast_adam_group {
 int gsrast_adam_step(int n_groups, const gsrast_adam_group* groups /* host array */, double beta1, double beta2, double eps,
                      int step /* 1-based */, void* stream);   /* betas in fp64: (1 - 0.999f) would be off by 1.3e-5 relative */
 
+/* ---- "next" row, rank 4 (second item): simple_knn._C.distCUDA2 ----
+ * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest neighbours (other indices; duplicates count).
+ * Replaces the un-vendored dependency imported at scene/saro_gaussian.py:21 and used at :187 (scale initialisation).
+ * points [P][3] fp32, mean_dist2 [P], scratch >= gsrast_knn_scratch_bytes(P) bytes; all device pointers.
+ * With fewer than 4 points the missing neighbours count as FLT_MAX, as in the original. */
+size_t gsrast_knn_scratch_bytes(int P);
+int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* scratch, void* stream);
+
 const char* gsrast_last_error(void);
 int gsrast_abi_version(void);
 

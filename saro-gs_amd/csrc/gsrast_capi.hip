@@ -15,6 +15,7 @@
 #include "gsrast_loss.h"
 #include "gsrast_epilogue.h"
 #include "gsrast_adam.h"
+#include "gsrast_knn.h"
 
 #include <atomic>
 #include <chrono>
@@ -720,6 +721,53 @@ int gsrast_adam_step(int n_groups, const gsrast_adam_group* groups, double beta1
     a.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(1.0 - std::pow(beta2, (double)step)));
     adam_step_kernel<<<(unsigned)blocks, ADAM_THREADS, 0, s>>>(a);
     GS_LAUNCHED("adam_step");
+    return GSRAST_OK;
+}
+
+// scratch: bbox (8 words) | codes A/B | index A/B | radix histogram | scan scratch | boxes
+namespace {
+struct KnnLayout { size_t bbox, cA, cB, iA, iB, hist, scan, boxes, total; };
+KnnLayout knn_layout(size_t P)
+{
+    KnnLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    const size_t Pp = P ? P : 1;
+    L.bbox = take(32); L.cA = take(Pp * 4); L.cB = take(Pp * 4); L.iA = take(Pp * 4); L.iB = take(Pp * 4);
+    const size_t hist_n = 256 * rs_blocks_n(Pp, GSRAST_DEPTH_ITEMS);
+    L.hist = take(hist_n * 4); L.scan = take(scan_tmp_elems(hist_n) * 4);
+    L.boxes = take(((Pp + KNN_BOX - 1) / KNN_BOX) * 6 * 4);
+    L.total = o + 256;
+    return L;
+}
+}
+size_t gsrast_knn_scratch_bytes(int P) { return knn_layout(P > 0 ? (size_t)P : 0).total; }
+
+int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* scratch, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0) return fail(GSRAST_E_ARG, "knn3: bad size");
+    if (P == 0) return GSRAST_OK;
+    if (!points || !mean_dist2 || !scratch) return fail(GSRAST_E_ARG, "knn3: NULL pointer");
+    const KnnLayout L = knn_layout((size_t)P);
+    unsigned* bbox = at<unsigned>(scratch, L.bbox);
+    uint32_t *cA = at<uint32_t>(scratch, L.cA), *cB = at<uint32_t>(scratch, L.cB);
+    uint32_t *iA = at<uint32_t>(scratch, L.iA), *iB = at<uint32_t>(scratch, L.iB);
+    const int nb = (P + 255) / 256;
+    knn_init_kernel<<<1, 64, 0, s>>>(bbox);
+    GS_LAUNCHED("knn_init");
+    knn_bbox_kernel<<<nb, 256, 0, s>>>(P, points, bbox);
+    GS_LAUNCHED("knn_bbox");
+    knn_morton_kernel<<<nb, 256, 0, s>>>(P, points, bbox, cA, iA);
+    GS_LAUNCHED("knn_morton");
+    int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(cA, iA, cB, iB, (uint32_t)P, 30, at<uint32_t>(scratch, L.hist), at<uint32_t>(scratch, L.scan), s);
+    if (rc != GSRAST_OK) return rc;
+    const uint32_t* order = (radix_passes(30) & 1) ? iB : iA;
+    const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
+    float* boxes = at<float>(scratch, L.boxes);
+    knn_boxes_kernel<<<nboxes, 256, 0, s>>>(P, points, order, boxes);
+    GS_LAUNCHED("knn_boxes");
+    knn_search_kernel<<<nb, 256, 0, s>>>(P, points, order, boxes, nboxes, mean_dist2);
+    GS_LAUNCHED("knn_search");
     return GSRAST_OK;
 }
 

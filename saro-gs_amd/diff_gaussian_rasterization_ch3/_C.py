@@ -33,6 +33,7 @@ EXPORTS = (
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
     "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
+    "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
 )
 
 
@@ -93,6 +94,10 @@ def lib() -> C.CDLL:
     L.gsrast_activate_forward.argtypes = [ci, ci] + [vp] * 16
     L.gsrast_activate_backward.restype = ci
     L.gsrast_activate_backward.argtypes = [ci] + [vp] * 14
+    L.gsrast_knn_scratch_bytes.restype = C.c_size_t
+    L.gsrast_knn_scratch_bytes.argtypes = [ci]
+    L.gsrast_knn3_mean_dist2.restype = ci
+    L.gsrast_knn3_mean_dist2.argtypes = [ci, vp, vp, vp, vp]
     L.gsrast_adam_step.restype = ci
     L.gsrast_adam_step.argtypes = [ci, C.POINTER(AdamGroupStruct), C.c_double, C.c_double, C.c_double, ci, vp]
     L.gsrast_last_error.restype = C.c_char_p
