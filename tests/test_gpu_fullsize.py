@@ -146,3 +146,27 @@ def test_backward_is_linear_in_the_upstream_gradient(name, P, W, H, scenes, rast
         assert bool(torch.isfinite(gc[k]).all())
         assert not bool(gc[k][dead].any()), k
     assert bool((ga["means2D"][:, 2] == 0).all())      # only .x/.y of the screen-space gradient are written
+
+
+def test_more_than_65536_tiles(orc, scenes, rast, gpu):
+    """4112 x 4112 pixels = 257 x 257 tiles: the run-compressed binning (<= 256 tile rows, 16-bit tile ids) and the
+    work-bucket launch order (u16 tile ids) step aside for the instance-level sort on 32-bit tile ids and
+    tile_order_kernel.  Few Gaussians, so the oracle still finishes in seconds: exact comparison."""
+    from gpu_harness import bits, run_hip
+    W = H = 4112
+    P = 400
+    sc = scenes.synth(P, 161, scale_mul=0.5)
+    cam = scenes.camera(0, 1, W, H)
+    g = scenes.upstream_grad(H, W, 162)
+    o32 = orc.render(sc, cam, g)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+    assert h["R"] == o32["R"]
+    np.testing.assert_array_equal(h["point_list"], o32["point_list"])       # tile_clip has no effect on this path
+    np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+    np.testing.assert_array_equal(h["n_contrib"], o32["n_contrib"])
+    np.testing.assert_array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+    np.testing.assert_array_equal(bits(h["out_depth"]), bits(o32["out_depth"]))
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
+        ref = o32[k].astype(np.float64)
+        err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
+        assert (err <= 1e-5 + 1e-3 * np.abs(ref)).all(), (k, float(err.max()))
