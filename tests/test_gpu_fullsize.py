@@ -170,3 +170,27 @@ def test_more_than_65536_tiles(orc, scenes, rast, gpu):
         ref = o32[k].astype(np.float64)
         err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
         assert (err <= 1e-5 + 1e-3 * np.abs(ref)).all(), (k, float(err.max()))
+
+
+@pytest.mark.parametrize("W,H", [(4128, 512), (512, 4096), (4112, 3984)], ids=["258_tile_columns", "256_tile_rows", "64k_tiles_run_path"])
+def test_extreme_aspect_ratios_on_the_run_path(W, H, orc, scenes, rast, gpu):
+    """Run-compressed binning at its limits: more than 256 tile columns (two radix passes over the runs), exactly 256
+    tile rows (8-bit row digit fully used), and just under 65536 tiles."""
+    from gpu_harness import bits, run_hip
+    P = 600
+    sc = scenes.synth(P, 171, scale_mul=0.7)
+    cam = scenes.camera(1, 3, W, H)
+    g = scenes.upstream_grad(H, W, 172)
+    o32 = orc.render(sc, cam, g)
+    for clip in (0, 1):
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=clip)
+        assert h["R"] == o32["R"]
+        if clip == 0:
+            np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+            np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+        np.testing.assert_array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+        np.testing.assert_array_equal(bits(h["out_depth"]), bits(o32["out_depth"]))
+        for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
+            ref = o32[k].astype(np.float64)
+            err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
+            assert (err <= 1e-5 + 1e-3 * np.abs(ref)).all(), (k, float(err.max()))
