@@ -489,14 +489,14 @@ def main():
     n_pre = 0
     if a.preroll_ms > 0:
         t_pre = time.perf_counter()
-        for _ in range(10):
-            wl.step(bucket, world)
-        torch.cuda.synchronize(dev)
-        per_step = vp.max_over_ranks((time.perf_counter() - t_pre) / 10.0, dev)     # same number on every rank
-        n_more = max(0, min(5000, int(a.preroll_ms * 1e-3 / max(per_step, 1e-5)) - 10))
-        for _ in range(n_more):
-            wl.step(bucket, world)
-        n_pre = 10 + n_more
+        while n_pre < 5000:
+            for _ in range(20):
+                wl.step(bucket, world)
+            n_pre += 20
+            torch.cuda.synchronize(dev)
+            # the same elapsed time on every rank, so every rank runs the same number of rounds (and collectives)
+            if vp.max_over_ranks(time.perf_counter() - t_pre, dev) * 1e3 >= a.preroll_ms:
+                break
     # warm-up happens inside timed(); reset the event totals after it by timing warm-up separately
     for _ in range(a.warmup):
         wl.step(bucket, world)
