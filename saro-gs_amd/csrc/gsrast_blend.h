@@ -172,10 +172,11 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     const bool contrib = !(alpha < 1.0f / 255.0f);
                     term = contrib && test_T < 0.0001f;
                     const bool upd = contrib && !term;
-                    const float w = upd ? alpha * T : 0.0f;                // fma(colour, 0, C) == C exactly
-                    C0 = __builtin_fmaf(b.z, w, C0);
-                    C1 = __builtin_fmaf(b.w, w, C1);
-                    C2 = __builtin_fmaf(c.x, w, C2);
+                    // forward.cu:361: C += feature * alpha * T, associated as in the source: (feature * alpha) * T
+                    const float Tm = upd ? T : 0.0f;                       // fma(x, 0, C) == C exactly
+                    C0 = __builtin_fmaf(b.z * alpha, Tm, C0);
+                    C1 = __builtin_fmaf(b.w * alpha, Tm, C1);
+                    C2 = __builtin_fmaf(c.x * alpha, Tm, C2);
                     Dm = (upd && T > 0.5f && test_T < 0.5f) ? c.y : Dm;
                     T = upd ? test_T : T;
                     last = upd ? base + j + 1 : last;
@@ -316,10 +317,10 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                     const float test_T = T[k] * (1.0f - alpha);
                     const bool fin = ok && (test_T < 0.0001f);
                     const bool upd = ok && !fin;
-                    const float w = upd ? alpha * T[k] : 0.0f;      // fma(c, 0, C) == C exactly
-                    C0[k] = __builtin_fmaf(b.z, w, C0[k]);
-                    C1[k] = __builtin_fmaf(b.w, w, C1[k]);
-                    C2[k] = __builtin_fmaf(c.x, w, C2[k]);
+                    const float Tm = upd ? T[k] : 0.0f;             // fma(x, 0, C) == C exactly; (feature * alpha) * T as in the source
+                    C0[k] = __builtin_fmaf(b.z * alpha, Tm, C0[k]);
+                    C1[k] = __builtin_fmaf(b.w * alpha, Tm, C1[k]);
+                    C2[k] = __builtin_fmaf(c.x * alpha, Tm, C2[k]);
                     Dm[k] = (upd && T[k] > 0.5f && test_T < 0.5f) ? c.y : Dm[k];
                     T[k] = upd ? test_T : T[k];
                     last[k] = upd ? base + j + 1 : last[k];
