@@ -5,14 +5,18 @@
 // emit one 64-bit key (tile << 32 | depth bits) per (Gaussian, tile) instance -> ONE stable radix
 // sort of all R instances over 32+log2(T) key bits -> boundary detection.
 //
-// What this build does instead (same final order, ~4x less HBM traffic on the R-sized arrays):
+// What this build does instead (same final order):
 //   1. stable sort of the P Gaussians by depth bits (4 x 8-bit passes over 8 B pairs);
-//   2. scan of tiles_touched in that depth order, emit instances in depth order with a 32-bit
-//      tile id as key;
-//   3. stable sort of the R instances by tile id only (ceil(log2(T)/8) = 2 passes at 1080p).
+//   2. default ("run-compressed", second half of this file): one 10-byte COLUMN RUN (x, y0, h) per tile column of a
+//      Gaussian's rectangle, rows clipped to the alpha >= 1/255 ellipse; the runs are sorted by column (one pass over
+//      Q ~ R/6 elements), then ONE instance-level pass by tile row expands them on the fly and writes every instance
+//      once (4 bytes); the tile ranges come from the sorted runs and the scanned row histogram;
+//      option binning=1 (and images with > 256 tile rows / > 65536 tiles): scan of tiles_touched in depth order, one
+//      (tile id, Gaussian) pair per instance, stable sort of the R instances by tile id (2 passes at 1080p).
 // A stable sort by tile of a depth-ordered (ties: Gaussian-index-ordered) sequence is exactly the
 // stable sort by (tile, depth) of the index-ordered sequence the reference produces, so
-// point_list and the tile ranges are identical to the reference's, bit for bit.
+// point_list and the tile ranges are identical to the reference's, bit for bit (with tile_clip=0;
+// with row clipping the lists are ordered subsequences of the reference's and the outputs are bit-identical).
 #pragma once
 #include "gsrast_common.h"
 
