@@ -1,12 +1,14 @@
 // gsrast_blend.h -- per-tile alpha blending, forward (front-to-back) and backward (back-to-front).
 //
 // One 256-lane workgroup (4 wave64) per 16x16 tile -- the tile size is pinned by key parity with
-// the reference (config.h:16-17).  Wave w owns pixel rows 4w..4w+3 of the tile, so a wave is a
-// 16x4 pixel strip.  The tile's depth-sorted instance list is staged through LDS in batches of 256
-// (48-byte records gathered with three 16-byte loads per lane); inside a batch every lane of a
-// wave reads the SAME record (LDS broadcast) and evaluates it for its own pixel.  A wave leaves a
-// batch as soon as all its lanes are saturated (exec mask empty), the workgroup leaves when every
-// wave has -- no block-wide counting, only a barrier-and vote per batch.
+// the reference (config.h:16-17).  A wave owns 64 pixels of the tile: an 8x8 block in the default forward kernel,
+// a 16x4 strip (rows 4w..4w+3) in the backward and in the un-culled variants.  The tile's depth-sorted instance list
+// is staged through LDS in batches (48-byte records gathered with three 16-byte loads per lane).  Default kernels
+// (*_cull_kernel): per round of 64 staged instances every lane tests ONE instance against the wave's pixel block
+// (strip_may_touch), the ballot is a 64-bit scalar mask, and only the survivors are evaluated -- each by all lanes, one
+// LDS broadcast read of the record, each lane for its own pixel.  A wave leaves a batch as soon as all its lanes are
+// saturated, the workgroup leaves when every wave has -- no block-wide counting, only a barrier-and vote per batch.
+// Workgroups take tiles heaviest-first (tile_from_buckets).
 //
 // Reference behaviour restated: forward.cu:261-393 (renderCUDA fwd), backward.cu:399-557
 // (renderCUDA bwd).  Order of tests per (pixel, instance) is parity-critical and kept:
