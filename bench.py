@@ -602,6 +602,15 @@ def main():
             d = timed(wl, a.sweep_steps, 3, None, 1, vp, dev)
             sweep[str(p)] = {"views_per_s": round(a.sweep_steps / d, 3), "ms_per_step": round(d / a.sweep_steps * 1e3, 4)}
         result["sweep_1080p"] = sweep
+        # the other single-GPU shapes BASELINE.json names (synthetic stand-ins): informational, same protocol
+        other = {}
+        for tag, p, w, h in (("cfg2_100k_800x800", 100_000, 800, 800), ("cfg3_1M_1352x1014", 1_000_000, 1352, 1014)):
+            del wl
+            torch.cuda.empty_cache()
+            wl = Workload(rast, scenes, p, w, h, deg, 0, 1, dev)
+            d = timed(wl, a.sweep_steps, 5, None, 1, vp, dev)
+            other[tag] = {"views_per_s": round(a.sweep_steps / d, 3), "ms_per_step": round(d / a.sweep_steps * 1e3, 4)}
+        result["baseline_configs"] = other
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
