@@ -22,7 +22,7 @@ namespace gsrast {
 
 #ifdef GSRAST_DEBUG_COUNTERS
 __device__ unsigned long long g_dbg[8];
-#define GS_COUNT(i, v) do { if (lane_id() == 0) atomicAdd(&g_dbg[i], (unsigned long long)(v)); } while (0)
+#define GS_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane_id() == 0) atomicAdd(&g_dbg[i], v_); } while (0)
 #else
 #define GS_COUNT(i, v) do { } while (0)
 #endif
@@ -705,7 +705,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                         }
                     }
                 }
-                GS_COUNT(4, 1);
+                GS_COUNT(4, 1); GS_COUNT(7, __popcll(__ballot(pos < last[0])));
                 if (!__any(contributed)) continue;
                 GS_COUNT(5, 1); GS_COUNT(6, __popcll(__ballot(contributed)));
                 float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;

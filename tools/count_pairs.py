@@ -19,6 +19,6 @@ try:
     L.gsrast_debug_counters(out, 1)
     v = list(out)
     print("fwd: survivor iterations %d, with a lane in range %d, with a contribution %d, contributing lanes %d (%.1f / iteration)" % (v[0], v[1], v[3], v[2], v[2] / max(v[1], 1)))
-    print("bwd: survivor iterations %d, with a contribution %d, contributing lanes %d (%.1f / contributing iteration)" % (v[4], v[5], v[6], v[6] / max(v[5], 1)))
+    print("bwd: survivor iterations %d, with a contribution %d, contributing lanes %d (%.1f / contributing iteration), lanes still in reach (pos < last) %.1f / iteration" % (v[4], v[5], v[6], v[6] / max(v[5], 1), v[7] / max(v[4], 1)))
 finally:
     shutil.copy("/tmp/orig.so", lib)
