@@ -21,7 +21,7 @@
 namespace gsrast {
 
 #ifdef GSRAST_DEBUG_COUNTERS
-__device__ unsigned long long g_dbg[8];
+__device__ unsigned long long g_dbg[16];
 #define GS_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane_id() == 0) atomicAdd(&g_dbg[i], v_); } while (0)
 #else
 #define GS_COUNT(i, v) do { } while (0)

@@ -943,8 +943,8 @@ int gsrast_loss_backward(int C, int H, int W, const float* img, const float* gt,
 #ifdef GSRAST_DEBUG_COUNTERS
 extern "C" int gsrast_debug_counters(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gsrast::g_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gsrast::g_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gsrast::g_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gsrast::g_dbg), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

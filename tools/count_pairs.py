@@ -12,12 +12,13 @@ try:
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, 1, torch.device("cuda:0"))
     L = _C.lib()
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 16)()
     wl.step(None, 1); torch.cuda.synchronize()
     L.gsrast_debug_counters(out, 1)
     wl.step(None, 1); torch.cuda.synchronize()
     L.gsrast_debug_counters(out, 1)
     v = list(out)
+    print("RAW", v)
     print("fwd: survivor iterations %d, with a lane in range %d, with a contribution %d, contributing lanes %d (%.1f / iteration)" % (v[0], v[1], v[3], v[2], v[2] / max(v[1], 1)))
     print("bwd: survivor iterations %d, with a contribution %d, contributing lanes %d (%.1f / contributing iteration), lanes still in reach (pos < last) %.1f / iteration" % (v[4], v[5], v[6], v[6] / max(v[5], 1), v[7] / max(v[4], 1)))
 finally:
