@@ -253,9 +253,18 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
         uint32_t tot, gtot;
         const uint32_t start = block_excl_scan(c0 + c1 + c2 + c3, &tot);
         const bool used = t <= mask;                                      // the row scan ran for mask + 1 digits only
-        const uint32_t dbase = block_excl_scan(used ? digit_total[t] : 0u, &gtot);   // elements with a smaller digit, globally
+        uint32_t before = 0, row_total = 0;
+        if (digit_total) {
+            if (used) { row_total = digit_total[t]; before = hist_scanned[(size_t)t * nblk + blockIdx.x]; }
+        } else if (used) {
+            // few blocks (nblk <= RS_SELF_SCAN_BLOCKS): the histogram rows are raw counts and every block sums its own
+            // prefix -- one launch per pass less, which is what a small sort costs (launch latency, not bandwidth)
+            const uint32_t* row = hist_scanned + (size_t)t * nblk;
+            for (uint32_t b = 0; b < nblk; b++) { const uint32_t c = row[b]; row_total += c; before += b < blockIdx.x ? c : 0u; }
+        }
+        const uint32_t dbase = block_excl_scan(row_total, &gtot);         // elements with a smaller digit, globally
         dstart[t] = start;
-        gbase[t] = dbase + (used ? hist_scanned[(size_t)t * nblk + blockIdx.x] : 0u);
+        gbase[t] = dbase + before;
         cnt[0][t] = start; cnt[1][t] = start + c0; cnt[2][t] = start + c0 + c1; cnt[3][t] = start + c0 + c1 + c2;
     }
     __syncthreads();

@@ -139,10 +139,14 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
         const uint32_t mask = (1u << w) - 1u;
         radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk);
         GS_LAUNCHED("radix_hist");
-        radix_rowscan_kernel<<<mask + 1, 256, 0, s>>>(hist, nblk, scan_tmp);     // one workgroup per digit value in use
-        GS_LAUNCHED("radix_rowscan");
+        const bool self_scan = nblk <= RS_SELF_SCAN_BLOCKS;      // the scatter blocks sum the few block counts themselves
+        if (!self_scan) {
+            radix_rowscan_kernel<<<mask + 1, 256, 0, s>>>(hist, nblk, scan_tmp);     // one workgroup per digit value in use
+            GS_LAUNCHED("radix_rowscan");
+        }
         const bool last = p == passes - 1;
-        radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist, scan_tmp, nblk,
+        radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist,
+                                                                     self_scan ? nullptr : scan_tmp, nblk,
                                                                      last ? gather_rect : nullptr, gather_tiles, gather_width);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);

@@ -55,6 +55,7 @@ constexpr int WORK_BUCKETS = 64;
 constexpr size_t BUCKET_MAX_TILES = 65535;     // tile ids are stored as u16
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
+constexpr uint32_t RS_SELF_SCAN_BLOCKS = 64;   // sorts of at most this many blocks skip the row-scan launch (radix_scatter_kernel)
 constexpr int RS_ITEMS = 16;        // keys per lane (32 measured slower: profiles/)
 constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
 constexpr int SC_CHUNK = 4096;      // scan: elements per block (256 threads x 16)
