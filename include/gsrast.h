@@ -219,6 +219,35 @@ int gsrast_adam_step(int n_groups, const gsrast_adam_group* groups /* host array
 size_t gsrast_knn_scratch_bytes(int P);
 int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* scratch, void* stream);
 
+/* ---- "next" row, rank 4 (first item): mip-mapped feature-plane lookup of the residual field ----
+ * Replaces nvdiffrast.torch.texture(grid, coords, mip_level_bias=levels, boundary_mode="clamp", max_mip_level=7|0) at
+ * scene/hexplane.py:49-56 together with the plane loop of interpolate_ms_features (scene/hexplane.py:95-139): every plane
+ * of every scale in one forward launch.  Published algorithm of that op (linear-mipmap-linear, level from the bias only)
+ * as restated in oracle/texture_oracle.py.
+ *   plane      channel-last level 0 [H][W][C] fp32 (hexplane.py:35 layout); u = pts[n][cu], v = pts[n][cv] in [0,1]
+ *              texture coordinates; bias = min(levels[n][cu], levels[n][cv]) (hexplane.py:46)
+ *   features   [N][F]; plane p adds its C channels at features[n][out_offset .. out_offset + C); planes sharing an
+ *              out_offset (the six planes of a scale) must be adjacent in the array and are summed in array order
+ *   C          power of two in [4, 64]; D = floats per pts / levels row (4 in the reference)
+ *   scratch    >= gsrast_hexplane_scratch_bytes() bytes (mip stacks: built by every forward call, as the op does)
+ * backward: grad_tex of every plane is overwritten with dL/dtex; d_pts / d_levels [N][D] optional (the reference detaches
+ * both, scene/saro_gaussian.py:780); mips_built != 0 says scratch still holds the forward's stacks of these textures.
+ * All pointers inside gsrast_plane and the tensor arguments are device pointers; `planes` itself is a host array. */
+typedef struct {
+    const float* tex;
+    float* grad_tex;        /* backward only */
+    int W, H;
+    int cu, cv;
+    int max_mip_level;      /* the op's max_mip_level: 0 = no mip stack */
+    int out_offset;
+} gsrast_plane;
+size_t gsrast_hexplane_scratch_bytes(int n_planes, const gsrast_plane* planes, int C);
+int gsrast_hexplane_forward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts,
+                            const float* levels, float* features, char* scratch, void* stream);
+int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts,
+                             const float* levels, const float* d_features, float* d_pts, float* d_levels, int mips_built,
+                             char* scratch, void* stream);
+
 const char* gsrast_last_error(void);
 int gsrast_abi_version(void);
 

@@ -16,6 +16,7 @@
 #include "gsrast_epilogue.h"
 #include "gsrast_adam.h"
 #include "gsrast_knn.h"
+#include "gsrast_hexplane.h"
 
 #include <atomic>
 #include <chrono>
@@ -265,6 +266,7 @@ export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     }
 }
 
+std::atomic<int> g_hex_lds{1};        // hexplane backward: LDS-resident pyramids where a plane fits (0 = global atomics everywhere)
 std::atomic<int> g_ppl_fwd{0}, g_ppl_bwd{0};   // pixels per lane of the blend kernels: 0 = auto, else 1 / 2 / 4
 std::atomic<int> g_cull{1}, g_lpt{1};                    // wave-level strip culling in the blend kernels (default on)
 
@@ -344,6 +346,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "sh_grad_factors")) { g_sh_grad_factors = value ? 1 : 0; return 0; }
     if (!strcmp(name, "speculative")) { g_speculative = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
+    if (!strcmp(name, "hexplane_lds")) { g_hex_lds = value ? 1 : 0; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
         if (name[0] != 'b') g_ppl_fwd = value;
@@ -369,6 +372,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "speculative")) return g_speculative.load();
     if (!strcmp(name, "redo_count")) return g_redo_count.load();
     if (!strcmp(name, "lpt")) return g_lpt.load();
+    if (!strcmp(name, "hexplane_lds")) return g_hex_lds.load();
     return GSRAST_E_ARG;
 }
 
@@ -772,6 +776,173 @@ int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* 
     GS_LAUNCHED("knn_boxes");
     knn_search_kernel<<<nb, 256, 0, s>>>(P, points, order, boxes, nboxes, mean_dist2);
     GS_LAUNCHED("knn_search");
+    return GSRAST_OK;
+}
+
+// ---- mip-mapped feature-plane lookup (gsrast_hexplane.h) ---------------------------------------------------------
+// scratch: value stacks (levels >= 1) of every plane | gradient stacks of every plane, each 256-byte aligned
+extern "C++" {
+namespace {
+struct HexLayout { size_t mips[HEX_MAX_PLANES], gmips[HEX_MAX_PLANES], gmips_begin, total; int levels[HEX_MAX_PLANES]; };
+// number of levels above 0 the published op builds: halve while an extent is > 1 and the limit allows; -1 = odd extent
+int hex_levels(int W, int H, int limit)
+{
+    int w = W, h = H, l = 0;
+    while ((w > 1 || h > 1) && l < limit) {
+        if ((w > 1 && (w & 1)) || (h > 1 && (h & 1))) return -1;
+        w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; l++;
+    }
+    return l;
+}
+const char* hex_check(int n_planes, const gsrast_plane* planes, int C, int D, int F)
+{
+    if (n_planes < 1 || n_planes > HEX_MAX_PLANES || !planes) return "hexplane: 1..24 planes";
+    if (C < 4 || C > 64 || (C & (C - 1))) return "hexplane: channels must be a power of two in [4, 64]";
+    if (D < 2 || D > 8 || F < C || (F & 3)) return "hexplane: 2..8 coordinates per point, feature rows a multiple of 4 floats";
+    for (int p = 0; p < n_planes; p++) {
+        const gsrast_plane& g = planes[p];
+        if (g.W < 1 || g.H < 1 || (long long)g.W * g.H > (1ll << 26)) return "hexplane: bad plane extent";
+        if (g.cu < 0 || g.cu >= D || g.cv < 0 || g.cv >= D) return "hexplane: coordinate column outside the point row";
+        if (g.max_mip_level < 0) return "hexplane: negative max_mip_level";
+        if (g.out_offset < 0 || (g.out_offset & 3) || g.out_offset + C > F) return "hexplane: feature block outside the row";
+        if (hex_levels(g.W, g.H, g.max_mip_level) < 0) return "hexplane: a mip level has an odd extent > 1 (limit max_mip_level)";
+        if (hex_levels(g.W, g.H, g.max_mip_level) >= HEX_MAX_LEVELS) return "hexplane: too many mip levels";
+    }
+    return nullptr;
+}
+HexLayout hex_layout(int n_planes, const gsrast_plane* planes, int C)
+{
+    HexLayout L{}; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) L.gmips_begin = o;
+        for (int p = 0; p < n_planes; p++) {
+            const int nl = hex_levels(planes[p].W, planes[p].H, planes[p].max_mip_level);
+            L.levels[p] = nl;
+            const size_t texels = hex_level_offset(planes[p].W, planes[p].H, nl + 1);
+            (pass ? L.gmips[p] : L.mips[p]) = take(texels * (size_t)C * 4);
+        }
+    }
+    L.total = o + 256;
+    return L;
+}
+void hex_fill(HexArgs& a, const HexLayout& L, int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, char* scratch, bool backward)
+{
+    a.n_planes = n_planes; a.C = C; a.N = N; a.D = D; a.F = F;
+    for (int p = 0; p < n_planes; p++) {
+        HexPlane& P = a.pl[p];
+        P.tex = planes[p].tex; P.grad = planes[p].grad_tex;
+        P.mips = at<float>(scratch, L.mips[p]); P.gmips = at<float>(scratch, L.gmips[p]);
+        P.W = planes[p].W; P.H = planes[p].H; P.cu = planes[p].cu; P.cv = planes[p].cv;
+        P.n_levels = L.levels[p]; P.out_offset = planes[p].out_offset; P.lds_ch = 0;
+        if (backward && g_hex_lds.load()) {
+            const size_t texels = (size_t)P.W * P.H + hex_level_offset(P.W, P.H, P.n_levels + 1);
+            for (int ch = 4; ch >= 1; ch >>= 1) if (texels * ch * 4 <= HEX_LDS_BYTES) { P.lds_ch = ch; break; }
+        }
+    }
+}
+int hex_build_mips(const HexArgs& a, hipStream_t s)
+{
+    int top = 0; unsigned long long widest[HEX_MAX_LEVELS + 1] = {0};
+    for (int p = 0; p < a.n_planes; p++) {
+        top = std::max(top, a.pl[p].n_levels);
+        for (int l = 1; l <= a.pl[p].n_levels; l++)
+            widest[l] = std::max(widest[l], (unsigned long long)hex_extent(a.pl[p].W, l) * hex_extent(a.pl[p].H, l) * (a.C >> 2));
+    }
+    for (int l = 1; l <= top; l++) {
+        hex_mip_build_kernel<<<dim3((unsigned)((widest[l] + 255) / 256), (unsigned)a.n_planes), 256, 0, s>>>(a, l);
+        GS_LAUNCHED("hex_mip_build");
+    }
+    return GSRAST_OK;
+}
+template <int CH>
+int hex_launch_lds(const HexArgs& a, const float* pts, const float* levels, const float* dy, hipStream_t s)
+{
+    HexLdsList list{}; size_t bytes = 0;
+    for (int p = 0; p < a.n_planes; p++) if (a.pl[p].lds_ch == CH) {
+        list.plane[list.n++] = p;
+        bytes = std::max(bytes, ((size_t)a.pl[p].W * a.pl[p].H + hex_level_offset(a.pl[p].W, a.pl[p].H, a.pl[p].n_levels + 1)) * CH * 4);
+    }
+    if (!list.n) return GSRAST_OK;
+    static std::atomic<size_t> s_attr{0};           // largest dynamic-LDS size this instance has been enabled for
+    if (bytes > s_attr.load()) {
+        GS_HIP(hipFuncSetAttribute((const void*)hex_grad_tex_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEX_LDS_BYTES));
+        s_attr = HEX_LDS_BYTES;
+    }
+    const int groups = a.C / CH;
+    // enough workgroups to fill the chip a few times over, but every one of them clears and flushes a whole pyramid
+    int chunks = std::max(1, std::min((a.N + 8191) / 8192, (1024 + groups * list.n - 1) / (groups * list.n)));
+    const int chunk_points = (a.N + chunks - 1) / chunks;
+    chunks = (a.N + chunk_points - 1) / chunk_points;
+    hex_grad_tex_lds_kernel<CH><<<dim3((unsigned)chunks, (unsigned)groups, (unsigned)list.n), HEX_LDS_THREADS, bytes, s>>>(a, list, pts, levels, dy, chunk_points);
+    GS_LAUNCHED("hex_grad_tex_lds");
+    return GSRAST_OK;
+}
+}
+}   // extern "C++"
+
+size_t gsrast_hexplane_scratch_bytes(int n_planes, const gsrast_plane* planes, int C)
+{
+    if (hex_check(n_planes, planes, C, 8, 64)) return 0;
+    return hex_layout(n_planes, planes, C).total;
+}
+
+int gsrast_hexplane_forward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts, const float* levels,
+                            float* features, char* scratch, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0) return fail(GSRAST_E_ARG, "hexplane_forward: bad size");
+    if (const char* e = hex_check(n_planes, planes, C, D, F)) return fail(GSRAST_E_ARG, e);
+    for (int p = 0; p < n_planes; p++) if (!planes[p].tex) return fail(GSRAST_E_ARG, "hexplane_forward: NULL plane");
+    if (!scratch || (N > 0 && (!pts || !levels || !features))) return fail(GSRAST_E_ARG, "hexplane_forward: NULL pointer");
+    const HexLayout L = hex_layout(n_planes, planes, C);
+    HexArgs a{};
+    hex_fill(a, L, N, D, C, F, n_planes, planes, scratch, false);
+    if (int rc = hex_build_mips(a, s)) return rc;
+    if (N == 0) return GSRAST_OK;
+    const unsigned long long lanes = (unsigned long long)N * (C >> 2);
+    hex_sample_fwd_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(a, pts, levels, features);
+    GS_LAUNCHED("hex_sample_fwd");
+    return GSRAST_OK;
+}
+
+int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts, const float* levels,
+                             const float* d_features, float* d_pts, float* d_levels, int mips_built, char* scratch, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0) return fail(GSRAST_E_ARG, "hexplane_backward: bad size");
+    if (const char* e = hex_check(n_planes, planes, C, D, F)) return fail(GSRAST_E_ARG, e);
+    for (int p = 0; p < n_planes; p++) if (!planes[p].tex || !planes[p].grad_tex) return fail(GSRAST_E_ARG, "hexplane_backward: NULL plane or gradient");
+    if (!scratch || (N > 0 && (!pts || !levels || !d_features))) return fail(GSRAST_E_ARG, "hexplane_backward: NULL pointer");
+    const HexLayout L = hex_layout(n_planes, planes, C);
+    HexArgs a{};
+    hex_fill(a, L, N, D, C, F, n_planes, planes, scratch, true);
+    for (int p = 0; p < n_planes; p++) GS_HIP(hipMemsetAsync(planes[p].grad_tex, 0, (size_t)planes[p].W * planes[p].H * C * 4, s));
+    if (N == 0) return GSRAST_OK;
+    bool any_global = false; int top_global = 0;
+    for (int p = 0; p < n_planes; p++) if (!a.pl[p].lds_ch) { any_global = true; top_global = std::max(top_global, a.pl[p].n_levels); }
+    if (any_global) {
+        if (top_global) GS_HIP(hipMemsetAsync(scratch + L.gmips_begin, 0, L.total - 256 - L.gmips_begin, s));
+        const unsigned long long lanes = (unsigned long long)N * C;
+        hex_grad_tex_global_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(a, pts, levels, d_features);
+        GS_LAUNCHED("hex_grad_tex_global");
+        for (int l = top_global; l >= 1; l--) {
+            unsigned long long widest = 0;
+            for (int p = 0; p < n_planes; p++) if (!a.pl[p].lds_ch && a.pl[p].n_levels >= l)
+                widest = std::max(widest, (unsigned long long)hex_extent(a.pl[p].W, l) * hex_extent(a.pl[p].H, l) * (C >> 2));
+            hex_mip_pull_kernel<<<dim3((unsigned)((widest + 255) / 256), (unsigned)n_planes), 256, 0, s>>>(a, l);
+            GS_LAUNCHED("hex_mip_pull");
+        }
+    }
+    if (int rc = hex_launch_lds<4>(a, pts, levels, d_features, s)) return rc;
+    if (int rc = hex_launch_lds<2>(a, pts, levels, d_features, s)) return rc;
+    if (int rc = hex_launch_lds<1>(a, pts, levels, d_features, s)) return rc;
+    if (d_pts || d_levels) {
+        if (!mips_built) if (int rc = hex_build_mips(a, s)) return rc;
+        const unsigned long long lanes = (unsigned long long)N * (C >> 2);
+        hex_grad_uv_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(a, pts, levels, d_features, d_pts, d_levels);
+        GS_LAUNCHED("hex_grad_uv");
+    }
     return GSRAST_OK;
 }
 

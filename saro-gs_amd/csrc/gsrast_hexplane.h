@@ -1,0 +1,362 @@
+// gsrast_hexplane.h -- mip-mapped feature-plane lookup of the scale-aware residual field, all planes and scales of the
+// field in ONE forward launch, and its backward (first item).  Replaces the un-vendored dependency
+// call `nvdiffrast.torch.texture(grid, coords, mip_level_bias=levels, boundary_mode="clamp", max_mip_level=7|0)` at
+// /root/reference/scene/hexplane.py:49-56 and the plane loop around it (hexplane.py:95-139: six planes summed per scale,
+// scales concatenated).  The published algorithm of that op is restated in oracle/texture_oracle.py (header there):
+//   mip stack   level l+1 = 2x2 box average of level l (2x1 / 1x2 once an extent is 1), built on every call
+//   level       flevel = clamp(bias, 0, n_levels), level0 = floor, second level + lerp only where flevel > 0
+//   per level   u = uv.x * w - 0.5 clamped to [0, w-1]; i1 = i0 + 1 unless the clamp hit; bilinear; a + f * (b - a)
+//   backward    texel gradients of both levels, pulled down the stack (transpose of the box average); uv and bias
+//               gradients on request (the reference detaches all three inputs: saro_gaussian.py:780)
+// Layout: a plane is channel-last [H][W][C] fp32 (what hexplane.py:35 produces by permute + contiguous; parameters kept in
+// torch.channels_last need no copy).  C = 32 floats = one 128-byte texel: the forward gives a point C/4 lanes, each
+// fetching a float4 of every texel, so a texel is one full cache line per lane group.  The work is a gather: 8 texels
+// x 128 B per point and plane (6 kB per point for six planes) against 16 B of coordinates and 128 B of output, bound by
+// the L2 / Infinity-Cache gather rate, not by HBM streaming.
+// Backward to the texels, two paths:
+//   * plane pyramid fits the LDS with CH channels (64x64 with mips: 5461 texels x 4 ch x 4 B = 87 kB): a workgroup owns
+//     (plane, channel group, point chunk), accumulates with LDS atomics, pulls the stack down inside the LDS and flushes
+//     level 0 only -- ~250 points hit every texel of such a plane, which is hopeless for global atomics;
+//   * larger planes (512x512: 8 M floats): global float atomics, a lane per channel so a wave's atomic covers whole
+//     128-byte texels; then one pull-down launch per level.
+#pragma once
+#include "gsrast_common.h"
+
+namespace gsrast {
+
+constexpr int HEX_MAX_PLANES = 24;     // 6 planes x 4 scales (arguments/__init__.py:89 multires [1, 2, 4, 8])
+constexpr int HEX_MAX_LEVELS = 16;
+struct HexPlane {
+    const float* tex;      // level 0 values [H][W][C]
+    float* mips;           // levels >= 1, packed one after the other (values)
+    float* grad;           // backward: level-0 gradient [H][W][C]
+    float* gmips;          // backward, global path: gradient of levels >= 1, packed like mips
+    int W, H;
+    int cu, cv;            // columns of pts / levels holding this plane's u and v
+    int n_levels;          // built levels above 0 (the clamp of flevel)
+    int out_offset;        // first channel of the plane's block in a feature row
+    int lds_ch;            // backward: channels per workgroup on the LDS path, 0 = global atomics
+    int pad_;
+};
+struct HexArgs { int n_planes, C, N, D, F, pad_; HexPlane pl[HEX_MAX_PLANES]; };
+
+__host__ __device__ inline int hex_extent(int e, int l) { const int s = e >> l; return s > 1 ? s : 1; }
+// texel offset of level l (>= 1) inside the packed stack of levels >= 1
+__host__ __device__ inline unsigned hex_level_offset(int W, int H, int l)
+{
+    unsigned off = 0;
+    for (int k = 1; k < l; k++) off += (unsigned)hex_extent(W, k) * (unsigned)hex_extent(H, k);
+    return off;
+}
+
+// ---- mip stack ----------------------------------------------------------------------------------------------
+// One launch per level, all planes that have it (blockIdx.y = plane).  A lane = one float4 of one output texel.
+__global__ void __launch_bounds__(256)
+hex_mip_build_kernel(HexArgs a, int level)
+{
+    const HexPlane& P = a.pl[blockIdx.y];
+    if (P.n_levels < level) return;
+    const int q4 = a.C >> 2;
+    const int w = hex_extent(P.W, level), h = hex_extent(P.H, level);
+    const int pw = hex_extent(P.W, level - 1), ph = hex_extent(P.H, level - 1);
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)(w * h * q4)) return;
+    const int q = i % q4, t = i / q4, x = t % w, y = t / w;
+    const float4* in = reinterpret_cast<const float4*>(level == 1 ? P.tex : P.mips + (size_t)hex_level_offset(P.W, P.H, level - 1) * a.C);
+    float4* out = reinterpret_cast<float4*>(P.mips + (size_t)hex_level_offset(P.W, P.H, level) * a.C);
+    float4 r;
+    if (pw > 1 && ph > 1) {
+        const float4 A = in[((size_t)(2 * y) * pw + 2 * x) * q4 + q], B = in[((size_t)(2 * y) * pw + 2 * x + 1) * q4 + q];
+        const float4 Cc = in[((size_t)(2 * y + 1) * pw + 2 * x) * q4 + q], D = in[((size_t)(2 * y + 1) * pw + 2 * x + 1) * q4 + q];
+        r = make_float4(0.25f * (A.x + B.x + Cc.x + D.x), 0.25f * (A.y + B.y + Cc.y + D.y), 0.25f * (A.z + B.z + Cc.z + D.z), 0.25f * (A.w + B.w + Cc.w + D.w));
+    } else {
+        const size_t i0 = pw > 1 ? (size_t)y * pw + 2 * x : (size_t)(2 * y) * pw + x;
+        const size_t i1 = pw > 1 ? i0 + 1 : i0 + pw;
+        const float4 A = in[i0 * q4 + q], B = in[i1 * q4 + q];
+        r = make_float4(0.5f * (A.x + B.x), 0.5f * (A.y + B.y), 0.5f * (A.z + B.z), 0.5f * (A.w + B.w));
+    }
+    out[(size_t)t * q4 + q] = r;
+}
+
+// Transpose of the build, top level first: children += weight * parent.  Distinct parents own distinct children, so no atomics.
+__global__ void __launch_bounds__(256)
+hex_mip_pull_kernel(HexArgs a, int level)
+{
+    const HexPlane& P = a.pl[blockIdx.y];
+    if (P.n_levels < level || P.lds_ch) return;          // LDS-path planes pull down inside the LDS
+    const int q4 = a.C >> 2;
+    const int w = hex_extent(P.W, level), h = hex_extent(P.H, level);
+    const int pw = hex_extent(P.W, level - 1), ph = hex_extent(P.H, level - 1);
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)(w * h * q4)) return;
+    const int q = i % q4, t = i / q4, x = t % w, y = t / w;
+    const float4 g = reinterpret_cast<const float4*>(P.gmips + (size_t)hex_level_offset(P.W, P.H, level) * a.C)[(size_t)t * q4 + q];
+    float4* out = reinterpret_cast<float4*>(level == 1 ? P.grad : P.gmips + (size_t)hex_level_offset(P.W, P.H, level - 1) * a.C);
+    const bool quad = pw > 1 && ph > 1;
+    const float wgt = quad ? 0.25f : 0.5f;
+    const float4 s = make_float4(wgt * g.x, wgt * g.y, wgt * g.z, wgt * g.w);
+    size_t idx[4]; int n;
+    if (quad) { idx[0] = (size_t)(2 * y) * pw + 2 * x; idx[1] = idx[0] + 1; idx[2] = idx[0] + pw; idx[3] = idx[2] + 1; n = 4; }
+    else if (pw > 1) { idx[0] = (size_t)y * pw + 2 * x; idx[1] = idx[0] + 1; n = 2; }
+    else { idx[0] = (size_t)(2 * y) * pw + x; idx[1] = idx[0] + pw; n = 2; }
+    for (int k = 0; k < n; k++) {
+        float4 o = out[idx[k] * q4 + q];
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        out[idx[k] * q4 + q] = o;
+    }
+}
+
+// ---- per-point addressing -----------------------------------------------------------------------------------
+struct HexTap { unsigned i00, i10, i01, i11; float fu, fv; };     // texel indices inside the level, bilinear fractions
+__device__ inline HexTap hex_tap(float u, float v, int w, int h)
+{
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));                      // NaN -> 0: indices stay inside the level
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const bool cx = x == 0.0f || x == (float)(w - 1), cy = y == 0.0f || y == (float)(h - 1);
+    const int ix = (int)floorf(x), iy = (int)floorf(y);
+    const int jx = ix + (cx ? 0 : 1), jy = iy + (cy ? 0 : 1);
+    HexTap t;
+    t.i00 = (unsigned)(iy * w + ix); t.i10 = (unsigned)(iy * w + jx); t.i01 = (unsigned)(jy * w + ix); t.i11 = (unsigned)(jy * w + jx);
+    t.fu = x - (float)ix; t.fv = y - (float)iy;
+    return t;
+}
+struct HexLevel { int l0, l1; float f; bool two; };
+__device__ inline HexLevel hex_level(float bias, int n_levels)
+{
+    HexLevel L;
+    const float fl = fminf(fmaxf(bias, 0.0f), (float)n_levels);
+    L.l0 = (int)floorf(fl);
+    L.two = fl > 0.0f;
+    L.l1 = L.two ? (L.l0 + 1 < n_levels ? L.l0 + 1 : n_levels) : 0;
+    L.f = L.two ? fl - (float)L.l0 : 0.0f;
+    return L;
+}
+__device__ inline float4 hex_bilerp(const float4* __restrict__ lv, const HexTap& t, int q4, int q)
+{
+    const float4 a00 = lv[(size_t)t.i00 * q4 + q], a10 = lv[(size_t)t.i10 * q4 + q];
+    const float4 a01 = lv[(size_t)t.i01 * q4 + q], a11 = lv[(size_t)t.i11 * q4 + q];
+    float4 r;
+#define GS_BL(c) { const float top = a00.c + t.fu * (a10.c - a00.c), bot = a01.c + t.fu * (a11.c - a01.c); r.c = top + t.fv * (bot - top); }
+    GS_BL(x) GS_BL(y) GS_BL(z) GS_BL(w)
+#undef GS_BL
+    return r;
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------
+// C/4 lanes per point (a float4 of channels each); every plane of a feature block is summed in registers, one store.
+__global__ void __launch_bounds__(256)
+hex_sample_fwd_kernel(HexArgs a, const float* __restrict__ pts, const float* __restrict__ levels, float* __restrict__ features)
+{
+    const int q4 = a.C >> 2;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = gid / q4;
+    const int q = (int)(gid % q4);
+    if (n >= (size_t)a.N) return;
+    const float* pn = pts + n * a.D;
+    const float* ln = levels + n * a.D;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int p = 0; p < a.n_planes; p++) {
+        const HexPlane& P = a.pl[p];
+        const float u = pn[P.cu], v = pn[P.cv];
+        const HexLevel L = hex_level(fminf(ln[P.cu], ln[P.cv]), P.n_levels);
+        const int w0 = hex_extent(P.W, L.l0), h0 = hex_extent(P.H, L.l0);
+        const float4* lv0 = reinterpret_cast<const float4*>(L.l0 ? P.mips + (size_t)hex_level_offset(P.W, P.H, L.l0) * a.C : P.tex);
+        float4 r = hex_bilerp(lv0, hex_tap(u, v, w0, h0), q4, q);
+        if (L.two) {
+            const int w1 = hex_extent(P.W, L.l1), h1 = hex_extent(P.H, L.l1);
+            const float4* lv1 = reinterpret_cast<const float4*>(L.l1 ? P.mips + (size_t)hex_level_offset(P.W, P.H, L.l1) * a.C : P.tex);
+            const float4 b = hex_bilerp(lv1, hex_tap(u, v, w1, h1), q4, q);
+            r.x += L.f * (b.x - r.x); r.y += L.f * (b.y - r.y); r.z += L.f * (b.z - r.z); r.w += L.f * (b.w - r.w);
+        }
+        acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        if (p + 1 == a.n_planes || a.pl[p + 1].out_offset != P.out_offset) {
+            reinterpret_cast<float4*>(features + n * a.F + P.out_offset)[q] = acc;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// ---- backward to the texels, global atomics -------------------------------------------------------------------
+// A lane per channel: a wave's atomic instruction covers 64 / C whole texels (C = 32: two 128-byte texels).
+__device__ inline void hex_scatter_global(float* __restrict__ lv, const HexTap& t, int C, int c, float g)
+{
+    const float w00 = (1.0f - t.fu) * (1.0f - t.fv), w10 = t.fu * (1.0f - t.fv), w01 = (1.0f - t.fu) * t.fv, w11 = t.fu * t.fv;
+    atomicAdd(lv + (size_t)t.i00 * C + c, g * w00);
+    atomicAdd(lv + (size_t)t.i10 * C + c, g * w10);
+    atomicAdd(lv + (size_t)t.i01 * C + c, g * w01);
+    atomicAdd(lv + (size_t)t.i11 * C + c, g * w11);
+}
+__global__ void __launch_bounds__(256)
+hex_grad_tex_global_kernel(HexArgs a, const float* __restrict__ pts, const float* __restrict__ levels, const float* __restrict__ dy)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = gid / a.C;
+    const int c = (int)(gid % a.C);
+    if (n >= (size_t)a.N) return;
+    const float* pn = pts + n * a.D;
+    const float* ln = levels + n * a.D;
+#pragma unroll 1
+    for (int p = 0; p < a.n_planes; p++) {
+        const HexPlane& P = a.pl[p];
+        if (P.lds_ch) continue;
+        const float g = dy[n * a.F + P.out_offset + c];
+        if (g == 0.0f) continue;
+        const float u = pn[P.cu], v = pn[P.cv];
+        const HexLevel L = hex_level(fminf(ln[P.cu], ln[P.cv]), P.n_levels);
+        float* lv0 = L.l0 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, L.l0) * a.C : P.grad;
+        hex_scatter_global(lv0, hex_tap(u, v, hex_extent(P.W, L.l0), hex_extent(P.H, L.l0)), a.C, c, g * (1.0f - L.f));
+        if (L.two) {
+            float* lv1 = L.l1 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, L.l1) * a.C : P.grad;
+            hex_scatter_global(lv1, hex_tap(u, v, hex_extent(P.W, L.l1), hex_extent(P.H, L.l1)), a.C, c, g * L.f);
+        }
+    }
+}
+
+// ---- backward to the texels, LDS-resident pyramid ---------------------------------------------------------------
+// blockIdx = (point chunk, channel group, entry of lds_planes).  tile = the whole stack (level 0 first) x CH channels.
+constexpr int HEX_LDS_THREADS = 1024;
+constexpr size_t HEX_LDS_BYTES = 160 * 1024;
+struct HexLdsList { int n; int plane[HEX_MAX_PLANES]; };
+template <int CH>
+__global__ void __launch_bounds__(HEX_LDS_THREADS)
+hex_grad_tex_lds_kernel(HexArgs a, HexLdsList list, const float* __restrict__ pts, const float* __restrict__ levels,
+                        const float* __restrict__ dy, int chunk_points)
+{
+    extern __shared__ float tile[];
+    const HexPlane& P = a.pl[list.plane[blockIdx.z]];
+    if (P.lds_ch != CH) return;
+    const int c0 = blockIdx.y * CH;
+    if (c0 >= a.C) return;
+    unsigned total = (unsigned)P.W * (unsigned)P.H + hex_level_offset(P.W, P.H, P.n_levels + 1);
+    for (unsigned i = threadIdx.x; i < total * CH; i += HEX_LDS_THREADS) tile[i] = 0.0f;
+    __syncthreads();
+    const size_t n0 = (size_t)blockIdx.x * chunk_points;
+    const size_t n1 = n0 + chunk_points < (size_t)a.N ? n0 + chunk_points : (size_t)a.N;
+    const unsigned base0 = (unsigned)P.W * (unsigned)P.H;          // levels >= 1 follow level 0
+    for (size_t n = n0 + threadIdx.x; n < n1; n += HEX_LDS_THREADS) {
+        float g[CH];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < CH; k++) { g[k] = dy[n * a.F + P.out_offset + c0 + k]; any |= g[k] != 0.0f; }
+        if (!any) continue;
+        const float u = pts[n * a.D + P.cu], v = pts[n * a.D + P.cv];
+        const HexLevel L = hex_level(fminf(levels[n * a.D + P.cu], levels[n * a.D + P.cv]), P.n_levels);
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            if (which == 1 && !L.two) break;
+            const int l = which ? L.l1 : L.l0;
+            const float wl = which ? L.f : 1.0f - L.f;
+            const HexTap t = hex_tap(u, v, hex_extent(P.W, l), hex_extent(P.H, l));
+            float* lv = tile + (size_t)(l ? base0 + hex_level_offset(P.W, P.H, l) : 0u) * CH;
+            const float w00 = (1.0f - t.fu) * (1.0f - t.fv), w10 = t.fu * (1.0f - t.fv), w01 = (1.0f - t.fu) * t.fv, w11 = t.fu * t.fv;
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const float gk = g[k] * wl;
+                atomicAdd(lv + t.i00 * CH + k, gk * w00);
+                atomicAdd(lv + t.i10 * CH + k, gk * w10);
+                atomicAdd(lv + t.i01 * CH + k, gk * w01);
+                atomicAdd(lv + t.i11 * CH + k, gk * w11);
+            }
+        }
+    }
+    __syncthreads();
+    // pull the stack down inside the LDS, top level first
+    for (int l = P.n_levels; l >= 1; l--) {
+        const int w = hex_extent(P.W, l), h = hex_extent(P.H, l), pw = hex_extent(P.W, l - 1), ph = hex_extent(P.H, l - 1);
+        const float* src = tile + (size_t)(base0 + hex_level_offset(P.W, P.H, l)) * CH;
+        float* dst = tile + (size_t)(l - 1 ? base0 + hex_level_offset(P.W, P.H, l - 1) : 0u) * CH;
+        const bool quad = pw > 1 && ph > 1;
+        for (unsigned i = threadIdx.x; i < (unsigned)(w * h * CH); i += HEX_LDS_THREADS) {
+            const int k = i % CH, t = i / CH, x = t % w, y = t / w;
+            const float gq = src[i] * (quad ? 0.25f : 0.5f);
+            if (quad) {
+                const unsigned b = (unsigned)((2 * y) * pw + 2 * x);
+                dst[b * CH + k] += gq; dst[(b + 1) * CH + k] += gq; dst[(b + pw) * CH + k] += gq; dst[(b + pw + 1) * CH + k] += gq;
+            } else if (pw > 1) {
+                const unsigned b = (unsigned)(y * pw + 2 * x);
+                dst[b * CH + k] += gq; dst[(b + 1) * CH + k] += gq;
+            } else {
+                const unsigned b = (unsigned)((2 * y) * pw + x);
+                dst[b * CH + k] += gq; dst[(b + pw) * CH + k] += gq;
+            }
+        }
+        __syncthreads();
+    }
+    for (unsigned i = threadIdx.x; i < base0 * CH; i += HEX_LDS_THREADS) {
+        const float gv = tile[i];
+        if (gv != 0.0f) atomicAdd(P.grad + (size_t)(i / CH) * a.C + c0 + (i % CH), gv);
+    }
+}
+
+// ---- backward to uv and bias (on request) ------------------------------------------------------------------------
+// Same lane layout as the forward; the C/4 lanes of a point reduce their channel sums with DPP shuffles; lane 0 of the
+// group accumulates over the planes and writes d_pts / d_levels rows (no atomics: the group owns the point).
+__device__ inline void hex_slopes(const float4* __restrict__ lv, const HexTap& t, int q4, int q, int w, int h, const float4& g,
+                                  float4& val, float& du, float& dv)
+{
+    const float4 a00 = lv[(size_t)t.i00 * q4 + q], a10 = lv[(size_t)t.i10 * q4 + q];
+    const float4 a01 = lv[(size_t)t.i01 * q4 + q], a11 = lv[(size_t)t.i11 * q4 + q];
+    du = 0.0f; dv = 0.0f;
+#define GS_SL(c) { const float top = a00.c + t.fu * (a10.c - a00.c), bot = a01.c + t.fu * (a11.c - a01.c); val.c = top + t.fv * (bot - top); \
+        du += g.c * (((a10.c - a00.c) * (1.0f - t.fv) + (a11.c - a01.c) * t.fv) * (float)w); \
+        dv += g.c * (((a01.c - a00.c) * (1.0f - t.fu) + (a11.c - a10.c) * t.fu) * (float)h); }
+    GS_SL(x) GS_SL(y) GS_SL(z) GS_SL(w)
+#undef GS_SL
+}
+__global__ void __launch_bounds__(256)
+hex_grad_uv_kernel(HexArgs a, const float* __restrict__ pts, const float* __restrict__ levels, const float* __restrict__ dy,
+                   float* __restrict__ d_pts, float* __restrict__ d_levels)
+{
+    const int q4 = a.C >> 2;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_raw = gid / q4;
+    const int q = (int)(gid % q4);
+    const bool live = n_raw < (size_t)a.N;
+    const size_t n = live ? n_raw : (size_t)a.N - 1;          // dead lanes shadow the last point: the shuffles need every lane
+    const float* pn = pts + n * a.D;
+    const float* ln = levels + n * a.D;
+    float dp[8], dl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { dp[k] = 0.0f; dl[k] = 0.0f; }
+#pragma unroll 1
+    for (int p = 0; p < a.n_planes; p++) {
+        const HexPlane& P = a.pl[p];
+        const float4 g = reinterpret_cast<const float4*>(dy + n * a.F + P.out_offset)[q];
+        const float u = pn[P.cu], v = pn[P.cv];
+        const float lu = ln[P.cu], lvv = ln[P.cv];
+        const HexLevel L = hex_level(fminf(lu, lvv), P.n_levels);
+        const int w0 = hex_extent(P.W, L.l0), h0 = hex_extent(P.H, L.l0);
+        const float4* lv0 = reinterpret_cast<const float4*>(L.l0 ? P.mips + (size_t)hex_level_offset(P.W, P.H, L.l0) * a.C : P.tex);
+        float4 va, vb = make_float4(0.f, 0.f, 0.f, 0.f);
+        float du0, dv0, du1 = 0.0f, dv1 = 0.0f;
+        hex_slopes(lv0, hex_tap(u, v, w0, h0), q4, q, w0, h0, g, va, du0, dv0);
+        float db = 0.0f;
+        if (L.two) {
+            const int w1 = hex_extent(P.W, L.l1), h1 = hex_extent(P.H, L.l1);
+            const float4* lv1 = reinterpret_cast<const float4*>(L.l1 ? P.mips + (size_t)hex_level_offset(P.W, P.H, L.l1) * a.C : P.tex);
+            hex_slopes(lv1, hex_tap(u, v, w1, h1), q4, q, w1, h1, g, vb, du1, dv1);
+            db = g.x * (vb.x - va.x) + g.y * (vb.y - va.y) + g.z * (vb.z - va.z) + g.w * (vb.w - va.w);
+        }
+        float du = (1.0f - L.f) * du0 + L.f * du1, dv = (1.0f - L.f) * dv0 + L.f * dv1;
+        for (int m = 1; m < q4; m <<= 1) {                      // q4 is a power of two <= 16: the group sits inside a DPP row
+            du += __shfl_xor(du, m); dv += __shfl_xor(dv, m); db += __shfl_xor(db, m);
+        }
+        // the bias is min(levels[cu], levels[cv]): its gradient goes to the smaller one (cu on a tie, as torch.min does)
+        const int cb = lvv < lu ? P.cv : P.cu;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            dp[k] += (k == P.cu ? du : 0.0f) + (k == P.cv ? dv : 0.0f);
+            dl[k] += k == cb ? db : 0.0f;
+        }
+    }
+    if (live && q == 0) {
+        for (int k = 0; k < a.D && k < 8; k++) {
+            if (d_pts) d_pts[n * a.D + k] = dp[k];
+            if (d_levels) d_levels[n * a.D + k] = dl[k];
+        }
+    }
+}
+
+} // namespace gsrast

@@ -34,6 +34,7 @@ EXPORTS = (
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
     "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
+    "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
 )
 
 
@@ -41,6 +42,12 @@ class AdamGroupStruct(C.Structure):
     """gsrast_adam_group (include/gsrast.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("lr_rows", C.c_void_p), ("lr", C.c_float), ("rows", C.c_int), ("width", C.c_int)]
+
+
+class PlaneStruct(C.Structure):
+    """gsrast_plane (include/gsrast.h)."""
+    _fields_ = [("tex", C.c_void_p), ("grad_tex", C.c_void_p), ("W", C.c_int), ("H", C.c_int), ("cu", C.c_int), ("cv", C.c_int),
+                ("max_mip_level", C.c_int), ("out_offset", C.c_int)]
 
 
 def lib() -> C.CDLL:
@@ -100,6 +107,12 @@ def lib() -> C.CDLL:
     L.gsrast_knn3_mean_dist2.argtypes = [ci, vp, vp, vp, vp]
     L.gsrast_adam_step.restype = ci
     L.gsrast_adam_step.argtypes = [ci, C.POINTER(AdamGroupStruct), C.c_double, C.c_double, C.c_double, ci, vp]
+    L.gsrast_hexplane_scratch_bytes.restype = C.c_size_t
+    L.gsrast_hexplane_scratch_bytes.argtypes = [ci, C.POINTER(PlaneStruct), ci]
+    L.gsrast_hexplane_forward.restype = ci
+    L.gsrast_hexplane_forward.argtypes = [ci, ci, ci, ci, ci, C.POINTER(PlaneStruct), vp, vp, vp, vp, vp]
+    L.gsrast_hexplane_backward.restype = ci
+    L.gsrast_hexplane_backward.argtypes = [ci, ci, ci, ci, ci, C.POINTER(PlaneStruct), vp, vp, vp, vp, vp, ci, vp, vp]
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
     if L.gsrast_abi_version() != 1:
