@@ -436,6 +436,90 @@ def knn_row(dev, P):
             "max_abs_err_rel_to_max": err}
 
 
+def hexplane_row(dev, P):
+    """"Next" row (first item): the residual field's mip-mapped plane lookup for P points, forward and
+    backward to the planes, at the two shipped field shapes (configs/dnerf/*.json: 64^3 x 128 frames; configs/neural_3D/*.json:
+    512^3 x 256 frames; 32 features, one scale), next to the same computation spelled with PyTorch ops on the same GPU
+    (avg_pool2d pyramid + grid_sample per level + lerp -- the structure tests/test_oracle_texture.py pins the oracle with)."""
+    import itertools
+    import torch.nn.functional as F
+    import fused_hexplane
+    coo = list(itertools.combinations(range(4), 2))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    out = {}
+    for tag, reso in (("dnerf_64x64x64x128", [64, 64, 64, 128]), ("neural3d_512x512x512x256", [512, 512, 512, 256])):
+        C = 32
+        grids = [torch.randn((1, C, reso[b], reso[a]), generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                 for (a, b) in coo]
+        pts = torch.rand((P, 4), generator=g).to(dev)
+        levels = torch.cat([torch.rand((P, 3), generator=g) * float(np.log2(reso[0])), torch.zeros((P, 1))], dim=1).to(dev)
+        dy = torch.randn((P, C), generator=g).to(dev)
+
+        def ours():
+            o = fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
+            o.backward(dy)
+            return o
+
+        def torch_ops():
+            acc = 0
+            for ci, (a, b) in enumerate(coo):
+                mm = 7 if b != 3 else 0
+                mips = [grids[ci]]
+                while mips[-1].shape[2] > 1 and len(mips) - 1 < mm:
+                    mips.append(F.avg_pool2d(mips[-1], 2))
+                n = len(mips) - 1
+                fl = torch.minimum(levels[:, a], levels[:, b]).clamp(0.0, float(n))
+                l0 = fl.floor().long()
+                l1 = torch.clamp(l0 + 1, max=n)
+                f = (fl - l0)[:, None]
+                grid = (2.0 * pts[:, [a, b]] - 1.0)[None, None]
+                va = torch.zeros((P, C), device=dev)
+                vb = torch.zeros((P, C), device=dev)
+                for l in range(n + 1):          # every level sampled for the points that use it
+                    ma, mb = l0 == l, l1 == l
+                    if bool(ma.any()) or bool(mb.any()):
+                        sm = F.grid_sample(mips[l], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, :, 0].t()
+                        va = torch.where(ma[:, None], sm, va)
+                        vb = torch.where(mb[:, None], sm, vb)
+                acc = acc + va + f * (vb - va)
+            acc.backward(dy)
+            return acc
+
+        res = {}
+        for name, fn, reps in (("ms", ours, 10), ("torch_ops_same_gpu_ms", torch_ops, 2)):
+            for _ in range(2 if fn is ours else 1):
+                for gr in grids: gr.grad = None
+                o = fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for gr in grids: gr.grad = None
+                o = fn()
+            torch.cuda.synchronize(dev)
+            res[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+            res["_out_" + name] = o.detach()
+            res["_grad_" + name] = grids[0].grad.detach().clone()
+        a_, b_ = res.pop("_out_ms"), res.pop("_out_torch_ops_same_gpu_ms")
+        ga, gb = res.pop("_grad_ms"), res.pop("_grad_torch_ops_same_gpu_ms")
+        res["max_abs_diff_vs_torch_ops"] = float((a_ - b_).abs().max())
+        res["plane_grad_rel_diff_vs_torch_ops"] = float((ga - gb).abs().max() / gb.abs().max())
+        # forward alone, and the gather it performs: 8 texels x 128 B per point and plane
+        with torch.no_grad():
+            for _ in range(2):
+                fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
+            torch.cuda.synchronize(dev)
+            res["forward_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+        res["gather_GBps_forward"] = round(P * 6 * 8 * C * 4 / (res["forward_ms"] * 1e-3) / 1e9, 1)
+        res["points"] = P
+        out[tag] = res
+        del grids
+    return out
+
+
 def main():
     a = parse()
     import view_parallel as vp
@@ -629,6 +713,10 @@ def main():
             result["next_rows"]["knn3_mean_dist2"] = knn_row(dev, P)
         except Exception as e:
             result["next_rows"]["knn3_mean_dist2"] = {"error": str(e)}
+        try:
+            result["next_rows"]["hexplane_field_fwd_bwd"] = hexplane_row(dev, P)
+        except Exception as e:      # noqa: BLE001
+            result["next_rows"]["hexplane_field_fwd_bwd"] = {"error": str(e)}
         try:
             result["next_rows"]["static_stage_training_iteration"] = iteration_row(rast, scenes, dev, P, W, H, deg)
         except Exception as e:

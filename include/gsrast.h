@@ -229,7 +229,8 @@ int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* 
  *   features   [N][F]; plane p adds its C channels at features[n][out_offset .. out_offset + C); planes sharing an
  *              out_offset (the six planes of a scale) must be adjacent in the array and are summed in array order
  *   C          power of two in [4, 64]; D = floats per pts / levels row (4 in the reference)
- *   scratch    >= gsrast_hexplane_scratch_bytes() bytes (mip stacks: built by every forward call, as the op does)
+ *   scratch    >= gsrast_hexplane_scratch_bytes() bytes (mip stacks: built by every forward call, as the op does; gradient
+ *              stacks and the sorted (plane, point) pairs of the backward)
  * backward: grad_tex of every plane is overwritten with dL/dtex; d_pts / d_levels [N][D] optional (the reference detaches
  * both, scene/saro_gaussian.py:780); mips_built != 0 says scratch still holds the forward's stacks of these textures.
  * All pointers inside gsrast_plane and the tensor arguments are device pointers; `planes` itself is a host array. */
@@ -241,7 +242,7 @@ typedef struct {
     int max_mip_level;      /* the op's max_mip_level: 0 = no mip stack */
     int out_offset;
 } gsrast_plane;
-size_t gsrast_hexplane_scratch_bytes(int n_planes, const gsrast_plane* planes, int C);
+size_t gsrast_hexplane_scratch_bytes(int n_planes, const gsrast_plane* planes, int C, int N);
 int gsrast_hexplane_forward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts,
                             const float* levels, float* features, char* scratch, void* stream);
 int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts,

@@ -266,7 +266,7 @@ export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     }
 }
 
-std::atomic<int> g_hex_lds{1};        // hexplane backward: LDS-resident pyramids where a plane fits (0 = global atomics everywhere)
+std::atomic<int> g_hex_scatter{0};    // hexplane backward to the texels: 0 = sorted runs, 1 = direct global atomics
 std::atomic<int> g_ppl_fwd{0}, g_ppl_bwd{0};   // pixels per lane of the blend kernels: 0 = auto, else 1 / 2 / 4
 std::atomic<int> g_cull{1}, g_lpt{1};                    // wave-level strip culling in the blend kernels (default on)
 
@@ -346,7 +346,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "sh_grad_factors")) { g_sh_grad_factors = value ? 1 : 0; return 0; }
     if (!strcmp(name, "speculative")) { g_speculative = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
-    if (!strcmp(name, "hexplane_lds")) { g_hex_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
         if (name[0] != 'b') g_ppl_fwd = value;
@@ -372,7 +372,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "speculative")) return g_speculative.load();
     if (!strcmp(name, "redo_count")) return g_redo_count.load();
     if (!strcmp(name, "lpt")) return g_lpt.load();
-    if (!strcmp(name, "hexplane_lds")) return g_hex_lds.load();
+    if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
 }
 
@@ -783,7 +783,7 @@ int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* 
 // scratch: value stacks (levels >= 1) of every plane | gradient stacks of every plane, each 256-byte aligned
 extern "C++" {
 namespace {
-struct HexLayout { size_t mips[HEX_MAX_PLANES], gmips[HEX_MAX_PLANES], gmips_begin, total; int levels[HEX_MAX_PLANES]; };
+struct HexLayout { size_t mips[HEX_MAX_PLANES], gmips[HEX_MAX_PLANES], gmips_begin, gmips_end, kA, kB, vA, vB, hist, scan, total; int levels[HEX_MAX_PLANES]; int cell_bits, key_bits; };
 // number of levels above 0 the published op builds: halve while an extent is > 1 and the limit allows; -1 = odd extent
 int hex_levels(int W, int H, int limit)
 {
@@ -810,7 +810,7 @@ const char* hex_check(int n_planes, const gsrast_plane* planes, int C, int D, in
     }
     return nullptr;
 }
-HexLayout hex_layout(int n_planes, const gsrast_plane* planes, int C)
+HexLayout hex_layout(int n_planes, const gsrast_plane* planes, int C, size_t N)
 {
     HexLayout L{}; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
@@ -823,6 +823,18 @@ HexLayout hex_layout(int n_planes, const gsrast_plane* planes, int C)
             (pass ? L.gmips[p] : L.mips[p]) = take(texels * (size_t)C * 4);
         }
     }
+    L.gmips_end = o;
+    // sorted-run backward: (key, point) pairs of every plane, double-buffered, + the radix sort's tables
+    size_t widest = 1;
+    for (int p = 0; p < n_planes; p++)
+        widest = std::max(widest, (size_t)planes[p].W * planes[p].H + hex_level_offset(planes[p].W, planes[p].H, L.levels[p] + 1));
+    L.cell_bits = 1; while (((size_t)1 << L.cell_bits) < widest) L.cell_bits++;
+    int pb = 0; while ((1 << pb) < n_planes) pb++;
+    L.key_bits = L.cell_bits + pb;
+    const size_t E = std::max<size_t>((size_t)n_planes * N, 1);
+    L.kA = take(E * 4); L.kB = take(E * 4); L.vA = take(E * 4); L.vB = take(E * 4);
+    const size_t hist_n = 256 * rs_blocks_n(E, RS_ITEMS);
+    L.hist = take(hist_n * 4); L.scan = take(scan_tmp_elems(hist_n) * 4);
     L.total = o + 256;
     return L;
 }
@@ -834,11 +846,7 @@ void hex_fill(HexArgs& a, const HexLayout& L, int N, int D, int C, int F, int n_
         P.tex = planes[p].tex; P.grad = planes[p].grad_tex;
         P.mips = at<float>(scratch, L.mips[p]); P.gmips = at<float>(scratch, L.gmips[p]);
         P.W = planes[p].W; P.H = planes[p].H; P.cu = planes[p].cu; P.cv = planes[p].cv;
-        P.n_levels = L.levels[p]; P.out_offset = planes[p].out_offset; P.lds_ch = 0;
-        if (backward && g_hex_lds.load()) {
-            const size_t texels = (size_t)P.W * P.H + hex_level_offset(P.W, P.H, P.n_levels + 1);
-            for (int ch = 4; ch >= 1; ch >>= 1) if (texels * ch * 4 <= HEX_LDS_BYTES) { P.lds_ch = ch; break; }
-        }
+        P.n_levels = L.levels[p]; P.out_offset = planes[p].out_offset;
     }
 }
 int hex_build_mips(const HexArgs& a, hipStream_t s)
@@ -855,36 +863,22 @@ int hex_build_mips(const HexArgs& a, hipStream_t s)
     }
     return GSRAST_OK;
 }
-template <int CH>
-int hex_launch_lds(const HexArgs& a, const float* pts, const float* levels, const float* dy, hipStream_t s)
+template <int C>
+int hex_launch_sorted(const HexArgs& a, int cell_bits, unsigned E, const uint32_t* keys, const uint32_t* vals, const float* pts,
+                      const float* levels, const float* dy, hipStream_t s)
 {
-    HexLdsList list{}; size_t bytes = 0;
-    for (int p = 0; p < a.n_planes; p++) if (a.pl[p].lds_ch == CH) {
-        list.plane[list.n++] = p;
-        bytes = std::max(bytes, ((size_t)a.pl[p].W * a.pl[p].H + hex_level_offset(a.pl[p].W, a.pl[p].H, a.pl[p].n_levels + 1)) * CH * 4);
-    }
-    if (!list.n) return GSRAST_OK;
-    static std::atomic<size_t> s_attr{0};           // largest dynamic-LDS size this instance has been enabled for
-    if (bytes > s_attr.load()) {
-        GS_HIP(hipFuncSetAttribute((const void*)hex_grad_tex_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEX_LDS_BYTES));
-        s_attr = HEX_LDS_BYTES;
-    }
-    const int groups = a.C / CH;
-    // enough workgroups to fill the chip a few times over, but every one of them clears and flushes a whole pyramid
-    int chunks = std::max(1, std::min((a.N + 8191) / 8192, (1024 + groups * list.n - 1) / (groups * list.n)));
-    const int chunk_points = (a.N + chunks - 1) / chunks;
-    chunks = (a.N + chunk_points - 1) / chunk_points;
-    hex_grad_tex_lds_kernel<CH><<<dim3((unsigned)chunks, (unsigned)groups, (unsigned)list.n), HEX_LDS_THREADS, bytes, s>>>(a, list, pts, levels, dy, chunk_points);
-    GS_LAUNCHED("hex_grad_tex_lds");
+    const unsigned long long groups = ((unsigned long long)E + HEX_RUN_CHUNK - 1) / HEX_RUN_CHUNK;
+    hex_grad_tex_sorted_kernel<C><<<(unsigned)((groups * C + 255) / 256), 256, 0, s>>>(a, cell_bits, E, keys, vals, pts, levels, dy);
+    GS_LAUNCHED("hex_grad_tex_sorted");
     return GSRAST_OK;
 }
 }
 }   // extern "C++"
 
-size_t gsrast_hexplane_scratch_bytes(int n_planes, const gsrast_plane* planes, int C)
+size_t gsrast_hexplane_scratch_bytes(int n_planes, const gsrast_plane* planes, int C, int N)
 {
-    if (hex_check(n_planes, planes, C, 8, 64)) return 0;
-    return hex_layout(n_planes, planes, C).total;
+    if (N < 0 || hex_check(n_planes, planes, C, 8, 64)) return 0;
+    return hex_layout(n_planes, planes, C, (size_t)N).total;
 }
 
 int gsrast_hexplane_forward(int N, int D, int C, int F, int n_planes, const gsrast_plane* planes, const float* pts, const float* levels,
@@ -895,7 +889,7 @@ int gsrast_hexplane_forward(int N, int D, int C, int F, int n_planes, const gsra
     if (const char* e = hex_check(n_planes, planes, C, D, F)) return fail(GSRAST_E_ARG, e);
     for (int p = 0; p < n_planes; p++) if (!planes[p].tex) return fail(GSRAST_E_ARG, "hexplane_forward: NULL plane");
     if (!scratch || (N > 0 && (!pts || !levels || !features))) return fail(GSRAST_E_ARG, "hexplane_forward: NULL pointer");
-    const HexLayout L = hex_layout(n_planes, planes, C);
+    const HexLayout L = hex_layout(n_planes, planes, C, (size_t)N);
     HexArgs a{};
     hex_fill(a, L, N, D, C, F, n_planes, planes, scratch, false);
     if (int rc = hex_build_mips(a, s)) return rc;
@@ -914,29 +908,43 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
     if (const char* e = hex_check(n_planes, planes, C, D, F)) return fail(GSRAST_E_ARG, e);
     for (int p = 0; p < n_planes; p++) if (!planes[p].tex || !planes[p].grad_tex) return fail(GSRAST_E_ARG, "hexplane_backward: NULL plane or gradient");
     if (!scratch || (N > 0 && (!pts || !levels || !d_features))) return fail(GSRAST_E_ARG, "hexplane_backward: NULL pointer");
-    const HexLayout L = hex_layout(n_planes, planes, C);
+    const HexLayout L = hex_layout(n_planes, planes, C, (size_t)N);
     HexArgs a{};
     hex_fill(a, L, N, D, C, F, n_planes, planes, scratch, true);
     for (int p = 0; p < n_planes; p++) GS_HIP(hipMemsetAsync(planes[p].grad_tex, 0, (size_t)planes[p].W * planes[p].H * C * 4, s));
     if (N == 0) return GSRAST_OK;
-    bool any_global = false; int top_global = 0;
-    for (int p = 0; p < n_planes; p++) if (!a.pl[p].lds_ch) { any_global = true; top_global = std::max(top_global, a.pl[p].n_levels); }
-    if (any_global) {
-        if (top_global) GS_HIP(hipMemsetAsync(scratch + L.gmips_begin, 0, L.total - 256 - L.gmips_begin, s));
+    int top = 0;
+    for (int p = 0; p < n_planes; p++) top = std::max(top, a.pl[p].n_levels);
+    if (top) GS_HIP(hipMemsetAsync(scratch + L.gmips_begin, 0, L.gmips_end - L.gmips_begin, s));
+    const unsigned long long E = (unsigned long long)n_planes * N;
+    if (g_hex_scatter.load() == 0 && L.key_bits <= 32 && E < 0xFFFFFFFFull) {
+        uint32_t *kA = at<uint32_t>(scratch, L.kA), *kB = at<uint32_t>(scratch, L.kB), *vA = at<uint32_t>(scratch, L.vA), *vB = at<uint32_t>(scratch, L.vB);
+        hex_keys_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)n_planes), 256, 0, s>>>(a, L.cell_bits, pts, levels, kA, vA);
+        GS_LAUNCHED("hex_keys");
+        if (int rc = radix_sort<uint32_t, uint32_t, RS_ITEMS>(kA, vA, kB, vB, (uint32_t)E, L.key_bits, at<uint32_t>(scratch, L.hist), at<uint32_t>(scratch, L.scan), s)) return rc;
+        const bool inB = radix_passes(L.key_bits) & 1;
+        const uint32_t *ks = inB ? kB : kA, *vs = inB ? vB : vA;
+        int rc;
+        switch (C) {
+            case 4: rc = hex_launch_sorted<4>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
+            case 8: rc = hex_launch_sorted<8>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
+            case 16: rc = hex_launch_sorted<16>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
+            case 32: rc = hex_launch_sorted<32>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
+            default: rc = hex_launch_sorted<64>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
+        }
+        if (rc) return rc;
+    } else {
         const unsigned long long lanes = (unsigned long long)N * C;
         hex_grad_tex_global_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(a, pts, levels, d_features);
         GS_LAUNCHED("hex_grad_tex_global");
-        for (int l = top_global; l >= 1; l--) {
-            unsigned long long widest = 0;
-            for (int p = 0; p < n_planes; p++) if (!a.pl[p].lds_ch && a.pl[p].n_levels >= l)
-                widest = std::max(widest, (unsigned long long)hex_extent(a.pl[p].W, l) * hex_extent(a.pl[p].H, l) * (C >> 2));
-            hex_mip_pull_kernel<<<dim3((unsigned)((widest + 255) / 256), (unsigned)n_planes), 256, 0, s>>>(a, l);
-            GS_LAUNCHED("hex_mip_pull");
-        }
     }
-    if (int rc = hex_launch_lds<4>(a, pts, levels, d_features, s)) return rc;
-    if (int rc = hex_launch_lds<2>(a, pts, levels, d_features, s)) return rc;
-    if (int rc = hex_launch_lds<1>(a, pts, levels, d_features, s)) return rc;
+    for (int l = top; l >= 1; l--) {
+        unsigned long long widest = 0;
+        for (int p = 0; p < n_planes; p++) if (a.pl[p].n_levels >= l)
+            widest = std::max(widest, (unsigned long long)hex_extent(a.pl[p].W, l) * hex_extent(a.pl[p].H, l) * (C >> 2));
+        hex_mip_pull_kernel<<<dim3((unsigned)((widest + 255) / 256), (unsigned)n_planes), 256, 0, s>>>(a, l);
+        GS_LAUNCHED("hex_mip_pull");
+    }
     if (d_pts || d_levels) {
         if (!mips_built) if (int rc = hex_build_mips(a, s)) return rc;
         const unsigned long long lanes = (unsigned long long)N * (C >> 2);

@@ -13,12 +13,9 @@
 // fetching a float4 of every texel, so a texel is one full cache line per lane group.  The work is a gather: 8 texels
 // x 128 B per point and plane (6 kB per point for six planes) against 16 B of coordinates and 128 B of output, bound by
 // the L2 / Infinity-Cache gather rate, not by HBM streaming.
-// Backward to the texels, two paths:
-//   * plane pyramid fits the LDS with CH channels (64x64 with mips: 5461 texels x 4 ch x 4 B = 87 kB): a workgroup owns
-//     (plane, channel group, point chunk), accumulates with LDS atomics, pulls the stack down inside the LDS and flushes
-//     level 0 only -- ~250 points hit every texel of such a plane, which is hopeless for global atomics;
-//   * larger planes (512x512: 8 M floats): global float atomics, a lane per channel so a wave's atomic covers whole
-//     128-byte texels; then one pull-down launch per level.
+// Backward to the texels: sorted runs accumulated in registers (default, see hex_grad_tex_sorted_kernel) or plain global
+// float atomics, a lane per channel (option hexplane_scatter = 1; also the reference point of the measurement); then one
+// pull-down launch per level.  (An LDS-resident pyramid with ds_add_f32 was built and measured slower than either.)
 #pragma once
 #include "gsrast_common.h"
 
@@ -30,13 +27,12 @@ struct HexPlane {
     const float* tex;      // level 0 values [H][W][C]
     float* mips;           // levels >= 1, packed one after the other (values)
     float* grad;           // backward: level-0 gradient [H][W][C]
-    float* gmips;          // backward, global path: gradient of levels >= 1, packed like mips
+    float* gmips;          // backward: gradient of levels >= 1, packed like mips
     int W, H;
     int cu, cv;            // columns of pts / levels holding this plane's u and v
     int n_levels;          // built levels above 0 (the clamp of flevel)
     int out_offset;        // first channel of the plane's block in a feature row
-    int lds_ch;            // backward: channels per workgroup on the LDS path, 0 = global atomics
-    int pad_;
+    int pad_[2];
 };
 struct HexArgs { int n_planes, C, N, D, F, pad_; HexPlane pl[HEX_MAX_PLANES]; };
 
@@ -83,7 +79,7 @@ __global__ void __launch_bounds__(256)
 hex_mip_pull_kernel(HexArgs a, int level)
 {
     const HexPlane& P = a.pl[blockIdx.y];
-    if (P.n_levels < level || P.lds_ch) return;          // LDS-path planes pull down inside the LDS
+    if (P.n_levels < level) return;
     const int q4 = a.C >> 2;
     const int w = hex_extent(P.W, level), h = hex_extent(P.H, level);
     const int pw = hex_extent(P.W, level - 1), ph = hex_extent(P.H, level - 1);
@@ -200,7 +196,6 @@ hex_grad_tex_global_kernel(HexArgs a, const float* __restrict__ pts, const float
 #pragma unroll 1
     for (int p = 0; p < a.n_planes; p++) {
         const HexPlane& P = a.pl[p];
-        if (P.lds_ch) continue;
         const float g = dy[n * a.F + P.out_offset + c];
         if (g == 0.0f) continue;
         const float u = pn[P.cu], v = pn[P.cv];
@@ -214,80 +209,186 @@ hex_grad_tex_global_kernel(HexArgs a, const float* __restrict__ pts, const float
     }
 }
 
-// ---- backward to the texels, LDS-resident pyramid ---------------------------------------------------------------
-// blockIdx = (point chunk, channel group, entry of lds_planes).  tile = the whole stack (level 0 first) x CH channels.
-constexpr int HEX_LDS_THREADS = 1024;
-constexpr size_t HEX_LDS_BYTES = 160 * 1024;
-struct HexLdsList { int n; int plane[HEX_MAX_PLANES]; };
-template <int CH>
-__global__ void __launch_bounds__(HEX_LDS_THREADS)
-hex_grad_tex_lds_kernel(HexArgs a, HexLdsList list, const float* __restrict__ pts, const float* __restrict__ levels,
-                        const float* __restrict__ dy, int chunk_points)
+// ---- backward to the texels, sorted runs (default) ------------------------------------------------------------------
+// Float atomics are the whole cost of the scatter: measured on MI355X, 1 M points x 6 planes x 8 texels x 32 channels take
+// 4.1 ms as global atomics (~365 G lane-atomics/s, whatever the contention) and 6.6 ms as LDS atomics (ds_add_f32 retires
+// about one lane per 3.5 clocks).  So the atomics themselves have to go: every (plane, point) pair gets the key
+//   plane | pyramid cell of its ORIGIN = (coarser level l1, floor texel (m, k) there)   [single-level points: (l0, texel)]
+// and the pairs are radix-sorted by it.  All pairs of one key touch the same 2x2 texels of level l1 and the same 4x4 texels
+// of level l1 - 1 (x0 = 2 x1 + 0.5, so floor(x0) - 2m is 0, 1 or 2).  A half-wave (lane = channel) walks a chunk of the sorted
+// list, accumulates those 20 texels in registers and flushes them with one atomic each when the key changes: a 64x64 plane
+// sees ~180 pairs per key, i.e. 20 atomics instead of 1440.  A lone pair flushes only the 8 texels it touched, so the
+// scheme is never worse than direct atomics.
+constexpr int HEX_RUN_CHUNK = 256;       // sorted pairs per half-wave (C = 32); 8 rounds of 32
+
+__device__ inline unsigned hex_origin_cell(const HexPlane& P, float u, float v, float bias)
 {
-    extern __shared__ float tile[];
-    const HexPlane& P = a.pl[list.plane[blockIdx.z]];
-    if (P.lds_ch != CH) return;
-    const int c0 = blockIdx.y * CH;
-    if (c0 >= a.C) return;
-    unsigned total = (unsigned)P.W * (unsigned)P.H + hex_level_offset(P.W, P.H, P.n_levels + 1);
-    for (unsigned i = threadIdx.x; i < total * CH; i += HEX_LDS_THREADS) tile[i] = 0.0f;
+    const HexLevel L = hex_level(bias, P.n_levels);
+    const int lo = (L.two && L.l1 != L.l0) ? L.l1 : L.l0;
+    const int w = hex_extent(P.W, lo), h = hex_extent(P.H, lo);
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const unsigned base = lo ? (unsigned)P.W * (unsigned)P.H + hex_level_offset(P.W, P.H, lo) : 0u;
+    return base + (unsigned)((int)floorf(y) * w + (int)floorf(x));
+}
+
+__global__ void __launch_bounds__(256)
+hex_keys_kernel(HexArgs a, int cell_bits, const float* __restrict__ pts, const float* __restrict__ levels,
+                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const HexPlane& P = a.pl[blockIdx.y];
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (unsigned)a.N) return;
+    const float* pn = pts + (size_t)n * a.D;
+    const float* ln = levels + (size_t)n * a.D;
+    const size_t e = (size_t)blockIdx.y * a.N + n;
+    keys[e] = ((uint32_t)blockIdx.y << cell_bits) | hex_origin_cell(P, pn[P.cu], pn[P.cv], fminf(ln[P.cu], ln[P.cv]));
+    vals[e] = n;
+}
+
+struct HexRun {            // decoded key: where the 4x4 (level lo - 1) and 2x2 (level lo) footprints live
+    float* pa; float* pb;  // level pointers (gradient stack), pa unused when lo == 0
+    int wa, ha, wb, hb;    // extents of the two levels
+    int m, k;              // origin texel at level lo
+    int off;               // the plane's channel block in a feature row
+};
+
+template <int C>
+__global__ void __launch_bounds__(256)
+hex_grad_tex_sorted_kernel(HexArgs a, int cell_bits, unsigned n_entries, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                           const float* __restrict__ pts, const float* __restrict__ levels, const float* __restrict__ dy)
+{
+    constexpr int G = C;                                   // lanes per group: one per channel
+    __shared__ HexPlane planes[HEX_MAX_PLANES];
+    for (int i = threadIdx.x; i < a.n_planes * (int)(sizeof(HexPlane) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(planes)[i] = reinterpret_cast<const uint32_t*>(a.pl)[i];
     __syncthreads();
-    const size_t n0 = (size_t)blockIdx.x * chunk_points;
-    const size_t n1 = n0 + chunk_points < (size_t)a.N ? n0 + chunk_points : (size_t)a.N;
-    const unsigned base0 = (unsigned)P.W * (unsigned)P.H;          // levels >= 1 follow level 0
-    for (size_t n = n0 + threadIdx.x; n < n1; n += HEX_LDS_THREADS) {
-        float g[CH];
-        bool any = false;
+    const unsigned group = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int c = threadIdx.x % G;
+    const unsigned e0 = group * (unsigned)HEX_RUN_CHUNK;
+    if (e0 >= n_entries) return;
+    const unsigned e1 = e0 + HEX_RUN_CHUNK < n_entries ? e0 + HEX_RUN_CHUNK : n_entries;
+    const uint32_t cell_mask = (1u << cell_bits) - 1u;
+
+    float A[4][4], B[2][2];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { g[k] = dy[n * a.F + P.out_offset + c0 + k]; any |= g[k] != 0.0f; }
-        if (!any) continue;
-        const float u = pts[n * a.D + P.cu], v = pts[n * a.D + P.cv];
-        const HexLevel L = hex_level(fminf(levels[n * a.D + P.cu], levels[n * a.D + P.cv]), P.n_levels);
+    for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int which = 0; which < 2; which++) {
-            if (which == 1 && !L.two) break;
-            const int l = which ? L.l1 : L.l0;
-            const float wl = which ? L.f : 1.0f - L.f;
-            const HexTap t = hex_tap(u, v, hex_extent(P.W, l), hex_extent(P.H, l));
-            float* lv = tile + (size_t)(l ? base0 + hex_level_offset(P.W, P.H, l) : 0u) * CH;
-            const float w00 = (1.0f - t.fu) * (1.0f - t.fv), w10 = t.fu * (1.0f - t.fv), w01 = (1.0f - t.fu) * t.fv, w11 = t.fu * t.fv;
+        for (int j = 0; j < 4; j++) A[r][j] = 0.0f;
+    B[0][0] = B[0][1] = B[1][0] = B[1][1] = 0.0f;
+    unsigned maskA = 0;
+    uint32_t run_key = 0xFFFFFFFFu;
+    HexRun R{};
+
+    auto flush = [&]() {
+        if (run_key == 0xFFFFFFFFu) return;
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const float gk = g[k] * wl;
-                atomicAdd(lv + t.i00 * CH + k, gk * w00);
-                atomicAdd(lv + t.i10 * CH + k, gk * w10);
-                atomicAdd(lv + t.i01 * CH + k, gk * w01);
-                atomicAdd(lv + t.i11 * CH + k, gk * w11);
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (maskA & (1u << (r * 4 + j))) {
+                    const int col = 2 * R.m + j, row = 2 * R.k + r;
+                    if (col < R.wa && row < R.ha) atomicAdd(R.pa + ((size_t)row * R.wa + col) * C + c, A[r][j]);
+                }
+                A[r][j] = 0.0f;
+            }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = R.m + j, row = R.k + r;
+                if (col < R.wb && row < R.hb) atomicAdd(R.pb + ((size_t)row * R.wb + col) * C + c, B[r][j]);
+                B[r][j] = 0.0f;
+            }
+        maskA = 0;
+    };
+
+    for (unsigned eb = e0; eb < e1; eb += G) {
+        // phase 1, lane = sorted pair: addressing of the pair's two levels, once (not once per channel)
+        const unsigned e = eb + c;
+        const bool have = e < e1;
+        const uint32_t key = have ? keys[e] : 0xFFFFFFFFu;
+        const uint32_t n = have ? vals[e] : 0u;
+        float fuA = 0.f, fvA = 0.f, fuB = 0.f, fvB = 0.f, f = 0.f;
+        int code = 0;                                       // sx | sy << 2 | two << 4 | direct << 5
+        if (have) {
+            const HexPlane& P = planes[key >> cell_bits];
+            const float u = pts[(size_t)n * a.D + P.cu], v = pts[(size_t)n * a.D + P.cv];
+            const HexLevel L = hex_level(fminf(levels[(size_t)n * a.D + P.cu], levels[(size_t)n * a.D + P.cv]), P.n_levels);
+            const bool two = L.two && L.l1 != L.l0;
+            const int lo = two ? L.l1 : L.l0;
+            const int wb = hex_extent(P.W, lo), hb = hex_extent(P.H, lo);
+            const HexTap tb = hex_tap(u, v, wb, hb);
+            fuB = tb.fu; fvB = tb.fv;
+            if (two) {
+                const int wa = hex_extent(P.W, L.l0), ha = hex_extent(P.H, L.l0);
+                const HexTap ta = hex_tap(u, v, wa, ha);
+                fuA = ta.fu; fvA = ta.fv; f = L.f;
+                const int sx = (int)(ta.i00 % (unsigned)wa) - 2 * (int)(tb.i00 % (unsigned)wb);
+                const int sy = (int)(ta.i00 / (unsigned)wa) - 2 * (int)(tb.i00 / (unsigned)wb);
+                code = 16 | ((sx & 3) | ((sy & 3) << 2));
+                if (sx < 0 || sx > 2 || sy < 0 || sy > 2) code = 32;      // outside the 4x4 window (never seen): direct atomics
+            }
+        }
+        const int cnt = (int)((e1 - eb) < (unsigned)G ? (e1 - eb) : (unsigned)G);
+        // phase 2, lane = channel: walk the pairs
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t kj = (uint32_t)__shfl((int)key, j, G);
+            const uint32_t nj = (uint32_t)__shfl((int)n, j, G);
+            const int cj = __shfl(code, j, G);
+            const float fua = __shfl(fuA, j, G), fva = __shfl(fvA, j, G), fub = __shfl(fuB, j, G), fvb = __shfl(fvB, j, G), fj = __shfl(f, j, G);
+            if (kj != run_key) {
+                flush();
+                run_key = kj;
+                const HexPlane& P = planes[kj >> cell_bits];
+                unsigned pc = kj & cell_mask;
+                int lo = 0;
+                const unsigned t0 = (unsigned)P.W * (unsigned)P.H;
+                if (pc >= t0) {
+                    pc -= t0; lo = 1;
+                    for (;;) { const unsigned t = (unsigned)hex_extent(P.W, lo) * (unsigned)hex_extent(P.H, lo); if (pc < t) break; pc -= t; lo++; }
+                }
+                R.wb = hex_extent(P.W, lo); R.hb = hex_extent(P.H, lo);
+                R.m = (int)(pc % (unsigned)R.wb); R.k = (int)(pc / (unsigned)R.wb);
+                R.pb = lo ? P.gmips + (size_t)hex_level_offset(P.W, P.H, lo) * C : P.grad;
+                R.wa = lo ? hex_extent(P.W, lo - 1) : 0; R.ha = lo ? hex_extent(P.H, lo - 1) : 0;
+                R.pa = lo > 1 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, lo - 1) * C : P.grad;
+                R.off = P.out_offset;
+            }
+            const float g = dy[(size_t)nj * a.F + R.off + c];
+            if (cj & 32) {                                   // safety net: this pair alone, straight to memory
+                const HexPlane& P = planes[kj >> cell_bits];
+                const float u = pts[(size_t)nj * a.D + P.cu], v = pts[(size_t)nj * a.D + P.cv];
+                const HexLevel L = hex_level(fminf(levels[(size_t)nj * a.D + P.cu], levels[(size_t)nj * a.D + P.cv]), P.n_levels);
+                float* lv0 = L.l0 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, L.l0) * C : P.grad;
+                float* lv1 = L.l1 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, L.l1) * C : P.grad;
+                hex_scatter_global(lv0, hex_tap(u, v, hex_extent(P.W, L.l0), hex_extent(P.H, L.l0)), C, c, g * (1.0f - L.f));
+                hex_scatter_global(lv1, hex_tap(u, v, hex_extent(P.W, L.l1), hex_extent(P.H, L.l1)), C, c, g * L.f);
+                continue;
+            }
+            const bool two = (cj & 16) != 0;
+            const float gb = two ? g * fj : g;
+            B[0][0] += gb * ((1.0f - fub) * (1.0f - fvb)); B[0][1] += gb * (fub * (1.0f - fvb));
+            B[1][0] += gb * ((1.0f - fub) * fvb);          B[1][1] += gb * (fub * fvb);
+            if (two) {
+                const int sx = cj & 3, sy = (cj >> 2) & 3;
+                const float ga = g * (1.0f - fj);
+                float wx[4], wy[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    wx[q] = q == sx ? 1.0f - fua : (q == sx + 1 ? fua : 0.0f);
+                    wy[q] = (q == sy ? 1.0f - fva : (q == sy + 1 ? fva : 0.0f)) * ga;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) A[r][q] += wy[r] * wx[q];
+                maskA |= (3u << sx) << (4 * sy) | (3u << sx) << (4 * (sy + 1));
             }
         }
     }
-    __syncthreads();
-    // pull the stack down inside the LDS, top level first
-    for (int l = P.n_levels; l >= 1; l--) {
-        const int w = hex_extent(P.W, l), h = hex_extent(P.H, l), pw = hex_extent(P.W, l - 1), ph = hex_extent(P.H, l - 1);
-        const float* src = tile + (size_t)(base0 + hex_level_offset(P.W, P.H, l)) * CH;
-        float* dst = tile + (size_t)(l - 1 ? base0 + hex_level_offset(P.W, P.H, l - 1) : 0u) * CH;
-        const bool quad = pw > 1 && ph > 1;
-        for (unsigned i = threadIdx.x; i < (unsigned)(w * h * CH); i += HEX_LDS_THREADS) {
-            const int k = i % CH, t = i / CH, x = t % w, y = t / w;
-            const float gq = src[i] * (quad ? 0.25f : 0.5f);
-            if (quad) {
-                const unsigned b = (unsigned)((2 * y) * pw + 2 * x);
-                dst[b * CH + k] += gq; dst[(b + 1) * CH + k] += gq; dst[(b + pw) * CH + k] += gq; dst[(b + pw + 1) * CH + k] += gq;
-            } else if (pw > 1) {
-                const unsigned b = (unsigned)(y * pw + 2 * x);
-                dst[b * CH + k] += gq; dst[(b + 1) * CH + k] += gq;
-            } else {
-                const unsigned b = (unsigned)((2 * y) * pw + x);
-                dst[b * CH + k] += gq; dst[(b + pw) * CH + k] += gq;
-            }
-        }
-        __syncthreads();
-    }
-    for (unsigned i = threadIdx.x; i < base0 * CH; i += HEX_LDS_THREADS) {
-        const float gv = tile[i];
-        if (gv != 0.0f) atomicAdd(P.grad + (size_t)(i / CH) * a.C + c0 + (i % CH), gv);
-    }
+    flush();
 }
 
 // ---- backward to uv and bias (on request) ------------------------------------------------------------------------

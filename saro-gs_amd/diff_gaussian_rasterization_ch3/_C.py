@@ -108,7 +108,7 @@ def lib() -> C.CDLL:
     L.gsrast_adam_step.restype = ci
     L.gsrast_adam_step.argtypes = [ci, C.POINTER(AdamGroupStruct), C.c_double, C.c_double, C.c_double, ci, vp]
     L.gsrast_hexplane_scratch_bytes.restype = C.c_size_t
-    L.gsrast_hexplane_scratch_bytes.argtypes = [ci, C.POINTER(PlaneStruct), ci]
+    L.gsrast_hexplane_scratch_bytes.argtypes = [ci, C.POINTER(PlaneStruct), ci, ci]
     L.gsrast_hexplane_forward.restype = ci
     L.gsrast_hexplane_forward.argtypes = [ci, ci, ci, ci, ci, C.POINTER(PlaneStruct), vp, vp, vp, vp, vp]
     L.gsrast_hexplane_backward.restype = ci

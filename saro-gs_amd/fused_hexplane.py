@@ -60,7 +60,7 @@ class _HexplaneFn(torch.autograd.Function):
         if lv.shape != p.shape:
             raise RuntimeError("hexplane lookup: levels must have the shape of pts")
         ps = _PlaneSet(texs, cols, max_mips, offsets)
-        nbytes = L.gsrast_hexplane_scratch_bytes(ps.n, ps.arr, Cn)
+        nbytes = L.gsrast_hexplane_scratch_bytes(ps.n, ps.arr, Cn, N)
         if nbytes == 0:
             L.gsrast_hexplane_forward(0, D, Cn, F, ps.n, ps.arr, None, None, None, None, None)     # sets the error text
             raise _lib._err(-1, "gsrast_hexplane_scratch_bytes")

@@ -23,7 +23,7 @@ def _close(got, want, tol, what):
     assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol:.0e} * {scale:.3g}"
 
 
-def _plane_case(gpu, W, H, C, mm, N, seed, lds):
+def _plane_case(gpu, W, H, C, mm, N, seed, scatter):
     import fused_hexplane
     from diff_gaussian_rasterization_ch3 import _C
     rng = np.random.default_rng(seed)
@@ -33,7 +33,7 @@ def _plane_case(gpu, W, H, C, mm, N, seed, lds):
     dy = rng.normal(size=(N, C)).astype(np.float32)
     bias = lv.min(axis=1)
     out, dtex, duv, dbias = tor.texture(np.transpose(tex, (1, 2, 0)), uv, bias, mm, dy)
-    assert _C.lib().gsrast_set_option(b"hexplane_lds", int(lds)) == 0
+    assert _C.lib().gsrast_set_option(b"hexplane_scatter", int(scatter)) == 0
     try:
         g = torch.tensor(tex[None], device=gpu, requires_grad=True)
         p = torch.tensor(uv, device=gpu, requires_grad=True)
@@ -42,7 +42,7 @@ def _plane_case(gpu, W, H, C, mm, N, seed, lds):
         o.backward(torch.tensor(dy, device=gpu))
         torch.cuda.synchronize()
     finally:
-        _C.lib().gsrast_set_option(b"hexplane_lds", 1)
+        _C.lib().gsrast_set_option(b"hexplane_scatter", 0)
     _close(o.detach().cpu().numpy(), out, 1e-5, "features")
     _close(g.grad[0].cpu().numpy(), np.transpose(dtex, (2, 0, 1)), 1e-5, "dL/dtex")
     # uv / bias gradients: compare where the oracle's discrete choices (floor of the texel coordinate and of the level) are
@@ -66,14 +66,16 @@ def _plane_case(gpu, W, H, C, mm, N, seed, lds):
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,C,mm", [(64, 64, 32, 7), (32, 8, 16, 7), (16, 25, 32, 0), (8, 2, 4, 7), (128, 128, 8, 7), (64, 128, 64, 0),
                                       (256, 256, 32, 7), (1, 1, 4, 7)])
-@pytest.mark.parametrize("lds", [1, 0])
-def test_single_plane_against_oracle(gpu, W, H, C, mm, lds):
-    _plane_case(gpu, W, H, C, mm, 3001, W * 7 + H + C + mm, lds)
+@pytest.mark.parametrize("scatter", [0, 1])
+def test_single_plane_against_oracle(gpu, W, H, C, mm, scatter):
+    """scatter 0 = sorted runs (default), 1 = direct global atomics."""
+    _plane_case(gpu, W, H, C, mm, 3001, W * 7 + H + C + mm, scatter)
 
 
 @pytest.mark.gpu
-def test_large_plane_global_path(gpu):
-    _plane_case(gpu, 512, 512, 32, 7, 20000, 5, 1)
+def test_large_plane(gpu):
+    _plane_case(gpu, 512, 512, 32, 7, 20000, 5, 0)
+    _plane_case(gpu, 512, 512, 32, 7, 20000, 6, 1)
 
 
 def _field(rng, reso, C, mults):
