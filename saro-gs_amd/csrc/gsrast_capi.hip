@@ -783,7 +783,7 @@ int gsrast_knn3_mean_dist2(int P, const float* points, float* mean_dist2, char* 
 // scratch: value stacks (levels >= 1) of every plane | gradient stacks of every plane, each 256-byte aligned
 extern "C++" {
 namespace {
-struct HexLayout { size_t mips[HEX_MAX_PLANES], gmips[HEX_MAX_PLANES], gmips_begin, gmips_end, kA, kB, vA, vB, hist, scan, total; int levels[HEX_MAX_PLANES]; int cell_bits, key_bits; };
+struct HexLayout { size_t mips[HEX_MAX_PLANES], gmips[HEX_MAX_PLANES], gmips_begin, gmips_end, kA, kB, vA, vB, pairs, hist, scan, total; int levels[HEX_MAX_PLANES]; int cell_bits, key_bits; };
 // number of levels above 0 the published op builds: halve while an extent is > 1 and the limit allows; -1 = odd extent
 int hex_levels(int W, int H, int limit)
 {
@@ -832,7 +832,7 @@ HexLayout hex_layout(int n_planes, const gsrast_plane* planes, int C, size_t N)
     int pb = 0; while ((1 << pb) < n_planes) pb++;
     L.key_bits = L.cell_bits + pb;
     const size_t E = std::max<size_t>((size_t)n_planes * N, 1);
-    L.kA = take(E * 4); L.kB = take(E * 4); L.vA = take(E * 4); L.vB = take(E * 4);
+    L.kA = take(E * 4); L.kB = take(E * 4); L.vA = take(E * 4); L.vB = take(E * 4); L.pairs = take(E * sizeof(HexPair));
     const size_t hist_n = 256 * rs_blocks_n(E, RS_ITEMS);
     L.hist = take(hist_n * 4); L.scan = take(scan_tmp_elems(hist_n) * 4);
     L.total = o + 256;
@@ -864,11 +864,11 @@ int hex_build_mips(const HexArgs& a, hipStream_t s)
     return GSRAST_OK;
 }
 template <int C>
-int hex_launch_sorted(const HexArgs& a, int cell_bits, unsigned E, const uint32_t* keys, const uint32_t* vals, const float* pts,
+int hex_launch_sorted(const HexArgs& a, int cell_bits, unsigned E, const uint32_t* keys, const uint32_t* vals, const HexPair* pairs, const float* pts,
                       const float* levels, const float* dy, hipStream_t s)
 {
     const unsigned long long groups = ((unsigned long long)E + HEX_RUN_CHUNK - 1) / HEX_RUN_CHUNK;
-    hex_grad_tex_sorted_kernel<C><<<(unsigned)((groups * C + 255) / 256), 256, 0, s>>>(a, cell_bits, E, keys, vals, pts, levels, dy);
+    hex_grad_tex_sorted_kernel<C><<<(unsigned)((groups * C + 255) / 256), 256, 0, s>>>(a, cell_bits, E, keys, vals, pairs, pts, levels, dy, g_ablate.load());
     GS_LAUNCHED("hex_grad_tex_sorted");
     return GSRAST_OK;
 }
@@ -917,20 +917,20 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
     for (int p = 0; p < n_planes; p++) top = std::max(top, a.pl[p].n_levels);
     if (top) GS_HIP(hipMemsetAsync(scratch + L.gmips_begin, 0, L.gmips_end - L.gmips_begin, s));
     const unsigned long long E = (unsigned long long)n_planes * N;
-    if (g_hex_scatter.load() == 0 && L.key_bits <= 32 && E < 0xFFFFFFFFull) {
+    if (g_hex_scatter.load() == 0 && L.key_bits <= 32 && E < 0xFFFFFFFFull && (unsigned long long)N * F < 0xFFFFFFFFull) {
         uint32_t *kA = at<uint32_t>(scratch, L.kA), *kB = at<uint32_t>(scratch, L.kB), *vA = at<uint32_t>(scratch, L.vA), *vB = at<uint32_t>(scratch, L.vB);
-        hex_keys_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)n_planes), 256, 0, s>>>(a, L.cell_bits, pts, levels, kA, vA);
+        hex_keys_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)n_planes), 256, 0, s>>>(a, L.cell_bits, pts, levels, kA, vA, at<HexPair>(scratch, L.pairs));
         GS_LAUNCHED("hex_keys");
         if (int rc = radix_sort<uint32_t, uint32_t, RS_ITEMS>(kA, vA, kB, vB, (uint32_t)E, L.key_bits, at<uint32_t>(scratch, L.hist), at<uint32_t>(scratch, L.scan), s)) return rc;
         const bool inB = radix_passes(L.key_bits) & 1;
         const uint32_t *ks = inB ? kB : kA, *vs = inB ? vB : vA;
         int rc;
         switch (C) {
-            case 4: rc = hex_launch_sorted<4>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
-            case 8: rc = hex_launch_sorted<8>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
-            case 16: rc = hex_launch_sorted<16>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
-            case 32: rc = hex_launch_sorted<32>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
-            default: rc = hex_launch_sorted<64>(a, L.cell_bits, (unsigned)E, ks, vs, pts, levels, d_features, s); break;
+            case 4: rc = hex_launch_sorted<4>(a, L.cell_bits, (unsigned)E, ks, vs, at<HexPair>(scratch, L.pairs), pts, levels, d_features, s); break;
+            case 8: rc = hex_launch_sorted<8>(a, L.cell_bits, (unsigned)E, ks, vs, at<HexPair>(scratch, L.pairs), pts, levels, d_features, s); break;
+            case 16: rc = hex_launch_sorted<16>(a, L.cell_bits, (unsigned)E, ks, vs, at<HexPair>(scratch, L.pairs), pts, levels, d_features, s); break;
+            case 32: rc = hex_launch_sorted<32>(a, L.cell_bits, (unsigned)E, ks, vs, at<HexPair>(scratch, L.pairs), pts, levels, d_features, s); break;
+            default: rc = hex_launch_sorted<64>(a, L.cell_bits, (unsigned)E, ks, vs, at<HexPair>(scratch, L.pairs), pts, levels, d_features, s); break;
         }
         if (rc) return rc;
     } else {

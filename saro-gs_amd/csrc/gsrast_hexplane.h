@@ -221,21 +221,17 @@ hex_grad_tex_global_kernel(HexArgs a, const float* __restrict__ pts, const float
 // scheme is never worse than direct atomics.
 constexpr int HEX_RUN_CHUNK = 256;       // sorted pairs per half-wave (C = 32); 8 rounds of 32
 
-__device__ inline unsigned hex_origin_cell(const HexPlane& P, float u, float v, float bias)
-{
-    const HexLevel L = hex_level(bias, P.n_levels);
-    const int lo = (L.two && L.l1 != L.l0) ? L.l1 : L.l0;
-    const int w = hex_extent(P.W, lo), h = hex_extent(P.H, lo);
-    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
-    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
-    const unsigned base = lo ? (unsigned)P.W * (unsigned)P.H + hex_level_offset(P.W, P.H, lo) : 0u;
-    return base + (unsigned)((int)floorf(y) * w + (int)floorf(x));
-}
-
+// Everything the accumulation needs to know about a (plane, point) pair, computed where the point rows are read in order
+// (the sorted walk would gather them at random) and fetched there as ONE 32-byte record.
+struct __attribute__((aligned(32))) HexPair {
+    float fuA, fvA, fuB, fvB, f;   // bilinear fractions at level lo - 1 (A) and lo (B); level lerp weight
+    uint32_t code;                 // sx | sy << 2 | two << 4 | direct << 5: position of A's 2x2 inside the run's 4x4 window
+    uint32_t gidx;                 // first float of the pair's dy block (host: N * F < 2^32)
+    uint32_t n;                    // the point
+};
 __global__ void __launch_bounds__(256)
 hex_keys_kernel(HexArgs a, int cell_bits, const float* __restrict__ pts, const float* __restrict__ levels,
-                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, HexPair* __restrict__ pairs)
 {
     const HexPlane& P = a.pl[blockIdx.y];
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,21 +239,41 @@ hex_keys_kernel(HexArgs a, int cell_bits, const float* __restrict__ pts, const f
     const float* pn = pts + (size_t)n * a.D;
     const float* ln = levels + (size_t)n * a.D;
     const size_t e = (size_t)blockIdx.y * a.N + n;
-    keys[e] = ((uint32_t)blockIdx.y << cell_bits) | hex_origin_cell(P, pn[P.cu], pn[P.cv], fminf(ln[P.cu], ln[P.cv]));
-    vals[e] = n;
+    const float u = pn[P.cu], v = pn[P.cv];
+    const HexLevel L = hex_level(fminf(ln[P.cu], ln[P.cv]), P.n_levels);
+    const bool two = L.two && L.l1 != L.l0;
+    const int lo = two ? L.l1 : L.l0;                       // the pair's origin level
+    const int wb = hex_extent(P.W, lo), hb = hex_extent(P.H, lo);
+    const HexTap tb = hex_tap(u, v, wb, hb);
+    float fuA = 0.f, fvA = 0.f, f = 0.f;
+    uint32_t code = 0;
+    if (two) {
+        const int wa = hex_extent(P.W, L.l0), ha = hex_extent(P.H, L.l0);
+        const HexTap ta = hex_tap(u, v, wa, ha);
+        fuA = ta.fu; fvA = ta.fv; f = L.f;
+        const int sx = (int)(ta.i00 % (unsigned)wa) - 2 * (int)(tb.i00 % (unsigned)wb);
+        const int sy = (int)(ta.i00 / (unsigned)wa) - 2 * (int)(tb.i00 / (unsigned)wb);
+        code = 16u | (uint32_t)((sx & 3) | ((sy & 3) << 2));
+        if (sx < 0 || sx > 2 || sy < 0 || sy > 2) code = 32u;       // outside the 4x4 window (never seen): direct atomics
+    }
+    const unsigned base = lo ? (unsigned)P.W * (unsigned)P.H + hex_level_offset(P.W, P.H, lo) : 0u;
+    keys[e] = ((uint32_t)blockIdx.y << cell_bits) | (base + tb.i00);
+    vals[e] = (uint32_t)e;
+    reinterpret_cast<float4*>(pairs + e)[0] = make_float4(fuA, fvA, tb.fu, tb.fv);
+    reinterpret_cast<float4*>(pairs + e)[1] = make_float4(f, __uint_as_float(code), __uint_as_float(n * (uint32_t)a.F + (uint32_t)P.out_offset), __uint_as_float(n));
 }
 
 struct HexRun {            // decoded key: where the 4x4 (level lo - 1) and 2x2 (level lo) footprints live
     float* pa; float* pb;  // level pointers (gradient stack), pa unused when lo == 0
     int wa, ha, wb, hb;    // extents of the two levels
     int m, k;              // origin texel at level lo
-    int off;               // the plane's channel block in a feature row
 };
 
 template <int C>
 __global__ void __launch_bounds__(256)
 hex_grad_tex_sorted_kernel(HexArgs a, int cell_bits, unsigned n_entries, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                           const float* __restrict__ pts, const float* __restrict__ levels, const float* __restrict__ dy)
+                           const HexPair* __restrict__ pairs, const float* __restrict__ pts, const float* __restrict__ levels,
+                           const float* __restrict__ dy, int ablate)
 {
     constexpr int G = C;                                   // lanes per group: one per channel
     __shared__ HexPlane planes[HEX_MAX_PLANES];
@@ -283,6 +299,7 @@ hex_grad_tex_sorted_kernel(HexArgs a, int cell_bits, unsigned n_entries, const u
 
     auto flush = [&]() {
         if (run_key == 0xFFFFFFFFu) return;
+        if (ablate & 2) { maskA = 0; return; }
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -305,37 +322,23 @@ hex_grad_tex_sorted_kernel(HexArgs a, int cell_bits, unsigned n_entries, const u
     };
 
     for (unsigned eb = e0; eb < e1; eb += G) {
-        // phase 1, lane = sorted pair: addressing of the pair's two levels, once (not once per channel)
+        // phase 1, lane = sorted pair: fetch the pair's record
         const unsigned e = eb + c;
         const bool have = e < e1;
         const uint32_t key = have ? keys[e] : 0xFFFFFFFFu;
-        const uint32_t n = have ? vals[e] : 0u;
         float fuA = 0.f, fvA = 0.f, fuB = 0.f, fvB = 0.f, f = 0.f;
-        int code = 0;                                       // sx | sy << 2 | two << 4 | direct << 5
+        int code = 0;
+        uint32_t gidx = 0, n = 0;
         if (have) {
-            const HexPlane& P = planes[key >> cell_bits];
-            const float u = pts[(size_t)n * a.D + P.cu], v = pts[(size_t)n * a.D + P.cv];
-            const HexLevel L = hex_level(fminf(levels[(size_t)n * a.D + P.cu], levels[(size_t)n * a.D + P.cv]), P.n_levels);
-            const bool two = L.two && L.l1 != L.l0;
-            const int lo = two ? L.l1 : L.l0;
-            const int wb = hex_extent(P.W, lo), hb = hex_extent(P.H, lo);
-            const HexTap tb = hex_tap(u, v, wb, hb);
-            fuB = tb.fu; fvB = tb.fv;
-            if (two) {
-                const int wa = hex_extent(P.W, L.l0), ha = hex_extent(P.H, L.l0);
-                const HexTap ta = hex_tap(u, v, wa, ha);
-                fuA = ta.fu; fvA = ta.fv; f = L.f;
-                const int sx = (int)(ta.i00 % (unsigned)wa) - 2 * (int)(tb.i00 % (unsigned)wb);
-                const int sy = (int)(ta.i00 / (unsigned)wa) - 2 * (int)(tb.i00 / (unsigned)wb);
-                code = 16 | ((sx & 3) | ((sy & 3) << 2));
-                if (sx < 0 || sx > 2 || sy < 0 || sy > 2) code = 32;      // outside the 4x4 window (never seen): direct atomics
-            }
+            const float4* rec = reinterpret_cast<const float4*>(pairs + vals[e]);
+            const float4 r0 = rec[0], r1 = rec[1];
+            fuA = r0.x; fvA = r0.y; fuB = r0.z; fvB = r0.w; f = r1.x;
+            code = (int)__float_as_uint(r1.y); gidx = __float_as_uint(r1.z); n = __float_as_uint(r1.w);
         }
         const int cnt = (int)((e1 - eb) < (unsigned)G ? (e1 - eb) : (unsigned)G);
-        // phase 2, lane = channel: walk the pairs
-        for (int j = 0; j < cnt; j++) {
+        // phase 2, lane = channel: walk the pairs, four at a time so their dy rows are in flight together
+        auto one = [&](int j, float g) {
             const uint32_t kj = (uint32_t)__shfl((int)key, j, G);
-            const uint32_t nj = (uint32_t)__shfl((int)n, j, G);
             const int cj = __shfl(code, j, G);
             const float fua = __shfl(fuA, j, G), fva = __shfl(fvA, j, G), fub = __shfl(fuB, j, G), fvb = __shfl(fvB, j, G), fj = __shfl(f, j, G);
             if (kj != run_key) {
@@ -354,10 +357,9 @@ hex_grad_tex_sorted_kernel(HexArgs a, int cell_bits, unsigned n_entries, const u
                 R.pb = lo ? P.gmips + (size_t)hex_level_offset(P.W, P.H, lo) * C : P.grad;
                 R.wa = lo ? hex_extent(P.W, lo - 1) : 0; R.ha = lo ? hex_extent(P.H, lo - 1) : 0;
                 R.pa = lo > 1 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, lo - 1) * C : P.grad;
-                R.off = P.out_offset;
             }
-            const float g = dy[(size_t)nj * a.F + R.off + c];
             if (cj & 32) {                                   // safety net: this pair alone, straight to memory
+                const uint32_t nj = (uint32_t)__shfl((int)n, j, G);
                 const HexPlane& P = planes[kj >> cell_bits];
                 const float u = pts[(size_t)nj * a.D + P.cu], v = pts[(size_t)nj * a.D + P.cv];
                 const HexLevel L = hex_level(fminf(levels[(size_t)nj * a.D + P.cu], levels[(size_t)nj * a.D + P.cv]), P.n_levels);
@@ -365,27 +367,38 @@ hex_grad_tex_sorted_kernel(HexArgs a, int cell_bits, unsigned n_entries, const u
                 float* lv1 = L.l1 ? P.gmips + (size_t)hex_level_offset(P.W, P.H, L.l1) * C : P.grad;
                 hex_scatter_global(lv0, hex_tap(u, v, hex_extent(P.W, L.l0), hex_extent(P.H, L.l0)), C, c, g * (1.0f - L.f));
                 hex_scatter_global(lv1, hex_tap(u, v, hex_extent(P.W, L.l1), hex_extent(P.H, L.l1)), C, c, g * L.f);
-                continue;
+                return;
             }
+            // (explicit FMAs: the library is built with -ffp-contract=off for the rasterizer's bit-exactness)
             const bool two = (cj & 16) != 0;
             const float gb = two ? g * fj : g;
-            B[0][0] += gb * ((1.0f - fub) * (1.0f - fvb)); B[0][1] += gb * (fub * (1.0f - fvb));
-            B[1][0] += gb * ((1.0f - fub) * fvb);          B[1][1] += gb * (fub * fvb);
+            const float ub = 1.0f - fub, vb = 1.0f - fvb;
+            B[0][0] = __builtin_fmaf(gb, ub * vb, B[0][0]);  B[0][1] = __builtin_fmaf(gb, fub * vb, B[0][1]);
+            B[1][0] = __builtin_fmaf(gb, ub * fvb, B[1][0]); B[1][1] = __builtin_fmaf(gb, fub * fvb, B[1][1]);
             if (two) {
-                const int sx = cj & 3, sy = (cj >> 2) & 3;
                 const float ga = g * (1.0f - fj);
-                float wx[4], wy[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    wx[q] = q == sx ? 1.0f - fua : (q == sx + 1 ? fua : 0.0f);
-                    wy[q] = (q == sy ? 1.0f - fva : (q == sy + 1 ? fva : 0.0f)) * ga;
+                const float ua = 1.0f - fua, y0 = ga * (1.0f - fva), y1 = ga * fva;
+                // the pair's 2x2 sits at (sx, sy) of the run's 4x4 window: one case per position keeps the window in registers
+#define GS_ACC(SY, SX) case (SY) * 4 + (SX): \
+                    A[SY][SX] = __builtin_fmaf(y0, ua, A[SY][SX]);         A[SY][SX + 1] = __builtin_fmaf(y0, fua, A[SY][SX + 1]); \
+                    A[SY + 1][SX] = __builtin_fmaf(y1, ua, A[SY + 1][SX]); A[SY + 1][SX + 1] = __builtin_fmaf(y1, fua, A[SY + 1][SX + 1]); \
+                    maskA |= (0x33u << (SX)) << (4 * (SY)); break;
+                switch (cj & 15) {
+                    GS_ACC(0, 0) GS_ACC(0, 1) GS_ACC(0, 2) GS_ACC(1, 0) GS_ACC(1, 1) GS_ACC(1, 2) GS_ACC(2, 0) GS_ACC(2, 1) GS_ACC(2, 2)
+                    default: break;
                 }
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) A[r][q] += wy[r] * wx[q];
-                maskA |= (3u << sx) << (4 * sy) | (3u << sx) << (4 * (sy + 1));
+#undef GS_ACC
             }
+        };
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            float g4[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t gi = (uint32_t)__shfl((int)gidx, (j0 + t) & (G - 1), G);       // past cnt: some valid row, unused
+                g4[t] = (ablate & 1) ? __uint_as_float(gi) : dy[(size_t)gi + c];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (j0 + t < cnt) { if (ablate & 4) B[0][0] += g4[t]; else one(j0 + t, g4[t]); }
         }
     }
     flush();

@@ -11,6 +11,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "dnerf"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 reso = [64, 64, 64, 128] if which == "dnerf" else [512, 512, 512, 256]
 dev = torch.device("cuda:0")
+from diff_gaussian_rasterization_ch3 import _C
+_C.lib().gsrast_set_option(b"ablate", int(os.environ.get("HEX_ABLATE", "0")))
 g = torch.Generator(device="cpu").manual_seed(0)
 coo = list(itertools.combinations(range(4), 2))
 grids = [torch.randn((1, 32, reso[b], reso[a]), generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for (a, b) in coo]
