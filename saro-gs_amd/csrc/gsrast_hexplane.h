@@ -128,12 +128,13 @@ __device__ inline HexLevel hex_level(float bias, int n_levels)
     L.f = L.two ? fl - (float)L.l0 : 0.0f;
     return L;
 }
-__device__ inline float4 hex_bilerp(const float4* __restrict__ lv, const HexTap& t, int q4, int q)
+// (explicit FMAs: the library is built with -ffp-contract=off for the rasterizer's bit-exactness; the forward is VALU-issue bound)
+__device__ inline float4 hex_bilerp(const float4* __restrict__ lv, const HexTap& t, unsigned q4, unsigned q)
 {
-    const float4 a00 = lv[(size_t)t.i00 * q4 + q], a10 = lv[(size_t)t.i10 * q4 + q];
-    const float4 a01 = lv[(size_t)t.i01 * q4 + q], a11 = lv[(size_t)t.i11 * q4 + q];
+    const float4 a00 = lv[t.i00 * q4 + q], a10 = lv[t.i10 * q4 + q];        // 32-bit indices: a level has < 2^26 texels of <= 16 float4
+    const float4 a01 = lv[t.i01 * q4 + q], a11 = lv[t.i11 * q4 + q];
     float4 r;
-#define GS_BL(c) { const float top = a00.c + t.fu * (a10.c - a00.c), bot = a01.c + t.fu * (a11.c - a01.c); r.c = top + t.fv * (bot - top); }
+#define GS_BL(c) { const float top = __builtin_fmaf(t.fu, a10.c - a00.c, a00.c), bot = __builtin_fmaf(t.fu, a11.c - a01.c, a01.c); r.c = __builtin_fmaf(t.fv, bot - top, top); }
     GS_BL(x) GS_BL(y) GS_BL(z) GS_BL(w)
 #undef GS_BL
     return r;
@@ -144,10 +145,16 @@ __device__ inline float4 hex_bilerp(const float4* __restrict__ lv, const HexTap&
 __global__ void __launch_bounds__(256)
 hex_sample_fwd_kernel(HexArgs a, const float* __restrict__ pts, const float* __restrict__ levels, float* __restrict__ features)
 {
-    const int q4 = a.C >> 2;
+    __shared__ unsigned level_off[HEX_MAX_PLANES][HEX_MAX_LEVELS];      // float4 offset of every level inside the plane's stack
+    const unsigned q4 = (unsigned)a.C >> 2;
+    for (int i = threadIdx.x; i < a.n_planes * HEX_MAX_LEVELS; i += blockDim.x) {
+        const int p = i / HEX_MAX_LEVELS, l = i % HEX_MAX_LEVELS;
+        level_off[p][l] = l <= a.pl[p].n_levels ? hex_level_offset(a.pl[p].W, a.pl[p].H, l) * (unsigned)a.C : 0u;
+    }
+    __syncthreads();
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = gid / q4;
-    const int q = (int)(gid % q4);
+    const unsigned q = (unsigned)(gid % q4);
     if (n >= (size_t)a.N) return;
     const float* pn = pts + n * a.D;
     const float* ln = levels + n * a.D;
@@ -158,13 +165,14 @@ hex_sample_fwd_kernel(HexArgs a, const float* __restrict__ pts, const float* __r
         const float u = pn[P.cu], v = pn[P.cv];
         const HexLevel L = hex_level(fminf(ln[P.cu], ln[P.cv]), P.n_levels);
         const int w0 = hex_extent(P.W, L.l0), h0 = hex_extent(P.H, L.l0);
-        const float4* lv0 = reinterpret_cast<const float4*>(L.l0 ? P.mips + (size_t)hex_level_offset(P.W, P.H, L.l0) * a.C : P.tex);
+        const float4* lv0 = reinterpret_cast<const float4*>(L.l0 ? P.mips + level_off[p][L.l0] : P.tex);
         float4 r = hex_bilerp(lv0, hex_tap(u, v, w0, h0), q4, q);
         if (L.two) {
             const int w1 = hex_extent(P.W, L.l1), h1 = hex_extent(P.H, L.l1);
-            const float4* lv1 = reinterpret_cast<const float4*>(L.l1 ? P.mips + (size_t)hex_level_offset(P.W, P.H, L.l1) * a.C : P.tex);
+            const float4* lv1 = reinterpret_cast<const float4*>(L.l1 ? P.mips + level_off[p][L.l1] : P.tex);
             const float4 b = hex_bilerp(lv1, hex_tap(u, v, w1, h1), q4, q);
-            r.x += L.f * (b.x - r.x); r.y += L.f * (b.y - r.y); r.z += L.f * (b.z - r.z); r.w += L.f * (b.w - r.w);
+            r.x = __builtin_fmaf(L.f, b.x - r.x, r.x); r.y = __builtin_fmaf(L.f, b.y - r.y, r.y);
+            r.z = __builtin_fmaf(L.f, b.z - r.z, r.z); r.w = __builtin_fmaf(L.f, b.w - r.w, r.w);
         }
         acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
         if (p + 1 == a.n_planes || a.pl[p + 1].out_offset != P.out_offset) {
