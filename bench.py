@@ -410,6 +410,104 @@ def iteration_row(rast, scenes, dev, P, W, H, deg):
             "pieces": "activate_gaussians -> GaussianRasterizer -> l1_dssim_loss -> backward -> GaussianAdam.step"}
 
 
+def dynamic_iteration_row(rast, scenes, dev, P, W, H, deg):
+    """A whole DYNAMIC-stage training iteration with every built row in place (scene/saro_gaussian.py:779-847 get_deformation
+    + train.py:190-250, one view): residual field (fused_hexplane) -> lifespan / motion / rotation+scale / SH MLPs (torch.nn,
+    fp32, the reference's layer shapes :104-110 with deform_hidden_dim 128, time encoding 4) -> activation epilogue with the
+    residuals -> rasterizer -> L1 + D-SSIM -> backward -> fused Adam (Gaussian groups) + torch Adam (MLPs, planes).
+    Field shape: configs/dnerf (64^3 x 128 frames, 32 features, one scale).  Also the cost of the MLP part alone, the next
+    piece this iteration is bound by."""
+    import itertools
+    import torch.nn as nn
+    import fused_adam, fused_epilogue, fused_hexplane, fused_loss
+    sc = scenes.synth(P, 0, sh_degree=deg)
+    cam = scenes.camera(0, 1, W, H)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
+    rs = rast.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]), scale_modifier=1.0,
+        viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
+    raster = rast.GaussianRasterizer(rs)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    raw = dict(xyz=t(sc["means3D"]), rotation=t(sc["rotations"]), scaling=torch.log(t(sc["scales"])),
+               opacity=torch.logit(t(sc["opacities"]).clamp(1e-4, 1 - 1e-4)), f_dc=t(sc["shs"][:, :1]), f_rest=t(sc["shs"][:, 1:]),
+               temporal_pos=torch.rand((P, 1), generator=g).to(dev))
+    raw = {k: v.requires_grad_(True) for k, v in raw.items()}
+    reso, C, Hd, nfreq = [64, 64, 64, 128], 32, 128, 4
+    coo = list(itertools.combinations(range(4), 2))
+    grids = [(0.1 * torch.randn((1, C, reso[b], reso[a]), generator=g)).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for (a, b) in coo]
+    emb = 1 + 2 * nfreq
+    mlp = lambda i, o: nn.Sequential(nn.Linear(i, Hd), nn.ReLU(), nn.Linear(Hd, Hd), nn.ReLU(), nn.Linear(Hd, o)).to(dev)  # noqa: E731
+    motion_mlp, rot_mlp, shs_mlp = mlp(C + emb, 3), mlp(C + emb, 7), mlp(C + emb, 48)
+    opacity_mlp = nn.Sequential(nn.Linear(C, Hd), nn.ReLU(), nn.Linear(Hd, Hd // 2), nn.ReLU(), nn.Linear(Hd // 2, 1), nn.Sigmoid()).to(dev)
+    for m in (motion_mlp, rot_mlp, shs_mlp):
+        nn.init.zeros_(m[-1].weight); nn.init.zeros_(m[-1].bias)      # residuals start at zero: the scene stays in view
+    lo, hi = raw["xyz"].detach().min(0).values, raw["xyz"].detach().max(0).values
+    base_scale = (hi - lo) / torch.tensor(reso[:3], device=dev, dtype=torch.float32)
+    freqs = (2.0 ** torch.arange(nfreq, device=dev, dtype=torch.float32))[None]
+    inv = torch.ones(P, 1, device=dev)
+    lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3, temporal_pos=1e-4)
+    opt_g = fused_adam.GaussianAdam([{"params": [raw[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in raw], eps=1e-15)
+    net_params = [p_ for m in (motion_mlp, rot_mlp, shs_mlp, opacity_mlp) for p_ in m.parameters()]
+    opt_n = torch.optim.Adam([{"params": net_params, "lr": 1.6e-4}, {"params": grids, "lr": 1.6e-3}], eps=1e-15, fused=True)
+    gt = torch.rand(3, H, W, device=dev)
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    timestamp = 0.37
+
+    def field():
+        with torch.no_grad():                                                     # hexplane.py:253-260, :237-249; inputs detached (:780)
+            pts = torch.cat(((raw["xyz"] - hi) / (lo - hi), raw["temporal_pos"] * (reso[3] / (reso[3] - 1.0))), dim=1)
+            sc_ = torch.exp(raw["scaling"]).clamp(min=base_scale / 2, max=base_scale / 2 * reso[0])
+            levels = torch.cat((torch.log2(2 * sc_ / base_scale), torch.zeros((P, 1), device=dev)), dim=1)
+        return fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
+
+    def heads(feat):
+        lifespan = 1 - opacity_mlp(feat)
+        lifespan = (1 - 1.0 / reso[3]) * lifespan + 1.0 / reso[3]
+        distance = timestamp - raw["temporal_pos"]
+        trbf = torch.exp(-4 * (distance / lifespan) ** 2)
+        with torch.no_grad():
+            x = distance * freqs
+            te = torch.cat((distance, torch.sin(x), torch.cos(x)), dim=1)
+        df = torch.cat((feat, te), dim=1)
+        return motion_mlp(df), rot_mlp(df), trbf, shs_mlp(df).reshape(-1, 16, 3)
+
+    def step():
+        mres, rres, trbf, sres = heads(field())
+        motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(
+            raw["xyz"], raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"],
+            motion_residual=mres, rot_residual=rres, trbfoutput=trbf, shs_residual=sres)
+        color, _, _ = raster(means3D=motion, means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
+        loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
+        opt_g.zero_grad(); opt_n.zero_grad(); m2.grad = None
+        loss.backward()
+        opt_g.step(); opt_n.step()
+
+    feat_fixed = field().detach()
+
+    def heads_only():
+        outs = heads(feat_fixed)
+        for p_ in net_params: p_.grad = None
+        raw["temporal_pos"].grad = None
+        sum(o.sum() for o in outs).backward()
+
+    def tm(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    ms, ms_heads = tm(step), tm(heads_only)
+    return {"ms": round(ms, 3), "iterations_per_s": round(1e3 / ms, 1), "mlp_heads_fwd_bwd_alone_ms": round(ms_heads, 3),
+            "gaussians": P, "image": [H, W], "field": "64x64x64x128, 32 features, 1 scale",
+            "pieces": "interpolate_ms_features -> torch.nn MLP heads (fp32) -> activate_gaussians(residuals) -> GaussianRasterizer -> "
+                      "l1_dssim_loss -> backward -> GaussianAdam.step + torch Adam(fused) for MLPs / planes"}
+
+
 def knn_row(dev, P):
     """"Next" row (second item): simple_knn.distCUDA2 for P points (the reference's random-init
     cube, dataset_readers.py:526), next to an exact k-d tree 3-NN on all host cores (scipy cKDTree, fp64)."""
@@ -717,6 +815,10 @@ def main():
             result["next_rows"]["hexplane_field_fwd_bwd"] = hexplane_row(dev, P)
         except Exception as e:      # noqa: BLE001
             result["next_rows"]["hexplane_field_fwd_bwd"] = {"error": str(e)}
+        try:
+            result["next_rows"]["dynamic_stage_training_iteration"] = dynamic_iteration_row(rast, scenes, dev, P, W, H, deg)
+        except Exception as e:      # noqa: BLE001
+            result["next_rows"]["dynamic_stage_training_iteration"] = {"error": str(e)}
         try:
             result["next_rows"]["static_stage_training_iteration"] = iteration_row(rast, scenes, dev, P, W, H, deg)
         except Exception as e:
