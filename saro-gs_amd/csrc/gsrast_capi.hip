@@ -17,6 +17,7 @@
 #include "gsrast_adam.h"
 #include "gsrast_knn.h"
 #include "gsrast_hexplane.h"
+#include "gsrast_mlp.h"
 
 #include <atomic>
 #include <chrono>
@@ -951,6 +952,24 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
         hex_grad_uv_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(a, pts, levels, d_features, d_pts, d_levels);
         GS_LAUNCHED("hex_grad_uv");
     }
+    return GSRAST_OK;
+}
+
+int gsrast_linear_wgrad(int M, int N1, int N2, const float* G, const float* X, float* dW, float* db, int accumulate, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (M < 0 || N1 < 1 || N2 < 1 || N1 > MLP_MAX_N || N2 > MLP_MAX_N) return fail(GSRAST_E_ARG, "linear_wgrad: widths must be in [1, 128]");
+    if (!dW || (M > 0 && (!G || !X))) return fail(GSRAST_E_ARG, "linear_wgrad: NULL pointer");
+    if (!accumulate) {
+        GS_HIP(hipMemsetAsync(dW, 0, (size_t)N1 * N2 * 4, s));
+        if (db) GS_HIP(hipMemsetAsync(db, 0, (size_t)N1 * 4, s));
+    }
+    if (M == 0) return GSRAST_OK;
+    int rows = (M + 1023) / 1024;                    // ~1000 workgroups share the rows
+    rows = std::max(256, (rows + 7) / 8 * 8);
+    const int chunks = (M + rows - 1) / rows;
+    mlp_wgrad_kernel<<<chunks, 256, 0, s>>>(G, X, M, N1, N2, rows, dW, db);
+    GS_LAUNCHED("mlp_wgrad");
     return GSRAST_OK;
 }
 

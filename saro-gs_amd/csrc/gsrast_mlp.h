@@ -1,0 +1,78 @@
+// gsrast_mlp.h -- weight / bias gradient of a Linear layer over ~1e6 rows on the fp32 matrix cores.
+// Beyond SURVEY.md 8f (all of its rows are built): this is the measured bottleneck of the DYNAMIC-stage iteration once they are
+// (DESIGN.md 8).  The reference's deformation heads (/root/reference/scene/saro_gaussian.py:104-110: four 3-layer nn.Linear
+// stacks, hidden width 128, evaluated for every Gaussian, :779-812) need, per layer and step,
+//     dW[N1][N2] = sum_r G[r][n1] * X[r][n2]     (G = gradient at the layer's output, X = its input; r over all P Gaussians)
+//     db[N1]     = sum_r G[r][n1]
+// -- a GEMM with K = P ~ 1e6 and a 128x128 (or smaller) result, which the BLAS library runs as 16 workgroups (10.5 + 4 ms of
+// the 24 ms the three heads take in torch at P = 1e6).  Here the rows are split over ~1000 workgroups (split-K); a wave owns
+// one 32-row block of dW and up to four 32-column blocks, streams two rows per v_mfma_f32_32x32x2_f32 straight from global
+// memory (the operand layout -- lane l holds element [l & 31] of row [l >> 5] -- IS a coalesced 128-byte read of each row, so no
+// LDS staging), and adds its partial block with float atomics at the end.  fp32 in, fp32 accumulate: an fmaf chain, like
+// the reference's fp32 Linear layers.
+#pragma once
+#include "gsrast_common.h"
+
+namespace gsrast {
+
+typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MLP_MAX_N = 128;          // layer widths up to 128 (the reference: 41 / 32 -> 128 -> 128 | 64 -> 3 | 7 | 48 | 1)
+
+__global__ void __launch_bounds__(256)
+mlp_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, int M, int N1, int N2, int rows_per_chunk,
+                 float* __restrict__ dW, float* __restrict__ db)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb1 = (N1 + 31) >> 5, nb2 = (N2 + 31) >> 5;
+    const int nb1p = nb1 <= 1 ? 1 : (nb1 == 2 ? 2 : 4);           // waves per workgroup spent on row blocks of dW
+    const int bi = wave % nb1p, jg = wave / nb1p, jstep = 4 / nb1p;
+    if (bi >= nb1 || jg >= nb2) return;
+    const int col = lane & 31, half = lane >> 5;
+    const int n1 = bi * 32 + col;
+    const bool a_ok = n1 < N1;
+    int bj[4]; bool b_ok[4]; int nj = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { bj[t] = jg + t * jstep; b_ok[t] = false; if (bj[t] < nb2) { nj = t + 1; b_ok[t] = bj[t] * 32 + col < N2; } }
+    mlp_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[t][v] = 0.0f;
+    float bsum = 0.0f;
+    const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < M ? r_begin + rows_per_chunk : M;
+    for (long long r0 = r_begin; r0 < r_end; r0 += 8) {
+        float a[4], b[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {                               // four k-steps (8 rows) in flight
+            const long long r = r0 + 2 * s + half;
+            const bool rok = r < r_end;
+            a[s] = (rok && a_ok) ? G[r * N1 + n1] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) b[s][t] = (rok && b_ok[t]) ? X[r * N2 + bj[t] * 32 + col] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            bsum += a[s];
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (t < nj) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s][t], acc[t], 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t >= nj) break;
+        const int n2 = bj[t] * 32 + col;
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int row = bi * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+            if (row < N1 && n2 < N2) atomicAdd(dW + (size_t)row * N2 + n2, acc[t][v]);
+        }
+    }
+    if (db && jg == 0) {
+        const float tot = bsum + __shfl_xor(bsum, 32);
+        if (half == 0 && a_ok) atomicAdd(db + n1, tot);
+    }
+}
+
+} // namespace gsrast

@@ -6,6 +6,12 @@ dev = torch.device("cuda:0")
 P, C, Hd, emb = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000, 32, 128, 9
 mlp = lambda i, o: nn.Sequential(nn.Linear(i, Hd), nn.ReLU(), nn.Linear(Hd, Hd), nn.ReLU(), nn.Linear(Hd, o)).to(dev)
 nets = [mlp(C + emb, 3), mlp(C + emb, 7), mlp(C + emb, 48)]
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "saro-gs_amd"))
+if os.environ.get("SPLITK", "0") == "1":
+    import fused_mlp
+    nets = [fused_mlp.convert_heads(n) for n in nets]
 x = torch.randn(P, C + emb, device=dev)
 for it in range(6):
     if it == 1:
