@@ -501,10 +501,15 @@ def dynamic_iteration_row(rast, scenes, dev, P, W, H, deg):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / n * 1e3
 
+    ms_torch, ms_heads_torch = tm(step), tm(heads_only)
+    import fused_mlp
+    for m in (motion_mlp, rot_mlp, shs_mlp, opacity_mlp):
+        fused_mlp.convert_heads(m)            # same parameters; weight / bias gradients by gsrast_linear_wgrad (split-K, fp32 MFMA)
     ms, ms_heads = tm(step), tm(heads_only)
     return {"ms": round(ms, 3), "iterations_per_s": round(1e3 / ms, 1), "mlp_heads_fwd_bwd_alone_ms": round(ms_heads, 3),
+            "with_plain_nn_linear_heads_ms": round(ms_torch, 3), "plain_nn_linear_heads_alone_ms": round(ms_heads_torch, 3),
             "gaussians": P, "image": [H, W], "field": "64x64x64x128, 32 features, 1 scale",
-            "pieces": "interpolate_ms_features -> torch.nn MLP heads (fp32) -> activate_gaussians(residuals) -> GaussianRasterizer -> "
+            "pieces": "interpolate_ms_features -> MLP heads (fp32; fused_mlp.SplitKLinear) -> activate_gaussians(residuals) -> GaussianRasterizer -> "
                       "l1_dssim_loss -> backward -> GaussianAdam.step + torch Adam(fused) for MLPs / planes"}
 
 

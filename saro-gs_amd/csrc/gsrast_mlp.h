@@ -18,6 +18,9 @@ namespace gsrast {
 typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MLP_MAX_N = 128;          // layer widths up to 128 (the reference: 41 / 32 -> 128 -> 128 | 64 -> 3 | 7 | 48 | 1)
 
+// NJ = 32-column blocks of dW per wave (1, 2 or 4); STEPS = k-steps (row pairs) whose operands are in flight together: the
+// loop is one memory latency per STEPS MFMA groups, so the skinny layers (NJ = 1: 64 cycles of MFMA per row pair) fly more.
+template <int NJ, int STEPS>
 __global__ void __launch_bounds__(256)
 mlp_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, int M, int N1, int N2, int rows_per_chunk,
                  float* __restrict__ dW, float* __restrict__ db)
@@ -30,37 +33,47 @@ mlp_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, int M
     const int col = lane & 31, half = lane >> 5;
     const int n1 = bi * 32 + col;
     const bool a_ok = n1 < N1;
-    int bj[4]; bool b_ok[4]; int nj = 0;
+    int bj[NJ]; bool b_ok[NJ]; int nj = 0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) { bj[t] = jg + t * jstep; b_ok[t] = false; if (bj[t] < nb2) { nj = t + 1; b_ok[t] = bj[t] * 32 + col < N2; } }
-    mlp_f32x16 acc[4];
+    for (int t = 0; t < NJ; t++) { bj[t] = jg + t * jstep; b_ok[t] = false; if (bj[t] < nb2) { nj = t + 1; b_ok[t] = bj[t] * 32 + col < N2; } }
+    mlp_f32x16 acc[NJ];
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < NJ; t++)
 #pragma unroll
         for (int v = 0; v < 16; v++) acc[t][v] = 0.0f;
     float bsum = 0.0f;
     const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
     const long long r_end = r_begin + rows_per_chunk < M ? r_begin + rows_per_chunk : M;
-    for (long long r0 = r_begin; r0 < r_end; r0 += 8) {
-        float a[4], b[4][4];
+    // double-buffered: the operands of the next STEPS row pairs are requested before the current ones enter the matrix core
+    float a[2][STEPS], b[2][STEPS][NJ];
+    auto fetch = [&](long long r0, float (&fa)[STEPS], float (&fb)[STEPS][NJ]) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {                               // four k-steps (8 rows) in flight
+        for (int s = 0; s < STEPS; s++) {
             const long long r = r0 + 2 * s + half;
             const bool rok = r < r_end;
-            a[s] = (rok && a_ok) ? G[r * N1 + n1] : 0.0f;
+            fa[s] = (rok && a_ok) ? G[r * N1 + n1] : 0.0f;
 #pragma unroll
-            for (int t = 0; t < 4; t++) b[s][t] = (rok && b_ok[t]) ? X[r * N2 + bj[t] * 32 + col] : 0.0f;
+            for (int t = 0; t < NJ; t++) fb[s][t] = (rok && b_ok[t]) ? X[r * N2 + bj[t] * 32 + col] : 0.0f;
         }
+    };
+    auto consume = [&](const float (&fa)[STEPS], const float (&fb)[STEPS][NJ]) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            bsum += a[s];
+        for (int s = 0; s < STEPS; s++) {
+            bsum += fa[s];
 #pragma unroll
-            for (int t = 0; t < 4; t++) if (t < nj) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NJ; t++) if (t < nj) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s][t], acc[t], 0, 0, 0);
         }
+    };
+    fetch(r_begin, a[0], b[0]);
+    for (long long r0 = r_begin; r0 < r_end; r0 += 4 * STEPS) {
+        fetch(r0 + 2 * STEPS, a[1], b[1]);          // past r_end: zeros, no loads
+        consume(a[0], b[0]);
+        fetch(r0 + 4 * STEPS, a[0], b[0]);
+        consume(a[1], b[1]);
     }
     // C/D layout of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < NJ; t++) {
         if (t >= nj) break;
         const int n2 = bj[t] * 32 + col;
 #pragma unroll
