@@ -6,7 +6,7 @@
    that exist in Python: utils/sh_utils.py:eval_sh (the SH polynomial the CUDA kernel
    forward.cu:20-71 implements) and utils/graphics_utils.py getWorld2View2 / getProjectionMatrix
    plus the scene/cameras.py:90-101 composition (the camera conventions every rasterizer input
-   obeys).  These pin oracle/gsrast_oracle.c:sh_to_rgb and saro-gs_amd/scenes.py against the
+   obeys) and graphics_utils.geom_transform_points (the point projection of forward.cu:193-198).  These pin oracle/gsrast_oracle.c:sh_to_rgb and saro-gs_amd/scenes.py against the
    reference itself.  Only inputs and outputs are stored -- no reference source.
 2. oracle_scene_*.npz -- small seeded scenes with the ORACLE's outputs (fp32 build for the
    bit-exact quantities, fp64 build for the gradients).  They guard against oracle drift and give
@@ -65,6 +65,11 @@ def ref_python_vectors():
         center = wv.inverse()[3, :3]                                                               # cameras.py:101
         Rs.append(Q); Ts.append(T); fovs.append((fovx, fovy))
         views.append(wv.numpy()); projs.append(pj.numpy()); fulls.append(full.numpy()); centers.append(center.numpy())
+    # --- point projection: graphics_utils.geom_transform_points (row-vector convention, + 1e-7 on w like forward.cu:195-197) ---
+    pts = rng.uniform(-4, 4, size=(300, 3))
+    out["proj_points"] = pts
+    out["proj_ndc"] = np.array([gfx.geom_transform_points(torch.from_numpy(pts), torch.from_numpy(f).double()).numpy() for f in fulls])
+    out["proj_view"] = np.array([gfx.geom_transform_points(torch.from_numpy(pts), torch.from_numpy(v).double()).numpy() for v in views])
     out.update(cam_R=np.array(Rs), cam_T=np.array(Ts), cam_fov=np.array(fovs), cam_world_view=np.array(views),
                cam_projection=np.array(projs), cam_full_proj=np.array(fulls), cam_center=np.array(centers))
     np.savez_compressed(os.path.join(HERE, "ref_python_vectors.npz"), **out)

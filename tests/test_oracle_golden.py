@@ -42,6 +42,31 @@ def test_camera_builders_match_reference_graphics_utils(scenes):
     assert abs(z["cam_projection"][0][2, 2] - (100.0 + 0.01) / (100.0 - 0.01)) < 1e-6
 
 
+def test_point_projection_matches_reference_geom_transform_points(orc, scenes):
+    """The oracle's screen positions and depths (forward.cu:193-198, :216, auxiliary.h ndc2Pix) against the reference's own
+    Python projection `graphics_utils.geom_transform_points` of the same points through the same matrices."""
+    z = np.load(os.path.join(G, "ref_python_vectors.npz"))
+    pts = z["proj_points"]
+    P, W, H = len(pts), 200, 144
+    sc = scenes.synth(P, 5, sh_degree=0)
+    sc["means3D"] = pts.astype(np.float32)
+    sc["bg"] = np.zeros(3, np.float32)
+    seen = 0
+    for k in range(len(z["cam_R"])):
+        fovx, fovy = z["cam_fov"][k]
+        cam = dict(image_height=H, image_width=W, tanfovx=float(np.tan(fovx / 2)), tanfovy=float(np.tan(fovy / 2)), scale_modifier=1.0,
+                   viewmatrix=z["cam_world_view"][k].astype(np.float32), projmatrix=z["cam_full_proj"][k].astype(np.float32),
+                   campos=z["cam_center"][k].astype(np.float32), prefiltered=False)
+        st = orc.forward(sc, cam)                     # fp32 build, as the kernel computes
+        vis = st["radii"] > 0
+        seen += int(vis.sum())
+        ndc, view = z["proj_ndc"][k], z["proj_view"][k]
+        want = np.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], axis=1)
+        np.testing.assert_allclose(st["means2D"][vis], want[vis], rtol=0, atol=2e-3)      # fp32 matrices, pixels
+        np.testing.assert_allclose(st["depths"][vis], view[vis, 2], rtol=2e-6, atol=2e-5)
+    assert seen > 100
+
+
 def _load_scene(f):
     z = np.load(f)
     sc = {k[3:]: z[k] for k in z.files if k.startswith("sc_")}
