@@ -87,6 +87,9 @@ class FlatGradBucket:
                 p.grad.copy_(v)
 
 
+_AVG_OK = True
+
+
 def allreduce_mean_inplace(flat: torch.Tensor, batch: int) -> None:
     """Mean over the batch of one flat gradient buffer, in place.  RCCL's AVG does the division inside
     the collective (no extra pass over the buffer); gloo has no AVG, so SUM then scale."""
@@ -94,11 +97,15 @@ def allreduce_mean_inplace(flat: torch.Tensor, batch: int) -> None:
         if batch != 1:
             flat.mul_(1.0 / batch)
         return
-    if dist.get_backend() == "nccl" and batch == dist.get_world_size():
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / batch)
+    global _AVG_OK
+    if _AVG_OK and dist.get_backend() == "nccl" and batch == dist.get_world_size():
+        try:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            return
+        except RuntimeError:            # a collective library without AVG: raised before anything is enqueued
+            _AVG_OK = False
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / batch)
 
 
 def exchange_gradients(arena, means3D: torch.Tensor, batch: int) -> None:
