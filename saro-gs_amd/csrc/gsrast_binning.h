@@ -582,11 +582,11 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
                              const uint32_t* __restrict__ counts_dev /* optional {R lo, Q, -, R hi}: speculative launch */,
                              uint32_t capR, int gx, int gy, const uint32_t* __restrict__ hist_scanned,
                              const uint32_t* __restrict__ digit_total, uint32_t nblk, uint2* __restrict__ ranges,
-                             uint32_t* __restrict__ bucket_cnt /* forward launch order: [64] counts (zeroed), or null */,
-                             uint16_t* __restrict__ bucket_list /* [64][T] */)
+                             uint32_t* __restrict__ bucket_cnt /* forward launch order: [8][64] counts (zeroed), or null */,
+                             uint16_t* __restrict__ bucket_list /* [8][64][Tg] */)
 {
     __shared__ int diff[257];
-    __shared__ uint32_t lcnt[WORK_BUCKETS], lbase[WORK_BUCKETS];
+    __shared__ uint32_t lcnt[XCD_GROUPS * WORK_BUCKETS], lbase[XCD_GROUPS * WORK_BUCKETS];
     const uint32_t x = blockIdx.x, y = threadIdx.x;
     bool overflow = false;
     if (counts_dev) {
@@ -613,16 +613,18 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
     work = before1 > before0 ? before1 - before0 : 0u;
     }
     if (bucket_cnt) {
-        // forward launch order: append this column's tiles to the work buckets (one global atomic per bucket and column)
-        if (y < (uint32_t)WORK_BUCKETS) lcnt[y] = 0;
+        // forward launch order: append this column's tiles to the work buckets of their XCD group (tile row mod 8); one global
+        // atomic per non-empty (group, bucket) and column
+        for (uint32_t i = y; i < (uint32_t)(XCD_GROUPS * WORK_BUCKETS); i += blockDim.x) lcnt[i] = 0;
         __syncthreads();
-        const uint32_t b = work_bucket(work);
+        const uint32_t idx = (y % (uint32_t)XCD_GROUPS) * WORK_BUCKETS + work_bucket(work);
         uint32_t slot = 0;
-        if (y < (uint32_t)gy) slot = atomicAdd(&lcnt[b], 1u);
+        if (y < (uint32_t)gy) slot = atomicAdd(&lcnt[idx], 1u);
         __syncthreads();
-        if (y < (uint32_t)WORK_BUCKETS) lbase[y] = lcnt[y] ? atomicAdd(&bucket_cnt[y], lcnt[y]) : 0u;
+        for (uint32_t i = y; i < (uint32_t)(XCD_GROUPS * WORK_BUCKETS); i += blockDim.x) lbase[i] = lcnt[i] ? atomicAdd(&bucket_cnt[i], lcnt[i]) : 0u;
         __syncthreads();
-        if (y < (uint32_t)gy) bucket_list[(size_t)b * ((size_t)gx * gy) + lbase[b] + slot] = (uint16_t)(y * (uint32_t)gx + x);
+        const size_t Tg = (size_t)gx * (size_t)((gy + XCD_GROUPS - 1) / XCD_GROUPS);
+        if (y < (uint32_t)gy) bucket_list[(size_t)idx * Tg + lbase[idx] + slot] = (uint16_t)(y * (uint32_t)gx + x);
     }
 }
 

@@ -36,10 +36,37 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles)
     return t;   // may be >= ntiles for the padded grid; caller checks
 }
 
-// Launch order without a sorting kernel: workgroup b takes entry b of the concatenation of the 64 work buckets
-// (gsrast_common.h: ImgLayout::bucket_cnt / bucket_list).  Every thread of the workgroup calls this.
+// Launch order without a sorting kernel: workgroup b belongs to XCD group b mod 8 and takes entry b / 8 of the concatenation of
+// that group's 64 work buckets (gsrast_common.h: XCD_GROUPS, ImgLayout::bucket_cnt [8][64] / bucket_list [8][64][Tg]).  Every
+// thread of the workgroup calls this; the result is >= ntiles for a workgroup past the end of its group's lists.
 __device__ __forceinline__ uint32_t tile_from_buckets(const uint32_t* __restrict__ cnt, const uint16_t* __restrict__ list,
-                                                      uint32_t T, uint32_t b, uint32_t* s_tile)
+                                                      uint32_t Tg, uint32_t b, uint32_t* s_tile)
+{
+    const uint32_t xg = b % (uint32_t)XCD_GROUPS, s = b / (uint32_t)XCD_GROUPS;
+    if (threadIdx.x < (unsigned)WORK_BUCKETS) {
+        const uint32_t c = cnt[xg * WORK_BUCKETS + threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (threadIdx.x >= (unsigned)d) incl += o; }
+        const uint32_t excl = incl - c;
+        if (s >= excl && s < incl) *s_tile = list[((size_t)xg * WORK_BUCKETS + threadIdx.x) * Tg + (s - excl)];
+        if (threadIdx.x == (unsigned)WORK_BUCKETS - 1u && s >= incl) *s_tile = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    return *s_tile;
+}
+// ... and the grouped producer (unused by the kernels of this file: the forward lists are filled by tile_ranges_from_runs_kernel)
+__device__ __forceinline__ void bucket_append(uint32_t* __restrict__ cnt, uint16_t* __restrict__ list, uint32_t Tg, uint32_t gx, uint32_t tile, uint32_t work)
+{
+    const uint32_t idx = ((tile / gx) % (uint32_t)XCD_GROUPS) * WORK_BUCKETS + work_bucket(work);
+    list[(size_t)idx * Tg + atomicAdd(&cnt[idx], 1u)] = (uint16_t)tile;
+}
+
+// The BACKWARD order stays one global heaviest-first sequence (64 buckets, [64][T] lists): grouping it by XCD as well cut the
+// backward's fetched bytes by 30 % but made it 15 % SLOWER -- neighbouring tiles then run at the same time and their gradient
+// atomics to the Gaussians they share collide.
+__device__ __forceinline__ uint32_t tile_from_buckets_global(const uint32_t* __restrict__ cnt, const uint16_t* __restrict__ list,
+                                                             uint32_t T, uint32_t b, uint32_t* s_tile)
 {
     if (threadIdx.x < (unsigned)WORK_BUCKETS) {
         const uint32_t c = cnt[threadIdx.x];
@@ -52,8 +79,7 @@ __device__ __forceinline__ uint32_t tile_from_buckets(const uint32_t* __restrict
     __syncthreads();
     return *s_tile;
 }
-// ... and the producer side for the backward order: one append per tile, by the forward blend
-__device__ __forceinline__ void bucket_append(uint32_t* __restrict__ cnt, uint16_t* __restrict__ list, uint32_t T, uint32_t tile, uint32_t work)
+__device__ __forceinline__ void bucket_append_global(uint32_t* __restrict__ cnt, uint16_t* __restrict__ list, uint32_t T, uint32_t tile, uint32_t work)
 {
     const uint32_t b = work_bucket(work);
     list[(size_t)b * T + atomicAdd(&cnt[b], 1u)] = (uint16_t)tile;
@@ -97,7 +123,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float4* __restrict__ rec2, const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
                       uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
-                      uint32_t* __restrict__ bucket_cnt /* [2][64] or null */, uint16_t* __restrict__ bucket_list /* [2][64][T] */,
+                      uint32_t* __restrict__ bucket_cnt /* fwd [8][64] | bwd [64], or null */, uint16_t* __restrict__ bucket_list /* fwd [8][64][Tg] | bwd [64][T] */,
                       int order_from_buckets)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
@@ -107,10 +133,12 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_tile;
 
-    if (blockIdx.x >= ntiles) return;
-    // heaviest tiles first
-    const uint32_t tile = order_from_buckets ? tile_from_buckets(bucket_cnt, bucket_list, ntiles, blockIdx.x, &s_tile)
+    if (!order_from_buckets && blockIdx.x >= ntiles) return;
+    // heaviest tiles first, per XCD group
+    const uint32_t Tg = xcd_group_tiles((uint32_t)gx, ntiles);
+    const uint32_t tile = order_from_buckets ? tile_from_buckets(bucket_cnt, bucket_list, Tg, blockIdx.x, &s_tile)
                                              : (order ? order[blockIdx.x] : blockIdx.x);
+    if (tile >= ntiles) return;                  // uniform: past the end of this group's lists
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
     const unsigned lane = lane_id(), wave = t >> 6;
@@ -216,7 +244,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     if (t == 0) {
         tile_max[tile] = s_max;
         // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
-        if (bucket_cnt) bucket_append(bucket_cnt + WORK_BUCKETS, bucket_list + (size_t)WORK_BUCKETS * ntiles, ntiles, tile, s_max);
+        if (bucket_cnt) bucket_append_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, tile, s_max);
     }
 }
 
@@ -240,7 +268,7 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                  const float4* __restrict__ rec2, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
-                 uint32_t* __restrict__ bucket_cnt /* [2][64] or null */, uint16_t* __restrict__ bucket_list /* [2][64][T] */)
+                 uint32_t* __restrict__ bucket_cnt /* fwd [8][64] | bwd [64], or null */, uint16_t* __restrict__ bucket_list /* fwd [8][64][Tg] | bwd [64][T] */)
 {
     using Cfg = BlendCfg<PPL>;
     constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
@@ -361,7 +389,7 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     if (t == 0) {
         tile_max[tile] = s_max;
         // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
-        if (bucket_cnt) bucket_append(bucket_cnt + WORK_BUCKETS, bucket_list + (size_t)WORK_BUCKETS * ntiles, ntiles, tile, s_max);
+        if (bucket_cnt) bucket_append_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, tile, s_max);
     }
 }
 
@@ -557,7 +585,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
                       float* __restrict__ dL_dmean2D /*[P][3]*/, float* __restrict__ dL_dconic /*[P][4]*/,
                       float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/,
-                      const uint32_t* __restrict__ bucket_cnt /* [2][64]: launch order from the [1] lists, or null */,
+                      const uint32_t* __restrict__ bucket_cnt /* fwd [8][64] | bwd [64]: launch order from the bwd lists, or null */,
                       const uint16_t* __restrict__ bucket_list)
 {
 #pragma clang fp contract(fast)
@@ -572,8 +600,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 
     __shared__ uint32_t s_tile;
     if (blockIdx.x >= ntiles) return;
-    // heaviest tiles first
-    const uint32_t tile = bucket_cnt ? tile_from_buckets(bucket_cnt + WORK_BUCKETS, bucket_list + (size_t)WORK_BUCKETS * ntiles, ntiles, blockIdx.x, &s_tile)
+    // heaviest tiles first (one global sequence: see tile_from_buckets_global)
+    const uint32_t tile = bucket_cnt ? tile_from_buckets_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, blockIdx.x, &s_tile)
                                      : (order ? order[blockIdx.x] : blockIdx.x);
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;

@@ -558,7 +558,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     };
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built) -> int {
         ProfScope ps(K_BLEND_FWD, s);
-        const uint32_t grid = ((T + 7) / 8) * 8;
+        uint32_t grid = ((T + 7) / 8) * 8;
         float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
         uint32_t* tm = at<uint32_t>(img, IL.tile_max);
         BlendArgs ba{};
@@ -568,7 +568,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && g_lpt.load()) {
-            if (buckets_ok && fwd_lists_built) ba.from_buckets = 1;      // the tile-range kernel already bucketed the tiles
+            if (buckets_ok && fwd_lists_built) { ba.from_buckets = 1; grid = (uint32_t)(XCD_GROUPS * xcd_group_tiles_host((size_t)cam.gx, (size_t)cam.gy)); }   // the tile-range kernel already bucketed the tiles
             else {
                 uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
                 tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, nullptr, ord);
@@ -613,7 +613,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     if (speculative && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
     if (speculative) g_redo_count++;
     if (speculative)    // redo: the truncated pass already appended every tile to the work buckets once
-        GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, 2 * WORK_BUCKETS * sizeof(uint32_t), s));
+        GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, (XCD_GROUPS + 1) * WORK_BUCKETS * sizeof(uint32_t), s));
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
         cap = R; capQ = Q;
         bin = (char*)binning_alloc(binning_ctx, bin_bytes(cap, capQ));

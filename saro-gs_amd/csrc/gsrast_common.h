@@ -53,6 +53,11 @@ struct ImgLayout {
 };
 constexpr int WORK_BUCKETS = 64;
 constexpr size_t BUCKET_MAX_TILES = 65535;     // tile ids are stored as u16
+// The work buckets are kept per XCD group: workgroup b of a launch runs on XCD b mod 8 (round-robin dispatch), and each of the
+// eight XCDs has its own L2.  A tile belongs to group (tile row mod 8), so the horizontal neighbours of a tile -- which share
+// most of its Gaussians -- are blended through the same L2, heaviest first within the group.
+constexpr int XCD_GROUPS = 8;
+static inline size_t xcd_group_tiles_host(size_t gx, size_t gy) { return gx * ((gy + XCD_GROUPS - 1) / XCD_GROUPS); }
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
 constexpr uint32_t RS_SELF_SCAN_BLOCKS = 64;   // sorts of at most this many blocks skip the row-scan launch (radix_scatter_kernel)
@@ -149,8 +154,9 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     if (!T) T = 1;
     L.final_T = take(N * 4); L.n_contrib = take(N * 4); L.ranges = take(T * 8); L.tile_max = take(T * 4);
     L.order_fwd = take(T * 4); L.order_bwd = take(T * 4);
-    L.bucket_cnt = take(2 * WORK_BUCKETS * 4);
-    L.bucket_list = take(T <= BUCKET_MAX_TILES ? 2 * WORK_BUCKETS * T * 2 : 0);
+    const size_t Tg = xcd_group_tiles_host((W + TILE_X - 1) / TILE_X, (H + TILE_Y - 1) / TILE_Y);      // list capacity of one (group, bucket)
+    L.bucket_cnt = take((XCD_GROUPS + 1) * WORK_BUCKETS * 4);            // forward: per XCD group; backward: one global set
+    L.bucket_list = take(T <= BUCKET_MAX_TILES ? (XCD_GROUPS * WORK_BUCKETS * (Tg ? Tg : 1) + WORK_BUCKETS * T) * 2 : 0);
     L.total = o + 256;
     return L;
 }
@@ -179,6 +185,7 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t w)
     const uint32_t key = 2u * (uint32_t)e + (e >= 1 ? ((w >> (e - 1)) & 1u) : 0u);      // 0 .. 63
     return key >= (uint32_t)WORK_BUCKETS - 2u ? 0u : (uint32_t)WORK_BUCKETS - 2u - key;
 }
+__device__ __forceinline__ uint32_t xcd_group_tiles(uint32_t gx, uint32_t ntiles) { return gx * ((ntiles / gx + XCD_GROUPS - 1) / XCD_GROUPS); }
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // exp(): three interchangeable implementations (option "exp_mode").

@@ -232,9 +232,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
                       uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val,
                       int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */,
-                      uint32_t* __restrict__ bucket_cnt /* [2][64] work-bucket counters of this call: zeroed here */)
+                      uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 2 * WORK_BUCKETS) bucket_cnt[threadIdx.x] = 0u;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
     const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
