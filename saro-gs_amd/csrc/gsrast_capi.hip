@@ -968,7 +968,7 @@ int gsrast_linear_wgrad(int M, int N1, int N2, const float* G, const float* X, f
     const int nb1 = (N1 + 31) / 32, nb2 = (N2 + 31) / 32;
     const int jstep = 4 / (nb1 <= 1 ? 1 : (nb1 == 2 ? 2 : 4));
     const int nj = (nb2 + jstep - 1) / jstep;         // 32-column blocks of dW per wave
-    int rows = (M + 511) / 512;                       // ~500 workgroups share the rows (each ends with N1 x N2 atomics)
+    int rows = (M + 1023) / 1024;                     // ~1000 workgroups share the rows (each ends with N1 x N2 atomics)
     rows = std::max(128, (rows + 31) / 32 * 32);
     const int chunks = (M + rows - 1) / rows;
     if (nj <= 1) mlp_wgrad_kernel<1, 16><<<chunks, 256, 0, s>>>(G, X, M, N1, N2, rows, dW, db);

@@ -44,32 +44,40 @@ mlp_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, int M
     float bsum = 0.0f;
     const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
     const long long r_end = r_begin + rows_per_chunk < M ? r_begin + rows_per_chunk : M;
-    // double-buffered: the operands of the next STEPS row pairs are requested before the current ones enter the matrix core
+    // double-buffered: the operands of the next STEPS row pairs are requested before the current ones enter the matrix core.
+    // The loads are unconditional (indices clamped, values masked on use): a branch around a load would make the compiler wait
+    // for ALL outstanding loads before the first MFMA, which undoes the double buffering.
+    const int n1c = a_ok ? n1 : N1 - 1;
+    int n2c[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; t++) n2c[t] = b_ok[t] ? bj[t] * 32 + col : N2 - 1;
     float a[2][STEPS], b[2][STEPS][NJ];
     auto fetch = [&](long long r0, float (&fa)[STEPS], float (&fb)[STEPS][NJ]) {
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            const long long r = r0 + 2 * s + half;
-            const bool rok = r < r_end;
-            fa[s] = (rok && a_ok) ? G[r * N1 + n1] : 0.0f;
+            long long r = r0 + 2 * s + half;
+            r = r < r_end ? r : r_end - 1;
+            fa[s] = G[r * N1 + n1c];
 #pragma unroll
-            for (int t = 0; t < NJ; t++) fb[s][t] = (rok && b_ok[t]) ? X[r * N2 + bj[t] * 32 + col] : 0.0f;
+            for (int t = 0; t < NJ; t++) fb[s][t] = X[r * N2 + n2c[t]];
         }
     };
-    auto consume = [&](const float (&fa)[STEPS], const float (&fb)[STEPS][NJ]) {
+    auto consume = [&](long long r0, const float (&fa)[STEPS], const float (&fb)[STEPS][NJ]) {
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            bsum += fa[s];
+            const bool rok = r0 + 2 * s + half < r_end;
+            const float av = (rok && a_ok) ? fa[s] : 0.0f;
+            bsum += av;
 #pragma unroll
-            for (int t = 0; t < NJ; t++) if (t < nj) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NJ; t++) if (t < nj) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ok[t] ? fb[s][t] : 0.0f, acc[t], 0, 0, 0);
         }
     };
     fetch(r_begin, a[0], b[0]);
     for (long long r0 = r_begin; r0 < r_end; r0 += 4 * STEPS) {
-        fetch(r0 + 2 * STEPS, a[1], b[1]);          // past r_end: zeros, no loads
-        consume(a[0], b[0]);
+        fetch(r0 + 2 * STEPS, a[1], b[1]);
+        consume(r0, a[0], b[0]);
         fetch(r0 + 4 * STEPS, a[0], b[0]);
-        consume(a[1], b[1]);
+        consume(r0 + 2 * STEPS, a[1], b[1]);
     }
     // C/D layout of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
