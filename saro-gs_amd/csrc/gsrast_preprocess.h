@@ -238,13 +238,24 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
     const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
+    // Every per-Gaussian input is requested up front, before the SH rows are staged: the kernel is latency-bound at its
+    // occupancy, and loads issued where they are first used (inside the visibility / area branches) put three more memory
+    // round trips behind the staging barrier.  Clamped index: lanes past P load a valid element and never use it.
+    const int ic = i < P ? i : P - 1;
+    const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
+    float s_in[3] = { 0.f, 0.f, 0.f };
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!cov3D_precomp) {                                   // uniform
+        s_in[0] = scales[3 * ic]; s_in[1] = scales[3 * ic + 1]; s_in[2] = scales[3 * ic + 2];
+        q_in = reinterpret_cast<const float4*>(rotations)[ic];
+    }
+    const float op_in = opacities[ic];
     if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
     if (i >= P) return;
     const float* my_sh = staged ? sh_lds + threadIdx.x * PP_SH_STRIDE : shs + (size_t)i * M * 3;
     const Cam cam = load_cam(cam_args);
     int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
 
-    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
     float ph[4], pv[3];
     xform4x4(p, cam.proj, ph);
     const float pw = 1.0f / (ph[3] + 0.0000001f);
@@ -256,11 +267,9 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * (size_t)i + k];
         } else {
-            const float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
-            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
-            const float q[4] = { qv.x, qv.y, qv.z, qv.w };
+            const float q[4] = { q_in.x, q_in.y, q_in.z, q_in.w };
             M3 Mm;
-            cov3d_from_scale_rot(s, cam.scale_mod, q, c6, Mm);
+            cov3d_from_scale_rot(s_in, cam.scale_mod, q, c6, Mm);
 #pragma unroll
             for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = c6[k];
         }
@@ -291,7 +300,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
                     for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
                 }
-                const float op = opacities[i];
+                const float op = op_in;
                 // Conservative pre-test for the blend kernels: power < thr  ==>  op*exp(power) < 1/255
                 // with a 2% margin, so skipping the exp for such pairs never changes a decision.
                 // (clamped at -80 so that exp() is only ever evaluated on [-80, 0]: gs_exp<., BOUNDED>)
@@ -444,9 +453,28 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int ncoef = (D + 1) * (D + 1);
     const bool staged = shs && M * 3 <= PP_SH_MAX;
     float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
+    // every per-Gaussian input is requested up front, before the SH rows are staged (see preprocess_fwd_kernel): the loads used
+    // to sit behind the staging barrier, the radius test and each other -- five memory round trips in a latency-bound kernel
+    const int ic = i < P ? i : P - 1;
+    const int radius_in = radii[ic];
+    const float mean[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
+    float s[3] = { 0.f, 0.f, 0.f };
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scales) {                                           // uniform
+        s[0] = scales[3 * ic]; s[1] = scales[3 * ic + 1]; s[2] = scales[3 * ic + 2];
+        q_in = reinterpret_cast<const float4*>(rotations)[ic];
+    }
+    const float4 dcon = reinterpret_cast<const float4*>(dL_dconic)[ic];
+    const float g2x = dL_dmean2D[3 * (size_t)ic], g2y = dL_dmean2D[3 * (size_t)ic + 1];
+    float dcol[3] = { 0.f, 0.f, 0.f };
+    unsigned char clamped_in = 0;
+    if (shs) {                                              // uniform
+        dcol[0] = dL_dcolor[3 * (size_t)ic]; dcol[1] = dL_dcolor[3 * (size_t)ic + 1]; dcol[2] = dL_dcolor[3 * (size_t)ic + 2];
+        clamped_in = clamped[ic];
+    }
     if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
     const Cam cam = load_cam(cam_args);
-    const bool live = i < P && radii[i] > 0;
+    const bool live = i < P && radius_in > 0;
     if (i < P && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = 0.0f;
@@ -466,16 +494,12 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
     }
     if (live) {
-    const float mean[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
     // 3D covariance: recomputed from scale / rotation when those are the inputs (bit-identical to what the forward
     // stored -- same function, same operands -- and 24 B / Gaussian less to read), else the caller's cov3D_precomp
     float c6[6];
-    float s[3] = { 0.f, 0.f, 0.f }, q[4] = { 0.f, 0.f, 0.f, 0.f };
+    float q[4] = { q_in.x, q_in.y, q_in.z, q_in.w };
     M3 Mm;
     if (scales) {
-        s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
-        const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
-        q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
         cov3d_from_scale_rot(s, cam.scale_mod, q, c6, Mm);
     } else {
 #pragma unroll
@@ -486,7 +510,6 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const float xgm = (cv.txtz < -cv.limx || cv.txtz > cv.limx) ? 0.0f : 1.0f;
     const float ygm = (cv.tytz < -cv.limy || cv.tytz > cv.limy) ? 0.0f : 1.0f;
     const float a = cv.a, b = cv.b, c = cv.c;
-    const float4 dcon = reinterpret_cast<const float4*>(dL_dconic)[i];
     const float dcx = dcon.x, dcy = dcon.y, dcz = dcon.w;
     const float denom = a * c - b * b;
     float dL_da = 0, dL_db = 0, dL_dc = 0;
@@ -537,15 +560,13 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const float* pj = cam.proj;
     const float mul1 = (pj[0] * mean[0] + pj[4] * mean[1] + pj[8] * mean[2] + pj[12]) * mw * mw;
     const float mul2 = (pj[1] * mean[0] + pj[5] * mean[1] + pj[9] * mean[2] + pj[13]) * mw * mw;
-    const float g2x = dL_dmean2D[3 * (size_t)i], g2y = dL_dmean2D[3 * (size_t)i + 1];
     dmean[0] += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
     dmean[1] += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
     dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
     if (shs) {
-        const float dcol[3] = { dL_dcolor[3 * (size_t)i], dL_dcolor[3 * (size_t)i + 1], dL_dcolor[3 * (size_t)i + 2] };
         if (sh_factors) {
             float gf[3];
-            sh_backward<true>(D, mean, cam.campos, staged ? my_lds : shs + (size_t)i * M * 3, clamped[i], dcol, dmean, nullptr, gf);
+            sh_backward<true>(D, mean, cam.campos, staged ? my_lds : shs + (size_t)i * M * 3, clamped_in, dcol, dmean, nullptr, gf);
 #pragma unroll
             for (int k = 0; k < 3; k++) dL_dsh[3 * (size_t)i + k] = gf[k];
         } else if (staged) {
@@ -553,11 +574,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             float shv[PP_SH_MAX];
 #pragma unroll
             for (int k = 0; k < PP_SH_MAX; k++) shv[k] = k < ncoef * 3 ? my_lds[k] : 0.0f;
-            sh_backward(D, mean, cam.campos, shv, clamped[i], dcol, dmean, my_lds);
+            sh_backward(D, mean, cam.campos, shv, clamped_in, dcol, dmean, my_lds);
             for (int k = ncoef * 3; k < M * 3; k++) my_lds[k] = 0.0f;
         } else {
             float* dsh = dL_dsh + (size_t)i * M * 3;
-            sh_backward(D, mean, cam.campos, shs + (size_t)i * M * 3, clamped[i], dcol, dmean, dsh);
+            sh_backward(D, mean, cam.campos, shs + (size_t)i * M * 3, clamped_in, dcol, dmean, dsh);
             for (int k = ncoef * 3; k < M * 3; k++) dsh[k] = 0.0f;
         }
     }
