@@ -42,6 +42,5 @@ def test_bench_two_ranks(exchange):
     out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "100000", "--exchange", exchange,
                      "--sweep", "", "--no-cpu-baseline"])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    d, _ = json.JSONDecoder().raw_decode(out.stdout[out.stdout.rfind('{"metric"'):])
     assert d["n_gpus"] == 2 and d["config"]["views_per_step"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
