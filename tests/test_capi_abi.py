@@ -78,3 +78,25 @@ def test_bad_arguments_fail_before_any_device_work(L, rast):
                            None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
     assert rc == -1
     assert L.gsrast_mark_visible(-1, None, None, None, None, None) == -1
+
+
+def test_widened_rows_reject_bad_arguments_without_a_device(rast, L):
+    """hexplane lookup / Linear weight gradient: argument checks run before any HIP call (no GPU here)."""
+    PS = rast._C.PlaneStruct
+    ok = (PS * 1)(PS(None, None, 64, 64, 0, 1, 7, 0))
+    n = L.gsrast_hexplane_scratch_bytes(1, ok, 32, 1000)
+    assert n > 2 * 1365 * 32 * 4                               # value + gradient stacks of levels >= 1 (1365 texels), + the sorted pairs
+    assert L.gsrast_hexplane_scratch_bytes(1, ok, 32, 2000) > n
+    odd = (PS * 1)(PS(None, None, 12, 10, 0, 1, 7, 0))         # 6 x 5 cannot be halved
+    assert L.gsrast_hexplane_scratch_bytes(1, odd, 32, 1000) == 0
+    assert L.gsrast_hexplane_scratch_bytes(1, ok, 12, 1000) == 0   # channels: power of two in [4, 64]
+    assert L.gsrast_hexplane_scratch_bytes(0, ok, 32, 1000) == 0
+    assert L.gsrast_hexplane_forward(10, 4, 32, 32, 1, odd, None, None, None, None, None) == -1
+    assert b"odd extent" in L.gsrast_last_error()
+    far = (PS * 1)(PS(None, None, 64, 64, 0, 5, 7, 0))         # coordinate column outside a 4-float point row
+    assert L.gsrast_hexplane_forward(10, 4, 32, 32, 1, far, None, None, None, None, None) == -1
+    off = (PS * 1)(PS(None, None, 64, 64, 0, 1, 7, 16))        # feature block [16, 48) outside a 32-float row
+    assert L.gsrast_hexplane_backward(10, 4, 32, 32, 1, off, None, None, None, None, None, 0, None, None) == -1
+    assert L.gsrast_linear_wgrad(10, 129, 8, None, None, None, None, 0, None) == -1
+    assert L.gsrast_linear_wgrad(10, 8, 0, None, None, None, None, 0, None) == -1
+    assert L.gsrast_linear_wgrad(10, 8, 8, None, None, None, None, 0, None) == -1      # NULL dW
