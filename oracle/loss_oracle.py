@@ -8,9 +8,11 @@ Follows /root/reference/utils/loss_utils.py:
   :48-68  _ssim            five depthwise convolutions with zero padding 5; C1 = 0.01^2, C2 = 0.03^2; mean
 and /root/reference/helper_train.py:50-53:  loss = (1 - lambda) * Ll1 + lambda * (1 - ssim).
 
-Pinning: utils/loss_utils.py cannot be imported here (it imports torchmetrics, absent from the image), so
-this restatement is "parity unpinned" against the reference itself; tests/test_loss.py cross-checks it
-against an independently written torch (conv2d + autograd, fp64) version of the same formulas.
+Pinning: PINNED against the reference itself -- tests/golden/make_golden.py imports utils/loss_utils.py (with an inert
+placeholder for its unused module-level `torchmetrics` import) and stores the window, l1_loss, ssim, the combined loss and its
+autograd gradient for three image pairs (tests/golden/loss_vectors.npz, keys ref_*); tests/test_oracle_golden.py checks this
+file against them.  tests/test_loss.py additionally cross-checks it against an independently written torch (conv2d +
+autograd, fp64) version of the same formulas.
 All arithmetic here is float64 on the fp32 window values.
 """
 from __future__ import annotations
@@ -22,7 +24,9 @@ import numpy as np
 
 def window2d() -> np.ndarray:
     g = np.array([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)], dtype=np.float32)
-    g = (g / g.sum(dtype=np.float32)).astype(np.float32)
+    # gauss / gauss.sum() (loss_utils.py:27): torch's CPU sum of these 11 floats is the correctly rounded one (a sequential or
+    # numpy pairwise fp32 sum lands 1 ulp lower) -- pinned by the reference's own window in tests/golden/loss_vectors.npz
+    g = (g / np.float32(g.astype(np.float64).sum())).astype(np.float32)
     return np.outer(g, g).astype(np.float32).astype(np.float64)
 
 

@@ -1096,9 +1096,12 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
 // ---- fused L1 + D-SSIM loss (gsrast_loss.h) ---------------------------------------------------
 namespace {
 LossWin make_window()
-{   // utils/loss_utils.py:25-27: exp() in double, stored as fp32, normalised in fp32
-    LossWin w; float sum = 0.f;
-    for (int i = 0; i < LW; i++) { w.w[i] = (float)exp(-(double)((i - LW / 2) * (i - LW / 2)) / (2.0 * 1.5 * 1.5)); sum += w.w[i]; }
+{   // utils/loss_utils.py:25-27: exp() in double, stored as fp32, divided (fp32) by the fp32 sum.  That sum is the correctly
+    // rounded one in the reference (torch's CPU reduction; a sequential fp32 sum lands 1 ulp lower): summed in double here,
+    // then rounded -- checked bit for bit against the reference's own window (tests/golden/loss_vectors.npz: ref_window_1d)
+    LossWin w; double dsum = 0.0;
+    for (int i = 0; i < LW; i++) { w.w[i] = (float)exp(-(double)((i - LW / 2) * (i - LW / 2)) / (2.0 * 1.5 * 1.5)); dsum += (double)w.w[i]; }
+    const float sum = (float)dsum;
     for (int i = 0; i < LW; i++) w.w[i] = w.w[i] / sum;
     return w;
 }

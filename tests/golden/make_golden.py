@@ -72,6 +72,7 @@ def ref_python_vectors():
     out["proj_view"] = np.array([gfx.geom_transform_points(torch.from_numpy(pts), torch.from_numpy(v).double()).numpy() for v in views])
     out.update(cam_R=np.array(Rs), cam_T=np.array(Ts), cam_fov=np.array(fovs), cam_world_view=np.array(views),
                cam_projection=np.array(projs), cam_full_proj=np.array(fulls), cam_center=np.array(centers))
+    out.update(ref_cov3d_vectors())
     np.savez_compressed(os.path.join(HERE, "ref_python_vectors.npz"), **out)
     print("wrote ref_python_vectors.npz")
 
@@ -103,12 +104,105 @@ def oracle_scenes():
         print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-if __name__ == "__main__":
-    if os.path.isdir(REF):
-        ref_python_vectors()
-    else:
-        print("no /root/reference here: keeping the committed ref_python_vectors.npz")
-    oracle_scenes()
+def _load_with_placeholders(name, path, absent, cuda_to_cpu=False):
+    """Import one of the reference's Python files whose module-level imports name packages this image lacks.
+    `absent`: module names (e.g. "cv2", "torchmetrics") that get an EMPTY placeholder module in sys.modules for the
+    duration of the import -- the functions used below never touch them.  cuda_to_cpu: utils/general_utils.py
+    creates its work tensors with a hard-coded device="cuda" (general_utils.py:115, :131, :190); this container has
+    no GPU, so the module's `torch` name is bound to a forwarding proxy whose zeros() maps that device string to
+    "cpu".  Neither placeholder supplies any arithmetic: every number stored comes out of the reference's own
+    statements (the rotation-matrix entries, R @ L, L @ L^T, strip_symmetric; the window, the five conv2d, the SSIM map)."""
+    import types
+    saved = {}
+    for m in absent:
+        saved[m] = sys.modules.get(m)
+        ph = types.ModuleType(m)
+        if m == "torchmetrics":
+            # loss_utils.py:16 imports this name and :101 instantiates it at module level (an MS-SSIM metric object that
+            # l1_loss / ssim never use): an inert callable returning None
+            ph.MultiScaleStructuralSimilarityIndexMeasure = lambda *a, **k: None
+        if m == "PIL":
+            ph.Image = None
+        sys.modules[m] = ph
+    try:
+        mod = _load(name, path)
+    finally:
+        for m, old in saved.items():
+            if old is None:
+                sys.modules.pop(m, None)
+            else:
+                sys.modules[m] = old
+    if cuda_to_cpu:
+        import torch
+
+        class _TorchOnCpu:
+            def __getattr__(self, k):
+                return getattr(torch, k)
+
+            @staticmethod
+            def zeros(*a, **kw):
+                if kw.get("device") == "cuda":
+                    kw["device"] = "cpu"
+                return torch.zeros(*a, **kw)
+        mod.torch = _TorchOnCpu()
+    return mod
+
+
+def ref_cov3d_vectors():
+    """cov3D of the reference's OWN Python: build_covariance_from_scaling_rotation (scene/saro_gaussian.py:33-37) =
+    strip_symmetric(L @ L^T), L = build_scaling_rotation(modifier * scaling, rotation) (utils/general_utils.py:113-205).
+    Pins the packing order [xx, xy, xz, yy, yz, zz], the quaternion convention (r, x, y, z) and Sigma = R S S^T R^T of
+    computeCov3D (forward.cu:118-152), in the oracle and in the HIP kernel.  Unit quaternions only: build_rotation
+    normalises, the CUDA kernel takes the quaternion as given (forward.cu:127), and SaRO-GS always passes normalised ones."""
+    import torch
+    gu = _load_with_placeholders("ref_general_utils", os.path.join(REF, "utils", "general_utils.py"), ("cv2",), cuda_to_cpu=True)
+    rng = np.random.default_rng(4321)
+    n = 384
+    scales = np.exp(rng.uniform(np.log(0.003), np.log(1.5), size=(n, 3))).astype(np.float32)
+    scales[:8] = np.float32(0.25)                                  # isotropic
+    scales[8:16, 0] *= np.float32(200.0)                           # needles
+    q = rng.normal(size=(n, 4))
+    q[16] = (1, 0, 0, 0); q[17] = (0, 1, 0, 0); q[18] = (0, 0, 1, 0); q[19] = (0, 0, 0, 1); q[20] = (-1, 0, 0, 0)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    q = (q.astype(np.float64) / np.linalg.norm(q.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)   # unit to fp32 rounding
+    out = {"cov_scales": scales, "cov_rotations": q}
+    for tag, mod in (("1", 1.0), ("0p7", 0.7)):
+        L = gu.build_scaling_rotation(mod * torch.from_numpy(scales), torch.from_numpy(q))      # saro_gaussian.py:34
+        cov = gu.strip_symmetric(L @ L.transpose(1, 2))                                          # :35-36
+        out["cov3D_mod" + tag] = cov.numpy()
+        # the same statements evaluated in float64 (inputs widened): tight check of the fp64 oracle build
+        L64 = gu.build_scaling_rotation(mod * torch.from_numpy(scales.astype(np.float64)), torch.from_numpy(q.astype(np.float64)))
+        out["cov3D_mod" + tag + "_R"] = gu.build_rotation(torch.from_numpy(q)).numpy()
+    return out
+
+
+def ref_loss_vectors():
+    """l1_loss / ssim of the reference's OWN utils/loss_utils.py:18-68 combined as helper_train.py:50-53, plus the
+    autograd gradient of that loss w.r.t. the rendered image: pins oracle/loss_oracle.py and the fused HIP loss."""
+    import torch
+    lu = _load_with_placeholders("ref_loss_utils", os.path.join(REF, "utils", "loss_utils.py"), ("torchmetrics",))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_loss
+    out = {"ref_window_1d": lu.gaussian(11, 1.5).numpy(), "ref_window_2d": lu.create_window(11, 1)[0, 0].numpy()}     # loss_utils.py:25-35
+    for tag, (C, H, W, seed, lam) in {"a": (3, 48, 64, 9, 0.2), "b": (3, 37, 53, 10, 0.2), "c": (1, 16, 16, 11, 0.5)}.items():
+        img, gt = test_loss._images(C, H, W, seed)
+        x = torch.from_numpy(img).clone().requires_grad_(True)
+        y = torch.from_numpy(gt)
+        l1 = lu.l1_loss(x, y)
+        s = lu.ssim(x, y)
+        loss = (1.0 - lam) * l1 + lam * (1.0 - s)                                                # helper_train.py:50-53
+        loss.backward()
+        out.update({f"ref_{tag}_img": img, f"ref_{tag}_gt": gt, f"ref_{tag}_lambda": np.float64(lam),
+                    f"ref_{tag}_loss_l1_ssim": np.array([loss.item(), l1.item(), s.item()], np.float64),
+                    f"ref_{tag}_grad": x.grad.numpy()})
+        # float64 evaluation of the same statements (window stays the reference's fp32 window widened)
+        x64 = torch.from_numpy(img.astype(np.float64)).requires_grad_(True)
+        y64 = torch.from_numpy(gt.astype(np.float64))
+        l64 = (1.0 - lam) * lu.l1_loss(x64, y64) + lam * (1.0 - lu.ssim(x64, y64))
+        l64.backward()
+        out[f"ref_{tag}_loss_f64"] = np.float64(l64.item())
+        out[f"ref_{tag}_grad_f64"] = x64.grad.numpy()
+    return out
 
 
 def loss_vectors():
@@ -119,9 +213,21 @@ def loss_vectors():
     from oracle import loss_oracle
     img, gt = test_loss._images(3, 48, 64, 9)
     out = np.array(loss_oracle.l1_dssim(img, gt, 0.2))
-    np.savez_compressed(os.path.join(HERE, "loss_vectors.npz"), img=img, gt=gt, lambda_dssim=np.float64(0.2), loss_l1_ssim=out)
-    print("wrote loss_vectors.npz", out)
+    extra = {}
+    path = os.path.join(HERE, "loss_vectors.npz")
+    if os.path.isdir(REF):
+        extra = ref_loss_vectors()
+    elif os.path.exists(path):          # no reference here: keep the committed reference-derived entries
+        old = np.load(path)
+        extra = {k: old[k] for k in old.files if k.startswith("ref_")}
+    np.savez_compressed(path, img=img, gt=gt, lambda_dssim=np.float64(0.2), loss_l1_ssim=out, **extra)
+    print("wrote loss_vectors.npz", out, sorted(extra)[:4])
 
 
 if __name__ == "__main__":
+    if os.path.isdir(REF):
+        ref_python_vectors()
+    else:
+        print("no /root/reference here: keeping the committed ref_python_vectors.npz")
+    oracle_scenes()
     loss_vectors()

@@ -582,3 +582,21 @@ def test_degenerate_image_sizes(W, H, orc, scenes, rast, gpu):
     h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
     _check_forward_exact(o32, h)
     _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+def test_cov3d_against_reference_python_vectors(scenes, rast, gpu):
+    """The HIP kernel's cov3D (state export) against the reference's OWN Python build_covariance_from_scaling_rotation
+    (utils/general_utils.py:113-205 composed as scene/saro_gaussian.py:33-37; vectors generated by importing the reference,
+    tests/golden/make_golden.py): packing order, quaternion convention, Sigma = R S S^T R^T, scale_modifier."""
+    import os
+    from test_oracle_golden import G, _cov_scene
+    z = np.load(os.path.join(G, "ref_python_vectors.npz"))
+    sc, cam = _cov_scene(scenes, z)
+    for tag, mod in (("1", 1.0), ("0p7", 0.7)):
+        cam["scale_modifier"] = mod
+        h = run_hip(rast, sc, cam, gpu)
+        want = z["cov3D_mod" + tag].astype(np.float64)
+        vis = h["radii"] > 0
+        assert vis.mean() > 0.9
+        tol = 2e-6 * np.abs(want).max(axis=1, keepdims=True)
+        assert (np.abs(h["cov3D"] - want)[vis] <= tol[vis]).all()

@@ -92,3 +92,58 @@ def test_oracle_reproduces_its_committed_outputs(orc):
         o64 = orc.render(sc, cam, z["dL_dcolor"], f64=True)
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
             np.testing.assert_allclose(o64[k], z["f64_" + k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def _cov_scene(scenes, z, W=160, H=128):
+    """The golden Gaussians placed in front of a camera (all visible), so the oracle / the kernel evaluate computeCov3D on them."""
+    scales, rots = z["cov_scales"], z["cov_rotations"]
+    n = len(scales)
+    sc = scenes.synth(n, 77, sh_degree=0)
+    sc["scales"], sc["rotations"] = scales, rots
+    rng = np.random.default_rng(5)
+    sc["means3D"] = rng.uniform(-0.4, 0.4, size=(n, 3)).astype(np.float32)
+    return sc, scenes.camera(0, 4, W, H)
+
+
+def test_cov3d_matches_reference_build_covariance(orc, scenes):
+    """cov3D (6 floats: xx, xy, xz, yy, yz, zz) against the reference's own Python: strip_symmetric(L @ L^T) with
+    L = build_scaling_rotation(modifier * scaling, rotation) (utils/general_utils.py:113-205 as composed in
+    scene/saro_gaussian.py:33-37) -- pins the packing, the quaternion convention and Sigma = R S S^T R^T of computeCov3D
+    (forward.cu:118-152) in the oracle."""
+    z = np.load(os.path.join(G, "ref_python_vectors.npz"))
+    assert len(z["cov_scales"]) >= 256
+    sc, cam = _cov_scene(scenes, z)
+    for tag, mod in (("1", 1.0), ("0p7", 0.7)):
+        cam["scale_modifier"] = mod
+        want = z["cov3D_mod" + tag].astype(np.float64)               # reference, fp32 arithmetic in torch
+        o32 = orc.forward(sc, cam)
+        o64 = orc.forward(sc, cam, st32=o32)
+        vis = o32["radii"] > 0
+        assert vis.mean() > 0.9
+        tol = 2e-6 * np.abs(want).max(axis=1, keepdims=True)          # two fp32 evaluations in different operation orders
+        assert (np.abs(o32["cov3D"] - want)[vis] <= tol[vis]).all()
+        assert (np.abs(o64["cov3D"] - want)[vis] <= tol[vis]).all()
+    # the rotation matrix itself: R[i][j] of build_rotation vs the oracle's cov3D for unit scales would lose the sign
+    # information, so check the axis images directly: Sigma = R diag(s^2) R^T with s = (2, 1, 0.5) identifies R up to sign per column
+    R = z["cov3D_mod1_R"].astype(np.float64)
+    s = np.array([2.0, 1.0, 0.5])
+    sc2, cam2 = _cov_scene(scenes, z)
+    sc2["scales"] = np.tile(s.astype(np.float32), (len(R), 1))
+    o32 = orc.forward(sc2, cam2)
+    S = np.einsum("nij,j,nkj->nik", R, s * s, R)
+    want6 = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1)
+    vis = o32["radii"] > 0
+    np.testing.assert_allclose(o32["cov3D"][vis], want6[vis], rtol=0, atol=4e-6)
+
+
+def test_loss_oracle_matches_reference_loss_utils():
+    """oracle/loss_oracle.py against the reference's own l1_loss / ssim (utils/loss_utils.py:18-68) combined as
+    helper_train.py:50-53, evaluated by importing the reference's Python (tests/golden/make_golden.py)."""
+    from oracle import loss_oracle
+    z = np.load(os.path.join(G, "loss_vectors.npz"))
+    np.testing.assert_array_equal(loss_oracle.window2d().astype(np.float32).view(np.uint32), z["ref_window_2d"].view(np.uint32))
+    for tag in ("a", "b", "c"):
+        img, gt, lam = z[f"ref_{tag}_img"], z[f"ref_{tag}_gt"], float(z[f"ref_{tag}_lambda"])
+        got = loss_oracle.l1_dssim(img, gt, lam)
+        np.testing.assert_allclose(got, z[f"ref_{tag}_loss_l1_ssim"], rtol=0, atol=2e-6)      # the reference ran in fp32
+        assert abs(got[0] - float(z[f"ref_{tag}_loss_f64"])) < 1e-9                           # ... and in fp64
