@@ -91,6 +91,8 @@ class Workload:
         L = self.leaves
         for p in list(L.values()) + [self.means2D]:
             p.grad = None
+        if bucket is not None:
+            bucket.zero_grad()          # start of a step: this backward writes into the arena (GradArena contract)
         color, radii, depth = self.raster(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"],
                                           shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)

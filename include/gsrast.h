@@ -71,11 +71,14 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
                    void* stream);
 
 /* Backward pass.  Replaces Rasterizer::backward, rasterizer.h:60-89.
- * On entry dL_dmean2D [P][3], dL_dconic [P][4], dL_dopacity [P] and dL_dcolor [P][3] must be
- * zero (they are accumulated with atomics, like the reference); dL_dmean3D [P][3],
- * dL_dcov3D [P][6], dL_dsh [P][M][3], dL_dscale [P][3], dL_drot [P][4] are fully overwritten
- * (zeros for culled Gaussians), so they need not be initialised.  dL_dcov3D may be NULL when scales / rotations
- * are given (it is then an intermediate nobody reads; the reference computes and returns it regardless).
+ * EVERY output array is fully overwritten (zeros for culled Gaussians), none has to be initialised -- the reference
+ * accumulates into nine zero-filled arrays (300 B / Gaussian of memset, rasterize_points.cu:150-158); here the blend
+ * backward accumulates into one 64-byte record per Gaussian inside geom_buffer (zero-filled by this call) and the
+ * per-Gaussian backward writes dL_dmean2D [P][3] (.z = 0), dL_dopacity [P], dL_dcolor [P][3], dL_dconic [P][4] (.z = 0,
+ * as the reference never writes it) from it, next to dL_dmean3D [P][3], dL_dcov3D [P][6], dL_dsh [P][M][3],
+ * dL_dscale [P][3], dL_drot [P][4].  May be NULL: dL_dconic (an intermediate), dL_dcolor unless colors_precomp is given,
+ * dL_dcov3D when scales / rotations are given (the reference computes and returns all three regardless).
+ * geom_buffer is written (the gradient records), binning_buffer / image_buffer are only read.
  * Returns 0 or GSRAST_E_*. */
 int gsrast_backward(int P, int D, int M, int R,
                     const float* background,
@@ -141,7 +144,57 @@ int gsrast_debug_export(int P, int R, int width, int height,
                         uint32_t* ranges /*[T][2]*/, float* final_T /*[H*W]*/,
                         uint32_t* n_contrib /*[H*W]*/, void* stream);
 
-/* Options: "exp_mode" 0 = fixed-sequence exp (bit-reproducible vs the CPU oracle), 1 = libm-grade
+/* ---- Reentrancy: per-call options and contexts ---------------------------------------------------------------------
+ * The reference's Rasterizer::{forward, backward} are stateless statics (rasterizer.h:24-83): any number of host threads
+ * may call them on different streams / devices.  The same holds here:
+ *   - everything that changes what a call computes or how it is scheduled is a field of gsrast_options, passed per call to
+ *     gsrast_forward_ex / gsrast_backward_ex (NULL = a snapshot of the process defaults, taken once at entry);
+ *   - the only state that outlives a forward call -- the capacity hints of the speculative launch and the counts of the last
+ *     call -- lives in a gsrast_context the caller owns (NULL = a context private to the calling host thread);
+ *   - gsrast_last_error() is per host thread.
+ * gsrast_forward / gsrast_backward are exactly gsrast_forward_ex(NULL, NULL, ...) / gsrast_backward_ex(NULL, ...).
+ * gsrast_set_option only edits the process DEFAULTS (plus the process-wide diagnostics "profile", "debug_sync"): callers that
+ * want different behaviour on different threads pass a gsrast_options instead. */
+typedef struct gsrast_options {
+    int exp_mode;             /* 0 fixed-sequence exp (default), 1 libm-grade expf, 2 v_exp_f32 */
+    int binning;              /* 0 run-compressed (default), 1 instance-level two-pass radix sort */
+    int tile_clip;            /* 1 (default) list a Gaussian only in tiles its alpha >= 1/255 ellipse reaches; 0 literal lists */
+    int cull;                 /* 1 (default) wave-level strip culling in the blend kernels */
+    int lpt;                  /* 1 (default) heaviest-tile-first launch order of the blend kernels */
+    int speculative;          /* 1 (default) enqueue binning + blend before num_rendered is read back */
+    int fwd_pixels_per_lane;  /* 0 auto (default), 1 / 2 / 4 */
+    int bwd_pixels_per_lane;  /* 0 auto (default), 1 / 2 / 4 */
+    int sh_grad_factors;      /* backward: dL_dsh receives the [P][3] factor, see gsrast_sh_grad_combine */
+    int reserved[7];          /* must be zero */
+} gsrast_options;
+void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
+typedef struct gsrast_context gsrast_context;
+gsrast_context* gsrast_context_create(void);
+void gsrast_context_destroy(gsrast_context* ctx);
+/* "last_instances" (num_rendered), "last_runs" (column runs) of the context's last forward call, "redo_count"
+ * (speculative launches that had to be repeated); ctx NULL = the calling thread's context. */
+int gsrast_context_query(const gsrast_context* ctx, const char* name);
+int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
+                      gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
+                      gsrast_alloc_fn binning_alloc, void* binning_ctx,
+                      gsrast_alloc_fn image_alloc, void* image_ctx,
+                      int P, int D, int M, const float* background, int width, int height,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, int prefiltered,
+                      float* out_color, float* out_depth, int* radii, void* stream);
+int gsrast_backward_ex(const gsrast_options* options,
+                       int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos,
+                       float tan_fovx, float tan_fovy, const int* radii,
+                       char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream);
+
+/* Process defaults of the options above (and process-wide diagnostics): "exp_mode" 0 = fixed-sequence exp (bit-reproducible vs the CPU oracle), 1 = libm-grade
  * expf, 2 = hardware v_exp_f32;  "profile" = bit mask of kernel ids (gsrast_profile_kernel_name) whose launches are bracketed
  * with HIP events on the launch stream, -1 = all, 0 = off;
  * "debug_sync" 0/1 = synchronise + check errors after every launch;
@@ -155,7 +208,7 @@ int gsrast_debug_export(int P, int R, int width, int height,
  * a capacity remembered from earlier calls (repeated with exact sizes if it did not fit), 0 = wait first;
  * "sh_grad_factors" see gsrast_sh_grad_combine.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
- * last forward call of the process, "redo_count" (speculative launches that had to be repeated). */
+ * last forward call of the CALLING THREAD's context, "redo_count" (= gsrast_context_query(NULL, name)). */
 int gsrast_set_option(const char* name, int value);
 int gsrast_get_option(const char* name);
 

@@ -406,8 +406,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                  const float4* __restrict__ rec2, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                  const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
-                 float* __restrict__ dL_dmean2D /*[P][3]*/, float* __restrict__ dL_dconic /*[P][4]*/,
-                 float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/)
+                 float* __restrict__ grec /*[P][GREC]: per-Gaussian gradient records, zero on entry*/)
 {
 #pragma clang fp contract(fast)
     using Cfg = BlendCfg<PPL>;
@@ -558,10 +557,9 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                 const float v5 = acc[5][slot], v6 = acc[6][slot], v7 = acc[7][slot], v8 = acc[8][slot];
                 const bool any = (v0 != 0.f) | (v1 != 0.f) | (v2 != 0.f) | (v3 != 0.f) | (v4 != 0.f) | (v5 != 0.f) | (v6 != 0.f) | (v7 != 0.f) | (v8 != 0.f);
                 if (any) {
-                    atomicAdd(&dL_dmean2D[3 * gid], v0); atomicAdd(&dL_dmean2D[3 * gid + 1], v1);
-                    atomicAdd(&dL_dconic[4 * gid], v2); atomicAdd(&dL_dconic[4 * gid + 1], v3); atomicAdd(&dL_dconic[4 * gid + 3], v4);
-                    atomicAdd(&dL_dopacity[gid], v5);
-                    atomicAdd(&dL_dcolors[3 * gid], v6); atomicAdd(&dL_dcolors[3 * gid + 1], v7); atomicAdd(&dL_dcolors[3 * gid + 2], v8);
+                    float* rec = grec + gid * GREC;
+                    atomicAdd(rec + 0, v0); atomicAdd(rec + 1, v1); atomicAdd(rec + 2, v2); atomicAdd(rec + 3, v3); atomicAdd(rec + 4, v4);
+                    atomicAdd(rec + 5, v5); atomicAdd(rec + 6, v6); atomicAdd(rec + 7, v7); atomicAdd(rec + 8, v8);
                 }
             }
         }
@@ -583,8 +581,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float4* __restrict__ rec2, const float* __restrict__ bg,
                       const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                       const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
-                      float* __restrict__ dL_dmean2D /*[P][3]*/, float* __restrict__ dL_dconic /*[P][4]*/,
-                      float* __restrict__ dL_dopacity /*[P]*/, float* __restrict__ dL_dcolors /*[P][3]*/,
+                      float* __restrict__ grec /*[P][GREC]: per-Gaussian gradient records, zero on entry*/,
                       const uint32_t* __restrict__ bucket_cnt /* fwd [8][64] | bwd [64]: launch order from the bwd lists, or null */,
                       const uint16_t* __restrict__ bucket_list)
 {
@@ -596,7 +593,10 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ float4 s1[BATCH];
     __shared__ float2 s2[BATCH];          // {blue, skip threshold}
     __shared__ uint32_t sid[BATCH];
-    __shared__ float acc[NW][9][BATCH];   // one accumulator slice per wave: plain LDS read-add-write, no LDS atomics
+    // one accumulator slice per wave (plain LDS read-add-write, no LDS atomics); a staged instance's nine sums are adjacent, like
+    // the record they are committed to
+    constexpr int AS = 12;
+    __shared__ __attribute__((aligned(16))) float acc[NW][BATCH][AS];
 
     __shared__ uint32_t s_tile;
     if (blockIdx.x >= ntiles) return;
@@ -656,11 +656,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const float4 c = rec2[g];
                 s2[slot] = make_float2(c.x, c.z);
             }
-#pragma unroll
-            for (int w = 0; w < NW; w++)
-#pragma unroll
-                for (int q = 0; q < 9; q++) acc[w][q][slot] = 0.0f;
         }
+        for (uint32_t q4 = t; q4 < (uint32_t)(NW * BATCH * AS / 4); q4 += NT) reinterpret_cast<float4*>(&acc[0][0][0])[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
 #pragma unroll 1
@@ -760,26 +757,20 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     const float v8[8] = { g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g };
                     const float tot = wave_sum8_transposed(v8, lane);
                     const float tb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(g_b)), 63));
-                    if (lane < 9u) acc[wave][lane][j] += (lane < 8u ? tot : tb) * commit_scale;
+                    if (lane < 9u) acc[wave][j][lane] += (lane < 8u ? tot : tb) * commit_scale;
                 }
             }
         }
         __syncthreads();
-        for (uint32_t slot = t; slot < cnt; slot += NT) {
-            const size_t gid = sid[slot];
-            float v[9];
+        // commit: 16 adjacent lanes per staged instance, lane q < 9 adds sum q to float q of the Gaussian's 64-byte record -- the nine
+        // atomics of a (tile, Gaussian) pair leave in ONE wave instruction and land in ONE cache line
+        for (uint32_t e = t; e < cnt * 16u; e += NT) {
+            const uint32_t slot = e >> 4, q = e & 15u;
+            if (q < 9u) {
+                float v = acc[0][slot][q];
 #pragma unroll
-            for (int q = 0; q < 9; q++) {
-                v[q] = acc[0][q][slot];
-#pragma unroll
-                for (int w = 1; w < NW; w++) v[q] += acc[w][q][slot];
-            }
-            const bool any = (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f) | (v[4] != 0.f) | (v[5] != 0.f) | (v[6] != 0.f) | (v[7] != 0.f) | (v[8] != 0.f);
-            if (any) {
-                atomicAdd(&dL_dmean2D[3 * gid], v[0]); atomicAdd(&dL_dmean2D[3 * gid + 1], v[1]);
-                atomicAdd(&dL_dconic[4 * gid], v[2]); atomicAdd(&dL_dconic[4 * gid + 1], v[3]); atomicAdd(&dL_dconic[4 * gid + 3], v[4]);
-                atomicAdd(&dL_dopacity[gid], v[5]);
-                atomicAdd(&dL_dcolors[3 * gid], v[6]); atomicAdd(&dL_dcolors[3 * gid + 1], v[7]); atomicAdd(&dL_dcolors[3 * gid + 2], v[8]);
+                for (int w = 1; w < NW; w++) v += acc[w][slot][q];
+                if (v != 0.f) atomicAdd(grec + (size_t)sid[slot] * GREC + q, v);
             }
         }
     }

@@ -34,7 +34,27 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_exp_mode{0}, g_profile{0}, g_debug_sync{0}, g_ablate{0};
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0};      // process-wide diagnostics (not per-call behaviour)
+
+// Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
+// snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
+// threads driving different streams / devices with different options cannot disturb each other.
+struct DefaultOptions {
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0};
+} g_def;
+gsrast_options snapshot_defaults()
+{
+    gsrast_options o{};
+    o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
+    o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
+    o.sh_grad_factors = g_def.sh_grad_factors;
+    return o;
+}
+bool options_valid(const gsrast_options& o)
+{
+    auto ppl_ok = [](int v) { return v == 0 || v == 1 || v == 2 || v == 4; };
+    return o.exp_mode >= 0 && o.exp_mode <= 2 && (o.binning == 0 || o.binning == 1) && ppl_ok(o.fwd_pixels_per_lane) && ppl_ok(o.bwd_pixels_per_lane);
+}
 
 int fail(int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -205,12 +225,19 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // Instances of the previous forward call: the binning buffer is requested for 1.25x that many BEFORE
 // the host waits for the real count, so the (Python) allocation callback runs while the GPU is still
 // busy with preprocess / depth sort instead of in the idle gap after the readback.
-std::atomic<uint32_t> g_R_hint{0}, g_Q_hint{0}, g_last_R{0}, g_last_Q{0};
-std::atomic<int> g_redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
-std::atomic<int> g_speculative{1};  // enqueue binning + blend before the host has read R / Q back (run-compressed path)
-std::atomic<int> g_sh_grad_factors{0};   // gsrast_backward writes the [P][3] factor of dL/dsh instead of dL/dsh (multi-GPU exchange)
-std::atomic<int> g_tile_clip{1};   // run-compressed binning only: drop the tiles of a Gaussian's rectangle its alpha >= 1/255 ellipse cannot reach
-std::atomic<int> g_binning{0};     // 0 = run-compressed binning when the image allows it, 1 = always the instance-level two-pass sort
+// These hints (and the counts of the last call) belong to a gsrast_context: one per caller that renders a sequence of similar
+// views.  The reference-shaped entry points use a context private to the calling host thread.
+} // namespace
+struct gsrast_context {
+    std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0};
+    std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
+};
+namespace {
+gsrast_context* thread_context()
+{   // deliberately leaked at thread exit (a few words): see Readback above for why nothing here has a destructor
+    thread_local gsrast_context* c = new gsrast_context();
+    return c;
+}
 
 CamArgs make_cam(const float* view, const float* proj, const float* campos, float tanx, float tany,
                  float scale_mod, int W, int H)
@@ -268,12 +295,9 @@ export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 }
 
 std::atomic<int> g_hex_scatter{0};    // hexplane backward to the texels: 0 = sorted runs, 1 = direct global atomics
-std::atomic<int> g_ppl_fwd{0}, g_ppl_bwd{0};   // pixels per lane of the blend kernels: 0 = auto, else 1 / 2 / 4
-std::atomic<int> g_cull{1}, g_lpt{1};                    // wave-level strip culling in the blend kernels (default on)
-
-int pick_ppl(uint32_t ntiles, bool backward)
+int pick_ppl(uint32_t ntiles, bool backward, const gsrast_options& o)
 {
-    const int forced = backward ? g_ppl_bwd.load() : g_ppl_fwd.load();
+    const int forced = backward ? o.bwd_pixels_per_lane : o.fwd_pixels_per_lane;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     // Measured on MI355X (profiles/): the forward is fastest with one pixel per lane (finest cull /
     // early-exit granularity, most waves in flight).  With per-wave accumulator slices the backward is
@@ -287,7 +311,7 @@ struct BlendArgs {
     uint32_t* bcnt = nullptr; uint16_t* blist = nullptr; int from_buckets = 0;   // launch order from the work buckets (ImgLayout)
     const uint2* ranges; const uint32_t* plist; const uint32_t* order; int W, H, gx; uint32_t T; const float4 *r0, *r1, *r2; const float* bg;
     float *oc, *od, *fT; uint32_t *nc, *tm;                       // forward outputs (fT / nc / tm: inputs of backward)
-    const float* dpix; float *dm2, *dcon, *dop, *dcol;            // backward
+    const float* dpix; float* grec;                              // backward
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -297,7 +321,7 @@ void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
 template <int MODE, int PPL, int ABL>
 void launch_bwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_bwd_kernel<MODE, PPL, ABL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol);
+    blend_bwd_kernel<MODE, PPL, ABL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.grec);
 }
 template <int MODE>
 void dispatch_fwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -307,7 +331,7 @@ void dispatch_fwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
 template <int MODE, int PPL>
 void launch_bwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
-    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.dm2, a.dcon, a.dop, a.dcol,
+    blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.grec,
                                                                  a.from_buckets ? a.bcnt : nullptr, a.blist);
 }
 template <int MODE>
@@ -334,24 +358,42 @@ extern "C" {
 int gsrast_abi_version(void) { return GSRAST_ABI_VERSION; }
 const char* gsrast_last_error(void) { return g_err.c_str(); }
 
+void gsrast_options_init(gsrast_options* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->tile_clip = 1; o->cull = 1; o->lpt = 1; o->speculative = 1;
+}
+gsrast_context* gsrast_context_create(void) { return new (std::nothrow) gsrast_context(); }
+void gsrast_context_destroy(gsrast_context* c) { delete c; }
+int gsrast_context_query(const gsrast_context* c, const char* name)
+{
+    if (!name) return GSRAST_E_ARG;
+    if (!c) c = thread_context();
+    if (!strcmp(name, "last_instances")) return (int)c->last_R.load();   // num_rendered / column runs of the context's last forward call
+    if (!strcmp(name, "last_runs")) return (int)c->last_Q.load();
+    if (!strcmp(name, "redo_count")) return c->redo_count.load();
+    return GSRAST_E_ARG;
+}
+
 int gsrast_set_option(const char* name, int value)
 {
     if (!name) return GSRAST_E_ARG;
-    if (!strcmp(name, "exp_mode")) { if (value < 0 || value > 2) return GSRAST_E_ARG; g_exp_mode = value; return 0; }
+    if (!strcmp(name, "exp_mode")) { if (value < 0 || value > 2) return GSRAST_E_ARG; g_def.exp_mode = value; return 0; }
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
-    if (!strcmp(name, "cull")) { g_cull = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_binning = value; return 0; }
-    if (!strcmp(name, "tile_clip")) { g_tile_clip = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "sh_grad_factors")) { g_sh_grad_factors = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "speculative")) { g_speculative = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "lpt")) { g_lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
+    if (!strcmp(name, "cull")) { g_def.cull = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.binning = value; return 0; }
+    if (!strcmp(name, "tile_clip")) { g_def.tile_clip = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "sh_grad_factors")) { g_def.sh_grad_factors = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "speculative")) { g_def.speculative = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return GSRAST_E_ARG;
-        if (name[0] != 'b') g_ppl_fwd = value;
-        if (name[0] != 'f') g_ppl_bwd = value;
+        if (name[0] != 'b') g_def.fwd_ppl = value;
+        if (name[0] != 'f') g_def.bwd_ppl = value;
         return 0;
     }
     return GSRAST_E_ARG;
@@ -359,20 +401,18 @@ int gsrast_set_option(const char* name, int value)
 int gsrast_get_option(const char* name)
 {
     if (!name) return GSRAST_E_ARG;
-    if (!strcmp(name, "exp_mode")) return g_exp_mode.load();
+    if (!strcmp(name, "exp_mode")) return g_def.exp_mode.load();
     if (!strcmp(name, "profile")) return g_profile.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
-    if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_ppl_fwd.load();
-    if (!strcmp(name, "bwd_pixels_per_lane")) return g_ppl_bwd.load();
-    if (!strcmp(name, "cull")) return g_cull.load();
-    if (!strcmp(name, "binning")) return g_binning.load();
-    if (!strcmp(name, "tile_clip")) return g_tile_clip.load();
-    if (!strcmp(name, "sh_grad_factors")) return g_sh_grad_factors.load();
-    if (!strcmp(name, "last_instances")) return (int)g_last_R.load();   // num_rendered / column runs of the last forward call
-    if (!strcmp(name, "last_runs")) return (int)g_last_Q.load();
-    if (!strcmp(name, "speculative")) return g_speculative.load();
-    if (!strcmp(name, "redo_count")) return g_redo_count.load();
-    if (!strcmp(name, "lpt")) return g_lpt.load();
+    if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
+    if (!strcmp(name, "bwd_pixels_per_lane")) return g_def.bwd_ppl.load();
+    if (!strcmp(name, "cull")) return g_def.cull.load();
+    if (!strcmp(name, "binning")) return g_def.binning.load();
+    if (!strcmp(name, "tile_clip")) return g_def.tile_clip.load();
+    if (!strcmp(name, "sh_grad_factors")) return g_def.sh_grad_factors.load();
+    if (!strcmp(name, "last_instances") || !strcmp(name, "last_runs") || !strcmp(name, "redo_count")) return gsrast_context_query(nullptr, name);
+    if (!strcmp(name, "speculative")) return g_def.speculative.load();
+    if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
 }
@@ -432,7 +472,25 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                    float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream)
 {
+    return gsrast_forward_ex(nullptr, nullptr, geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+                             background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                             cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth,
+                             radii, stream);
+}
+
+int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
+                      gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_alloc_fn binning_alloc,
+                      void* binning_ctx, gsrast_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                      const float* background, int width, int height, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales,
+                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream)
+{
     (void)prefiltered; // the reference only traps when a prefiltered point is culled (auxiliary.h:156-160)
+    const gsrast_options o = options ? *options : snapshot_defaults();
+    if (!options_valid(o)) return fail(GSRAST_E_ARG, "forward: bad option value");
+    if (!ctx) ctx = thread_context();
     hipStream_t s = (hipStream_t)stream;
     const int W = width, H = height;
     if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return fail(GSRAST_E_ARG, "forward: bad P / image size / SH degree");
@@ -472,7 +530,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     uint32_t* scalars = at<uint32_t>(geom, GL.scalars);
 
     // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
-    const bool runbin = g_binning.load() == 0 && cam.gy <= 256 && T <= 65536u;
+    const bool runbin = o.binning == 0 && cam.gy <= 256 && T <= 65536u;
     const bool buckets_ok = T <= BUCKET_MAX_TILES;      // launch order of the blend kernels from work buckets (u16 tile ids)
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
@@ -480,7 +538,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
             P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
             colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
             at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
-            (runbin && g_tile_clip.load()) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt));
+            (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt));
         GS_LAUNCHED("preprocess_fwd");
     }
     {
@@ -515,8 +573,8 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     char* bin = nullptr;
     static const bool trace = getenv("GSRAST_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
-    if (const uint32_t hint = g_R_hint.load()) {
-        cap = grow(hint); capQ = grow(g_Q_hint.load());
+    if (const uint32_t hint = ctx->R_hint.load()) {
+        cap = grow(hint); capQ = grow(ctx->Q_hint.load());
         bin = (char*)binning_alloc(binning_ctx, bin_bytes(cap, capQ));
         if (!bin) cap = capQ = 0;
     }
@@ -537,7 +595,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
             emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
-                                                                   g_tile_clip.load(), capQ_, rkA, rvA);
+                                                                   o.tile_clip, capQ_, rkA, rvA);
             GS_LAUNCHED("emit_column_runs"); }
         const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
         {   ProfScope ps(K_SORT_TILE, s);
@@ -564,10 +622,10 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
         BlendArgs ba{};
         ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
         ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
-        const int ppl = pick_ppl(T, false);
-        const bool cull = g_cull.load() != 0 && g_ppl_fwd.load() == 0;   // a forced pixels-per-lane selects the un-culled template
+        const int ppl = pick_ppl(T, false, o);
+        const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
-        if (cull && g_lpt.load()) {
+        if (cull && o.lpt) {
             if (buckets_ok && fwd_lists_built) { ba.from_buckets = 1; grid = (uint32_t)(XCD_GROUPS * xcd_group_tiles_host((size_t)cam.gx, (size_t)cam.gy)); }   // the tile-range kernel already bucketed the tiles
             else {
                 uint32_t* ord = at<uint32_t>(img, IL.order_fwd);
@@ -576,7 +634,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
                 ba.order = ord;
             }
         }
-        switch (g_exp_mode.load()) {
+        switch (o.exp_mode) {
         case 0: if (cull) launch_fwd_cull<0>(grid, s, ba); else dispatch_fwd<0>(ppl, grid, s, ba); break;
         case 1: if (cull) launch_fwd_cull<1>(grid, s, ba); else dispatch_fwd<1>(ppl, grid, s, ba); break;
         default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
@@ -591,7 +649,7 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     // Speculative launch: with a buffer sized from the previous call, binning and blend are enqueued BEFORE the host knows
     // R and Q (the kernels read the counts on the device), so the GPU never idles on the read-back.  If the counts turn
     // out not to fit, the device published empty ranges and the two pieces are simply launched again with exact sizes.
-    const bool speculative = runbin && bin != nullptr && g_speculative.load() != 0;
+    const bool speculative = runbin && bin != nullptr && o.speculative != 0;
     if (speculative) {
         int rc = launch_run_binning(bin, cap, capQ, capQ, scalars);
         if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true);
@@ -607,11 +665,11 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
     const uint32_t R = counts[0], Q = counts[1];
     // capacity hints decay slowly: consecutive calls render different views, a buffer sized for the largest recent one
     // keeps the speculative launch valid
-    { const uint32_t hr = g_R_hint.load(), hq = g_Q_hint.load();
-      g_R_hint = R > hr - hr / 16 ? R : hr - hr / 16; g_Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
-    g_last_R = R; g_last_Q = Q;
+    { const uint32_t hr = ctx->R_hint.load(), hq = ctx->Q_hint.load();
+      ctx->R_hint = R > hr - hr / 16 ? R : hr - hr / 16; ctx->Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
+    ctx->last_R = R; ctx->last_Q = Q;
     if (speculative && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
-    if (speculative) g_redo_count++;
+    if (speculative) ctx->redo_count++;
     if (speculative)    // redo: the truncated pass already appended every tile to the work buckets once
         GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, (XCD_GROUPS + 1) * WORK_BUCKETS * sizeof(uint32_t), s));
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)
@@ -998,13 +1056,32 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
                     const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream)
 {
+    return gsrast_backward_ex(nullptr, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                              cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                              image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                              dL_dscale, dL_drot, stream);
+}
+
+int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                       float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                       const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream)
+{
+    const gsrast_options o = options ? *options : snapshot_defaults();
+    if (!options_valid(o)) return fail(GSRAST_E_ARG, "backward: bad option value");
     hipStream_t s = (hipStream_t)stream;
     const int W = width, H = height;
     if (P < 0 || R < 0 || W <= 0 || H <= 0) return fail(GSRAST_E_ARG, "backward: bad sizes");
     if (P == 0) return GSRAST_OK;
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail(GSRAST_E_ARG, "backward: NULL state buffer");
     if (!means3D || !radii || !viewmatrix || !projmatrix || !dL_dpix || !background) return fail(GSRAST_E_ARG, "backward: NULL required input");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D) return fail(GSRAST_E_ARG, "backward: NULL gradient output");
+    if (!dL_dmean2D || !dL_dopacity || !dL_dmean3D) return fail(GSRAST_E_ARG, "backward: NULL gradient output");
+    if (colors_precomp && !dL_dcolor) return fail(GSRAST_E_ARG, "backward: colors_precomp path needs dL_dcolor");
+    if (dL_dconic && ((uintptr_t)dL_dconic & 15)) return fail(GSRAST_E_ARG, "backward: dL_dconic must be 16-byte aligned");
+    if (rotations && (((uintptr_t)rotations | (uintptr_t)dL_drot) & 15)) return fail(GSRAST_E_ARG, "backward: rotations / dL_drot must be 16-byte aligned");
     if (cov3D_precomp && !dL_dcov3D) return fail(GSRAST_E_ARG, "backward: cov3D_precomp path needs dL_dcov3D");
     const bool use_sh = shs && !colors_precomp;
     const bool use_sr = !cov3D_precomp;
@@ -1019,6 +1096,9 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
     const uint32_t* plist = bin ? at<uint32_t>(bin, 0) : nullptr;     // BinLayout: point_list lives at offset 0
     const float4* rec0 = at<float4>(geom, GL.rec0); const float4* rec1 = at<float4>(geom, GL.rec1); const float4* rec2 = at<float4>(geom, GL.rec2);
 
+    // per-Gaussian gradient records: the only memory the backward accumulates into (64 B / Gaussian, in the geometry buffer)
+    float* grec = at<float>(geom, GL.grec);
+    GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
     if (R > 0) {
         ProfScope ps(K_BLEND_BWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;
@@ -1028,10 +1108,10 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         BlendArgs ba{};
         ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
         ba.bg = background; ba.fT = const_cast<float*>(fT); ba.nc = const_cast<uint32_t*>(nc); ba.tm = const_cast<uint32_t*>(tm);
-        ba.dpix = dL_dpix; ba.dm2 = dL_dmean2D; ba.dcon = dL_dconic; ba.dop = dL_dopacity; ba.dcol = dL_dcolor;
-        const int ppl = pick_ppl(T, true);
-        const bool cull = g_cull.load() != 0;
-        if (cull && g_lpt.load()) {
+        ba.dpix = dL_dpix; ba.grec = grec;
+        const int ppl = pick_ppl(T, true, o);
+        const bool cull = o.cull != 0;
+        if (cull && o.lpt) {
             if (T <= BUCKET_MAX_TILES) {      // the forward blend appended every tile to the backward work buckets
                 ba.bcnt = const_cast<uint32_t*>(at<uint32_t>(img, IL.bucket_cnt)); ba.blist = const_cast<uint16_t*>(at<uint16_t>(img, IL.bucket_list));
                 ba.from_buckets = 1;
@@ -1045,7 +1125,7 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         if (g_ablate.load() == 1) launch_bwd<0, 4, 1>(grid, s, ba);
         else if (g_ablate.load() == 2) launch_bwd<0, 4, 2>(grid, s, ba);
         else
-        switch (g_exp_mode.load()) {
+        switch (o.exp_mode) {
         case 0: if (cull) dispatch_bwd_cull<0>(ppl, grid, s, ba); else dispatch_bwd<0>(ppl, grid, s, ba); break;
         case 1: if (cull) dispatch_bwd_cull<1>(ppl, grid, s, ba); else dispatch_bwd<1>(ppl, grid, s, ba); break;
         default: if (cull) dispatch_bwd_cull<2>(ppl, grid, s, ba); else dispatch_bwd<2>(ppl, grid, s, ba); break;
@@ -1057,8 +1137,8 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
         preprocess_bwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, radii, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
-            use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, dL_dmean2D, dL_dconic, dL_dcolor,
-            dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, (use_sh && g_sh_grad_factors.load()) ? 1 : 0);
+            use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, reinterpret_cast<const float4*>(grec),
+            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, (use_sh && o.sh_grad_factors) ? 1 : 0);
         GS_LAUNCHED("preprocess_bwd");
     }
     return GSRAST_OK;

@@ -28,10 +28,14 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   offsets  u32[P]      inclusive scan of tiles[] in depth order
 //   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
 //   scalars  u32[64]     [0] = num_rendered
+//   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
+//                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
+//                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
     size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, total;
+        hist, scan_tmp, scalars, grec, total;
 };
+constexpr int GREC = 16;            // floats per gradient record
 // Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
 //   valA/B u32[C] x2  Gaussian id ping-pong (valA at offset 0 = the final point_list)
 //   keyA/B u32[C] x2  tile id ping-pong (16-bit ids up to 65 536 tiles), hist u32[256*nblk(C)], scan_tmp
@@ -98,6 +102,7 @@ static inline GeomLayout geom_layout(size_t P)
     size_t st = scan_tmp_elems(hist_n) > scan_tmp_elems(Pp) ? scan_tmp_elems(hist_n) : scan_tmp_elems(Pp);
     L.scan_tmp = take(st * 4);
     L.scalars = take(256);
+    L.grec = take(Pp * GREC * 4);
     L.total = o + 256;
     return L;
 }

@@ -442,8 +442,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ shs, const unsigned char* __restrict__ clamped,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ cov3D /* internal or precomp */, CamArgs cam_args,
-                      const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic,
-                      const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans3D,
+                      const float4* __restrict__ grec /* [P][4]: the blend backward's gradient records (GeomLayout::grec) */,
+                      float* __restrict__ dL_dmean2D /* [P][3] out */, float* __restrict__ dL_dconic /* [P][4] out, may be null */,
+                      float* __restrict__ dL_dopacity /* [P] out */, float* __restrict__ dL_dcolor /* [P][3] out, may be null */,
+                      float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drot,
                       int sh_factors /* dL_dsh is [P][3]: receives the factor g of every Gaussian instead of the rows */)
@@ -464,17 +466,23 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         s[0] = scales[3 * ic]; s[1] = scales[3 * ic + 1]; s[2] = scales[3 * ic + 2];
         q_in = reinterpret_cast<const float4*>(rotations)[ic];
     }
-    const float4 dcon = reinterpret_cast<const float4*>(dL_dconic)[ic];
-    const float g2x = dL_dmean2D[3 * (size_t)ic], g2y = dL_dmean2D[3 * (size_t)ic + 1];
-    float dcol[3] = { 0.f, 0.f, 0.f };
+    // the Gaussian's gradient record: {dL/dmean2D.x, .y, dL/dconic a, b | c, dL/dopacity, dL/dr, dL/dg | dL/db, ...} -- three 16-byte
+    // loads from one 64-byte line (zero for a Gaussian no tile listed)
+    const float4 gr0 = grec[4 * (size_t)ic], gr1 = grec[4 * (size_t)ic + 1], gr2 = grec[4 * (size_t)ic + 2];
+    const float4 dcon = make_float4(gr0.z, gr0.w, 0.0f, gr1.x);          // reference layout: .z is never written (backward.cu:549-551)
+    const float g2x = gr0.x, g2y = gr0.y;
+    const float dcol[3] = { gr1.z, gr1.w, gr2.x };
     unsigned char clamped_in = 0;
-    if (shs) {                                              // uniform
-        dcol[0] = dL_dcolor[3 * (size_t)ic]; dcol[1] = dL_dcolor[3 * (size_t)ic + 1]; dcol[2] = dL_dcolor[3 * (size_t)ic + 2];
-        clamped_in = clamped[ic];
-    }
+    if (shs) clamped_in = clamped[ic];                      // uniform
     if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
     const Cam cam = load_cam(cam_args);
     const bool live = i < P && radius_in > 0;
+    if (i < P) {    // the screen-space gradients leave in the reference's arrays (rasterize_points.cu:150-158), written once
+        dL_dmean2D[3 * (size_t)i] = g2x; dL_dmean2D[3 * (size_t)i + 1] = g2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+        dL_dopacity[i] = gr1.y;
+        if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = dcol[0]; dL_dcolor[3 * (size_t)i + 1] = dcol[1]; dL_dcolor[3 * (size_t)i + 2] = dcol[2]; }
+        if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[i] = dcon;
+    }
     if (i < P && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dmeans3D[3 * (size_t)i + k] = 0.0f;

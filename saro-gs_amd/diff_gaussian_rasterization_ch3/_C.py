@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import List, Optional, Tuple
 
 import torch
@@ -35,7 +36,45 @@ EXPORTS = (
     "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward", "gsrast_linear_wgrad",
+    "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query",
+    "gsrast_forward_ex", "gsrast_backward_ex",
 )
+
+
+class OptionsStruct(C.Structure):
+    """gsrast_options (include/gsrast.h): everything that changes what ONE call computes / how it is scheduled."""
+    _fields_ = [("exp_mode", C.c_int), ("binning", C.c_int), ("tile_clip", C.c_int), ("cull", C.c_int), ("lpt", C.c_int),
+                ("speculative", C.c_int), ("fwd_pixels_per_lane", C.c_int), ("bwd_pixels_per_lane", C.c_int),
+                ("sh_grad_factors", C.c_int), ("reserved", C.c_int * 7)]
+
+
+# Per-call options are kept PER HOST THREAD on the Python side and travel with every call (gsrast_forward_ex /
+# gsrast_backward_ex): two threads rendering on two streams with different options never see each other's settings.
+PER_CALL_OPTIONS = ("exp_mode", "binning", "tile_clip", "cull", "lpt", "speculative", "fwd_pixels_per_lane", "bwd_pixels_per_lane")
+_OPTION_DEFAULTS = dict(exp_mode=0, binning=0, tile_clip=1, cull=1, lpt=1, speculative=1, fwd_pixels_per_lane=0, bwd_pixels_per_lane=0)
+_OPTION_RANGE = dict(exp_mode=(0, 1, 2), binning=(0, 1), fwd_pixels_per_lane=(0, 1, 2, 4), bwd_pixels_per_lane=(0, 1, 2, 4))
+_tls = threading.local()
+
+
+def _thread_options() -> dict:
+    o = getattr(_tls, "options", None)
+    if o is None:
+        o = _tls.options = dict(_OPTION_DEFAULTS)
+    return o
+
+
+def current_options() -> dict:
+    """A copy of the calling thread's per-call options.  The autograd node stores it at forward time: autograd runs the
+    backward on ITS OWN worker thread, which must use the options of the thread that issued the forward."""
+    return dict(_thread_options())
+
+
+def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None) -> OptionsStruct:
+    o = OptionsStruct()
+    for k, v in (_thread_options() if options is None else options).items():
+        setattr(o, k, int(v))
+    o.sh_grad_factors = int(bool(sh_grad_factors))
+    return o
 
 
 class AdamGroupStruct(C.Structure):
@@ -67,6 +106,17 @@ def lib() -> C.CDLL:
     L.gsrast_backward.restype = ci
     L.gsrast_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.gsrast_forward_ex.restype = ci
+    L.gsrast_forward_ex.argtypes = [vp, C.POINTER(OptionsStruct)] + L.gsrast_forward.argtypes
+    L.gsrast_backward_ex.restype = ci
+    L.gsrast_backward_ex.argtypes = [C.POINTER(OptionsStruct)] + L.gsrast_backward.argtypes
+    L.gsrast_options_init.restype = None
+    L.gsrast_options_init.argtypes = [C.POINTER(OptionsStruct)]
+    L.gsrast_context_create.restype = vp
+    L.gsrast_context_destroy.restype = None
+    L.gsrast_context_destroy.argtypes = [vp]
+    L.gsrast_context_query.restype = ci
+    L.gsrast_context_query.argtypes = [vp, C.c_char_p]
     L.gsrast_mark_visible.restype = ci
     L.gsrast_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
     for name in ("gsrast_geometry_bytes",):
@@ -161,7 +211,14 @@ class GradArena:
     unpack copies (the same idea as DDP's gradient-as-bucket-view).  The screen-space gradient
     (means2D) is deliberately NOT in the bucket: the reference only ever uses its per-view norm
     (train.py:212), which is reduced separately as a [P] statistic.  Not part of the reference's _C:
-    without an arena the outputs are ordinary tensors, exactly as before."""
+    without an arena the outputs are ordinary tensors, exactly as before.
+
+    Contract: the arena holds the gradients of ONE step.  The first backward after ``zero_grad()`` writes its leaf gradients
+    into the arena (autograd adopts the views as ``.grad``); a further backward before the next ``zero_grad()`` -- the
+    reference's batch loop, or ``views_of_rank`` yielding several views per rank -- gets ordinary tensors, which autograd
+    ADDS into those ``.grad`` views (the sum of the views' gradients, as ``cache_gradient`` keeps it,
+    scene/saro_gaussian.py:242-247).  With ``sh_factors=True`` a second backward raises: the factor buffer holds exactly one
+    view's factor.  Call ``zero_grad()`` (after ``optimizer.zero_grad(set_to_none=True)``) at the start of every step."""
 
     ORDER = (("means3D", 3), ("sh", None), ("opacity", 1), ("scales", 3), ("rotations", 4))
     # sh_factors=True: the dense part first (one contiguous all-reduce), dL/dsh last -- it is not exchanged at all: the
@@ -176,14 +233,20 @@ class GradArena:
         self.offsets, o = {}, 0
         for name, _ in order:
             self.offsets[name] = o
-            o += P * self.widths[name]
+            o += ((P * self.widths[name] + 3) // 4) * 4        # every segment starts on a 16-byte boundary (float4 stores of dL/drot)
         self.flat = torch.zeros(o, dtype=torch.float32, device=device)
+        self.dirty = False                                     # a backward has written this step's gradients
         if sh_factors:
             self.dense = self.flat[: self.offsets["sh"]]                      # 11 floats / Gaussian: the all-reduced part
             self.chunk = ((3 * P + 3 + 3) // 4) * 4                            # [3P g | 3 campos | pad], 16-byte multiple
             self.factor = torch.zeros(self.chunk, dtype=torch.float32, device=device)
             self.gathered = torch.zeros(self.world * self.chunk, dtype=torch.float32, device=device)
         self.last_degree = 0
+
+    def zero_grad(self) -> None:
+        """Start of a step: the next backward writes into the arena again.  (Does not touch memory: the backward overwrites
+        every element; set the leaves' .grad to None first, or autograd would add the arena to itself.)"""
+        self.dirty = False
 
     def take(self, name: str, shape, zero: bool) -> torch.Tensor:
         n = self.P * self.widths[name]
@@ -258,7 +321,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     try:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rendered = L.gsrast_forward(
+            rendered = L.gsrast_forward_ex(
+                None, C.byref(_options_struct()),       # context: the calling thread's own (capacity hints of the speculative launch)
                 arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
                 P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
@@ -273,10 +337,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer):
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, *, options: Optional[dict] = None):
     """Backward.  Mirrors RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-194): returns
     ``(dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6],
-    dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])``."""
+    dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])``.  `options` (not in the reference): the per-call options to use
+    instead of the calling thread's (current_options() captured at forward time)."""
     dev = _require_gpu(means3D)
     L = lib()
     P = int(means3D.shape[0])
@@ -288,32 +353,30 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dout_color = f(dL_dout_color, "dL_dout_color")
     M = int(sh.shape[1]) if sh.numel() != 0 else 0
     opts = dict(dtype=torch.float32, device=dev)
-    # accumulated with atomics -> zero-filled (44 B/Gaussian); everything else is written exactly
-    # once by the fused per-Gaussian backward kernel, so no 300 B/Gaussian memset as in the reference
     use_sh = sh.numel() != 0 and colors.numel() == 0
     use_sr = cov3D_precomp.numel() == 0
     ar = _grad_arena
     if ar is not None and not (ar.P == P and ar.M == M and use_sh and use_sr and ar.flat.device == dev):
         ar = None                       # the arena only serves the SH + scale/rotation training path
+    if ar is not None and ar.dirty:     # a second backward of the same step (GradArena docstring)
+        if ar.sh_factors:
+            raise RuntimeError("GradArena(sh_factors=True): a second backward before zero_grad() would overwrite the first view's "
+                               "factor; use one view per rank and exchange, or the plain arena (which accumulates)")
+        ar = None                       # ordinary tensors: autograd adds them into the arena views it adopted as .grad
+    if ar is not None:
+        ar.dirty = True
 
     def out(name, shape, zero):
         if ar is not None and name in ar.offsets:
             return ar.take(name, shape, zero)
         return torch.zeros(shape, **opts) if zero else torch.empty(shape, **opts)
 
-    # the four atomically accumulated arrays share ONE zero-filled allocation (one fill kernel, 44 B/Gaussian)
-    if ar is None:
-        zbuf = torch.zeros(P * 11, **opts)
-        dL_dmeans2D = zbuf[: 3 * P].view(P, 3)
-        dL_dconic = zbuf[3 * P: 7 * P].view(P, 2, 2)
-        dL_dopacity = zbuf[7 * P: 8 * P].view(P, 1)
-        dL_dcolors = zbuf[8 * P: 11 * P].view(P, NUM_CHANNELS)
-    else:
-        zbuf = torch.zeros(P * 10, **opts)
-        dL_dmeans2D = zbuf[: 3 * P].view(P, 3)
-        dL_dconic = zbuf[3 * P: 7 * P].view(P, 2, 2)
-        dL_dcolors = zbuf[7 * P: 10 * P].view(P, NUM_CHANNELS)
-        dL_dopacity = out("opacity", (P, 1), True)
+    # Nothing is zero-filled here: the library accumulates into its own 64-byte-per-Gaussian records inside geomBuffer and
+    # writes every returned array exactly once (include/gsrast.h).  dL_dconic (an intermediate of the reference) is not
+    # requested at all.
+    dL_dmeans2D = torch.empty((P, 3), **opts)
+    dL_dopacity = out("opacity", (P, 1), False)
+    dL_dcolors = torch.empty((P, NUM_CHANNELS), **opts)
     dL_dmeans3D = out("means3D", (P, 3), False)
     # with scales / rotations dL_dcov3D is an intermediate nobody reads (the autograd node returns None for the absent
     # cov3D_precomp input): not computed, not written -- the binding returns an empty tensor in its place
@@ -331,20 +394,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             sh_out = ar.factor.data_ptr() if factors else _ptr(dL_dsh)
-            if factors:
-                L.gsrast_set_option(b"sh_grad_factors", 1)
-            try:
-                rc = L.gsrast_backward(
-                    P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-                    _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
-                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
-                    dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                    dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
-                    dL_drotations.data_ptr(), stream)
-            finally:
-                if factors:
-                    L.gsrast_set_option(b"sh_grad_factors", 0)
+            rc = L.gsrast_backward_ex(
+                C.byref(_options_struct(sh_grad_factors=factors, options=options)),      # per call: no process-wide switch is flipped
+                P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
+                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
+                dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
+                dL_drotations.data_ptr(), stream)
         if rc != 0:
             raise _err(rc, "gsrast_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
@@ -385,11 +443,28 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
 
 # ---- not part of the reference's _C: options, profiling and the parity-test state export --------
 def set_option(name: str, value: int) -> None:
-    if lib().gsrast_set_option(name.encode(), int(value)) != 0:
+    """Per-call options (PER_CALL_OPTIONS; "pixels_per_lane" sets both directions) are set for the CALLING THREAD and passed
+    with each of its calls; the process-wide diagnostics ("profile", "debug_sync", "hexplane_scatter", ...) go to the library."""
+    value = int(value)
+    names = ("fwd_pixels_per_lane", "bwd_pixels_per_lane") if name == "pixels_per_lane" else (name,)
+    if all(n in _OPTION_DEFAULTS for n in names):
+        for n in names:
+            if n in _OPTION_RANGE:
+                if value not in _OPTION_RANGE[n]:
+                    raise ValueError(f"gsrast: unknown option or bad value: {name}={value}")
+                _thread_options()[n] = value
+            else:
+                _thread_options()[n] = 1 if value else 0
+        return
+    if lib().gsrast_set_option(name.encode(), value) != 0:
         raise ValueError(f"gsrast: unknown option or bad value: {name}={value}")
 
 
 def get_option(name: str) -> int:
+    if name == "pixels_per_lane":
+        name = "fwd_pixels_per_lane"
+    if name in _OPTION_DEFAULTS:
+        return int(_thread_options()[name])
     return int(lib().gsrast_get_option(name.encode()))
 
 

@@ -57,12 +57,20 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         rs = raster_settings
+        ar = _C._grad_arena
+        if ar is not None and ar.sh_factors and sh.numel() != 0 and sh.requires_grad and not sh.is_leaf:
+            # factor mode completes shs.grad later (sh_grad_combine writes the arena): that only reaches the parameters if
+            # shs itself is the leaf.  cat(features_dc, features_rest) (get_features) would copy the unfinished buffer.
+            raise RuntimeError("GradArena(sh_factors=True) needs the rasterizer's `shs` to be a leaf tensor; for "
+                               "cat(features_dc, features_rest) or shs + residual use GradArena(sh_factors=False) + "
+                               "view_parallel.allreduce_mean_inplace")
         num_rendered, color, radii, geom_buf, bin_buf, img_buf, depth = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
             rs.sh_degree, rs.campos, rs.prefiltered)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.gs_options = _C.current_options()      # the backward runs on autograd's thread: it must use THIS thread's options
         # opacities are not saved: the state buffer keeps them next to the conic (REF:84)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buf, bin_buf, img_buf)
@@ -81,7 +89,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
-            geom_buf, ctx.num_rendered, bin_buf, img_buf)
+            geom_buf, ctx.num_rendered, bin_buf, img_buf, options=ctx.gs_options)
         # one gradient per forward input, in input order; absent optionals get None
         def opt(g, x):
             return g if x.numel() != 0 else None

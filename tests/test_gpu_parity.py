@@ -474,6 +474,7 @@ def test_sh_gradient_factor_exchange(deg, scenes, rast, gpu):
     try:
         chunks, dense = [], torch.zeros_like(arena.dense)
         for k in range(V):
+            arena.zero_grad()           # every "rank" starts its own step
             lv = run(k)
             chunks.append(arena.factor.clone())
             dense += arena.dense
@@ -600,3 +601,115 @@ def test_cov3d_against_reference_python_vectors(scenes, rast, gpu):
         assert vis.mean() > 0.9
         tol = 2e-6 * np.abs(want).max(axis=1, keepdims=True)
         assert (np.abs(h["cov3D"] - want)[vis] <= tol[vis]).all()
+
+
+def test_grad_arena_contract(scenes, rast, gpu):
+    """GradArena: P not a multiple of 4 (every segment still starts 16-byte aligned: dL/drot leaves through float4 stores); a second
+    backward of the same step ADDS (the reference's batch loop, cache_gradient); factor mode refuses what it cannot do -- a second
+    backward before zero_grad(), or an `shs` that is not a leaf (cat(features_dc, features_rest))."""
+    import torch
+    from conftest import settings_from
+    P, W, H = 3001, 128, 96
+    sc = scenes.synth(P, 83)
+    g = torch.as_tensor(scenes.upstream_grad(H, W, 84), device=gpu)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    _C = rast._C
+
+    def render(leaves, k, shs=None):
+        cam = scenes.camera(k, 4, W, H)
+        rs = settings_from(rast, cam, sc, gpu)
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        color, _, _ = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                  shs=leaves["shs"] if shs is None else shs, scales=leaves["scales"], rotations=leaves["rotations"])
+        return color
+
+    def fresh():
+        return {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+
+    plain = fresh()
+    for k in (0, 1):
+        render(plain, k).backward(g)                 # autograd sums the two views' gradients
+    arena = _C.GradArena(P, 16, gpu)
+    assert all(o % 4 == 0 for o in arena.offsets.values()) and arena.flat.data_ptr() % 16 == 0
+    _C.set_grad_arena(arena)
+    try:
+        lv = fresh()
+        arena.zero_grad()
+        for k in (0, 1):
+            render(lv, k).backward(g)
+        lo, hi = arena.flat.data_ptr(), arena.flat.data_ptr() + arena.flat.numel() * 4
+        for n in plain:
+            a, b = plain[n].grad, lv[n].grad
+            assert lo <= b.data_ptr() < hi, f"{n}.grad left the arena"
+            assert ((a - b).abs() <= 1e-6 + 1e-4 * a.abs()).all(), n
+    finally:
+        _C.set_grad_arena(None)
+    fa = _C.GradArena(P, 16, gpu, sh_factors=True, world=1)
+    _C.set_grad_arena(fa)
+    try:
+        lv = fresh()
+        fa.zero_grad()
+        render(lv, 0).backward(g)
+        with pytest.raises(RuntimeError, match="second backward"):
+            render(lv, 1).backward(g)
+        fa.zero_grad()
+        dc, rest = lv["shs"].detach()[:, :1].clone().requires_grad_(True), lv["shs"].detach()[:, 1:].clone().requires_grad_(True)
+        with pytest.raises(RuntimeError, match="leaf"):
+            render(lv, 0, shs=torch.cat([dc, rest], dim=1))
+    finally:
+        _C.set_grad_arena(None)
+
+
+def test_two_threads_two_streams_different_options(orc, scenes, rast, gpu):
+    """The C ABI is reentrant (include/gsrast.h, gsrast_forward_ex / gsrast_backward_ex): two host threads on two streams, each
+    with its OWN options (thread A: the reference's literal lists + instance-level binning + 2 pixels per lane in the backward;
+    thread B: product defaults), interleaved for many iterations, reproduce their single-threaded results bit for bit (forward)
+    and within the float-atomic band (backward)."""
+    import threading
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    jobs = {"A": dict(P=6000, W=320, H=208, seed=91, opts=dict(tile_clip=0, binning=1, bwd_pixels_per_lane=2, speculative=0)),
+            "B": dict(P=9000, W=256, H=256, seed=92, opts=dict())}
+
+    def run(job, n_iter, out, opts_after=None):
+        for k, v in job["opts"].items():
+            _C.set_option(k, v)                       # per-thread
+        sc = scenes.synth(job["P"], job["seed"])
+        cam = scenes.camera(1, 3, job["W"], job["H"])
+        rs = settings_from(rast, cam, sc, gpu)
+        g = t(scenes.upstream_grad(job["H"], job["W"], job["seed"] + 1))
+        stream = torch.cuda.Stream(device=gpu)
+        res = []
+        with torch.cuda.stream(stream):
+            for _ in range(n_iter):
+                lv = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+                m2 = torch.zeros((job["P"], 3), device=gpu, requires_grad=True)
+                color, radii, depth = rast.GaussianRasterizer(rs)(means3D=lv["means3D"], means2D=m2, opacities=lv["opacities"], shs=lv["shs"],
+                                                                  scales=lv["scales"], rotations=lv["rotations"])
+                color.backward(g)
+                res.append((color.detach().clone(), depth.clone(), radii.clone(), {k: v.grad.clone() for k, v in lv.items()}, _C.get_option("last_instances")))
+            stream.synchronize()
+        out.extend(res)
+        if opts_after is not None:
+            opts_after.update({k: _C.get_option(k) for k in ("tile_clip", "binning", "bwd_pixels_per_lane")})
+
+    single = {}
+    for name, job in jobs.items():                    # single-threaded references, each in a fresh thread (fresh per-thread options)
+        out = []
+        th = threading.Thread(target=run, args=(job, 1, out)); th.start(); th.join()
+        single[name] = out[0]
+    outs, seen = {"A": [], "B": []}, {"A": {}, "B": {}}
+    ths = [threading.Thread(target=run, args=(jobs[n], 12, outs[n], seen[n])) for n in ("A", "B")]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    assert seen["A"] == dict(tile_clip=0, binning=1, bwd_pixels_per_lane=2) and seen["B"] == dict(tile_clip=1, binning=0, bwd_pixels_per_lane=0)
+    assert _C.get_option("tile_clip") == 1 and _C.get_option("binning") == 0        # the main thread's options were never touched
+    for n in ("A", "B"):
+        c0, d0, r0, g0, R0 = single[n]
+        assert len(outs[n]) == 12
+        for c, d, r, gr, R in outs[n]:
+            assert torch.equal(c, c0) and torch.equal(d, d0) and torch.equal(r, r0) and R == R0
+            for k in g0:
+                assert ((gr[k] - g0[k]).abs() <= 1e-6 + 1e-4 * g0[k].abs()).all(), (n, k)
