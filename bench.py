@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--sweep-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ablate", type=int, default=0, help="kernel ablation experiments (not a valid bench)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option for A/B experiments (repeatable)")
     ap.add_argument("--ppl", type=int, default=0, help="force pixels per lane of both blend kernels (0 = auto)")
     ap.add_argument("--ppl-fwd", type=int, default=0)
     ap.add_argument("--ppl-bwd", type=int, default=0)
@@ -645,6 +646,9 @@ def main():
     exp_mode = _C.get_option("exp_mode")
     if a.ablate:
         _C.set_option("ablate", a.ablate)
+    for kv in a.opt:
+        name, _, val = kv.partition("=")
+        _C.set_option(name, int(val))
     if a.ppl:
         _C.set_option("pixels_per_lane", a.ppl)
     if a.ppl_fwd:

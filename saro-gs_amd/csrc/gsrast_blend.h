@@ -573,6 +573,11 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
 // strip still needs; the ballots are 64-bit SGPR masks, the blend loop walks their union with
 // s_ff1 and enters pixel slot k only if bit j of mask k is set -- a scalar branch, no VALU work for
 // untouched strips.
+// Measured alternatives for the last steps of the cross-lane sums (all slower than the in-register butterfly below, 0.43 ms):
+// ds_add_f32 LDS atomics after three butterfly steps, 8 lanes per address: 0.91 ms; after four steps, 4 lanes per address:
+// 0.55 ms (same-address LDS atomics serialise); row totals combined through a 36-float LDS scratch (one ds_write_b32 + one
+// ds_read_b128 instead of the two ds_bpermute exchanges and the ninth value's row_bcast steps): 0.44 ms (one more LDS round trip
+// in the dependency chain costs more than the exchanges it removes).
 template <int EXPMODE, int PPL>
 __global__ void __launch_bounds__(256 / PPL)
 blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -596,7 +601,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     // one accumulator slice per wave (plain LDS read-add-write, no LDS atomics); a staged instance's nine sums are adjacent, like
     // the record they are committed to
     constexpr int AS = 12;
-    __shared__ __attribute__((aligned(16))) float acc[NW][BATCH][AS];
+    constexpr int NS = NW;                          // accumulator slices
+    __shared__ __attribute__((aligned(16))) float acc[NS][BATCH][AS];
 
     __shared__ uint32_t s_tile;
     if (blockIdx.x >= ntiles) return;
@@ -643,7 +649,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     }
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     // factor applied by lane l (< 8) when it commits value l: {mean.x, mean.y, conic a, b, c, opacity, r, g}
-    const float commit_scale = lane == 0 ? -ddelx_dx : lane == 1 ? -ddely_dy : (lane >= 2 && lane <= 4) ? -0.5f : 1.0f;
+    const unsigned kind = lane;
+    const float commit_scale = kind == 0 ? -ddelx_dx : kind == 1 ? -ddely_dy : (kind >= 2 && kind <= 4) ? -0.5f : 1.0f;
 
     for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
@@ -657,7 +664,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 s2[slot] = make_float2(c.x, c.z);
             }
         }
-        for (uint32_t q4 = t; q4 < (uint32_t)(NW * BATCH * AS / 4); q4 += NT) reinterpret_cast<float4*>(&acc[0][0][0])[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t q4 = t; q4 < (uint32_t)(NS * BATCH * AS / 4); q4 += NT) reinterpret_cast<float4*>(&acc[0][0][0])[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
 #pragma unroll 1
@@ -769,7 +776,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
             if (q < 9u) {
                 float v = acc[0][slot][q];
 #pragma unroll
-                for (int w = 1; w < NW; w++) v += acc[w][slot][q];
+                for (int w = 1; w < NS; w++) v += acc[w][slot][q];
                 if (v != 0.f) atomicAdd(grec + (size_t)sid[slot] * GREC + q, v);
             }
         }
