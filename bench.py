@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--exp-mode", type=int, default=None, help="0 fixed-sequence (default), 1 ocml, 2 v_exp_f32")
     ap.add_argument("--sweep", type=str, default="100000,300000,1000000,3000000",
                     help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
-    ap.add_argument("--sweep-steps", type=int, default=10)
+    ap.add_argument("--sweep-steps", type=int, default=None, help="ignored: sweep points use --steps / --warmup like the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ablate", type=int, default=0, help="kernel ablation experiments (not a valid bench)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option for A/B experiments (repeatable)")
@@ -179,6 +179,129 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     if trace or d.max() > 20.0 * max(float(np.median(d)), 0.05):
         print("step host ms:", " ".join(f"{x:.2f}" for x in d), file=sys.stderr)
     return vp.max_over_ranks(dt, dev)
+
+
+def _profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def roofline_of(st, bwd_ms, P):
+    """The contract's roofline object for blend_bwd_cull_kernel: algorithmic bytes (N*20 + R_eff*40 + R_eff*36 per
+    launch) / its mean launch duration (HIP events on the launch stream, this run) / 8 TB/s.  `traffic` and `valu` are NOT
+    measured in this run: they are the per-launch PMC counters of the committed rocprofv3 passes (profiles/pmc_blend_bwd*.json
+    with the same number of Gaussians, collected by tools/collect_profiles.sh), priced with the measured issue costs of
+    profiles/r02_valu_calib.json / r02_valu_mix.json."""
+    bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
+    achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+    traffic, valu, src = None, None, None
+    for name in ("pmc_blend_bwd.json", "pmc_blend_bwd_3M.json"):
+        pj = _profile_json(name)
+        if pj and pj.get("gaussians", 1_000_000 if name == "pmc_blend_bwd.json" else 3_000_000) == P:
+            traffic, src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
+            vi = pj.get("valu_wave_insts_per_launch")
+            mix, cal = _profile_json("r02_valu_mix.json"), _profile_json("r02_valu_calib.json")
+            if vi and bwd_ms > 0 and mix and cal:
+                cyc = mix["kernels"]["blend_bwd_cull_kernel"]["avg_cycles_per_valu_inst"]
+                fma = max(r["wave_insts_per_s"] for r in cal["results"] if r["op"] == "v_fma_f32")
+                rate = vi / (bwd_ms * 1e-3)
+                valu = {"wave_insts_per_launch": vi, "wave_insts_per_s": round(rate, 1),
+                        "frac_of_measured_v_fma_f32_rate": round(rate / fma, 3),
+                        "avg_cycles_per_inst": cyc, "issue_slot_frac": round(vi * cyc / (1024 * 2.4e9 * bwd_ms * 1e-3), 3),
+                        "note": "SQ_INSTS_VALU per launch (committed rocprofv3 pass) x the kernel's static instruction mix priced with the "
+                                "MEASURED issue cost of each class (full-rate fma/mul/add 2.4 cycles per wave64 instruction and SIMD, "
+                                "half-rate dpp/cmp/cndmask/min/cvt/ldexp 4.1, quarter-rate rcp/exp 8.1: tools/valu_calib.hip) / "
+                                "(1024 SIMDs x 2.4 GHz x this run's launch duration)",
+                        "source": [src, "profiles/r02_valu_calib.json", "profiles/r02_valu_mix.json"]}
+            break
+    return {"kernel": "blend_bwd_cull_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_source": (src + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, committed; not measured in this run)") if src else None,
+            "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": round(bwd_ms, 4),
+            "note": "VALU-issue-bound kernel (valu.issue_slot_frac): see DESIGN.md 4; pair-evaluations/s is the telling rate",
+            "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
+            "valu": valu}
+
+
+def stage_table(_C, wl, st, P, deg, H):
+    """Per-stage device times (every stage bracketed with HIP events; separate, untimed pass) next to this build's algorithmic
+    bytes per launch."""
+    dev = wl.dev
+    _C.profile_reset()
+    _C.set_option("profile", -1)
+    for _ in range(10):
+        wl.step(None, 1)
+    torch.cuda.synchronize(dev)
+    pk = _C.profile_read()
+    _C.set_option("profile", 0)
+    C = (deg + 1) ** 2
+    Pv, R, Re, N, T = st["P_vis"], st["R"], st["R_eff"], st["N"], st["T"]
+    Rl, Q = st["R_listed"], st["Q"]
+    passes_t = 2 if T > 256 else 1
+    run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
+    alg = {
+        "preprocess_fwd": P * (44 + 12 * C) + Pv * 96 + P * 8,
+        "sort_depth": P * 20 * 4,
+        "scan_tiles": P * 12 if run_binning else P * 24,
+        # run-compressed: Q column runs of 10 B emitted, sorted by column (one pass), expanded once into Rl instances
+        "emit_instances": (P * 40 + Q * 10) if run_binning else (P * 24 + R * 6),
+        "sort_tile": (Q * 22 + Q * 16 + Rl * 4) if run_binning else R * 14 * passes_t,
+        "tile_ranges": T * 8 if run_binning else R * 2 + T * 8,
+        "blend_fwd": Re * 44 + N * 24,
+        "blend_bwd": N * 20 + Re * 76,
+        "preprocess_bwd": P * (24 * C + 173 + 64 + 28),       # + the gradient record read + dL/dmean2D, dL/dopacity, dL/dcolor written
+    }
+    per_kernel = {}
+    for name, nbytes in alg.items():
+        ms = pk[name][0] / max(pk[name][1], 1)
+        per_kernel[name] = {"ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+                            "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                            "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+    return per_kernel, pk
+
+
+def measure_point(rast, scenes, vp, P, W, H, deg, dev, steps, warmup, full=False):
+    """One more workload with the headline's protocol (same steps / warm-up).  full: also the roofline object and the stage table."""
+    _C = rast._C
+    wl = Workload(rast, scenes, P, W, H, deg, 0, 1, dev)
+    kid = {_C.lib().gsrast_profile_kernel_name(k).decode(): k for k in range(_C.lib().gsrast_profile_kernel_count())}
+    for _ in range(warmup):
+        wl.step(None, 1)
+    torch.cuda.synchronize(dev)
+    _C.profile_reset()
+    if full:
+        _C.set_option("profile", 1 << kid["blend_bwd"])
+    d = timed(wl, steps, 0, None, 1, vp, dev)
+    out = {"views_per_s": round(steps / d, 3), "ms_per_step": round(d / steps * 1e3, 4), "steps": steps, "warmup": warmup}
+    if full:
+        prof = _C.profile_read()
+        _C.set_option("profile", 0)
+        st = wl.stats()
+        bwd_ms = prof["blend_bwd"][0] / max(prof["blend_bwd"][1], 1)
+        out["config"] = {"gaussians": P, "width": W, "height": H, "instances_R": st["R"], "instances_listed": st["R_listed"],
+                         "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"]}
+        out["roofline"] = roofline_of(st, bwd_ms, P)
+        out["per_stage"], _ = stage_table(_C, wl, st, P, deg, H)
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def survey_metric(wl, steps, dev):
+    """SURVEY.md 8(d) / BASELINE.md 2 as written: 1 / median(t_fwd + t_bwd), device-synchronised wall clock around each call pair."""
+    ts = []
+    for _ in range(steps):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        wl.step(None, 1)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"views_per_s": round(1.0 / med, 3), "median_ms": round(med * 1e3, 4), "calls": steps,
+            "protocol": "1 / median over per-call device-synchronised wall-clock times of one forward + backward (SURVEY.md 8d)"}
 
 
 def cpu_baseline(scenes, P, W, H, deg, budget_s):
@@ -700,63 +823,16 @@ def main():
     _C.set_option("profile", 0)
 
     st = wl.stats()
-    # ---- per-stage device times (all stages bracketed with events; separate, untimed pass) ----
-    per_kernel = None
+    per_kernel, pk = (None, None)
     if world == 1:
-        _C.profile_reset()
-        _C.set_option("profile", -1)
-        for _ in range(10):
-            wl.step(None, 1)
-        torch.cuda.synchronize(dev)
-        pk = _C.profile_read()
-        _C.set_option("profile", 0)
-        C = (deg + 1) ** 2
-        Pv, R, Re, N, T = st["P_vis"], st["R"], st["R_eff"], st["N"], st["T"]
-        Rl, Q = st["R_listed"], st["Q"]
-        passes_t = 2 if T > 256 else 1
-        run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
-        alg = {   # algorithmic HBM bytes per launch of THIS build's stages
-            "preprocess_fwd": P * (44 + 12 * C) + Pv * 96 + P * 8,
-            "sort_depth": P * 20 * 4,
-            "scan_tiles": P * 12 if run_binning else P * 24,
-            # run-compressed: Q column runs of 10 B emitted, sorted by column (one pass), expanded once into Rl instances
-            "emit_instances": (P * 40 + Q * 10) if run_binning else (P * 24 + R * 6),
-            "sort_tile": (Q * 22 + Q * 16 + Rl * 4) if run_binning else R * 14 * passes_t,
-            "tile_ranges": T * 8 if run_binning else R * 2 + T * 8,
-            "blend_fwd": Re * 44 + N * 24,
-            "blend_bwd": N * 20 + Re * 76,
-            "preprocess_bwd": P * (24 * C + 173),
-        }
-        per_kernel = {}
-        for name, nbytes in alg.items():
-            ms = pk[name][0] / max(pk[name][1], 1)
-            per_kernel[name] = {"ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
-                                "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
-                                "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+        per_kernel, pk = stage_table(_C, wl, st, P, deg, H)
     result = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt
         bwd_ms = prof["blend_bwd"][0] / max(prof["blend_bwd"][1], 1)
         fwd_ms = pk["blend_fwd"][0] / max(pk["blend_fwd"][1], 1) if per_kernel else 0.0   # separate all-stages pass
-        # K5 = N*20 + R_eff*40 + R_eff*36 bytes per launch
-        bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
         fwd_bytes = st["R_eff"] * 44 + st["N"] * 24
-        achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-        traffic, valu = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get("hbm_bytes_per_launch")
-                vi = pj.get("valu_wave_insts_per_launch")
-                if vi and bwd_ms > 0:
-                    # a wave64 VALU instruction occupies its SIMD16 for 4 cycles; 1024 SIMDs at 2.4 GHz
-                    valu = {"wave_insts_per_launch": vi, "issue_slot_frac": round(vi * 4.0 / (1024 * 2.4e9 * bwd_ms * 1e-3), 3),
-                            "note": "fraction of the chip's VALU issue slots the kernel's VALU instructions need in its measured "
-                                    "duration (SQ_INSTS_VALU from profiles/, 4 cycles each, 1024 SIMDs, 2.4 GHz): the binding resource"}
-            except Exception:
-                traffic = None
         result = {
             "metric": "rendered views/s (fwd+bwd) at 1080p vs #Gaussians",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -769,13 +845,7 @@ def main():
                        "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
                        "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],
                        "blended_pairs_fwd": st["pairs_fwd"]},
-            "roofline": {"kernel": "blend_bwd_cull_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": bwd_bytes,
-                         "avg_launch_ms": round(bwd_ms, 4),
-                         "note": "VALU/atomic-bound kernel: see DESIGN.md; pair-evaluations/s is the telling rate",
-                         "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
-                         "valu": valu},
+            "roofline": roofline_of(st, bwd_ms, P),
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,
@@ -785,24 +855,23 @@ def main():
     # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----
     if world == 1 and a.sweep:
         sweep = {}
+        result["survey_metric"] = survey_metric(wl, a.steps, dev)
+        del wl
+        torch.cuda.empty_cache()
         for p in [int(x) for x in a.sweep.split(",") if x]:
             if p == P:
-                sweep[str(p)] = {"views_per_s": result["value"], "ms_per_step": result["ms_per_step"]}
+                sweep[str(p)] = {"views_per_s": result["value"], "ms_per_step": result["ms_per_step"], "steps": a.steps, "warmup": a.warmup}
                 continue
-            del wl
-            torch.cuda.empty_cache()
-            wl = Workload(rast, scenes, p, W, H, deg, 0, 1, dev)
-            d = timed(wl, a.sweep_steps, 3, None, 1, vp, dev)
-            sweep[str(p)] = {"views_per_s": round(a.sweep_steps / d, 3), "ms_per_step": round(d / a.sweep_steps * 1e3, 4)}
+            full = p == 3_000_000           # BASELINE.json configs[4]: the 3 M stress gets its own roofline object and stage table
+            m = measure_point(rast, scenes, vp, p, W, H, deg, dev, a.steps, a.warmup, full=full)
+            if full:
+                result["cfg5_3M_1080p"] = m
+            sweep[str(p)] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup")}
         result["sweep_1080p"] = sweep
         # the other single-GPU shapes BASELINE.json names (synthetic stand-ins): informational, same protocol
         other = {}
         for tag, p, w, h in (("cfg2_100k_800x800", 100_000, 800, 800), ("cfg3_1M_1352x1014", 1_000_000, 1352, 1014)):
-            del wl
-            torch.cuda.empty_cache()
-            wl = Workload(rast, scenes, p, w, h, deg, 0, 1, dev)
-            d = timed(wl, a.sweep_steps, 5, None, 1, vp, dev)
-            other[tag] = {"views_per_s": round(a.sweep_steps / d, 3), "ms_per_step": round(d / a.sweep_steps * 1e3, 4)}
+            other[tag] = measure_point(rast, scenes, vp, p, w, h, deg, dev, a.steps, a.warmup)
         result["baseline_configs"] = other
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

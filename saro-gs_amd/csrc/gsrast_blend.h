@@ -111,7 +111,11 @@ __device__ __forceinline__ bool strip_may_touch(const float4 a, const float cz, 
     const float q1 = 0.5f * (A * dxc * dxc + C * dy1 * dy1) + B * dxc * dy1;
     const float q2 = 0.5f * (A * dx2 * dx2 + C * dyc * dyc) + B * dx2 * dyc;
     const float qmin = fminf(q1, q2);
-    return -qmin >= thr + 0.01f;     // also false when thr > 0 (opacity below 1/255)
+    // The box minimum above is exact for a positive definite conic only.  The reference rejects det == 0 and nothing else
+    // (forward.cu:220): fp32 cancellation on needle-shaped Gaussians can leave an indefinite conic, which the blend still
+    // evaluates pixel by pixel -- such an instance is never culled here (it stays bit-identical, just not skipped).
+    const bool pd = A > 0.0f && C > 0.0f && A * C > B * B;
+    return (pd ? -qmin >= thr + 0.01f : true) && !(thr > 0.0f);     // thr > 0: opacity below 1/255, no pixel can pass
 }
 
 // Forward blend, 4 wave64 per tile, one pixel per lane, with wave-level culling (see above).
@@ -740,6 +744,10 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 GS_COUNT(4, 1); GS_COUNT(7, __popcll(__ballot(pos < last[0])));
                 if (!__any(contributed)) continue;
                 GS_COUNT(5, 1); GS_COUNT(6, __popcll(__ballot(contributed)));
+#if defined(GSRAST_ABLATE_REDUCE) && GSRAST_ABLATE_REDUCE == 1      // timing experiment: no products, no cross-lane sums
+                asm volatile("" :: "v"(dch[0]), "v"(dLa[0]), "v"(Gk[0]));
+                continue;
+#endif
                 float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {
@@ -762,6 +770,10 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     // total of value l & 7), the ninth through the DPP chain to lane 63, read back as a scalar;
                     // lanes 0..8 then commit all nine into this wave's accumulator slice with ONE LDS read-add-write.
                     const float v8[8] = { g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g };
+#if defined(GSRAST_ABLATE_REDUCE) && GSRAST_ABLATE_REDUCE == 2      // timing experiment: products, but no cross-lane sums
+                    asm volatile("" :: "v"(g_mx), "v"(g_my), "v"(g_ca), "v"(g_cb), "v"(g_cc), "v"(g_op), "v"(g_r), "v"(g_g), "v"(g_b));
+                    continue;
+#endif
                     const float tot = wave_sum8_transposed(v8, lane);
                     const float tb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(g_b)), 63));
                     if (lane < 9u) acc[wave][j][lane] += (lane < 8u ? tot : tb) * commit_scale;

@@ -2,24 +2,26 @@
 # Runs on the GPU box (via gpurun): default bench, rocprofv3 kernel-trace stats of the same command,
 # and the two HBM-traffic PMC passes.  Everything lands in gpurun_out/profiles_<tag>/ ; copy what is
 # to be judged into profiles/ (tools/install_profiles.py does that and derives pmc_blend_bwd.json).
-tag=${1:-r01}
+# usage: tools/collect_profiles.sh <tag> [bench args, e.g. --gaussians 3000000]
+tag=${1:-r01}; shift
+extra="$@"
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py > $out/bench_${tag}.json 2> $out/bench_${tag}.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python bench.py --sweep "" --no-cpu-baseline > $out/bench_${tag}_under_rocprof.json 2> $out/rocprof.err
+timeout 600 python bench.py $extra > $out/bench_${tag}.json 2> $out/bench_${tag}.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python bench.py $extra --sweep "" --no-cpu-baseline > $out/bench_${tag}_under_rocprof.json 2> $out/rocprof.err
 f=$(ls $out/trace/*kernel_trace.csv 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/rocprof_summary.py $f > $out/${tag}_kernel_stats.txt
 s=$(ls $out/trace/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$s" ] && cp $s $out/${tag}_rocprofv3_kernel_stats.csv
 rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python bench.py --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_$c.err
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python bench.py $extra --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_$c.err
   f=$(ls $out/pmc_$c/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_$c.txt
   rm -rf $out/pmc_$c
 done
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o pmc -- python bench.py --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_sq.err
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o pmc -- python bench.py $extra --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_sq.err
 f=$(ls $out/pmc_sq/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_SQ.txt
 rm -rf $out/pmc_sq

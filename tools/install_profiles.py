@@ -3,6 +3,7 @@
 (the per-launch HBM traffic bench.py reports as roofline.traffic)."""
 import json, os, re, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+suffix = sys.argv[2] if len(sys.argv) > 2 else ""          # e.g. "_3M": profiles/pmc_blend_bwd_3M.json (bench.py picks the file by #Gaussians)
 src = os.path.join("gpurun_out", f"profiles_{tag}")
 os.makedirs("profiles", exist_ok=True)
 for f in os.listdir(src):
@@ -34,5 +35,10 @@ if fetch_kb is not None and write_kb is not None:
                 d["lds_wave_insts_per_launch"] = named.get("SQ_INSTS_LDS")
                 d["sq_source"] = f"profiles/{tag}_pmc_SQ.txt"
                 break
-    json.dump(d, open(os.path.join("profiles", "pmc_blend_bwd.json"), "w"), indent=1)
+    bj = os.path.join(src, f"bench_{tag}_under_rocprof.json")
+    try:
+        d["gaussians"] = json.loads(open(bj).read().strip().splitlines()[-1])["config"]["gaussians"]
+    except Exception:
+        pass
+    json.dump(d, open(os.path.join("profiles", f"pmc_blend_bwd{suffix}.json"), "w"), indent=1)
     print(d)

@@ -16,11 +16,15 @@
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-enum Op { FMA, MUL, ADD, PK_FMA, PK_MUL, EXP, RCP, LDEXP, RNDNE, ADD_DPP_SHR, ADD_DPP_QUAD, ADD_DPP_BCAST, CNDMASK, MOV_DPP, CMP, FMA_DEP1, BPERMUTE, READLANE, NOPS, CNDMASK_VCC, MIN, CVT_I32, SUB_U32, LSHL_ADD, CMP_SGPR, PERMLANE32, FMA_SALU };
+enum Op { FMA, MUL, ADD, PK_FMA, PK_MUL, EXP, RCP, LDEXP, RNDNE, ADD_DPP_SHR, ADD_DPP_QUAD, ADD_DPP_BCAST, CNDMASK, MOV_DPP, CMP, FMA_DEP1, BPERMUTE, READLANE, NOPS, CNDMASK_VCC, MIN, CVT_I32, SUB_U32, LSHL_ADD, CMP_SGPR, PERMLANE32, FMA_SALU, MOV, AND, MAX, LSHLREV, MAD_U24, FMAC, FMAMK, SUBREV, ADD_U32, XOR, MED3, MUL_LO, CMP_CND_VCC, CMP_CND_SGPR, SAND_CND_VCC, CND_VCC_SMOV, CXX_SELECT };
 static const char* kNames[] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_exp_f32", "v_rcp_f32", "v_ldexp_f32", "v_rndne_f32",
                                 "v_add_f32_dpp row_shr:1", "v_add_f32_dpp quad_perm", "v_add_f32_dpp row_bcast:15", "v_cndmask_b32_e64 (sgpr mask)", "v_mov_b32_dpp row_shr:1",
                                 "v_cmp_lt_f32 (vcc)", "v_fma_f32 one dependent chain", "ds_bpermute_b32", "v_readlane_b32", "s_nop 0", "v_cndmask_b32_e32 (vcc)", "v_min_f32", "v_cvt_i32_f32", "v_sub_u32", "v_lshl_add_u32",
-                                "v_cmp_lt_f32_e64 (sgpr pair)", "v_permlane32_swap", "v_fma_f32 + s_add_u32 interleaved (counted: the v_fma)" };
+                                "v_cmp_lt_f32_e64 (sgpr pair)", "v_permlane32_swap", "v_fma_f32 + s_add_u32 interleaved (counted: the v_fma)", "v_mov_b32", "v_and_b32", "v_max_f32", "v_lshlrev_b32", "v_mad_u32_u24",
+                                "v_fmac_f32", "v_fmamk_f32", "v_subrev_f32", "v_add_u32", "v_xor_b32", "v_med3_f32", "v_mul_lo_u32",
+                                "pair: v_cmp_lt_f32 vcc + v_cndmask_b32_e32 vcc (counted: pairs)", "pair: v_cmp_lt_f32_e64 sgpr + v_cndmask_b32_e64 sgpr (counted: pairs)",
+                                "pair: s_and_b64 vcc + v_cndmask_b32_e32 vcc (counted: pairs)", "v_cndmask_b32_e32 vcc (vcc written once by s_mov_b64)",
+                                "C++ select a = a < b ? a * c : a + d (counted: selects; compiler's code)" };
 
 constexpr int CHAINS = 8, UNROLL = 64;
 
@@ -36,7 +40,8 @@ __global__ void __launch_bounds__(256) calib_kernel(float* out, int iters, unsig
     const int idx = (int)((threadIdx.x * 4u) ^ 4u);
     const unsigned long long selmask = 0x5555555555555555ull ^ (unsigned long long)iters;
     unsigned sacc = 0;
-    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a[0]), "v"(1.01f) : "vcc");
+    if constexpr (OP == CND_VCC_SMOV) asm volatile("s_mov_b64 vcc, %0" :: "s"(selmask) : "vcc");
+    else asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a[0]), "v"(1.01f) : "vcc");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
 #pragma unroll
@@ -63,6 +68,23 @@ __global__ void __launch_bounds__(256) calib_kernel(float* out, int iters, unsig
                 else if constexpr (OP == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[u]) : "v"(1));
                 else if constexpr (OP == CMP_SGPR) { unsigned long long m; asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a[u]), "v"(b)); asm volatile("" :: "s"(m)); }
                 else if constexpr (OP == PERMLANE32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[u]), "+v"(a[(u + 1) % CHAINS]));
+                else if constexpr (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[u]) : "v"(b));
+                else if constexpr (OP == AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[u]) : "v"(0x7fffffff));
+                else if constexpr (OP == MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[u]) : "v"(b));
+                else if constexpr (OP == LSHLREV) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[u]));
+                else if constexpr (OP == MAD_U24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[u]) : "v"(3), "v"(1));
+                else if constexpr (OP == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[u]) : "v"(b), "v"(c));
+                else if constexpr (OP == FMAMK) asm volatile("v_fmamk_f32 %0, %0, 0x3f7fff58, %1" : "+v"(a[u]) : "v"(c));
+                else if constexpr (OP == SUBREV) asm volatile("v_subrev_f32 %0, %1, %0" : "+v"(a[u]) : "v"(c));
+                else if constexpr (OP == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[u]) : "v"(1));
+                else if constexpr (OP == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[u]) : "v"(1));
+                else if constexpr (OP == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(b), "v"(c));
+                else if constexpr (OP == MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[u]) : "v"(3));
+                else if constexpr (OP == CMP_CND_VCC) { asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(a[u]) : "v"(b), "v"(c) : "vcc"); }
+                else if constexpr (OP == CMP_CND_SGPR) { unsigned long long m; asm volatile("v_cmp_lt_f32_e64 %1, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %3, %1" : "+v"(a[u]), "=&s"(m) : "v"(b), "v"(c)); }
+                else if constexpr (OP == SAND_CND_VCC) { asm volatile("s_and_b64 vcc, %1, exec\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(a[u]) : "s"(selmask), "v"(c) : "vcc"); }
+                else if constexpr (OP == CND_VCC_SMOV) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[u]) : "v"(b) : );
+                else if constexpr (OP == CXX_SELECT) { a[u] = a[u] < b ? a[u] * 0.999f : a[u] + c; }
                 else if constexpr (OP == FMA_SALU) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(b), "v"(c)); asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc)); }
                 else if constexpr (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[u]));
                 else if constexpr (OP == CMP) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a[u]), "v"(b) : "vcc");
@@ -131,7 +153,14 @@ int main()
     sweep<CNDMASK>(d_out, d_ticks, first); sweep<MOV_DPP>(d_out, d_ticks, first); sweep<CMP>(d_out, d_ticks, first);
     sweep<FMA_DEP1>(d_out, d_ticks, first); sweep<BPERMUTE>(d_out, d_ticks, first); sweep<READLANE>(d_out, d_ticks, first); sweep<NOPS>(d_out, d_ticks, first);
     sweep<CNDMASK_VCC>(d_out, d_ticks, first); sweep<MIN>(d_out, d_ticks, first); sweep<CVT_I32>(d_out, d_ticks, first); sweep<SUB_U32>(d_out, d_ticks, first);
-    sweep<LSHL_ADD>(d_out, d_ticks, first); sweep<CMP_SGPR>(d_out, d_ticks, first); sweep<PERMLANE32>(d_out, d_ticks, first); sweep<FMA_SALU>(d_out, d_ticks, first);
+    sweep<LSHL_ADD>(d_out, d_ticks, first); sweep<CMP_SGPR>(d_out, d_ticks, first); sweep<PERMLANE32>(d_out, d_ticks, first);
+    sweep<MOV>(d_out, d_ticks, first); sweep<AND>(d_out, d_ticks, first); sweep<MAX>(d_out, d_ticks, first); sweep<LSHLREV>(d_out, d_ticks, first);
+    sweep<MAD_U24>(d_out, d_ticks, first); sweep<FMAC>(d_out, d_ticks, first); sweep<FMAMK>(d_out, d_ticks, first); sweep<SUBREV>(d_out, d_ticks, first);
+    sweep<ADD_U32>(d_out, d_ticks, first); sweep<XOR>(d_out, d_ticks, first); sweep<MED3>(d_out, d_ticks, first); sweep<MUL_LO>(d_out, d_ticks, first);
+    sweep<CMP_CND_VCC>(d_out, d_ticks, first); sweep<SAND_CND_VCC>(d_out, d_ticks, first); sweep<CXX_SELECT>(d_out, d_ticks, first);
+    // (a pair "v_cmp_lt_f32_e64 s[N:N+1] + v_cndmask_b32_e64 ... s[N:N+1]" written as ONE asm statement did not terminate at
+    // 4 waves per SIMD on the GPU box -- a VALU-written SGPR pair read back by the next VALU instruction with no compiler-inserted
+    // wait states -- and is deliberately not part of the sweep)
     printf("\n ]}\n");
     return 0;
 }
