@@ -206,7 +206,9 @@ int gsrast_backward_ex(const gsrast_options* options,
  * "pixels_per_lane" (+ "fwd_" / "bwd_" prefixed) 0 = auto, 1 / 2 / 4.  Returns 0 or GSRAST_E_ARG.
  * "speculative" 1 (default) = binning + forward blend are enqueued before the host has read num_rendered back, against
  * a capacity remembered from earlier calls (repeated with exact sizes if it did not fit), 0 = wait first;
- * "sh_grad_factors" see gsrast_sh_grad_combine.
+ * "sh_grad_factors" see gsrast_sh_grad_combine;
+ * "bwd_transposed" (process-wide A/B switch) 1 (default) = the one-pixel-per-lane backward blend sums across lanes once per
+ * group of eight staged instances (blend_bwd_cull_t_kernel), 0 = nine wave reductions per surviving (wave, instance) pair.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
  * last forward call of the CALLING THREAD's context, "redo_count" (= gsrast_context_query(NULL, name)). */
 int gsrast_set_option(const char* name, int value);

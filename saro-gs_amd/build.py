@@ -22,6 +22,8 @@ FLAGS = [
     "-ffp-contract=off",                            # FMAs only where written: bit parity with the oracle
     "-fhip-fp32-correctly-rounded-divide-sqrt",     # IEEE divide / sqrt in the per-Gaussian kernels
     "-munsafe-fp-atomics",                          # hardware global_atomic_add_f32, no CAS loop
+    "-fno-slp-vectorize",                           # packed fp32 VALU is half rate on gfx950 (tools/valu_calib.hip): SLP-formed v_pk_* plus the
+                                                    # v_mov shuffles that feed them cost more than the scalar ops (blend_bwd -5 %)
     "-Wall", "-Wno-unused-function",
 ]
 

@@ -744,10 +744,6 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 GS_COUNT(4, 1); GS_COUNT(7, __popcll(__ballot(pos < last[0])));
                 if (!__any(contributed)) continue;
                 GS_COUNT(5, 1); GS_COUNT(6, __popcll(__ballot(contributed)));
-#if defined(GSRAST_ABLATE_REDUCE) && GSRAST_ABLATE_REDUCE == 1      // timing experiment: no products, no cross-lane sums
-                asm volatile("" :: "v"(dch[0]), "v"(dLa[0]), "v"(Gk[0]));
-                continue;
-#endif
                 float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {
@@ -770,10 +766,6 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     // total of value l & 7), the ninth through the DPP chain to lane 63, read back as a scalar;
                     // lanes 0..8 then commit all nine into this wave's accumulator slice with ONE LDS read-add-write.
                     const float v8[8] = { g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g };
-#if defined(GSRAST_ABLATE_REDUCE) && GSRAST_ABLATE_REDUCE == 2      // timing experiment: products, but no cross-lane sums
-                    asm volatile("" :: "v"(g_mx), "v"(g_my), "v"(g_ca), "v"(g_cb), "v"(g_cc), "v"(g_op), "v"(g_r), "v"(g_g), "v"(g_b));
-                    continue;
-#endif
                     const float tot = wave_sum8_transposed(v8, lane);
                     const float tb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(g_b)), 63));
                     if (lane < 9u) acc[wave][j][lane] += (lane < 8u ? tot : tb) * commit_scale;
@@ -789,6 +781,196 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 float v = acc[0][slot][q];
 #pragma unroll
                 for (int w = 1; w < NS; w++) v += acc[w][slot][q];
+                if (v != 0.f) atomicAdd(grec + (size_t)sid[slot] * GREC + q, v);
+            }
+        }
+    }
+}
+
+// Backward blend, one pixel per lane, with the cross-lane sums TRANSPOSED out of the per-pair loop.
+// In blend_bwd_cull_kernel every surviving (wave, instance) pair pays for nine 64-lane reductions (21 DPP steps, 7 selects, two
+// ds_bpermute exchanges: measured 33 % of the kernel, the nine products another 15 %).  Here the divergent part of a pair only
+// leaves two numbers per pixel -- u = G dL/dalpha and dch = alpha T -- in an LDS strip [instance][pixel]; after a group of
+// eight staged instances the wave turns round: lane (k, jj) = (lane & 7, lane >> 3) walks pixels k, k + 8, ... of instance jj and
+// accumulates that instance's nine sums in registers (14 full-rate FMA-class instructions per 8 pixels x 8 instances, no
+// cross-lane traffic), and ONE three-step butterfly over the 8-lane groups finishes all eight instances at once.  Per staged
+// instance and wave that is ~52 issue cycles instead of ~160 per surviving pair.  The geometric sums are taken about the pixel
+// itself (dx, dy recomputed from the instance's mean: identical operands to the per-pair formulation).
+template <int EXPMODE>
+__global__ void __launch_bounds__(256)
+blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                        const uint32_t* __restrict__ order, int W, int H,
+                        int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                        const float4* __restrict__ rec2, const float* __restrict__ bg,
+                        const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                        const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
+                        float* __restrict__ grec /*[P][GREC]: per-Gaussian gradient records, zero on entry*/,
+                        const uint32_t* __restrict__ bucket_cnt, const uint16_t* __restrict__ bucket_list)
+{
+#pragma clang fp contract(fast)
+    constexpr int NT = 256, BATCH = 64, NW = 4;
+    constexpr int GB = 8;            // instances per group
+    constexpr int PS = 72;           // float2 slots per instance row: 64 pixels + 8 of padding (row stride = 16 banks mod 64: the
+                                     // transposed phase's ds_read_b64 of lanes (k, jj), jj = 0..3 within a 32-lane group, are conflict-free)
+    constexpr int AS = 12;
+    __shared__ float4 s0[BATCH];
+    __shared__ float4 s1[BATCH];
+    __shared__ float2 s2[BATCH];          // {blue, skip threshold}
+    __shared__ uint32_t sid[BATCH];
+    __shared__ __attribute__((aligned(16))) float acc[BATCH][AS];       // the batch's sums, shared by the four waves (LDS float adds to distinct addresses)
+    // {u, dch} of the current group, [instance][pixel of the wave's strip]
+    __shared__ float2 pbuf[NW][GB][PS];
+    __shared__ float4 dpt[NW][64];        // dL/dpixel of the strip's pixels, for the transposed phase
+    __shared__ uint32_t s_tile;
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t tile = bucket_cnt ? tile_from_buckets_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, blockIdx.x, &s_tile)
+                                     : (order ? order[blockIdx.x] : blockIdx.x);
+    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    const uint32_t t = threadIdx.x;
+    const unsigned lane = lane_id(), wave = t >> 6;
+    const uint32_t px = tx * TILE_X + (t & 15u), py = ty * TILE_Y + (t >> 4);
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const uint32_t n_all = range.y - range.x;
+    const uint32_t tm = tile_max[tile];
+    const uint32_t n = tm < n_all ? tm : n_all;       // instances at list position >= n touch no pixel
+    const size_t plane = (size_t)W * H;
+    const float sx0 = (float)(tx * TILE_X), sx1 = sx0 + 15.0f;
+    const float sy0 = (float)(ty * TILE_Y + wave * 4u);
+
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const size_t pid = (size_t)W * py + px;
+    const float Tf = inside ? final_T[pid] : 0.0f;
+    float T = Tf;
+    const uint32_t last = inside ? n_contrib[pid] : 0u;
+    const float dp0 = inside ? dL_dpix[pid] : 0.f, dp1 = inside ? dL_dpix[plane + pid] : 0.f, dp2 = inside ? dL_dpix[2 * plane + pid] : 0.f;
+    const float tfbg = -Tf * (bg0 * dp0 + bg1 * dp1 + bg2 * dp2);
+    float ac0 = 0.f, ac1 = 0.f, ac2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    uint32_t strip_last;
+    {
+        uint32_t m = last;                            // deepest position the strip needs (wave-uniform)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+        strip_last = __builtin_amdgcn_readfirstlane(m);
+    }
+    dpt[wave][lane] = make_float4(dp0, dp1, dp2, 0.0f);
+    // transposed phase: this lane's role
+    const unsigned k = lane & 7u, jj = lane >> 3;
+    const float commit_scale = k == 0 ? -0.5f * (float)W : k == 1 ? -0.5f * (float)H : (k >= 2 && k <= 4) ? -0.5f : 1.0f;
+    const float pxk0 = sx0 + (float)k, pxk1 = pxk0 + 8.0f;       // columns of pixels k + 16 r and k + 8 + 16 r of the strip
+
+    for (uint32_t base = 0; base < n; base += BATCH) {
+        __syncthreads();
+        if (t < (uint32_t)BATCH) {
+            const uint32_t i = base + t;
+            if (i < n) {
+                const uint32_t g = point_list[range.x + (n - 1 - i)];
+                sid[t] = g;
+                s0[t] = rec0[g]; s1[t] = rec1[g];
+                const float4 c = rec2[g];
+                s2[t] = make_float2(c.x, c.z);
+            }
+        } else if (t - (uint32_t)BATCH < (uint32_t)(BATCH * AS / 4)) {
+            reinterpret_cast<float4*>(&acc[0][0])[t - BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
+        uint64_t mk;
+        {
+            const uint32_t spos = n - 1 - (base + lane);      // list position of this lane's instance
+            const bool valid = lane < cnt;
+            const float4 a = valid ? s0[lane] : make_float4(0.f, 0.f, 1.f, 0.f);
+            const float czv = valid ? s1[lane].x : 1.f;
+            const float thr = valid ? s2[lane].y : 1.f;
+            mk = __ballot(valid && spos < strip_last && strip_may_touch(a, czv, thr, sx0, sx1, sy0, sy0 + 3.0f));
+        }
+#pragma unroll 1
+        for (uint32_t g = 0; g < (uint32_t)(BATCH / GB); g++) {
+            uint32_t walk = (uint32_t)(mk >> (GB * g)) & ((1u << GB) - 1u);
+            if (!walk) continue;                                            // scalar: no instance of the group can touch the strip
+            uint32_t alive = 0;
+            while (walk) {
+                const uint32_t jb = (uint32_t)__builtin_ctz(walk);
+                walk &= walk - 1;
+                const uint32_t j = g * GB + jb;
+                const uint32_t pos = n - 1 - (base + j);
+                const float4 a = s0[j];
+                const float4 b = s1[j];
+                float2 c = s2[j];
+                asm volatile("" : "+v"(c.x));       // keep the blue channel's LDS read with the others (see blend_bwd_cull_kernel)
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float q = __builtin_fmaf(b.x * dy, dy, (a.z * dx) * dx);
+                const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+                // exp and alpha inside the first divergent region; the alpha >= 1/255 test and its ballot outside (a compare straight
+                // into an SGPR pair: a bool carried out of the branch costs a v_cndmask + v_cmp to become a mask again)
+                float G = 0.f, alpha = 0.f;
+                if (pos < last && power <= 0.0f && power >= c.y) {
+                    G = gs_exp<EXPMODE, true>(power);
+                    alpha = b.y * G;
+                    alpha = alpha < 0.99f ? alpha : 0.99f;
+                }
+                const bool ok = !(alpha < 1.0f / 255.0f);          // lanes that skipped the region: alpha = 0
+                GS_COUNT(4, 1); GS_COUNT(7, __popcll(__ballot(pos < last)));
+                if (__ballot(ok) == 0ull) continue;
+                GS_COUNT(5, 1); GS_COUNT(6, __popcll(__ballot(ok)));
+                float u = 0.f, dch = 0.f;
+                if (ok) {
+                    const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T = T * rcp1ma;
+                    const float c0 = b.z, c1 = b.w, c2 = c.x;
+                    ac0 = last_alpha * lc0 + (1.f - last_alpha) * ac0; lc0 = c0;
+                    ac1 = last_alpha * lc1 + (1.f - last_alpha) * ac1; lc1 = c1;
+                    ac2 = last_alpha * lc2 + (1.f - last_alpha) * ac2; lc2 = c2;
+                    float dL_dalpha = (c0 - ac0) * dp0 + (c1 - ac1) * dp1 + (c2 - ac2) * dp2;
+                    last_alpha = alpha;
+                    dL_dalpha *= T;
+                    dL_dalpha += tfbg * rcp1ma;
+                    dch = alpha * T; u = G * dL_dalpha;
+                }
+                alive |= 1u << jb;
+                pbuf[wave][jb][lane] = make_float2(u, dch);
+            }
+            if (!alive) continue;
+            __builtin_amdgcn_wave_barrier();            // same wave: the LDS executes its accesses in order, no s_barrier needed
+            // ---- transposed phase: lane (k, jj) sums pixels k, k + 8, ..., k + 56 of instance jj ----
+            const uint32_t j = g * GB + jj;
+            const float4 a = s0[j];
+            const float4 b = s1[j];
+            const float dxa = a.x - pxk0, dxb = a.x - pxk1;
+            float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
+            const float2* urow = &pbuf[wave][jj][k];
+            const float4* prow = &dpt[wave][k];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float2 ud = urow[i * 8];
+                asm volatile("" ::: "memory");                       // keeps the 8-byte reads apart: merged into ds_read2_b64 they cost 8 LDS cycles per pair, apart 2 each
+                const float uu = ud.x, dd = ud.y;
+                float4 dp = prow[i * 8];
+                asm volatile("" : "+v"(dp.w));                       // all four components "used": one ds_read_b128 (4 LDS cycles), not a ds_read_b96 (8)
+                const float dx = (i & 1) ? dxb : dxa;
+                const float dy = a.y - (sy0 + (float)(i >> 1));
+                const float gxv = uu * dx, gyv = uu * dy;            // the opacity factor of dL/dG = opacity * dL/dalpha is applied once, below
+                Sx += gxv; Sy += gyv;
+                Sxx = __builtin_fmaf(gxv, dx, Sxx); Sxy = __builtin_fmaf(gxv, dy, Sxy); Syy = __builtin_fmaf(gyv, dy, Syy);
+                Su += uu;
+                Cr = __builtin_fmaf(dd, dp.x, Cr); Cg = __builtin_fmaf(dd, dp.y, Cg); Cb = __builtin_fmaf(dd, dp.z, Cb);
+            }
+            Sx *= b.y; Sy *= b.y; Sxx *= b.y; Sxy *= b.y; Syy *= b.y;
+            const float v8[8] = { Sx * a.z + Sy * a.w, Sy * b.x + Sx * a.w, Sxx, Sxy, Syy, Su, Cr, Cg };
+            const float tot = group8_sum8_transposed(v8, lane);     // lane (k, jj): total of value k for instance jj
+            const float tb = group8_sum(Cb);
+            if ((alive >> jj) & 1u) {
+                lds_add_f32(&acc[j][k], tot * commit_scale);
+                if (k == 0u) lds_add_f32(&acc[j][8], tb);
+            }
+        }
+        __syncthreads();
+        // commit: 16 adjacent lanes per staged instance, lane q < 9 adds sum q to float q of the Gaussian's 64-byte record
+        for (uint32_t e = t; e < cnt * 16u; e += NT) {
+            const uint32_t slot = e >> 4, q = e & 15u;
+            if (q < 9u) {
+                const float v = acc[slot][q];
                 if (v != 0.f) atomicAdd(grec + (size_t)sid[slot] * GREC + q, v);
             }
         }

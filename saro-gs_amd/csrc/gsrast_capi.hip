@@ -334,9 +334,15 @@ void launch_bwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
     blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.grec,
                                                                  a.from_buckets ? a.bcnt : nullptr, a.blist);
 }
+std::atomic<int> g_bwd_transposed{1};     // 1: blend_bwd_cull_t_kernel for one pixel per lane (default); 0: blend_bwd_cull_kernel<.., 1> (A/B switch)
 template <int MODE>
 void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
+    if (ppl == 1 && g_bwd_transposed.load()) {
+        blend_bwd_cull_t_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.grec,
+                                                           a.from_buckets ? a.bcnt : nullptr, a.blist);
+        return;
+    }
     if (ppl == 4) launch_bwd_cull<MODE, 4>(grid, s, a); else if (ppl == 2) launch_bwd_cull<MODE, 2>(grid, s, a); else launch_bwd_cull<MODE, 1>(grid, s, a);
 }
 template <int MODE>
@@ -383,6 +389,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
+    if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
     if (!strcmp(name, "cull")) { g_def.cull = value ? 1 : 0; return 0; }
     if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.binning = value; return 0; }
     if (!strcmp(name, "tile_clip")) { g_def.tile_clip = value ? 1 : 0; return 0; }

@@ -292,6 +292,41 @@ __device__ __forceinline__ float wave_sum8_transposed(const float (&v)[8], unsig
     return y;
 }
 
+// The same butterfly over the eight lanes of an aligned 8-lane GROUP (three steps): afterwards lane l holds the total of
+// value (l & 7) over its group.  Step three pairs lane l with l ^ 4: row_shl:4 serves the lanes with bit 2 clear, row_shr:4
+// those with bit 2 set (a lane without a source adds 0 and is not the one selected).
+__device__ __forceinline__ float group8_sum8_transposed(const float (&v)[8], unsigned lane)
+{
+    const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
+    float w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float a = dpp_pair_sum<0xB1>(v[2 * i]);
+        const float b = dpp_pair_sum<0xB1>(v[2 * i + 1]);
+        w[i] = b0 ? b : a;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float a = dpp_pair_sum<0x4E>(w[2 * i]);
+        const float b = dpp_pair_sum<0x4E>(w[2 * i + 1]);
+        x[i] = b1 ? b : a;
+    }
+    const float lo = dpp_add<0x104>(x[0]);                     // row_shl:4: + lane l + 4
+    const float hi = dpp_add<0x114>(x[1]);                     // row_shr:4: + lane l - 4
+    return b2 ? hi : lo;
+}
+// Plain sum over the aligned 8-lane group, valid in every lane of it.
+__device__ __forceinline__ float group8_sum(float v)
+{
+    v = dpp_pair_sum<0xB1>(v);
+    v = dpp_pair_sum<0x4E>(v);
+    return dpp_pair_sum<0x141>(v);                             // row_half_mirror: the group's other quad (all its lanes hold the same sum)
+}
+__device__ __forceinline__ void lds_add_f32(float* p, float v)      // ds_add_f32, no return value, nothing to wait for
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Lanes of the wave whose digit equals mine (among `valid` lanes); only the low `nbits` (wave-uniform,
 // <= 8) bits of the digit can differ, so only those are balloted.
 __device__ __forceinline__ uint64_t wave_match8(uint32_t d, bool valid, int nbits = 8)

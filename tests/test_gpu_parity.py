@@ -304,6 +304,27 @@ def test_tile_clipping_output_invariance(name, P, W, H, scale_mul, aniso, opac_m
     assert 0 < kept < o32["R"], "clipping should drop something on these scenes"
 
 
+def test_backward_blend_per_pair_reduction_variant(orc, scenes, rast, gpu):
+    """One pixel per lane has two backward blend kernels: the default blend_bwd_cull_t_kernel (cross-lane sums transposed out
+    of the per-pair loop) and blend_bwd_cull_kernel<.., 1> (nine wave reductions per surviving pair; library switch
+    "bwd_transposed" = 0).  Both meet the strict bar."""
+    P, W, H = 6000, 200, 150
+    sc = scenes.synth(P, 73, scale_mul=0.8)
+    cam = scenes.camera(1, 5, W, H)
+    g = scenes.upstream_grad(H, W, 74)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    names = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"]
+    for v in (0, 1):
+        rast._C.set_option("bwd_transposed", v)
+        try:
+            h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
+        finally:
+            rast._C.set_option("bwd_transposed", 1)
+        _check_forward_exact(o32, h)
+        _check_grads(o64, o32, h, names, strict=True)
+
+
 @pytest.mark.parametrize("cull", [0, 1])
 @pytest.mark.parametrize("ppl", [0, 1, 2, 4])
 def test_pixels_per_lane_variants(ppl, cull, orc, scenes, rast, gpu):
