@@ -152,12 +152,32 @@ __device__ __forceinline__ uint32_t dev_count(uint32_t n, const uint32_t* __rest
 // Histogram: order does not matter here, so plain LDS atomics (per-wave private counters keep
 // contention inside a wave; a uniform digit costs at most 64 LDS cycles per round, still far below
 // the HBM time of the keys).
+// Adaptive pass count of the 32-bit depth sort (SortAdapt, host side: radix_sort): the first pass also reduces the minimum and
+// maximum of the visible keys (per block here, over the blocks in one extra workgroup of its row scan); keys that agree in
+// their top byte -- view depths inside one [2^(2k-127), 2^(2k-125)) bracket, e.g. everything between 2 and 8 -- are fully sorted
+// after THREE 8-bit passes, so the fourth pass's three kernels return at once.  So that a depth range which merely STRADDLES such
+// a boundary (1.9 .. 6) qualifies too, passes two to four take their digits from key - base, base = minimum key with its low
+// byte cleared (pass one has already used the raw low byte, which subtracting `base` does not change): the verdict is then
+// "maximum - base fits 24 bits", i.e. any depth range narrower than 2^24 float steps.  The host cannot know that when it enqueues
+// them, so every kernel reads the verdict from device memory (`sig` = significant key bits) and passes two and three pick their
+// buffers accordingly (A -> B -> C -> A instead of A -> B -> A -> B -> A): the sorted sequence ends in A either way.
+enum : int { RA_MINMAX = 1, RA_IN_ALT = 2, RA_SKIP = 4, RA_OUT_ALT = 8, RA_LAST_IF_SHORT = 16 };
+__device__ __forceinline__ bool sort_is_short(const uint32_t* __restrict__ sig) { return sig && sig[0] <= 24u; }   // sig[1] = base
+
 template <typename KeyT, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
-                  uint32_t* __restrict__ block_hist, uint32_t nblk)
+                  uint32_t* __restrict__ block_hist, uint32_t nblk,
+                  const KeyT* __restrict__ keys_alt = nullptr, const uint32_t* __restrict__ sig = nullptr, int adapt = 0,
+                  uint32_t* __restrict__ block_minmax = nullptr)
 {
     __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t s_mm[2];
+    const bool is_short = sort_is_short(sig);
+    if ((adapt & RA_SKIP) && is_short) return;
+    if ((adapt & RA_IN_ALT) && is_short) keys = keys_alt;
+    if ((adapt & RA_MINMAX) && threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; }
+    const uint32_t base = sig ? sig[1] : 0u;
     n = dev_count(n, n_dev);
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < 1024; k += RS_THREADS) (&cnt[0][0])[k] = 0;
@@ -172,19 +192,49 @@ radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __r
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
-        if (i < n) atomicAdd(&cnt[wave][(key[r] >> shift) & mask], 1u);
+        if (i < n) atomicAdd(&cnt[wave][((key[r] - base) >> shift) & mask], 1u);
+    }
+    if (adapt & RA_MINMAX) {     // key 0xFFFFFFFF marks a culled Gaussian (preprocess_fwd_kernel): it sorts to the end under any pass count
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t i = wbase + r * 64 + lane;
+            if (i < n && (uint32_t)key[r] != 0xFFFFFFFFu) { lo = min(lo, (uint32_t)key[r]); hi = max(hi, (uint32_t)key[r]); }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
+        if (lane == 0) { atomicMin(&s_mm[0], lo); atomicMax(&s_mm[1], hi); }
     }
     __syncthreads();
     const uint32_t t = threadIdx.x;
     if (t <= mask) block_hist[(size_t)t * nblk + blockIdx.x] = cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];   // rows past the digit range are never read
+    if ((adapt & RA_MINMAX) && t < 2) block_minmax[2 * blockIdx.x + t] = s_mm[t];
 }
 
 // One workgroup per digit: in-place exclusive scan of that digit's row of block counts, row total
 // out.  The scatter kernel adds the exclusive prefix over digit totals itself, so a radix pass is
 // three launches (histogram, row scan, scatter) instead of five.
 __global__ void __launch_bounds__(256)
-radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t* __restrict__ digit_total)
+radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t* __restrict__ digit_total,
+                     uint32_t* __restrict__ sig = nullptr, int adapt = 0, const uint32_t* __restrict__ block_minmax = nullptr, uint32_t ndigits = 0)
 {
+    if ((adapt & RA_SKIP) && sort_is_short(sig)) return;
+    if ((adapt & RA_MINMAX) && blockIdx.x == ndigits) {      // the extra workgroup of the first pass: min / max over the blocks -> sig
+        __shared__ uint32_t mm[2];
+        if (threadIdx.x == 0) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
+        __syncthreads();
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint32_t b = threadIdx.x; b < nblk; b += 256) { lo = min(lo, block_minmax[2 * b]); hi = max(hi, block_minmax[2 * b + 1]); }
+        atomicMin(&mm[0], lo); atomicMax(&mm[1], hi);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t b = mm[0] > mm[1] ? 0u : (mm[0] & ~0xFFu);
+            const uint32_t span = mm[0] > mm[1] ? 0u : mm[1] - b;
+            sig[0] = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+            sig[1] = b;
+        }
+        return;
+    }
     uint32_t* row = block_hist + (size_t)blockIdx.x * nblk;
     uint32_t carry = 0;
     for (uint32_t c0 = 0; c0 < nblk; c0 += 256 * 8) {
@@ -210,8 +260,19 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
                      const uint32_t* __restrict__ hist_scanned /* per-digit exclusive row scans */,
                      const uint32_t* __restrict__ digit_total, uint32_t nblk,
                      const uint2* __restrict__ gather_rect /* optional, last depth pass only */,
-                     uint32_t* __restrict__ gather_tiles, uint32_t* __restrict__ gather_width)
+                     uint32_t* __restrict__ gather_tiles, uint32_t* __restrict__ gather_width,
+                     const KeyT* __restrict__ keys_in_alt = nullptr, const ValT* __restrict__ vals_in_alt = nullptr,
+                     KeyT* __restrict__ keys_out_alt = nullptr, ValT* __restrict__ vals_out_alt = nullptr,
+                     const uint32_t* __restrict__ sig = nullptr, int adapt = 0)
 {
+    {
+        const bool is_short = sort_is_short(sig);
+        if ((adapt & RA_SKIP) && is_short) return;
+        if ((adapt & RA_IN_ALT) && is_short) { keys_in = keys_in_alt; vals_in = vals_in_alt; }
+        if ((adapt & RA_OUT_ALT) && is_short) { keys_out = keys_out_alt; vals_out = vals_out_alt; }
+        if ((adapt & RA_LAST_IF_SHORT) && !is_short) gather_rect = nullptr;      // this pass gathers only when it is the last one
+    }
+    const uint32_t base = (sig && shift > 0) ? sig[1] : 0u;      // pass one runs before `base` exists and does not need it (low byte of base = 0)
     n = dev_count(n, n_dev);
     // Ranks -> block-local order in LDS -> coalesced write-out: after the exchange consecutive lanes
     // hold consecutive elements of the same digit, whose global destinations are consecutive too.
@@ -239,7 +300,7 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        const uint32_t d = (key[r] >> shift) & mask;
+        const uint32_t d = ((key[r] - base) >> shift) & mask;
         const uint64_t m = wave_match8(d, valid, nbits);
         const uint32_t prev = wc[d];
         const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
@@ -272,7 +333,7 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
-            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t d = ((key[r] - base) >> shift) & mask;
             const uint32_t slot = cnt[wave][d] + rk[r];
             xk[slot] = (KeyT)key[r]; xv[slot] = val[r];
         }
@@ -286,7 +347,7 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
         if (slot < nvalid) {
             const KeyT kk = xk[slot];
             const uint32_t k = (uint32_t)kk;
-            const uint32_t d = (k >> shift) & mask;
+            const uint32_t d = ((k - base) >> shift) & mask;
             const uint32_t pos = gbase[d] + (slot - dstart[d]);
             keys_out[pos] = kk;
             const ValT vv = xv[slot];

@@ -146,15 +146,41 @@ int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
 // ITEMS = elements per lane: a workgroup sorts 256 * ITEMS consecutive elements.  The R-sized sort wants 16 (long
 // contiguous runs in the write-out); the P- and Q-sized ones have too few elements to fill 256 CUs with 4096-element
 // chunks (1 M Gaussians = 245 workgroups) and run faster with smaller ones.
+// Device-side pass-count adaptation of the 32-bit depth sort (gsrast_binning.h: RA_*): a third buffer pair, the per-block
+// key minima / maxima of pass 0, and the word that receives the number of significant key bits.
+template <typename KeyT, typename ValT> struct SortAdapt { KeyT* kC; ValT* vC; uint32_t* block_minmax; uint32_t* sig; };
+
 template <typename KeyT, typename ValT = uint32_t, int ITEMS = RS_ITEMS>
 int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s,
                const uint2* gather_rect = nullptr, uint32_t* gather_tiles = nullptr, uint32_t* gather_width = nullptr,
-               const uint32_t* n_dev = nullptr /* n is a capacity, the real count is on the device (dev_count) */)
+               const uint32_t* n_dev = nullptr /* n is a capacity, the real count is on the device (dev_count) */,
+               const SortAdapt<KeyT, ValT>* ad = nullptr)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nblk = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
     const int passes = radix_passes(bits);
+    if (ad && passes == 4 && bits == 32 && nblk > RS_SELF_SCAN_BLOCKS) {
+        // A -> B -> (short ? C : A) -> (short ? A : B) -> [A]: see RA_* in gsrast_binning.h.  The result is in (kA, vA).
+        const uint32_t mask = 255u;
+        for (int p = 0; p < 4; p++) {
+            const int shift = 8 * p;
+            const KeyT* kin = (p & 1) ? kB : kA; const ValT* vin = (p & 1) ? vB : vA;      // the long sort's ping-pong
+            KeyT* kout = (p & 1) ? kA : kB; ValT* vout = (p & 1) ? vA : vB;
+            const int hmode = p == 0 ? RA_MINMAX : p == 2 ? RA_IN_ALT : p == 3 ? RA_SKIP : 0;
+            const int smode = p == 1 ? RA_OUT_ALT : p == 2 ? (RA_IN_ALT | RA_OUT_ALT | RA_LAST_IF_SHORT) : p == 3 ? RA_SKIP : 0;
+            radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kin, n, n_dev, shift, mask, hist, nblk, ad->kC, p ? ad->sig : nullptr, hmode, ad->block_minmax);
+            GS_LAUNCHED("radix_hist");
+            radix_rowscan_kernel<<<mask + 1 + (p == 0 ? 1 : 0), 256, 0, s>>>(hist, nblk, scan_tmp, ad->sig, p == 0 ? RA_MINMAX : p == 3 ? RA_SKIP : 0, ad->block_minmax, mask + 1);
+            GS_LAUNCHED("radix_rowscan");
+            // pass 1 writes C when short; pass 2 reads C and writes A when short (and gathers: it is then the last pass)
+            radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kin, vin, kout, vout, n, n_dev, shift, mask, hist, scan_tmp, nblk,
+                                                                         p >= 2 ? gather_rect : nullptr, gather_tiles, gather_width,
+                                                                         ad->kC, ad->vC, p == 1 ? ad->kC : kA, p == 1 ? ad->vC : vA, ad->sig, smode);
+            GS_LAUNCHED("radix_scatter");
+        }
+        return GSRAST_OK;
+    }
     int shift = 0;
     for (int p = 0; p < passes; p++) {
         const int w = (bits - shift + (passes - p) - 1) / (passes - p);   // remaining bits spread evenly (7+6 == 6+7 measured)
@@ -551,7 +577,8 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     {
         ProfScope ps(K_SORT_DEPTH, s);
         // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
-        int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets);
+        const SortAdapt<uint32_t, uint32_t> ad{ at<uint32_t>(geom, GL.keyC), at<uint32_t>(geom, GL.valC), at<uint32_t>(geom, GL.sort_minmax), scalars + 8 };
+        int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets, nullptr, &ad);
         if (rc != GSRAST_OK) return rc;
     }
     const uint32_t* order = vA; // 4 passes -> back in A

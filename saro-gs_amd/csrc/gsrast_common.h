@@ -27,13 +27,14 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   keyA/B   u32[P] x2   depth-sort ping-pong keys        valA/B u32[P] x2   ping-pong values
 //   offsets  u32[P]      inclusive scan of tiles[] in depth order
 //   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
-//   scalars  u32[64]     [0] = num_rendered
+//   scalars  u32[64]     [0] = num_rendered ... [8] = significant bits of the depth keys (adaptive pass count of the depth sort)
+//   keyC/valC u32[P] x2  third buffer pair of the depth sort, sort_minmax u32[2 nblk]: per-block key minimum / maximum
 //   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
     size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, grec, total;
+        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
 // Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
@@ -103,6 +104,8 @@ static inline GeomLayout geom_layout(size_t P)
     L.scan_tmp = take(st * 4);
     L.scalars = take(256);
     L.grec = take(Pp * GREC * 4);
+    L.keyC = take(Pp * 4); L.valC = take(Pp * 4);                               // third buffer pair of the adaptive depth sort
+    L.sort_minmax = take(2 * rs_blocks_n(Pp, GSRAST_DEPTH_ITEMS) * 4);
     L.total = o + 256;
     return L;
 }

@@ -232,3 +232,25 @@ def test_extreme_aspect_ratios_on_the_run_path(W, H, orc, scenes, rast, gpu):
             ref = o32[k].astype(np.float64)
             err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
             assert (err <= 1e-5 + 1e-3 * np.abs(ref)).all(), (k, float(err.max()))
+
+
+@pytest.mark.parametrize("radius,short", [(4.0, True), (9.0, True), (2.6, False), (1.5, False)],
+                         ids=["depths_1p7_to_6p3_three_passes", "depths_cross_8_three_passes", "wide_range_four_passes", "near_plane_four_passes"])
+def test_adaptive_depth_sort_pass_count(radius, short, orc, scenes, rast, gpu):
+    """The depth sort of > 131072 Gaussians decides ON THE DEVICE whether its fourth 8-bit pass is needed: digits of passes 2-4
+    are taken from key - base (base = smallest visible key, low byte cleared), and a key span below 2^24 is sorted after three
+    passes -- also when the depths straddle a power of two (camera distance 4: 1.7 .. 6.3; distance 9: across 8).  Wide depth
+    ranges run all four passes.  Either way the lists equal the oracle's 64-bit key sort entry by entry."""
+    from gpu_harness import bits, run_hip
+    P, W, H = 300_000, 640, 480
+    sc = scenes.synth(P, 5)
+    cam = scenes.camera(1, 7, W, H, radius=radius)
+    o32 = orc.render(sc, cam)
+    h = run_hip(rast, sc, cam, gpu, tile_clip=0)
+    d = o32["depths"][o32["radii"] > 0].view(np.uint32).astype(np.int64)
+    assert ((d.max() - (d.min() & ~0xFF)) < (1 << 24)) == short           # the regime this case is meant to exercise
+    assert h["R"] == o32["R"]
+    np.testing.assert_array_equal(h["keys_sorted"], o32["keys_sorted"])
+    np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+    np.testing.assert_array_equal(bits(h["out_color"]), bits(o32["out_color"]))
