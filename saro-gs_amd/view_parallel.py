@@ -157,3 +157,94 @@ def max_over_ranks(x: float, device: torch.device) -> float:
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+class StepBucket:
+    """Gradient cache of one training step over an arbitrary set of leaves -- the reference's `_xyz_grd`, `_features_dc_grd`, ...,
+    `mlp_grd[...]` (scene/saro_gaussian.py:226-265) as ONE flat fp32 buffer, so the cross-rank sum is one collective.  Built once
+    for a fixed list of named leaves (the dynamic stage: six per-Gaussian groups + `_temporal_pos` = 60 floats per Gaussian, the
+    four MLP heads and the hex-plane grids, saro_gaussian.py:306-319); rebuilt by the caller after densification changes P."""
+
+    def __init__(self, leaves: Dict[str, torch.Tensor]):
+        self.names = list(leaves.keys())
+        self.leaves = [leaves[n] for n in self.names]
+        dev = self.leaves[0].device if self.leaves else torch.device("cpu")
+        self.flat = torch.zeros(sum(p.numel() for p in self.leaves), dtype=torch.float32, device=dev)
+        self.views, o = [], 0
+        for p in self.leaves:
+            self.views.append(self.flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+
+    def zero(self) -> None:                     # zero_gradient_cache (saro_gaussian.py:249-264)
+        for p in self.leaves:                   # the previous step's .grad are views of this buffer: detach them first, or the
+            p.grad = None                       # next backward would accumulate straight into the cache
+        self.flat.zero_()
+
+    def cache(self) -> None:
+        """cache_gradient (saro_gaussian.py:226-247): add every leaf's .grad of the view just rendered; a leaf the view did not
+        reach (grad None: the reference skips MLP weights without a gradient, :232) adds nothing.  Then optimizer.zero_grad(
+        set_to_none=True) of train.py:221."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.leaves) if p.grad is not None]
+        if have:
+            torch._foreach_add_([v for v, _ in have], [g for _, g in have])
+        for p in self.leaves:
+            p.grad = None
+
+    def assign(self, ratio: float) -> None:     # set_batch_gradient (saro_gaussian.py:266-294): .grad = cache * (1 / batch)
+        self.flat.mul_(ratio)
+        for v, p in zip(self.views, self.leaves):
+            p.grad = v
+
+
+def distributed_step(bucket: StepBucket, views: Sequence, render_loss_fn, batch: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """One training iteration's gradient computation, sharded one view per rank -- the drop-in for the reference's sequential batch
+    loop (train.py:190-226) with its gradient caching (scene/saro_gaussian.py:226-294) and densification statistics
+    (train.py:279-292), same results up to fp32 summation order.
+
+        for every view of this rank (views_of_rank):   out = render_loss_fn(view); out["loss"].backward()
+            out: {"loss": scalar, "viewspace_points": the [P,3] means2D tensor whose .grad the rasterizer fills,
+                  "visibility_filter": bool [P], "radii": int [P]}                       (getrenderparts, helper_train.py)
+            statistics: ||viewspace_points.grad[:, :2]|| (train.py:212), visibility, radii                     -- per view
+            bucket.cache()                                                               -- cache_gradient + zero_grad
+        ONE all-reduce(SUM) of the flat gradient cache, started asynchronously, overlapped with the three small statistic
+        reductions (SUM of gradient norms, SUM of visibility counts, MAX of radii); then leaf.grad = sum / batch
+        (set_batch_gradient) -- the optimizer step that follows is the caller's, identical on every rank.
+
+    Returns what train.py:279-292 derives for the densification: "visibility_count" [P], "visibility_filter" [P] (count > 0),
+    "radii" [P] (max over the batch), "viewspace_point_grad" [P,1] (sum of the per-view norms / visibility count where
+    visible), plus "loss" (mean over the batch, for logging).  `batch` defaults to len(views)."""
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    world = dist.get_world_size() if multi else 1
+    batch = len(views) if batch is None else batch
+    bucket.zero()
+    grad_norm = vis_count = max_radii = None
+    loss_sum = None
+    for i in views_of_rank(len(views), rank, world):
+        out = render_loss_fn(views[i])
+        out["loss"].backward()
+        vsp = out["viewspace_points"]
+        gn = torch.norm(vsp.grad[:, :2], dim=-1)                                    # train.py:212
+        vis = out["visibility_filter"].to(gn.dtype)
+        rad = out["radii"].to(gn.dtype)
+        grad_norm = gn if grad_norm is None else grad_norm + gn
+        vis_count = vis if vis_count is None else vis_count + vis
+        max_radii = rad if max_radii is None else torch.maximum(max_radii, rad)
+        loss_sum = out["loss"].detach() if loss_sum is None else loss_sum + out["loss"].detach()
+        vsp.grad = None
+        bucket.cache()
+    if grad_norm is None:       # a rank without a view in this iteration (batch < world) still takes part in the collectives
+        P = bucket.leaves[0].shape[0]
+        z = torch.zeros(P, dtype=torch.float32, device=bucket.flat.device)
+        grad_norm, vis_count, max_radii, loss_sum = z, z.clone(), z.clone(), torch.zeros((), device=bucket.flat.device)
+    work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, async_op=True) if multi else None
+    reduce_densification_stats(grad_norm, vis_count, max_radii)
+    if multi:
+        dist.all_reduce(loss_sum, op=dist.ReduceOp.SUM)
+        work.wait()
+    bucket.assign(1.0 / batch)
+    visible = vis_count > 0
+    vgrad = grad_norm.clone()
+    vgrad[visible] = vgrad[visible] / vis_count[visible]                            # train.py:286-287
+    return {"visibility_count": vis_count, "visibility_filter": visible, "radii": max_radii,
+            "viewspace_point_grad": vgrad.unsqueeze(1), "loss": loss_sum / batch}

@@ -37,6 +37,15 @@ def test_factor_exchange_equals_plain_allreduce():
     assert sorted(r for r, _ in reports) == ["0", "1"] and all(ok == "True" for _, ok in reports), out.stdout[-2000:]
 
 
+def test_distributed_step_equals_reference_batch_loop_on_the_real_chain():
+    """view_parallel.distributed_step (4 views on 2 ranks) over epilogue -> rasterizer -> loss against the sequential batch loop."""
+    out = _torchrun([os.path.join("tests", "mr_step_check.py")])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    import re
+    reports = re.findall(r"STEP_CHECK rank (\d+) worst \S+ stats_ok (True|False)", out.stdout)
+    assert sorted(r for r, _ in reports) == ["0", "1"] and all(ok == "True" for _, ok in reports), out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("exchange", ["factors", "allreduce"])
 def test_bench_two_ranks(exchange):
     out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "100000", "--exchange", exchange,

@@ -81,3 +81,113 @@ def test_two_ranks_match_sequential_accumulation(tmp_path, orc, scenes):
     np.testing.assert_allclose(got["grad_norm"], sum(np.linalg.norm(o["dL_dmeans2D"][:, :2], axis=1) for o in outs), rtol=1e-5)
     np.testing.assert_array_equal(got["vis"], sum((o["radii"] > 0).astype(np.float32) for o in outs))
     np.testing.assert_array_equal(got["radii"], np.maximum(outs[0]["radii"], outs[1]["radii"]).astype(np.float32))
+
+
+# ---- distributed_step: the reference's batch loop (train.py:190-226, saro_gaussian.py:226-294), one view per rank ----------------
+class _DynamicStageModel(torch.nn.Module):
+    """Leaves shaped like SaRO-GS's dynamic stage (saro_gaussian.py:306-319): six per-Gaussian groups + _temporal_pos (60 floats per
+    Gaussian), MLP heads, hex-plane grids.  The "renderer" is a smooth torch stand-in (no rasterizer on CPU): what is under test is
+    the step's bookkeeping, which never looks inside the render."""
+
+    def __init__(self, P, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        r = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g) * 0.3)  # noqa: E731
+        self._xyz, self._features_dc, self._features_rest = r(P, 3), r(P, 1, 3), r(P, 15, 3)
+        self._opacity, self._scaling, self._rotation, self._temporal_pos = r(P, 1), r(P, 3), r(P, 4), r(P, 1)
+        self.motion_mlp = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        self.opacity_mlp = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+        self.unused_mlp = torch.nn.Linear(4, 4)            # never reached by a render: its .grad stays None (saro_gaussian.py:232)
+        self.grids = torch.nn.ParameterList([r(4, 8, 8), r(4, 8, 8)])
+        with torch.no_grad():
+            for m in (self.motion_mlp, self.opacity_mlp, self.unused_mlp):
+                for w in m.parameters():
+                    w.copy_(torch.randn(w.shape, generator=g) * 0.2)
+
+    def leaves(self):
+        return dict(self.named_parameters())
+
+    def render_loss(self, k):
+        t = 0.37 * (k + 1)
+        P = self._xyz.shape[0]
+        plane = self.grids[k % 2]
+        iu = (torch.arange(P) * 3 + k) % 8
+        feat = plane[:, iu, (iu * 5 + 1) % 8].T                                     # [P, 4] "plane lookup"
+        h = torch.cat([self._xyz, self._temporal_pos * t, feat], dim=1)            # [P, 8]
+        pos = self._xyz + self.motion_mlp(h) * np.sin(t)
+        means2D = torch.zeros((P, 3), requires_grad=True)
+        screen = pos[:, :2] * np.cos(t) + means2D[:, :2]
+        vis = (pos[:, 2].detach() + 0.1 * k) > -0.2
+        radii = ((self._scaling.detach().exp().amax(1) * 7 + k).to(torch.int32)) * vis.to(torch.int32)
+        w = torch.sigmoid(self._opacity[:, 0] + self.opacity_mlp(h)[:, 0]) * torch.exp(-(screen ** 2).sum(1)) * vis
+        colour = self._features_dc[:, 0].sum(1) + self._features_rest.mean(1).sum(1) * np.cos(t)
+        loss = (w * colour).sum() / P + 1e-2 * (self._rotation ** 2).sum() / P + 1e-2 * (self._scaling * t).sum() / P
+        return {"loss": loss, "viewspace_points": means2D, "visibility_filter": vis, "radii": radii}
+
+
+def _reference_loop(model, views):
+    """train.py:190-226 + :279-292 spelled as the reference spells it."""
+    leaves = model.leaves()
+    cache = {n: torch.zeros_like(p) for n, p in leaves.items()}                    # zero_gradient_cache
+    point_grad, visf, rads, loss_last = [], [], [], 0.0
+    for k in views:
+        out = model.render_loss(k)
+        out["loss"].backward()
+        point_grad.append(torch.norm(out["viewspace_points"].grad[:, :2], dim=-1))
+        rads.append(out["radii"]); visf.append(out["visibility_filter"])
+        for n, p in leaves.items():                                                # cache_gradient
+            if p.grad is not None:
+                cache[n] += p.grad.clone()
+        for p in leaves.values():                                                  # optimizer.zero_grad(set_to_none=True)
+            p.grad = None
+        loss_last += float(out["loss"].detach())
+    grads = {n: c * (1 / len(views)) for n, c in cache.items()}                    # set_batch_gradient
+    count = torch.stack(visf, 1).sum(1)
+    vfilter = count > 0
+    radii = torch.stack(rads, 1).max(1)[0]
+    g = torch.stack(point_grad, 1).sum(1)
+    g[vfilter] = g[vfilter] / count[vfilter]
+    return grads, dict(visibility_count=count, visibility_filter=vfilter, radii=radii, viewspace_point_grad=g.unsqueeze(1), loss=loss_last / len(views))
+
+
+def _step_worker(rank, world, port, out_dir, n_views):
+    for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import view_parallel as vp
+    vp.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = _DynamicStageModel(257, 11)                    # replicated parameters: same seed on every rank
+    bucket = vp.StepBucket(model.leaves())
+    stats = vp.distributed_step(bucket, list(range(n_views)), model.render_loss)
+    stats2 = vp.distributed_step(bucket, list(range(n_views)), model.render_loss)      # a second step starts from a clean cache
+    for k in ("viewspace_point_grad", "radii", "visibility_count"):
+        assert torch.equal(stats[k], stats2[k])
+    if rank == 0:
+        torch.save({"grads": {n: p.grad.clone() for n, p in model.leaves().items() if p.grad is not None},
+                    "stats": {k: v.clone() for k, v in stats.items()}}, os.path.join(out_dir, "step.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_views", [2, 4, 3, 1], ids=["one_view_per_rank", "two_views_per_rank", "uneven", "fewer_views_than_ranks"])
+def test_distributed_step_equals_the_reference_batch_loop(tmp_path, n_views):
+    world = 2
+    mp.spawn(_step_worker, args=(world, _free_port(), str(tmp_path), n_views), nprocs=world, join=True)
+    got = torch.load(tmp_path / "step.pt")
+    model = _DynamicStageModel(257, 11)
+    want_g, want_s = _reference_loop(model, list(range(n_views)))
+    n_per_gaussian = sum(int(np.prod(p.shape[1:])) for n, p in model.leaves().items() if n.startswith("_"))
+    assert n_per_gaussian == 60                                                    # the dynamic stage's per-Gaussian leaves
+    assert set(got["grads"]) == set(want_g)                                        # every leaf gets a .grad, like set_batch_gradient
+    for n in want_g:
+        np.testing.assert_allclose(got["grads"][n].numpy(), want_g[n].numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
+    assert float(got["grads"]["unused_mlp.weight"].abs().max()) == 0.0
+    assert float(got["grads"]["motion_mlp.0.weight"].abs().max()) > 0 and float(got["grads"]["grids.0"].abs().max()) > 0
+    s = got["stats"]
+    np.testing.assert_array_equal(s["visibility_count"].numpy(), want_s["visibility_count"].numpy().astype(np.float32))
+    np.testing.assert_array_equal(s["visibility_filter"].numpy(), want_s["visibility_filter"].numpy())
+    np.testing.assert_array_equal(s["radii"].numpy(), want_s["radii"].numpy().astype(np.float32))
+    np.testing.assert_allclose(s["viewspace_point_grad"].numpy(), want_s["viewspace_point_grad"].numpy(), rtol=2e-5, atol=1e-9)
+    assert abs(float(s["loss"]) - want_s["loss"]) < 1e-5
