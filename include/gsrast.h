@@ -165,7 +165,10 @@ typedef struct gsrast_options {
     int fwd_pixels_per_lane;  /* 0 auto (default), 1 / 2 / 4 */
     int bwd_pixels_per_lane;  /* 0 auto (default), 1 / 2 / 4 */
     int sh_grad_factors;      /* backward: dL_dsh receives the [P][3] factor, see gsrast_sh_grad_combine */
-    int reserved[7];          /* must be zero */
+    int side_stream;          /* 1 (default) forward: the colour kernel (SH -> RGB) runs on a stream of the context, forked off
+                                 `stream` at entry and joined in front of the blend, beside the depth sort and the binning;
+                                 0 = everything on `stream` */
+    int reserved[6];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 typedef struct gsrast_context gsrast_context;

@@ -3,7 +3,9 @@
 // One 256-lane workgroup (4 wave64) per 16x16 tile -- the tile size is pinned by key parity with
 // the reference (config.h:16-17).  A wave owns 64 pixels of the tile: an 8x8 block in the default forward kernel,
 // a 16x4 strip (rows 4w..4w+3) in the backward and in the un-culled variants.  The tile's depth-sorted instance list
-// is staged through LDS in batches (48-byte records gathered with three 16-byte loads per lane).  Default kernels
+// is staged through LDS in batches (48-byte records gathered with three 16-byte loads per lane: rec0 {x, y, conic.x, conic.y},
+// rec1 {conic.z, opacity, depth, skip threshold}, rec2 {r, g, b, -}; rec2 comes from the colour kernel, which runs beside the
+// depth sort on its own stream).  Default kernels
 // (*_cull_kernel): per round of 64 staged instances every lane tests ONE instance against the wave's pixel block
 // (strip_may_touch), the ballot is a 64-bit scalar mask, and only the survivors are evaluated -- each by all lanes, one
 // LDS broadcast read of the record, each lane for its own pixel.  A wave leaves a batch as soon as all its lanes are
@@ -185,8 +187,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
             if (slot < cnt) {
                 const float4 a = s0[slot];
                 const float4 b = s1[slot];
-                const float4 c = s2[slot];
-                touch = strip_may_touch(a, b.x, c.z, sx0, sx1, sy0, sy1);
+                touch = strip_may_touch(a, b.x, b.w, sx0, sx1, sy0, sy1);
             }
             uint64_t mask = __ballot(touch);
             while (mask) {
@@ -199,8 +200,8 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const float power = gs_power(a.z, a.w, b.x, dx, dy);
                 bool term = false;
                 // ONE divergent region; inside it the reference's nested tests (forward.cu:368-381) are selects
-                if (power <= 0.0f && power >= c.z) {
-                    float alpha = b.y * gs_exp<EXPMODE, true>(power);      // c.z >= -80: the bounded exp is exact here
+                if (power <= 0.0f && power >= b.w) {
+                    float alpha = b.y * gs_exp<EXPMODE, true>(power);      // b.w >= -80: the bounded exp is exact here
                     alpha = alpha < 0.99f ? alpha : 0.99f;
                     const float test_T = T * (1.0f - alpha);
                     const bool contrib = !(alpha < 1.0f / 255.0f);
@@ -208,10 +209,10 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     const bool upd = contrib && !term;
                     // forward.cu:361: C += feature * alpha * T, associated as in the source: (feature * alpha) * T
                     const float Tm = upd ? T : 0.0f;                       // fma(x, 0, C) == C exactly
-                    C0 = __builtin_fmaf(b.z * alpha, Tm, C0);
-                    C1 = __builtin_fmaf(b.w * alpha, Tm, C1);
-                    C2 = __builtin_fmaf(c.x * alpha, Tm, C2);
-                    Dm = (upd && T > 0.5f && test_T < 0.5f) ? c.y : Dm;
+                    C0 = __builtin_fmaf(c.x * alpha, Tm, C0);
+                    C1 = __builtin_fmaf(c.y * alpha, Tm, C1);
+                    C2 = __builtin_fmaf(c.z * alpha, Tm, C2);
+                    Dm = (upd && T > 0.5f && test_T < 0.5f) ? b.z : Dm;
                     T = upd ? test_T : T;
                     last = upd ? base + j + 1 : last;
                     pxa = term ? FAR : pxa;
@@ -336,8 +337,8 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                 const float dy = a.y - pyf[k];
                 const float q = __builtin_fmaf(b.x * dy, dy, xx);
                 power[k] = __builtin_fmaf(-0.5f, q, -(xy * dy));
-                // c.z: conservative "alpha < 1/255" pre-test, see preprocess_fwd_kernel
-                hit[k] = !done[k] && !(power[k] > 0.0f) && !(power[k] < c.z);
+                // b.w: conservative "alpha < 1/255" pre-test, see preprocess_fwd_kernel
+                hit[k] = !done[k] && !(power[k] > 0.0f) && !(power[k] < b.w);
                 any_hit = any_hit || hit[k];
             }
             if (!any_hit) continue;
@@ -352,10 +353,10 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                     const bool fin = ok && (test_T < 0.0001f);
                     const bool upd = ok && !fin;
                     const float Tm = upd ? T[k] : 0.0f;             // fma(x, 0, C) == C exactly; (feature * alpha) * T as in the source
-                    C0[k] = __builtin_fmaf(b.z * alpha, Tm, C0[k]);
-                    C1[k] = __builtin_fmaf(b.w * alpha, Tm, C1[k]);
-                    C2[k] = __builtin_fmaf(c.x * alpha, Tm, C2[k]);
-                    Dm[k] = (upd && T[k] > 0.5f && test_T < 0.5f) ? c.y : Dm[k];
+                    C0[k] = __builtin_fmaf(c.x * alpha, Tm, C0[k]);
+                    C1[k] = __builtin_fmaf(c.y * alpha, Tm, C1[k]);
+                    C2[k] = __builtin_fmaf(c.z * alpha, Tm, C2[k]);
+                    Dm[k] = (upd && T[k] > 0.5f && test_T < 0.5f) ? b.z : Dm[k];
                     T[k] = upd ? test_T : T[k];
                     last[k] = upd ? base + j + 1 : last[k];
                     done[k] = done[k] || fin;
@@ -417,7 +418,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     constexpr int NT = Cfg::NT, BATCH = Cfg::BATCH;
     __shared__ float4 s0[BATCH];
     __shared__ float4 s1[BATCH];
-    __shared__ float2 s2[BATCH];          // {blue, skip threshold}
+    __shared__ float4 s2[BATCH];          // {r, g, b, -}
     __shared__ uint32_t sid[BATCH];
     __shared__ float acc[9][BATCH];
 
@@ -462,9 +463,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
             if (i < n) {
                 const uint32_t g = point_list[range.x + (n - 1 - i)];
                 sid[slot] = g;
-                s0[slot] = rec0[g]; s1[slot] = rec1[g];
-                const float4 c = rec2[g];
-                s2[slot] = make_float2(c.x, c.z);
+                s0[slot] = rec0[g]; s1[slot] = rec1[g]; s2[slot] = rec2[g];
             }
 #pragma unroll
             for (int q = 0; q < 9; q++) acc[q][slot] = 0.0f;
@@ -479,7 +478,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
             if (!__any(reach)) continue;               // nobody in this wave got this deep
             const float4 a = s0[j];
             const float4 b = s1[j];
-            const float2 c = s2[j];
+            const float4 c = s2[j];
             const float dx = a.x - pxf;
             const float xx = (a.z * dx) * dx;
             const float xy = a.w * dx;
@@ -490,7 +489,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                 dyv[k] = dy;
                 const float q = __builtin_fmaf(b.x * dy, dy, xx);
                 power[k] = __builtin_fmaf(-0.5f, q, -(xy * dy));
-                hit[k] = pos < last[k] && !(power[k] > 0.0f) && !(power[k] < c.y);
+                hit[k] = pos < last[k] && !(power[k] > 0.0f) && !(power[k] < b.w);
                 any_hit = any_hit || hit[k];
             }
             if (!__any(any_hit)) continue;
@@ -509,7 +508,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                 const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
                 T[k] = T[k] * rcp1ma;
                 const float dch = alpha * T[k];
-                const float c0 = b.z, c1 = b.w, c2 = c.x;
+                const float c0 = c.x, c1 = c.y, c2 = c.z;
                 ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
                 ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
                 ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
@@ -600,7 +599,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     constexpr int NT = Cfg::NT, BATCH = 64, NW = NT / 64;
     __shared__ float4 s0[BATCH];
     __shared__ float4 s1[BATCH];
-    __shared__ float2 s2[BATCH];          // {blue, skip threshold}
+    __shared__ float4 s2[BATCH];          // {r, g, b, -}
     __shared__ uint32_t sid[BATCH];
     // one accumulator slice per wave (plain LDS read-add-write, no LDS atomics); a staged instance's nine sums are adjacent, like
     // the record they are committed to
@@ -663,9 +662,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
             if (i < n) {
                 const uint32_t g = point_list[range.x + (n - 1 - i)];
                 sid[slot] = g;
-                s0[slot] = rec0[g]; s1[slot] = rec1[g];
-                const float4 c = rec2[g];
-                s2[slot] = make_float2(c.x, c.z);
+                s0[slot] = rec0[g]; s1[slot] = rec1[g]; s2[slot] = rec2[g];
             }
         }
         for (uint32_t q4 = t; q4 < (uint32_t)(NS * BATCH * AS / 4); q4 += NT) reinterpret_cast<float4*>(&acc[0][0][0])[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -682,7 +679,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const bool valid = slot < cnt;
                 const float4 a = valid ? s0[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
                 const float czv = valid ? s1[slot].x : 1.f;
-                const float thr = valid ? s2[slot].y : 1.f;
+                const float thr = valid ? s1[slot].w : 1.f;
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {
                     const bool touch = valid && spos < strip_last[k] &&
@@ -698,8 +695,8 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const uint32_t pos = n - 1 - (base + j);
                 const float4 a = s0[j];
                 const float4 b = s1[j];
-                float2 c = s2[j];
-                // keep the blue channel's LDS read up here with the others: sunk into the contributing branch (where it is
+                float4 c = s2[j];
+                // keep the colour's LDS read up here with the others: sunk into the contributing branch (where it is
                 // first used) its latency is exposed on every iteration (measured: +8 % kernel time)
                 asm volatile("" : "+v"(c.x));
                 const float dx = a.x - pxf;
@@ -718,7 +715,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     const float dy = a.y - pyf[k];
                     const float q = __builtin_fmaf(b.x * dy, dy, xx);
                     const float power = __builtin_fmaf(-0.5f, q, -(xy * dy));
-                    if (pos < last[k] && power <= 0.0f && power >= c.y) {
+                    if (pos < last[k] && power <= 0.0f && power >= b.w) {
                         const float G = gs_exp<EXPMODE, true>(power);
                         float alpha = b.y * G;
                         alpha = alpha < 0.99f ? alpha : 0.99f;
@@ -729,7 +726,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                             // (folding the current pair into ac right after use -- ac += alpha (c - ac), no last_alpha /
                             // last_color state -- is 7 VALU shorter but measured 4 % SLOWER: it makes ac wait for this
                             // iteration's exp; here everything ac needs is known when the iteration starts)
-                            const float c0 = b.z, c1 = b.w, c2 = c.x;
+                            const float c0 = c.x, c1 = c.y, c2 = c.z;
                             ac0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * ac0[k]; lc0[k] = c0;
                             ac1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * ac1[k]; lc1[k] = c1;
                             ac2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * ac2[k]; lc2[k] = c2;
@@ -815,7 +812,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     constexpr int AS = 12;
     __shared__ float4 s0[BATCH];
     __shared__ float4 s1[BATCH];
-    __shared__ float2 s2[BATCH];          // {blue, skip threshold}
+    __shared__ float4 s2[BATCH];          // {r, g, b, -}
     __shared__ uint32_t sid[BATCH];
     __shared__ __attribute__((aligned(16))) float acc[BATCH][AS];       // the batch's sums, shared by the four waves (LDS float adds to distinct addresses)
     // {u, dch} of the current group, [instance][pixel of the wave's strip]
@@ -867,9 +864,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
             if (i < n) {
                 const uint32_t g = point_list[range.x + (n - 1 - i)];
                 sid[t] = g;
-                s0[t] = rec0[g]; s1[t] = rec1[g];
-                const float4 c = rec2[g];
-                s2[t] = make_float2(c.x, c.z);
+                s0[t] = rec0[g]; s1[t] = rec1[g]; s2[t] = rec2[g];
             }
         } else if (t - (uint32_t)BATCH < (uint32_t)(BATCH * AS / 4)) {
             reinterpret_cast<float4*>(&acc[0][0])[t - BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -882,7 +877,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
             const bool valid = lane < cnt;
             const float4 a = valid ? s0[lane] : make_float4(0.f, 0.f, 1.f, 0.f);
             const float czv = valid ? s1[lane].x : 1.f;
-            const float thr = valid ? s2[lane].y : 1.f;
+            const float thr = valid ? s1[lane].w : 1.f;
             mk = __ballot(valid && spos < strip_last && strip_may_touch(a, czv, thr, sx0, sx1, sy0, sy0 + 3.0f));
         }
 #pragma unroll 1
@@ -897,15 +892,15 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 const uint32_t pos = n - 1 - (base + j);
                 const float4 a = s0[j];
                 const float4 b = s1[j];
-                float2 c = s2[j];
-                asm volatile("" : "+v"(c.x));       // keep the blue channel's LDS read with the others (see blend_bwd_cull_kernel)
+                float4 c = s2[j];
+                asm volatile("" : "+v"(c.x));       // keep the colour's LDS read with the others (see blend_bwd_cull_kernel)
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float q = __builtin_fmaf(b.x * dy, dy, (a.z * dx) * dx);
                 const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
                 // exp and alpha inside the first divergent region; the alpha >= 1/255 test and its ballot outside (a compare straight
                 // into an SGPR pair: a bool carried out of the branch costs a v_cndmask + v_cmp to become a mask again)
                 float G = 0.f, alpha = 0.f;
-                if (pos < last && power <= 0.0f && power >= c.y) {
+                if (pos < last && power <= 0.0f && power >= b.w) {
                     G = gs_exp<EXPMODE, true>(power);
                     alpha = b.y * G;
                     alpha = alpha < 0.99f ? alpha : 0.99f;
@@ -918,7 +913,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 if (ok) {
                     const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T = T * rcp1ma;
-                    const float c0 = b.z, c1 = b.w, c2 = c.x;
+                    const float c0 = c.x, c1 = c.y, c2 = c.z;
                     ac0 = last_alpha * lc0 + (1.f - last_alpha) * ac0; lc0 = c0;
                     ac1 = last_alpha * lc1 + (1.f - last_alpha) * ac1; lc1 = c1;
                     ac2 = last_alpha * lc2 + (1.f - last_alpha) * ac2; lc2 = c2;

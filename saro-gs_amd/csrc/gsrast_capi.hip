@@ -19,6 +19,7 @@
 #include "gsrast_hexplane.h"
 #include "gsrast_mlp.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -40,14 +41,14 @@ std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0};      // process-wid
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
 // threads driving different streams / devices with different options cannot disturb each other.
 struct DefaultOptions {
-    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0};
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1};
 } g_def;
 gsrast_options snapshot_defaults()
 {
     gsrast_options o{};
     o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
     o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
-    o.sh_grad_factors = g_def.sh_grad_factors;
+    o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream;
     return o;
 }
 bool options_valid(const gsrast_options& o)
@@ -73,10 +74,10 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 // ---- per-kernel device timing (option "profile") -------------------------------------------
 enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
-                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COUNT };
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
                                             "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
-                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd" };
+                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color" };
 struct Pending { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<Pending> g_pending;
@@ -254,9 +255,12 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // These hints (and the counts of the last call) belong to a gsrast_context: one per caller that renders a sequence of similar
 // views.  The reference-shaped entry points use a context private to the calling host thread.
 } // namespace
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 struct gsrast_context {
     std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0};
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
+    SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
+    std::mutex mu;
 };
 namespace {
 gsrast_context* thread_context()
@@ -299,7 +303,7 @@ export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __r
         conic_opacity[4 * i] = vis ? a.z : 0.f; conic_opacity[4 * i + 1] = vis ? a.w : 0.f;
         conic_opacity[4 * i + 2] = vis ? b.x : 0.f; conic_opacity[4 * i + 3] = vis ? b.y : 0.f;
     }
-    if (rgb) { rgb[3 * i] = vis ? b.z : 0.f; rgb[3 * i + 1] = vis ? b.w : 0.f; rgb[3 * i + 2] = vis ? c.x : 0.f; }
+    if (rgb) { rgb[3 * i] = vis ? c.x : 0.f; rgb[3 * i + 1] = vis ? c.y : 0.f; rgb[3 * i + 2] = vis ? c.z : 0.f; }
     if (clamped) {
         const unsigned cl = vis ? clamped_in[i] : 0u;
         clamped[3 * i] = cl & 1u; clamped[3 * i + 1] = (cl >> 1) & 1u; clamped[3 * i + 2] = (cl >> 2) & 1u;
@@ -394,10 +398,19 @@ void gsrast_options_init(gsrast_options* o)
 {
     if (!o) return;
     memset(o, 0, sizeof *o);
-    o->tile_clip = 1; o->cull = 1; o->lpt = 1; o->speculative = 1;
+    o->tile_clip = 1; o->cull = 1; o->lpt = 1; o->speculative = 1; o->side_stream = 1;
 }
 gsrast_context* gsrast_context_create(void) { return new (std::nothrow) gsrast_context(); }
-void gsrast_context_destroy(gsrast_context* c) { delete c; }
+void gsrast_context_destroy(gsrast_context* c)
+{
+    if (!c) return;
+    for (SideStream& x : c->side) {
+        if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
+        if (x.fork) (void)hipEventDestroy(x.fork);
+        if (x.join) (void)hipEventDestroy(x.join);
+    }
+    delete c;
+}
 int gsrast_context_query(const gsrast_context* c, const char* name)
 {
     if (!name) return GSRAST_E_ARG;
@@ -421,6 +434,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "tile_clip")) { g_def.tile_clip = value ? 1 : 0; return 0; }
     if (!strcmp(name, "sh_grad_factors")) { g_def.sh_grad_factors = value ? 1 : 0; return 0; }
     if (!strcmp(name, "speculative")) { g_def.speculative = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "side_stream")) { g_def.side_stream = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -445,6 +459,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "sh_grad_factors")) return g_def.sh_grad_factors.load();
     if (!strcmp(name, "last_instances") || !strcmp(name, "last_runs") || !strcmp(name, "redo_count")) return gsrast_context_query(nullptr, name);
     if (!strcmp(name, "speculative")) return g_def.speculative.load();
+    if (!strcmp(name, "side_stream")) return g_def.side_stream.load();
     if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
@@ -565,12 +580,46 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
     const bool runbin = o.binning == 0 && cam.gy <= 256 && T <= 65536u;
     const bool buckets_ok = T <= BUCKET_MAX_TILES;      // launch order of the blend kernels from work buckets (u16 tile ids)
+    // Colour half of the per-Gaussian forward (SH -> RGB: most of its bytes) on the context's side stream, forked off the
+    // caller's stream here and joined in front of the blend: it overlaps the geometry kernel, the depth sort and the binning.
+    SideStream* side = nullptr;
+    hipStream_t cs = s;
+    if (o.side_stream) {
+        int device = 0;
+        GS_HIP(hipGetDevice(&device));
+        if (device >= 0 && device < 32) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            SideStream& x = ctx->side[device];
+            if (!x.stream) {
+                // lowest priority: its one bandwidth-heavy kernel should fill the gaps the latency-bound sort kernels leave, not
+                // compete with them for compute units
+                int prio_least = 0, prio_greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+                GS_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, prio_least));
+                GS_HIP(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
+                GS_HIP(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
+            }
+            side = &x;
+        }
+    }
+    if (side) {
+        GS_HIP(hipEventRecord(side->fork, s));                 // the inputs (and the buffers just handed out) are ordered on s
+        GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+        cs = side->stream;
+    }
+    {
+        ProfScope ps(K_COLOR, cs);
+        preprocess_color_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, cs>>>(
+            P, D, M, means3D, colors_precomp ? nullptr : shs, colors_precomp, cam_pos, rec2, at<unsigned char>(geom, GL.clamped));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
+    }
+    if (side) GS_HIP(hipEventRecord(side->join, side->stream));
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
-        preprocess_fwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
-            P, D, M, means3D, scales, rotations, opacities, colors_precomp ? nullptr : shs, cov3D_precomp,
-            colors_precomp, cam, radii, depths, rec0, rec1, rec2, at<float>(geom, GL.cov3D),
-            at<unsigned char>(geom, GL.clamped), tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
+        preprocess_fwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+            P, means3D, scales, rotations, opacities, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
+            tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
             (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt));
         GS_LAUNCHED("preprocess_fwd");
     }
@@ -649,6 +698,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         return GSRAST_OK;
     };
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built) -> int {
+        if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));       // the colours (rec2) are the blend's input
         ProfScope ps(K_BLEND_FWD, s);
         uint32_t grid = ((T + 7) / 8) * 8;
         float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);

@@ -16,8 +16,8 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 // Geometry (per Gaussian), replaces GeometryState (reference rasterizer_impl.h:30-45):
 //   depths   f32[P]      view-space z (also the low 32 key bits)
 //   rec0     float4[P]   {mean2D.x, mean2D.y, conic.x, conic.y}     \  gathered by the blend
-//   rec1     float4[P]   {conic.z, opacity, r, g}                    > kernels, 48 B / instance
-//   rec2     float4[P]   {b, depth, skip_threshold, 0}              /
+//   rec1     float4[P]   {conic.z, opacity, depth, skip_threshold}   > kernels, 48 B / instance
+//   rec2     float4[P]   {r, g, b, 0}   (colour kernel, side stream) /
 //   cov3D    f32[6P]     upper triangle (only when built from scale/rotation)
 //   clamped  u8[P]       bit c set <=> colour channel c was clamped at 0
 //   tiles    u32[P]      tiles touched

@@ -221,26 +221,57 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P,
 }
 
 // -------------------------------------------------------------------------------------------
-// K1 forward.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
+// K1 forward, colour half (forward.cu:20-71 computeColorFromSH, the colour lines of :237-246): SH -> RGB + clamp flags, or the
+// caller's colors_precomp, into rec2.  It depends on nothing the geometry half produces -- so gsrast_forward runs it on a
+// low-priority side stream, beside the geometry kernel, the depth sort and the binning (all latency-bound), and joins it in
+// front of the blend, the first kernel to read a colour.  Evaluated for every Gaussian (a culled one is never read).
+// (A grid-stride version limited to 2-4 workgroups per CU was measured: no better -- the sort kernels it runs beside slow
+// down by the memory latency under load, not by a lack of wave slots.)
 __global__ void __launch_bounds__(PP_THREADS)
-preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                        const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
+                        float4* __restrict__ rec2, unsigned char* __restrict__ clamped)
+{
+    __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
+    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+    const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
+    const int ic = i < P ? i : P - 1;
+    const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };       // requested before the staging barrier
+    if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
+    if (i >= P) return;
+    float col[3];
+    unsigned cl = 0;
+    if (!colors_precomp) {
+        const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
+        const float* my_sh = staged ? sh_lds + threadIdx.x * PP_SH_STRIDE : shs + (size_t)i * M * 3;
+        sh_to_rgb(D, p, campos, my_sh, col);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
+    }
+    rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+    clamped[i] = (unsigned char)cl;
+}
+
+// K1 forward, geometry half.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
-                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-                      const float* __restrict__ colors_precomp, CamArgs cam_args, int* __restrict__ radii,
+                      const float* __restrict__ cov3D_precomp, CamArgs cam_args, int* __restrict__ radii,
                       float* __restrict__ depths, float4* __restrict__ rec0, float4* __restrict__ rec1,
-                      float4* __restrict__ rec2, float* __restrict__ cov3D, unsigned char* __restrict__ clamped,
+                      float* __restrict__ cov3D,
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
                       uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val,
                       int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */,
                       uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
-    __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
-    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
-    const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
-    // Every per-Gaussian input is requested up front, before the SH rows are staged: the kernel is latency-bound at its
-    // occupancy, and loads issued where they are first used (inside the visibility / area branches) put three more memory
-    // round trips behind the staging barrier.  Clamped index: lanes past P load a valid element and never use it.
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Every per-Gaussian input is requested up front: loads issued where they are first used (inside the visibility / area
+    // branches) put three more memory round trips into a latency-bound kernel.  Clamped index: lanes past P load a valid
+    // element and never use it.
     const int ic = i < P ? i : P - 1;
     const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
     float s_in[3] = { 0.f, 0.f, 0.f };
@@ -250,9 +281,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         q_in = reinterpret_cast<const float4*>(rotations)[ic];
     }
     const float op_in = opacities[ic];
-    if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
     if (i >= P) return;
-    const float* my_sh = staged ? sh_lds + threadIdx.x * PP_SH_STRIDE : shs + (size_t)i * M * 3;
     const Cam cam = load_cam(cam_args);
     int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
 
@@ -290,16 +319,6 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             tile_rect(px, py, rad, cam.gx, cam.gy, rmin, rmax);
             const int area = (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]);
             if (area != 0) {
-                float col[3];
-                unsigned cl = 0;
-                if (!colors_precomp) {
-                    sh_to_rgb(D, p, cam.campos, my_sh, col);
-#pragma unroll
-                    for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
-                }
                 const float op = op_in;
                 // Conservative pre-test for the blend kernels: power < thr  ==>  op*exp(power) < 1/255
                 // with a 2% margin, so skipping the exp for such pairs never changes a decision.
@@ -307,9 +326,7 @@ preprocess_fwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                 const float thr = op > 0.0f ? fmaxf(logf(1.0f / (255.0f * op)) - 0.02f, -80.0f) : 1.0f;
                 depths[i] = pv[2];
                 rec0[i] = make_float4(px, py, con0, con1);
-                rec1[i] = make_float4(con2, op, col[0], col[1]);
-                rec2[i] = make_float4(col[2], pv[2], thr, 0.0f);
-                clamped[i] = (unsigned char)cl;
+                rec1[i] = make_float4(con2, op, pv[2], thr);
                 rad_out = rad; ntiles = (uint32_t)area;
                 key = __float_as_uint(pv[2]);
                 if (clip_rect) {

@@ -97,6 +97,28 @@ def synth(P: int, seed: int = 0, sh_degree: int = 3, scale_mul: float = 1.0) -> 
                 bg=np.zeros(3, dtype=np.float32))
 
 
+def synth_shell(P: int, seed: int = 0, sh_degree: int = 3, radius: float = 1.25, thickness: float = 0.02) -> Dict[str, np.ndarray]:
+    """A second occlusion regime for the same P and resolutions: Gaussians on a thin spherical SHELL (a surface, like a trained
+    scene) instead of a solid cube.  A camera ray crosses two thin layers, so a tile consumes most of its depth-sorted list before
+    the transmittance saturates (R_eff ~ R), where the cube's lists are cut after a few per cent (R_eff / R = 7.5 % at 1 M).
+    Scales follow the neighbour spacing on the sphere (sqrt(4 pi r^2 / P)), everything else as synth()."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(P, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    means = (d * (radius + thickness * rng.normal(size=(P, 1)))).astype(np.float32)
+    s = 0.6 * math.sqrt(4.0 * math.pi * radius * radius / max(P, 1))
+    scales = np.exp(rng.uniform(math.log(s / 3.0), math.log(3.0 * s), size=(P, 3))).astype(np.float32)
+    q = rng.normal(size=(P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    opac = (1.0 / (1.0 + np.exp(-rng.normal(0.0, 2.0, size=(P, 1))))).astype(np.float32)
+    M = 16
+    shs = np.zeros((P, M, 3), dtype=np.float32)
+    shs[:, 0, :] = rng.uniform(-1.77, 1.77, size=(P, 3))
+    shs[:, 1:, :] = rng.normal(0.0, 0.1, size=(P, M - 1, 3))
+    return dict(means3D=means, scales=scales, rotations=q.astype(np.float32), opacities=opac,
+                shs=shs.astype(np.float32), sh_degree=int(sh_degree), bg=np.zeros(3, dtype=np.float32))
+
+
 def upstream_grad(H: int, W: int, seed: int) -> np.ndarray:
     """dL/dcolor used by bench and parity tests: N(0,1)/(3HW), SURVEY.md 8(d)."""
     rng = np.random.default_rng(seed)

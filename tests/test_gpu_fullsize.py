@@ -39,7 +39,7 @@ def _forward_state(rast, rs, ten, P, W, H):
     return R, color, radii, depth, st
 
 
-FULL = CONFIGS[:2] + [("bench_1M_1080p", 1_000_000, 1920, 1080), CONFIGS[2]]
+FULL = CONFIGS[:2] + [("bench_1M_1080p", 1_000_000, 1920, 1080), CONFIGS[2], ("shell_1M_1080p", 1_000_000, 1920, 1080)]
 
 
 @pytest.mark.parametrize("name,P,W,H", FULL, ids=[c[0] for c in FULL])
@@ -49,11 +49,16 @@ def test_full_size_oracle_equality(name, P, W, H, orc, scenes, rast, gpu):
     1e-5 (+1e-4 relative) of the fp64 truth with the bench's upstream gradient N(0,1)/(3HW)."""
     from gpu_harness import bits, run_hip
     from test_gpu_parity import _check_forward_exact, _check_grads
-    sc = scenes.synth(P, 0)
+    sc = scenes.synth_shell(P, 0) if name.startswith("shell") else scenes.synth(P, 0)     # shell: a surface-like scene, R_eff ~ R
     cam = scenes.camera(0, 1, W, H)
     g = scenes.upstream_grad(H, W, 1)
     orc.set_exp_mode(0)
     o32 = orc.render(sc, cam, g)
+    if name.startswith("shell"):
+        gy, gx = (H + 15) // 16, (W + 15) // 16
+        nc = np.zeros((gy * 16, gx * 16), np.int64); nc[:H, :W] = o32["n_contrib"]
+        r_eff = int(nc.reshape(gy, 16, gx, 16).max(axis=(1, 3)).sum())
+        assert r_eff > 0.5 * o32["R"], (r_eff, o32["R"])          # the regime this scene exists for
     o64 = orc.render(sc, cam, g, f64=True)
     names = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"]
     for clip in ((1,) if P > 2_000_000 else (0, 1)):       # 3 M: the product default only (the 75 M-entry literal lists are
