@@ -73,7 +73,8 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
 /* Backward pass.  Replaces Rasterizer::backward, rasterizer.h:60-89.
  * EVERY output array is fully overwritten (zeros for culled Gaussians), none has to be initialised -- the reference
  * accumulates into nine zero-filled arrays (300 B / Gaussian of memset, rasterize_points.cu:150-158); here the blend
- * backward accumulates into one 64-byte record per Gaussian inside geom_buffer (zero-filled by this call) and the
+ * backward accumulates into one 64-byte record per Gaussian inside geom_buffer (zero-filled by the forward, and again by
+ * this call unless options->grads_zeroed says it is the first backward on that state) and the
  * per-Gaussian backward writes dL_dmean2D [P][3] (.z = 0), dL_dopacity [P], dL_dcolor [P][3], dL_dconic [P][4] (.z = 0,
  * as the reference never writes it) from it, next to dL_dmean3D [P][3], dL_dcov3D [P][6], dL_dsh [P][M][3],
  * dL_dscale [P][3], dL_drot [P][4].  May be NULL: dL_dconic (an intermediate), dL_dcolor unless colors_precomp is given,
@@ -168,7 +169,9 @@ typedef struct gsrast_options {
     int side_stream;          /* 1 (default) forward: the colour kernel (SH -> RGB) runs on a stream of the context, forked off
                                  `stream` at entry and joined in front of the blend, beside the depth sort and the binning;
                                  0 = everything on `stream` */
-    int reserved[6];          /* must be zero */
+    int grads_zeroed;         /* backward: 1 = no backward has run on this forward's geometry buffer yet (the forward leaves the
+                                 gradient records zero), so the 64 B / Gaussian zero-fill is skipped; 0 (default) = fill */
+    int reserved[5];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 typedef struct gsrast_context gsrast_context;

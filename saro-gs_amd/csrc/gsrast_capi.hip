@@ -610,7 +610,8 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     {
         ProfScope ps(K_COLOR, cs);
         preprocess_color_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, cs>>>(
-            P, D, M, means3D, colors_precomp ? nullptr : shs, colors_precomp, cam_pos, rec2, at<unsigned char>(geom, GL.clamped));
+            P, D, M, means3D, colors_precomp ? nullptr : shs, colors_precomp, cam_pos, rec2, at<unsigned char>(geom, GL.clamped),
+            at<float4>(geom, GL.grec));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
     }
@@ -1181,8 +1182,9 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
     const float4* rec0 = at<float4>(geom, GL.rec0); const float4* rec1 = at<float4>(geom, GL.rec1); const float4* rec2 = at<float4>(geom, GL.rec2);
 
     // per-Gaussian gradient records: the only memory the backward accumulates into (64 B / Gaussian, in the geometry buffer)
+    // (the forward leaves them zero: a caller that knows this is the first backward on this state says so and saves the fill)
     float* grec = at<float>(geom, GL.grec);
-    GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
+    if (!o.grads_zeroed) GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
     if (R > 0) {
         ProfScope ps(K_BLEND_BWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;

@@ -230,10 +230,16 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P,
 __global__ void __launch_bounds__(PP_THREADS)
 preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                         const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
-                        float4* __restrict__ rec2, unsigned char* __restrict__ clamped)
+                        float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
+                        float4* __restrict__ grec4 /* [P][4]: the backward's gradient records, zero-filled here, off the critical path */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+    {   // this workgroup's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
+        const size_t q0 = (size_t)blockIdx.x * PP_THREADS * 4, q1 = (size_t)P * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
     const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
     const int ic = i < P ? i : P - 1;
     const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };       // requested before the staging barrier

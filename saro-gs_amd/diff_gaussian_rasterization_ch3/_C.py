@@ -45,7 +45,7 @@ class OptionsStruct(C.Structure):
     """gsrast_options (include/gsrast.h): everything that changes what ONE call computes / how it is scheduled."""
     _fields_ = [("exp_mode", C.c_int), ("binning", C.c_int), ("tile_clip", C.c_int), ("cull", C.c_int), ("lpt", C.c_int),
                 ("speculative", C.c_int), ("fwd_pixels_per_lane", C.c_int), ("bwd_pixels_per_lane", C.c_int),
-                ("sh_grad_factors", C.c_int), ("side_stream", C.c_int), ("reserved", C.c_int * 6)]
+                ("sh_grad_factors", C.c_int), ("side_stream", C.c_int), ("grads_zeroed", C.c_int), ("reserved", C.c_int * 5)]
 
 
 # Per-call options are kept PER HOST THREAD on the Python side and travel with every call (gsrast_forward_ex /
@@ -69,11 +69,12 @@ def current_options() -> dict:
     return dict(_thread_options())
 
 
-def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None) -> OptionsStruct:
+def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None, grads_zeroed: bool = False) -> OptionsStruct:
     o = OptionsStruct()
     for k, v in (_thread_options() if options is None else options).items():
         setattr(o, k, int(v))
     o.sh_grad_factors = int(bool(sh_grad_factors))
+    o.grads_zeroed = int(bool(grads_zeroed))
     return o
 
 
@@ -337,11 +338,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, *, options: Optional[dict] = None):
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, *, options: Optional[dict] = None,
+                                 first_backward: bool = False):
     """Backward.  Mirrors RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-194): returns
     ``(dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6],
     dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])``.  `options` (not in the reference): the per-call options to use
-    instead of the calling thread's (current_options() captured at forward time)."""
+    instead of the calling thread's (current_options() captured at forward time); `first_backward`: no backward has touched
+    geomBuffer since its forward, whose gradient records are therefore still zero (the library skips its zero-fill)."""
     dev = _require_gpu(means3D)
     L = lib()
     P = int(means3D.shape[0])
@@ -395,7 +398,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             stream = torch.cuda.current_stream(dev).cuda_stream
             sh_out = ar.factor.data_ptr() if factors else _ptr(dL_dsh)
             rc = L.gsrast_backward_ex(
-                C.byref(_options_struct(sh_grad_factors=factors, options=options)),      # per call: no process-wide switch is flipped
+                C.byref(_options_struct(sh_grad_factors=factors, options=options, grads_zeroed=first_backward)),      # per call: no process-wide switch is flipped
                 P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
                 _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),

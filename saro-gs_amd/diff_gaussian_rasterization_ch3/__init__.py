@@ -71,6 +71,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.gs_options = _C.current_options()      # the backward runs on autograd's thread: it must use THIS thread's options
+        ctx.gs_backwards = 0                       # backwards run on this state (retain_graph): only the first finds zeroed records
         # opacities are not saved: the state buffer keeps them next to the conic (REF:84)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buf, bin_buf, img_buf)
@@ -89,7 +90,8 @@ class _RasterizeGaussians(torch.autograd.Function):
          grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
-            geom_buf, ctx.num_rendered, bin_buf, img_buf, options=ctx.gs_options)
+            geom_buf, ctx.num_rendered, bin_buf, img_buf, options=ctx.gs_options, first_backward=ctx.gs_backwards == 0)
+        ctx.gs_backwards += 1
         # one gradient per forward input, in input order; absent optionals get None
         def opt(g, x):
             return g if x.numel() != 0 else None

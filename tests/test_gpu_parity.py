@@ -734,3 +734,30 @@ def test_two_threads_two_streams_different_options(orc, scenes, rast, gpu):
             assert torch.equal(c, c0) and torch.equal(d, d0) and torch.equal(r, r0) and R == R0
             for k in g0:
                 assert ((gr[k] - g0[k]).abs() <= 1e-6 + 1e-4 * g0[k].abs()).all(), (n, k)
+
+
+def test_second_backward_on_the_same_forward_state(scenes, rast, gpu):
+    """retain_graph: the forward leaves the per-Gaussian gradient records zero and the FIRST backward skips their zero-fill
+    (options.grads_zeroed); a second backward on the same state must fill them again -- both give the same gradients."""
+    import torch
+    from conftest import settings_from
+    P, W, H = 5000, 160, 128
+    sc = scenes.synth(P, 191)
+    cam = scenes.camera(1, 4, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    g = t(scenes.upstream_grad(H, W, 192))
+    lv = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    color, _, _ = rast.GaussianRasterizer(rs)(means3D=lv["means3D"], means2D=m2, opacities=lv["opacities"], shs=lv["shs"],
+                                              scales=lv["scales"], rotations=lv["rotations"])
+    color.backward(g, retain_graph=True)
+    first = {k: v.grad.clone() for k, v in lv.items()}
+    first["m2"] = m2.grad.clone()
+    for v in list(lv.values()) + [m2]:
+        v.grad = None
+    color.backward(g)
+    for k, v in list(lv.items()) + [("m2", m2)]:
+        a, b = first[k], v.grad
+        assert float(a.abs().max()) > 0
+        assert ((a - b).abs() <= 1e-7 + 1e-4 * a.abs()).all(), k
