@@ -161,8 +161,15 @@ __device__ __forceinline__ uint32_t dev_count(uint32_t n, const uint32_t* __rest
 // "maximum - base fits 24 bits", i.e. any depth range narrower than 2^24 float steps.  The host cannot know that when it enqueues
 // them, so every kernel reads the verdict from device memory (`sig` = significant key bits) and passes two and three pick their
 // buffers accordingly (A -> B -> C -> A instead of A -> B -> A -> B -> A): the sorted sequence ends in A either way.
-enum : int { RA_MINMAX = 1, RA_IN_ALT = 2, RA_SKIP = 4, RA_OUT_ALT = 8, RA_LAST_IF_SHORT = 16 };
-__device__ __forceinline__ bool sort_is_short(const uint32_t* __restrict__ sig) { return sig && sig[0] <= 24u; }   // sig[1] = base
+// RA_ASSUME: the host did not even enqueue the fourth pass, because the previous forward of the same context found a short span
+// (consecutive views of one scene): every kernel then behaves as if the verdict were "short", and the first pass's extra
+// workgroup raises sig[2] when that was wrong -- the host reads it back with the instance counts and repeats the sort with four
+// passes (gsrast_forward: the same redo path as an undersized speculative binning buffer).
+enum : int { RA_MINMAX = 1, RA_IN_ALT = 2, RA_SKIP = 4, RA_OUT_ALT = 8, RA_LAST_IF_SHORT = 16, RA_ASSUME = 32 };
+__device__ __forceinline__ bool sort_is_short(const uint32_t* __restrict__ sig, int adapt = 0)      // sig[1] = base, sig[2] = wrong assumption
+{
+    return (adapt & RA_ASSUME) || (sig && sig[0] <= 24u);
+}
 
 template <typename KeyT, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
@@ -173,7 +180,7 @@ radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __r
 {
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t s_mm[2];
-    const bool is_short = sort_is_short(sig);
+    const bool is_short = sort_is_short(sig, adapt);
     if ((adapt & RA_SKIP) && is_short) return;
     if ((adapt & RA_IN_ALT) && is_short) keys = keys_alt;
     if ((adapt & RA_MINMAX) && threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; }
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(256)
 radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t* __restrict__ digit_total,
                      uint32_t* __restrict__ sig = nullptr, int adapt = 0, const uint32_t* __restrict__ block_minmax = nullptr, uint32_t ndigits = 0)
 {
-    if ((adapt & RA_SKIP) && sort_is_short(sig)) return;
+    if ((adapt & RA_SKIP) && sort_is_short(sig, adapt)) return;
     if ((adapt & RA_MINMAX) && blockIdx.x == ndigits) {      // the extra workgroup of the first pass: min / max over the blocks -> sig
         __shared__ uint32_t mm[2];
         if (threadIdx.x == 0) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
@@ -232,6 +239,7 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
             const uint32_t span = mm[0] > mm[1] ? 0u : mm[1] - b;
             sig[0] = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
             sig[1] = b;
+            sig[2] = ((adapt & RA_ASSUME) && sig[0] > 24u) ? 1u : 0u;
         }
         return;
     }
@@ -266,7 +274,7 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
                      const uint32_t* __restrict__ sig = nullptr, int adapt = 0)
 {
     {
-        const bool is_short = sort_is_short(sig);
+        const bool is_short = sort_is_short(sig, adapt);
         if ((adapt & RA_SKIP) && is_short) return;
         if ((adapt & RA_IN_ALT) && is_short) { keys_in = keys_in_alt; vals_in = vals_in_alt; }
         if ((adapt & RA_OUT_ALT) && is_short) { keys_out = keys_out_alt; vals_out = vals_out_alt; }

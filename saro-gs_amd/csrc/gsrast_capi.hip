@@ -149,7 +149,7 @@ int radix_passes(int bits) { int p = (bits + 7) / 8; return p ? p : 1; }
 // chunks (1 M Gaussians = 245 workgroups) and run faster with smaller ones.
 // Device-side pass-count adaptation of the 32-bit depth sort (gsrast_binning.h: RA_*): a third buffer pair, the per-block
 // key minima / maxima of pass 0, and the word that receives the number of significant key bits.
-template <typename KeyT, typename ValT> struct SortAdapt { KeyT* kC; ValT* vC; uint32_t* block_minmax; uint32_t* sig; };
+template <typename KeyT, typename ValT> struct SortAdapt { KeyT* kC; ValT* vC; uint32_t* block_minmax; uint32_t* sig; bool assume_short; };
 
 template <typename KeyT, typename ValT = uint32_t, int ITEMS = RS_ITEMS>
 int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
@@ -164,15 +164,16 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
     if (ad && passes == 4 && bits == 32 && nblk > RS_SELF_SCAN_BLOCKS) {
         // A -> B -> (short ? C : A) -> (short ? A : B) -> [A]: see RA_* in gsrast_binning.h.  The result is in (kA, vA).
         const uint32_t mask = 255u;
-        for (int p = 0; p < 4; p++) {
+        const int as = ad->assume_short ? RA_ASSUME : 0;
+        for (int p = 0; p < (ad->assume_short ? 3 : 4); p++) {
             const int shift = 8 * p;
             const KeyT* kin = (p & 1) ? kB : kA; const ValT* vin = (p & 1) ? vB : vA;      // the long sort's ping-pong
             KeyT* kout = (p & 1) ? kA : kB; ValT* vout = (p & 1) ? vA : vB;
-            const int hmode = p == 0 ? RA_MINMAX : p == 2 ? RA_IN_ALT : p == 3 ? RA_SKIP : 0;
-            const int smode = p == 1 ? RA_OUT_ALT : p == 2 ? (RA_IN_ALT | RA_OUT_ALT | RA_LAST_IF_SHORT) : p == 3 ? RA_SKIP : 0;
+            const int hmode = (p == 0 ? RA_MINMAX : p == 2 ? RA_IN_ALT : p == 3 ? RA_SKIP : 0) | as;
+            const int smode = (p == 1 ? RA_OUT_ALT : p == 2 ? (RA_IN_ALT | RA_OUT_ALT | RA_LAST_IF_SHORT) : p == 3 ? RA_SKIP : 0) | as;
             radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kin, n, n_dev, shift, mask, hist, nblk, ad->kC, p ? ad->sig : nullptr, hmode, ad->block_minmax);
             GS_LAUNCHED("radix_hist");
-            radix_rowscan_kernel<<<mask + 1 + (p == 0 ? 1 : 0), 256, 0, s>>>(hist, nblk, scan_tmp, ad->sig, p == 0 ? RA_MINMAX : p == 3 ? RA_SKIP : 0, ad->block_minmax, mask + 1);
+            radix_rowscan_kernel<<<mask + 1 + (p == 0 ? 1 : 0), 256, 0, s>>>(hist, nblk, scan_tmp, ad->sig, (p == 0 ? RA_MINMAX : p == 3 ? RA_SKIP : 0) | as, ad->block_minmax, mask + 1);
             GS_LAUNCHED("radix_rowscan");
             // pass 1 writes C when short; pass 2 reads C and writes A when short (and gathers: it is then the last pass)
             radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kin, vin, kout, vout, n, n_dev, shift, mask, hist, scan_tmp, nblk,
@@ -259,6 +260,7 @@ struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, joi
 struct gsrast_context {
     std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0};
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
+    std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
     std::mutex mu;
 };
@@ -364,6 +366,7 @@ void launch_bwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
     blend_bwd_cull_kernel<MODE, PPL><<<grid, 256 / PPL, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.grec,
                                                                  a.from_buckets ? a.bcnt : nullptr, a.blist);
 }
+std::atomic<int> g_sort_hint{1};          // 1: enqueue three depth-sort passes when the context's last forward had short keys (A/B switch)
 std::atomic<int> g_bwd_transposed{1};     // 1: blend_bwd_cull_t_kernel for one pixel per lane (default); 0: blend_bwd_cull_kernel<.., 1> (A/B switch)
 template <int MODE>
 void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -429,6 +432,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "sort_hint")) { g_sort_hint = value ? 1 : 0; return 0; }
     if (!strcmp(name, "cull")) { g_def.cull = value ? 1 : 0; return 0; }
     if (!strcmp(name, "binning")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.binning = value; return 0; }
     if (!strcmp(name, "tile_clip")) { g_def.tile_clip = value ? 1 : 0; return 0; }
@@ -624,15 +628,16 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
             (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt));
         GS_LAUNCHED("preprocess_fwd");
     }
-    {
-        ProfScope ps(K_SORT_DEPTH, s);
-        // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
-        const SortAdapt<uint32_t, uint32_t> ad{ at<uint32_t>(geom, GL.keyC), at<uint32_t>(geom, GL.valC), at<uint32_t>(geom, GL.sort_minmax), scalars + 8 };
-        int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets, nullptr, &ad);
-        if (rc != GSRAST_OK) return rc;
-    }
-    const uint32_t* order = vA; // 4 passes -> back in A
-    {
+    const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
+    const bool assume_short = adaptive_sort && g_sort_hint.load() != 0 && ctx->depth_short.load() != 0;
+    auto sort_and_scan = [&](bool assume) -> int {
+        {
+            ProfScope ps(K_SORT_DEPTH, s);
+            // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
+            const SortAdapt<uint32_t, uint32_t> ad{ at<uint32_t>(geom, GL.keyC), at<uint32_t>(geom, GL.valC), at<uint32_t>(geom, GL.sort_minmax), scalars + 8, assume };
+            int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets, nullptr, &ad);
+            if (rc != GSRAST_OK) return rc;
+        }
         ProfScope ps(K_SCAN_TILES, s);
         int rc;
         if (runbin) {   // only the widths are scanned (-> run offsets, Q); num_rendered is just the sum of the tile counts
@@ -642,8 +647,10 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
             if (rc != GSRAST_OK) return rc;
             rc = scan_u32(woffsets, nullptr, (uint32_t)P, woffsets, true, scan_tmp, scalars + 1, s);   // column runs
         }
-        if (rc != GSRAST_OK) return rc;
-    }
+        return rc;
+    };
+    { int rc = sort_and_scan(assume_short); if (rc != GSRAST_OK) return rc; }
+    const uint32_t* order = vA; // the sorted sequence ends in A under every pass count
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
     // reference rasterizer_impl.cu:311 (the run-compressed path writes every tile's range itself, empty ones included)
@@ -728,9 +735,11 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         return GSRAST_OK;
     };
 
-    uint32_t counts[4] = { 0, 0, 0, 0 };      // {instances R (low word), column runs Q, -, R (high word, run-compressed path)}
+    // {instances R (low word), column runs Q, -, R (high word, run-compressed path), ..., [8] significant depth-key bits,
+    //  [9] key base, [10] "three sort passes were assumed and were not enough"}
+    uint32_t counts[12] = { 0 };
     Readback* rb = nullptr;
-    { int rc = read_u32_begin(scalars, s, 4, &rb); if (rc != GSRAST_OK) return rc; }
+    { int rc = read_u32_begin(scalars, s, 12, &rb); if (rc != GSRAST_OK) return rc; }
     // Speculative launch: with a buffer sized from the previous call, binning and blend are enqueued BEFORE the host knows
     // R and Q (the kernels read the counts on the device), so the GPU never idles on the read-back.  If the counts turn
     // out not to fit, the device published empty ranges and the two pieces are simply launched again with exact sizes.
@@ -740,7 +749,18 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true);
         if (rc != GSRAST_OK) return rc;
     }
-    { int rc = read_u32_finish(rb, scalars, s, counts, 4); if (rc != GSRAST_OK) return rc; }
+    { int rc = read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
+    bool sort_redone = false;
+    if (adaptive_sort) {
+        if (assume_short && counts[10] != 0) {      // the scene's depth range widened: sort again with all four passes, then as after
+            ctx->redo_count++;                      // an undersized speculative launch (everything enqueued so far used a wrong order)
+            int rc = sort_and_scan(false);
+            if (rc == GSRAST_OK) rc = read_u32(scalars, s, counts, 12);
+            if (rc != GSRAST_OK) return rc;
+            sort_redone = true;
+        }
+        ctx->depth_short = counts[8] <= 24u ? 1 : 0;
+    }
     if (runbin && counts[3] != 0) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     auto t2 = std::chrono::steady_clock::now();
     if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u%s\n",
@@ -753,8 +773,8 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     { const uint32_t hr = ctx->R_hint.load(), hq = ctx->Q_hint.load();
       ctx->R_hint = R > hr - hr / 16 ? R : hr - hr / 16; ctx->Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
     ctx->last_R = R; ctx->last_Q = Q;
-    if (speculative && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
-    if (speculative) ctx->redo_count++;
+    if (speculative && !sort_redone && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
+    if (speculative && !sort_redone) ctx->redo_count++;
     if (speculative)    // redo: the truncated pass already appended every tile to the work buckets once
         GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, (XCD_GROUPS + 1) * WORK_BUCKETS * sizeof(uint32_t), s));
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)

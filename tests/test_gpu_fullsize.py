@@ -259,3 +259,27 @@ def test_adaptive_depth_sort_pass_count(radius, short, orc, scenes, rast, gpu):
     np.testing.assert_array_equal(h["point_list"], o32["point_list"])
     np.testing.assert_array_equal(h["ranges"], o32["ranges"])
     np.testing.assert_array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+
+
+def test_depth_sort_pass_hint_follows_the_scene(orc, scenes, rast, gpu):
+    """The context remembers whether the last forward's depth keys were short and then enqueues three sort passes instead of
+    four; when the next view's depth range is wide after all, the device says so in the read-back and the sort is repeated
+    (redo_count).  Sequence short, short, wide, wide, short: every forward equals the oracle, exactly one redo."""
+    from gpu_harness import run_hip
+    P, W, H = 200_000, 480, 360
+    sc = scenes.synth(P, 6)
+    _C = rast._C
+    want = {}
+    redo0 = None
+    for step, radius in enumerate([4.0, 4.0, 2.6, 2.6, 4.0]):
+        cam = scenes.camera(2, 7, W, H, radius=radius)
+        if radius not in want:
+            want[radius] = orc.render(sc, cam)
+        o32 = want[radius]
+        if step == 1:
+            redo0 = _C.get_option("redo_count")
+        h = run_hip(rast, sc, cam, gpu, tile_clip=0)            # two forwards per call (state export + autograd module)
+        np.testing.assert_array_equal(h["point_list"], o32["point_list"], err_msg=f"step {step}")
+        np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+        np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+    assert _C.get_option("redo_count") - redo0 == 1
