@@ -205,7 +205,7 @@ def roofline_of(st, bwd_ms, P):
             vi = pj.get("valu_wave_insts_per_launch")
             mix, cal = _profile_json("r02_valu_mix.json"), _profile_json("r02_valu_calib.json")
             if vi and bwd_ms > 0 and mix and cal:
-                cyc = mix["kernels"]["blend_bwd_cull_kernel"]["avg_cycles_per_valu_inst"]
+                cyc = mix["kernels"]["blend_bwd_cull_t_kernel"]["avg_cycles_per_valu_inst"]
                 fma = max(r["wave_insts_per_s"] for r in cal["results"] if r["op"] == "v_fma_f32")
                 rate = vi / (bwd_ms * 1e-3)
                 valu = {"wave_insts_per_launch": vi, "wave_insts_per_s": round(rate, 1),
@@ -217,7 +217,7 @@ def roofline_of(st, bwd_ms, P):
                                 "(1024 SIMDs x 2.4 GHz x this run's launch duration)",
                         "source": [src, "profiles/r02_valu_calib.json", "profiles/r02_valu_mix.json"]}
             break
-    return {"kernel": "blend_bwd_cull_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+    return {"kernel": "blend_bwd_cull_t_kernel", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": (src + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, committed; not measured in this run)") if src else None,
             "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": round(bwd_ms, 4),

@@ -4,17 +4,23 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under saro-gs_amd/ may import, link or call this file.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
  *
- * PARITY PINNING STATUS: "parity unpinned" for the kernels.
+ * PARITY PINNING STATUS: "parity unpinned" against a RUNNING reference -- pinned piecewise against everything reachable.
  *   The reference implementation of this path exists only as CUDA (.cu) sources that include
  *   <cuda.h>, "cuda_runtime.h", <cooperative_groups.h> and <cub/cub.cuh>; none of those headers
  *   exist in this image and the reference ships no tests or golden vectors for the path
- *   (SURVEY.md section 4).  It is therefore unbuildable here and this file is an independent
+ *   (SURVEY.md section 4).  It is therefore unbuildable here (no oracle/_ref) and this file is an independent
  *   restatement of the published algorithm, following the reference file:line cited at every
- *   function.  What IS pinned against the reference itself: the SH colour evaluation and the
- *   camera-matrix conventions, through golden vectors generated by importing the reference's
- *   own Python (utils/sh_utils.py eval_sh, utils/graphics_utils.py) -- see
- *   tests/golden/make_golden.py and tests/test_oracle_golden.py.  The backward formulas are
- *   additionally checked against finite differences of the forward (tests/test_oracle_grad.py).
+ *   function.  What pins it (DESIGN.md section 5 has the table):
+ *     - against the reference's OWN Python, imported by tests/golden/make_golden.py: SH colour (utils/sh_utils.py eval_sh), the
+ *       camera-matrix conventions and the point projection (utils/graphics_utils.py, scene/cameras.py), cov3D -- packing,
+ *       quaternion convention, R S S^T R^T, scale_modifier (utils/general_utils.py build_scaling_rotation / strip_symmetric as
+ *       composed in scene/saro_gaussian.py:33-37)                                      -> tests/test_oracle_golden.py;
+ *     - against an independent derivation (tests/math_renderer.py: torch float64 + autograd, written from the mathematics,
+ *       no code or derivation shared with this file): cov2D / conic / radius / tile rectangle, the compositing recurrence,
+ *       median depth, and ALL hand-derived backward formulas (this file's gradients equal autograd's to 1e-7 relative)
+ *                                                                                      -> tests/test_oracle_independent.py;
+ *     - finite differences of the forward reproduce the backward                      -> tests/test_oracle_grad.py.
+ *   Not pinnable here: that the CUDA binary evaluates these formulas in exactly this association (FMA contraction).
  *
  * RST = /root/reference/submodules/gaussian_rasterization_ch3/cuda_rasterizer
  *

@@ -2,8 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 leg; never by the product package under saro-gs_amd/.  See the C file's header for what the
-oracle restates and for its pinning status ("parity unpinned" for the kernels; SH evaluation and
-camera conventions pinned against the reference's Python).
+oracle restates and for its pinning status (no running reference here; SH colour, camera conventions, point projection
+and cov3D pinned against the reference's own Python, everything else -- including every backward formula -- against an
+independent torch-autograd derivation, tests/test_oracle_independent.py).
 """
 from __future__ import annotations
 

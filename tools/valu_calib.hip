@@ -128,6 +128,7 @@ void run(int wps, int iters, float* d_out, unsigned long long* d_ticks, bool fir
     const double cyc_nominal = 2.4e9 / (rate / 1024.0);
     printf("%s  {\"op\": \"%s\", \"waves_per_simd\": %d, \"wave_insts_per_s\": %.4g, \"cycles_per_inst_per_simd_at_2.4GHz\": %.3f, \"kernel_ms\": %.4f, \"memtime_ticks_per_us\": %.1f}",
            first ? "" : ",\n", kNames[OP], wps, rate, cyc_nominal, best_ms, ticks_per_us);
+    fflush(stdout);
     hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
@@ -157,10 +158,10 @@ int main()
     sweep<MOV>(d_out, d_ticks, first); sweep<AND>(d_out, d_ticks, first); sweep<MAX>(d_out, d_ticks, first); sweep<LSHLREV>(d_out, d_ticks, first);
     sweep<MAD_U24>(d_out, d_ticks, first); sweep<FMAC>(d_out, d_ticks, first); sweep<FMAMK>(d_out, d_ticks, first); sweep<SUBREV>(d_out, d_ticks, first);
     sweep<ADD_U32>(d_out, d_ticks, first); sweep<XOR>(d_out, d_ticks, first); sweep<MED3>(d_out, d_ticks, first); sweep<MUL_LO>(d_out, d_ticks, first);
-    sweep<CMP_CND_VCC>(d_out, d_ticks, first); sweep<SAND_CND_VCC>(d_out, d_ticks, first); sweep<CXX_SELECT>(d_out, d_ticks, first);
-    // (a pair "v_cmp_lt_f32_e64 s[N:N+1] + v_cndmask_b32_e64 ... s[N:N+1]" written as ONE asm statement did not terminate at
-    // 4 waves per SIMD on the GPU box -- a VALU-written SGPR pair read back by the next VALU instruction with no compiler-inserted
-    // wait states -- and is deliberately not part of the sweep)
+    sweep<CMP_CND_VCC>(d_out, d_ticks, first);
+    // (pairs written as ONE asm statement in which the second instruction reads a mask the first has just written to an SGPR pair
+    // or, through the scalar unit, to vcc -- "v_cmp_e64 s[N:N+1] + v_cndmask_e64 s[N:N+1]", "s_and_b64 vcc + v_cndmask_e32" -- did
+    // not terminate on the GPU box: no compiler-inserted wait states inside an asm statement.  They are deliberately not swept.)
     printf("\n ]}\n");
     return 0;
 }

@@ -17,8 +17,10 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "saro-gs_amd", "csrc", "gsrast_capi.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics"]
-KERNELS = {"blend_bwd_cull_kernel": r"^_ZN6gsrast21blend_bwd_cull_kernelILi0ELi1E", "blend_fwd_cull_kernel": r"^_ZN6gsrast21blend_fwd_cull_kernelILi0E"}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics",
+         "-fno-slp-vectorize"]      # = saro-gs_amd/build.py
+KERNELS = {"blend_bwd_cull_t_kernel": r"^_ZN6gsrast23blend_bwd_cull_t_kernelILi0E", "blend_bwd_cull_kernel": r"^_ZN6gsrast21blend_bwd_cull_kernelILi0ELi1E",
+           "blend_fwd_cull_kernel": r"^_ZN6gsrast21blend_fwd_cull_kernelILi0E"}
 
 # instruction classes: full rate (one wave64 instruction per ~2.4 cycles of a SIMD), half rate, quarter rate -- membership from
 # the calibration run; mnemonics it did not cover fall into `half` (most of the ISA is half rate on this part)
@@ -67,7 +69,7 @@ def main():
         start = next(i for i, l in enumerate(asm) if re.match(pat, l))
         end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
         body = [l for l in asm[start:end] if l.startswith("\t") and not l.strip().startswith((";", "."))]
-        ff1 = next(i for i, l in enumerate(body) if "s_ff1_i32_b64" in l)
+        ff1 = next(i for i, l in enumerate(body) if "s_ff1_i32_b" in l)
         bar = next(i for i in range(ff1, len(body)) if "s_barrier" in body[i])
         loop = body[ff1:bar]
 
