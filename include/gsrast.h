@@ -174,6 +174,8 @@ typedef struct gsrast_options {
     int reserved[5];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
+/* A context may be used by one host thread at a time (it owns one side stream and one fork / join event pair per device); contexts
+ * are independent of each other.  Destroy it only after the calls that used it have returned. */
 typedef struct gsrast_context gsrast_context;
 gsrast_context* gsrast_context_create(void);
 void gsrast_context_destroy(gsrast_context* ctx);
