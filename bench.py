@@ -796,6 +796,9 @@ def main():
         # of all 59 floats.  Both give the batch-mean gradient of set_batch_gradient (saro_gaussian.py:266-276).
         bucket = _C.GradArena(P, 16, dev, sh_factors=(a.exchange == "factors"), world=world)
         _C.set_grad_arena(bucket)
+        if a.exchange == "factors":
+            import view_parallel
+            view_parallel.overlap_factor_exchange(True)     # the all-gather starts between the two phases of the backward
 
     names = [_C.lib().gsrast_profile_kernel_name(k).decode() for k in range(_C.lib().gsrast_profile_kernel_count())]
     kid = {n: i for i, n in enumerate(names)}

@@ -171,7 +171,10 @@ typedef struct gsrast_options {
                                  0 = everything on `stream` */
     int grads_zeroed;         /* backward: 1 = no backward has run on this forward's geometry buffer yet (the forward leaves the
                                  gradient records zero), so the 64 B / Gaussian zero-fill is skipped; 0 (default) = fill */
-    int reserved[5];          /* must be zero */
+    int backward_phase;       /* backward: 0 (default) everything; 1 = the blend backward only (fills the gradient records and, with
+                                 sh_grad_factors, writes the factors: all a multi-GPU caller needs to START its exchange); 2 = the
+                                 per-Gaussian backward only (the rest of the outputs).  1 then 2 on the same arguments == 0 */
+    int reserved[4];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one fork / join event pair per device); contexts

@@ -54,7 +54,8 @@ gsrast_options snapshot_defaults()
 bool options_valid(const gsrast_options& o)
 {
     auto ppl_ok = [](int v) { return v == 0 || v == 1 || v == 2 || v == 4; };
-    return o.exp_mode >= 0 && o.exp_mode <= 2 && (o.binning == 0 || o.binning == 1) && ppl_ok(o.fwd_pixels_per_lane) && ppl_ok(o.bwd_pixels_per_lane);
+    return o.exp_mode >= 0 && o.exp_mode <= 2 && (o.binning == 0 || o.binning == 1) && ppl_ok(o.fwd_pixels_per_lane) && ppl_ok(o.bwd_pixels_per_lane) &&
+           o.backward_phase >= 0 && o.backward_phase <= 2;
 }
 
 int fail(int code, const char* what, hipError_t e = hipSuccess)
@@ -1204,8 +1205,9 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
     // per-Gaussian gradient records: the only memory the backward accumulates into (64 B / Gaussian, in the geometry buffer)
     // (the forward leaves them zero: a caller that knows this is the first backward on this state says so and saves the fill)
     float* grec = at<float>(geom, GL.grec);
-    if (!o.grads_zeroed) GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
-    if (R > 0) {
+    const bool do_blend = o.backward_phase != 2, do_geom = o.backward_phase != 1;
+    if (do_blend && !o.grads_zeroed) GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
+    if (do_blend && R > 0) {
         ProfScope ps(K_BLEND_BWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;
         const uint2* ranges = at<uint2>(img, IL.ranges);
@@ -1238,7 +1240,11 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
         }
         GS_LAUNCHED("blend_bwd");
     }
-    {
+    if (do_blend && use_sh && o.sh_grad_factors) {      // dL_dsh is [P][3] in this mode: the factor, final after the blend backward
+        sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh);
+        GS_LAUNCHED("sh_factor");
+    }
+    if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
         preprocess_bwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(

@@ -458,6 +458,24 @@ __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const f
     dmean[2] += (-o0 * o2 * dd0 - o1 * o2 * dd1 + (sum2 - o2 * o2) * dd2) * inv32;
 }
 
+// The factor of dL/dsh (see sh_backward<FACTORS>): g = the blend backward's colour gradient with the clamped channels masked,
+// zero for a culled Gaussian -- final as soon as the blend backward has run.  Written by this small kernel so that a multi-GPU
+// caller can start exchanging the factors WHILE the per-Gaussian backward (below) is still running (backward_phase).
+__global__ void __launch_bounds__(256)
+sh_factor_kernel(int P, const int* __restrict__ radii, const unsigned char* __restrict__ clamped, const float4* __restrict__ grec,
+                 float* __restrict__ g_out /* [P][3] */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool live = radii[i] > 0;
+    const float4 r1 = grec[4 * (size_t)i + 1], r2 = grec[4 * (size_t)i + 2];
+    const unsigned cl = clamped[i];
+    const float dcol[3] = { r1.z, r1.w, r2.x };
+#pragma unroll
+    for (int c = 0; c < 3; c++)      // the same product as sh_backward's (sign of zero, NaN propagation)
+        g_out[3 * (size_t)i + c] = live ? dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f) : 0.0f;
+}
+
 // K6 + K7 fused.  Every output row is written exactly once (zeros for culled Gaussians), so the
 // caller does not have to zero-fill the five output arrays.  dL/dsh leaves through LDS (coalesced).
 __global__ void __launch_bounds__(PP_THREADS)
@@ -471,7 +489,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drot,
-                      int sh_factors /* dL_dsh is [P][3]: receives the factor g of every Gaussian instead of the rows */)
+                      int sh_factors /* the caller exchanges dL/dsh by its factor (sh_factor_kernel has written it): dL_dsh rows are not written */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
@@ -514,7 +532,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
         }
         if (shs) {
-            if (sh_factors) { for (int k = 0; k < 3; k++) dL_dsh[3 * (size_t)i + k] = 0.0f; }
+            if (sh_factors) { }
             else if (staged) { for (int k = 0; k < M * 3; k++) my_lds[k] = 0.0f; }
             else { for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = 0.0f; }
         }
@@ -596,10 +614,8 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
     if (shs) {
         if (sh_factors) {
-            float gf[3];
+            float gf[3];     // the factor itself left with sh_factor_kernel, right after the blend backward
             sh_backward<true>(D, mean, cam.campos, staged ? my_lds : shs + (size_t)i * M * 3, clamped_in, dcol, dmean, nullptr, gf);
-#pragma unroll
-            for (int k = 0; k < 3; k++) dL_dsh[3 * (size_t)i + k] = gf[k];
         } else if (staged) {
             // the lane's coefficients move LDS -> registers first: its LDS row is then reused for dL/dsh
             float shv[PP_SH_MAX];

@@ -45,7 +45,7 @@ class OptionsStruct(C.Structure):
     """gsrast_options (include/gsrast.h): everything that changes what ONE call computes / how it is scheduled."""
     _fields_ = [("exp_mode", C.c_int), ("binning", C.c_int), ("tile_clip", C.c_int), ("cull", C.c_int), ("lpt", C.c_int),
                 ("speculative", C.c_int), ("fwd_pixels_per_lane", C.c_int), ("bwd_pixels_per_lane", C.c_int),
-                ("sh_grad_factors", C.c_int), ("side_stream", C.c_int), ("grads_zeroed", C.c_int), ("reserved", C.c_int * 5)]
+                ("sh_grad_factors", C.c_int), ("side_stream", C.c_int), ("grads_zeroed", C.c_int), ("backward_phase", C.c_int), ("reserved", C.c_int * 4)]
 
 
 # Per-call options are kept PER HOST THREAD on the Python side and travel with every call (gsrast_forward_ex /
@@ -69,12 +69,14 @@ def current_options() -> dict:
     return dict(_thread_options())
 
 
-def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None, grads_zeroed: bool = False) -> OptionsStruct:
+def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None, grads_zeroed: bool = False,
+                    backward_phase: int = 0) -> OptionsStruct:
     o = OptionsStruct()
     for k, v in (_thread_options() if options is None else options).items():
         setattr(o, k, int(v))
     o.sh_grad_factors = int(bool(sh_grad_factors))
     o.grads_zeroed = int(bool(grads_zeroed))
+    o.backward_phase = int(backward_phase)
     return o
 
 
@@ -258,11 +260,20 @@ class GradArena:
 
 
 _grad_arena: Optional[GradArena] = None
+_factor_ready_hook = None
 
 
 def set_grad_arena(arena: Optional[GradArena]) -> None:
     global _grad_arena
     _grad_arena = arena
+
+
+def set_factor_ready_hook(fn) -> None:
+    """fn(arena) is called INSIDE the backward of a factor-mode arena, between the blend backward (after which arena.factor --
+    the view's factor of dL/dsh and its camera position -- is final on the current stream) and the per-Gaussian backward:
+    view_parallel starts the asynchronous all-gather of the factors there, so that it runs beside the second phase."""
+    global _factor_ready_hook
+    _factor_ready_hook = fn
 
 
 class _Arena:
@@ -397,15 +408,26 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             sh_out = ar.factor.data_ptr() if factors else _ptr(dL_dsh)
-            rc = L.gsrast_backward_ex(
-                C.byref(_options_struct(sh_grad_factors=factors, options=options, grads_zeroed=first_backward)),      # per call: no process-wide switch is flipped
-                P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii.contiguous()),
-                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
-                dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
-                dL_drotations.data_ptr(), stream)
+            radii_c = radii.contiguous()
+
+            def call(phase):      # options travel per call: no process-wide switch is flipped
+                return L.gsrast_backward_ex(
+                    C.byref(_options_struct(sh_grad_factors=factors, options=options, grads_zeroed=first_backward, backward_phase=phase)),
+                    P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                    _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii_c),
+                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
+                    dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                    dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
+                    dL_drotations.data_ptr(), stream)
+
+            if factors and _factor_ready_hook is not None:
+                rc = call(1)                     # blend backward + the factors
+                if rc == 0:
+                    _factor_ready_hook(ar)       # e.g. the asynchronous all-gather of the factors
+                    rc = call(2)                 # the per-Gaussian backward, beside it
+            else:
+                rc = call(0)
         if rc != 0:
             raise _err(rc, "gsrast_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations

@@ -129,11 +129,28 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int) -> None:
         raise ValueError(f"arena was built for {arena.world} ranks, the process group has {n_views}")
     allreduce_mean_inplace(arena.dense, batch)
     if multi:
-        dist.all_gather_into_tensor(arena.gathered, arena.factor)
+        pending = getattr(arena, "_gather_work", None)
+        if pending is not None:                    # started inside the backward (overlap_factor_exchange)
+            pending.wait()
+            arena._gather_work = None
+        else:
+            dist.all_gather_into_tensor(arena.gathered, arena.factor)
         chunks = arena.gathered
     else:
         chunks = arena.factor
     _C.sh_grad_combine(arena, means3D, chunks, n_views, 1.0 / batch)
+
+
+def overlap_factor_exchange(enable: bool = True) -> None:
+    """Start the all-gather of the dL/dsh factors INSIDE the backward, as soon as the blend backward has produced them, so that it
+    runs beside the per-Gaussian backward (the rasterizer's two-phase backward, options.backward_phase).  exchange_gradients then
+    only waits for it.  Costs nothing with one rank."""
+    from diff_gaussian_rasterization_ch3 import _C
+
+    def hook(arena):
+        if dist.is_initialized() and dist.get_world_size() > 1 and getattr(arena, "world", 1) == dist.get_world_size():
+            arena._gather_work = dist.all_gather_into_tensor(arena.gathered, arena.factor, async_op=True)
+    _C.set_factor_ready_hook(hook if enable else None)
 
 
 def reduce_densification_stats(point_grad_norm: torch.Tensor, visible_count: torch.Tensor,

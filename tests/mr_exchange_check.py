@@ -23,21 +23,29 @@ def main():
     P, W, H, deg = 20000, 320, 240, 3
     wl = bench.Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=world, dev=dev)
     res = {}
-    for mode in ("allreduce", "factors"):
-        arena = _C.GradArena(P, 16, dev, sh_factors=(mode == "factors"), world=world)
+    started = []
+    for mode in ("allreduce", "factors", "factors_overlapped"):
+        arena = _C.GradArena(P, 16, dev, sh_factors=(mode != "allreduce"), world=world)
         _C.set_grad_arena(arena)
+        if mode == "factors_overlapped":      # the all-gather starts inside the backward, between its two phases
+            vp.overlap_factor_exchange(True)
+            inner = _C._factor_ready_hook
+            _C.set_factor_ready_hook(lambda ar: (inner(ar), started.append(getattr(ar, "_gather_work", None) is not None)))
         wl.step(arena, world)
         torch.cuda.synchronize()
         res[mode] = {k: v.grad.detach().clone() for k, v in wl.leaves.items()}
         _C.set_grad_arena(None)
+        vp.overlap_factor_exchange(False)
+    assert started == [True] and getattr(arena, "_gather_work", None) is None, started
     worst = 0.0
     for k in res["allreduce"]:
-        a, b = res["allreduce"][k], res["factors"][k]
-        err = ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item()     # <= 1: within 1e-6 abs + 1e-4 rel
-        worst = max(worst, err)
+        for other_mode in ("factors", "factors_overlapped"):
+            a, b = res["allreduce"][k], res[other_mode][k]
+            err = ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item()     # <= 1: within 1e-6 abs + 1e-4 rel
+            worst = max(worst, err)
         assert a.abs().max().item() > 0, k
     # every rank must hold the same averaged gradient
-    flat = torch.cat([v.reshape(-1) for v in res["factors"].values()])
+    flat = torch.cat([v.reshape(-1) for v in list(res["factors"].values()) + list(res["factors_overlapped"].values())])
     other = flat.clone()
     torch.distributed.broadcast(other, src=0)
     same = bool(((flat - other).abs() <= 1e-7 + 1e-5 * other.abs()).all())

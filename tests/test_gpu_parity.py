@@ -761,3 +761,53 @@ def test_second_backward_on_the_same_forward_state(scenes, rast, gpu):
         a, b = first[k], v.grad
         assert float(a.abs().max()) > 0
         assert ((a - b).abs() <= 1e-7 + 1e-4 * a.abs()).all(), k
+
+
+def test_two_phase_backward_factor_ready_hook(scenes, rast, gpu):
+    """options.backward_phase: phase 1 (blend backward) leaves the view's dL/dsh factor final -- what a multi-GPU caller needs to
+    start its all-gather (view_parallel.overlap_factor_exchange) -- and phase 2 (per-Gaussian backward) the rest; 1 then 2 is the
+    one-call backward.  Through the Python hook: the factor seen by the hook is the factor after the whole backward, and every
+    gradient equals the hook-less run's (float-atomic order apart)."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H, deg = 5000, 200, 144, 3
+    sc = scenes.synth(P, 171, sh_degree=deg, scale_mul=1.3)
+    sc["shs"][::7, 0, :] = -3.0        # some clamped colour channels: their factor is masked
+    cam = scenes.camera(1, 4, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    g = t(scenes.upstream_grad(H, W, 172))
+    rs = settings_from(rast, cam, sc, gpu)
+
+    def run():
+        leaves = {n: t(sc[n]).requires_grad_(True) for n in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        color, radii, _ = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                      shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        color.backward(g)
+        torch.cuda.synchronize()
+        return leaves, m2, radii
+
+    arena = _C.GradArena(P, 16, gpu, sh_factors=True, world=1)
+    _C.set_grad_arena(arena)
+    seen = []
+    try:
+        arena.zero_grad()
+        run()
+        one_call = {"factor": arena.factor.clone(), "dense": arena.dense.clone()}
+        _C.set_factor_ready_hook(lambda ar: seen.append((ar.factor.clone(), ar.dense.clone())))
+        arena.zero_grad()
+        arena.dense.fill_(float("nan"))            # phase 2 writes every dense gradient
+        lv, m2, radii = run()
+    finally:
+        _C.set_factor_ready_hook(None)
+        _C.set_grad_arena(None)
+    assert len(seen) == 1
+    at_hook, dense_at_hook = seen[0]
+    assert torch.equal(at_hook, arena.factor), "the factor must be final when the hook runs"
+    assert torch.isnan(dense_at_hook).all(), "phase 1 must not touch the per-Gaussian outputs"
+    assert not torch.isnan(arena.dense).any() and not torch.isnan(m2.grad).any()
+    for a, b, what in ((one_call["factor"], arena.factor, "factor"), (one_call["dense"], arena.dense, "dense")):
+        assert ((a - b).abs() <= 1e-6 + 1e-4 * a.abs()).all(), what
+    fac = arena.factor[: 3 * P].reshape(P, 3)
+    assert fac.abs().max() > 0 and not fac[radii == 0].any()

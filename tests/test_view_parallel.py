@@ -191,3 +191,42 @@ def test_distributed_step_equals_the_reference_batch_loop(tmp_path, n_views):
     np.testing.assert_array_equal(s["radii"].numpy(), want_s["radii"].numpy().astype(np.float32))
     np.testing.assert_allclose(s["viewspace_point_grad"].numpy(), want_s["viewspace_point_grad"].numpy(), rtol=2e-5, atol=1e-9)
     assert abs(float(s["loss"]) - want_s["loss"]) < 1e-5
+
+
+# ---- overlapped factor exchange: the all-gather starts from the hook of the two-phase backward ---------------------------------
+def _overlap_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import types
+    import view_parallel as vp
+    from diff_gaussian_rasterization_ch3 import _C
+    vp.init_from_env("gloo")
+    chunk = 16
+    arena = types.SimpleNamespace(world=world, factor=torch.full((chunk,), float(rank + 1)), gathered=torch.zeros(world * chunk))
+    assert _C._factor_ready_hook is None
+    vp.overlap_factor_exchange(True)
+    _C._factor_ready_hook(arena)                     # what rasterize_gaussians_backward does between the two phases
+    work = arena._gather_work
+    assert work is not None
+    flat = torch.ones(4) * rank                      # a collective issued behind it (the dense all-reduce): same order on all ranks
+    vp.allreduce_mean_inplace(flat, world)
+    work.wait()
+    want = torch.cat([torch.full((chunk,), float(r + 1)) for r in range(world)])
+    ok = torch.equal(arena.gathered, want) and torch.allclose(flat, torch.ones(4) * (world - 1) / 2)
+    # an arena built for another world size is left alone (exchange_gradients raises for it later)
+    other = types.SimpleNamespace(world=world + 1, factor=arena.factor, gathered=arena.gathered)
+    _C._factor_ready_hook(other)
+    ok = ok and not hasattr(other, "_gather_work")
+    vp.overlap_factor_exchange(False)
+    ok = ok and _C._factor_ready_hook is None
+    vp.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(ok))
+    dist.destroy_process_group()
+
+
+def test_overlapped_factor_all_gather_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["True", "True"]
