@@ -194,38 +194,44 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 const uint32_t j = r * 64 + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1;
                 const float4 a = s0[j];
-                const float4 c = s2[j];
-                const float dx = a.x - pxa, dy = a.y - pyf;
                 const float4 b = s1[j];
+                const float4 c = s2[j];
+                // three ds_read_b128 from one address register, up front: left alone the compiler sinks b.y, b.z and the colour
+                // behind the tests as ds_read2_b32 + ds_read_b96 (8 LDS cycles where a b128 takes 4) and two more address moves
+                asm volatile("" :: "v"(b.y), "v"(b.z), "v"(c.x), "v"(c.w));
+                const float dx = a.x - pxa, dy = a.y - pyf;
                 const float power = gs_power(a.z, a.w, b.x, dx, dy);
-                bool term = false;
-                // ONE divergent region; inside it the reference's nested tests (forward.cu:368-381) are selects
-                if (power <= 0.0f && power >= b.w) {
-                    float alpha = b.y * gs_exp<EXPMODE, true>(power);      // b.w >= -80: the bounded exp is exact here
-                    alpha = alpha < 0.99f ? alpha : 0.99f;
-                    const float test_T = T * (1.0f - alpha);
-                    const bool contrib = !(alpha < 1.0f / 255.0f);
-                    term = contrib && test_T < 0.0001f;
-                    const bool upd = contrib && !term;
-                    // forward.cu:361: C += feature * alpha * T, associated as in the source: (feature * alpha) * T
-                    const float Tm = upd ? T : 0.0f;                       // fma(x, 0, C) == C exactly
-                    C0 = __builtin_fmaf(c.x * alpha, Tm, C0);
-                    C1 = __builtin_fmaf(c.y * alpha, Tm, C1);
-                    C2 = __builtin_fmaf(c.z * alpha, Tm, C2);
-                    Dm = (upd && T > 0.5f && test_T < 0.5f) ? b.z : Dm;
-                    T = upd ? test_T : T;
-                    last = upd ? base + j + 1 : last;
-                    pxa = term ? FAR : pxa;
-#ifdef GSRAST_DEBUG_COUNTERS
-                    { const uint64_t cm = __ballot(upd); const uint64_t em = __ballot(true);
-                      if (lane == (uint32_t)__builtin_ctzll(em)) { atomicAdd(&g_dbg[1], 1ull); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(cm)); if (cm) atomicAdd(&g_dbg[3], 1ull); } }
-#endif
-                }
+                // The reference's nested tests (forward.cu:368-381) as wave-uniform 64-bit masks: every test is ONE compare straight
+                // into a scalar register pair, the masks are combined on the scalar unit and come back as a lane predicate for free
+                // (inverse ballot).  No lane-private bool exists, so nothing has to be carried out of a divergent region (a
+                // v_cndmask + v_cmp per flag) and the loop's own masks (`alive`, `mask`) stay scalar.  The arithmetic runs on all
+                // lanes -- a wave instruction costs the same whatever the exec mask -- and lanes outside m_in compute garbage
+                // that no mask lets through.
+                const uint64_t m_in = __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(power >= b.w);
                 GS_COUNT(0, 1);
-                const uint64_t tm = __ballot(term);
-                if (tm) {
-                    alive &= ~tm;
-                    if (alive == 0ull) { mask = 0; r = FB / 64u; }                // wave saturated
+                if (m_in == 0ull) continue;
+                float alpha = b.y * gs_exp<EXPMODE, true>(power);          // b.w >= -80: the bounded exp is exact here
+                alpha = alpha < 0.99f ? alpha : 0.99f;
+                const float test_T = T * (1.0f - alpha);
+                const uint64_t m_contrib = m_in & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+                const uint64_t m_low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                const uint64_t m_upd = m_contrib & ~m_low, m_term = m_contrib & m_low;
+                if (__builtin_amdgcn_inverse_ballot_w64(m_upd)) {
+                    // forward.cu:361: C += feature * alpha * T, associated as in the source: (feature * alpha) * T
+                    C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                    C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                    C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                    Dm = (T > 0.5f && test_T < 0.5f) ? b.z : Dm;
+                    T = test_T;
+                    last = base + j + 1;
+                }
+#ifdef GSRAST_DEBUG_COUNTERS
+                if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(m_upd)); if (m_upd) atomicAdd(&g_dbg[3], 1ull); }
+#endif
+                if (m_term) {                                              // rare: some pixel is done
+                    pxa = __builtin_amdgcn_inverse_ballot_w64(m_term) ? FAR : pxa;
+                    alive &= ~m_term;
+                    if (alive == 0ull) { mask = 0; r = FB / 64u; }        // wave saturated
                 }
             }
         }
@@ -810,9 +816,10 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     constexpr int PS = 72;           // float2 slots per instance row: 64 pixels + 8 of padding (row stride = 16 banks mod 64: the
                                      // transposed phase's ds_read_b64 of lanes (k, jj), jj = 0..3 within a 32-lane group, are conflict-free)
     constexpr int AS = 12;
-    __shared__ float4 s0[BATCH];
-    __shared__ float4 s1[BATCH];
-    __shared__ float4 s2[BATCH];          // {r, g, b, -}
+    __shared__ float4 srec[3][BATCH];     // the staged instances' records: rec0 | rec1 | rec2 {r, g, b, -}
+    float4* const s0 = srec[0];
+    float4* const s1 = srec[1];
+    float4* const s2 = srec[2];
     __shared__ uint32_t sid[BATCH];
     __shared__ __attribute__((aligned(16))) float acc[BATCH][AS];       // the batch's sums, shared by the four waves (LDS float adds to distinct addresses)
     // {u, dch} of the current group, [instance][pixel of the wave's strip]
@@ -843,7 +850,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     const uint32_t last = inside ? n_contrib[pid] : 0u;
     const float dp0 = inside ? dL_dpix[pid] : 0.f, dp1 = inside ? dL_dpix[plane + pid] : 0.f, dp2 = inside ? dL_dpix[2 * plane + pid] : 0.f;
     const float tfbg = -Tf * (bg0 * dp0 + bg1 * dp1 + bg2 * dp2);
-    float ac0 = 0.f, ac1 = 0.f, ac2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    float ac0 = 0.f, ac1 = 0.f, ac2 = 0.f;
     uint32_t strip_last;
     {
         uint32_t m = last;                            // deepest position the strip needs (wave-uniform)
@@ -857,19 +864,30 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     const float commit_scale = k == 0 ? -0.5f * (float)W : k == 1 ? -0.5f * (float)H : (k >= 2 && k <= 4) ? -0.5f : 1.0f;
     const float pxk0 = sx0 + (float)k, pxk1 = pxk0 + 8.0f;       // columns of pixels k + 16 r and k + 8 + 16 r of the strip
 
+    // Staging is software-pipelined: wave w < 3 fetches record w of the 64 instances of the NEXT batch (and the ids of the batch
+    // after that) into registers right after the barrier that opens a batch, so the two dependent global latencies
+    // (point_list -> record) pass while the batch is processed instead of with the whole workgroup waiting between two barriers.
+    const float4* const recw = wave == 0u ? rec0 : (wave == 1u ? rec1 : rec2);
+    const auto staged_id = [&](uint32_t b) -> uint32_t {
+        const uint32_t i = b + lane;
+        return (wave < 3u && i < n) ? point_list[range.x + (n - 1 - i)] : 0xFFFFFFFFu;
+    };
+    uint32_t id_cur = staged_id(0), id_next = staged_id(BATCH);
+    float4 pre = id_cur != 0xFFFFFFFFu ? recw[id_cur] : make_float4(0.f, 0.f, 0.f, 0.f);
+
     for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
-        if (t < (uint32_t)BATCH) {
-            const uint32_t i = base + t;
-            if (i < n) {
-                const uint32_t g = point_list[range.x + (n - 1 - i)];
-                sid[t] = g;
-                s0[t] = rec0[g]; s1[t] = rec1[g]; s2[t] = rec2[g];
-            }
-        } else if (t - (uint32_t)BATCH < (uint32_t)(BATCH * AS / 4)) {
-            reinterpret_cast<float4*>(&acc[0][0])[t - BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave < 3u) {
+            if (id_cur != 0xFFFFFFFFu) { srec[wave][lane] = pre; if (wave == 0u) sid[lane] = id_cur; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BATCH * AS / 4 / 64; r++)
+                reinterpret_cast<float4*>(&acc[0][0])[r * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        id_cur = id_next;
+        if (id_cur != 0xFFFFFFFFu) pre = recw[id_cur];
+        id_next = staged_id(base + 2 * BATCH);
         const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
         uint64_t mk;
         {
@@ -892,33 +910,36 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 const uint32_t pos = n - 1 - (base + j);
                 const float4 a = s0[j];
                 const float4 b = s1[j];
-                float4 c = s2[j];
-                asm volatile("" : "+v"(c.x));       // keep the colour's LDS read with the others (see blend_bwd_cull_kernel)
+                const float4 c = s2[j];
+                asm volatile("" :: "v"(b.z), "v"(c.x), "v"(c.w));       // three ds_read_b128 up front (see blend_fwd_cull_kernel)
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float q = __builtin_fmaf(b.x * dy, dy, (a.z * dx) * dx);
                 const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-                // exp and alpha inside the first divergent region; the alpha >= 1/255 test and its ballot outside (a compare straight
-                // into an SGPR pair: a bool carried out of the branch costs a v_cndmask + v_cmp to become a mask again)
-                float G = 0.f, alpha = 0.f;
-                if (pos < last && power <= 0.0f && power >= b.w) {
-                    G = gs_exp<EXPMODE, true>(power);
-                    alpha = b.y * G;
-                    alpha = alpha < 0.99f ? alpha : 0.99f;
-                }
-                const bool ok = !(alpha < 1.0f / 255.0f);          // lanes that skipped the region: alpha = 0
+                // The tests as wave-uniform masks (see blend_fwd_cull_kernel): one compare each, straight into a scalar register pair,
+                // combined on the scalar unit; exp and alpha are evaluated on all lanes (same cost) and only masks decide.
+                const uint64_t m_in = __builtin_amdgcn_ballot_w64(pos < last) & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                      __builtin_amdgcn_ballot_w64(power >= b.w);
                 GS_COUNT(4, 1); GS_COUNT(7, __popcll(__ballot(pos < last)));
-                if (__ballot(ok) == 0ull) continue;
-                GS_COUNT(5, 1); GS_COUNT(6, __popcll(__ballot(ok)));
+                if (m_in == 0ull) continue;
+                const float G = gs_exp<EXPMODE, true>(power);
+                float alpha = b.y * G;
+                alpha = alpha < 0.99f ? alpha : 0.99f;
+                const uint64_t m_ok = m_in & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+                if (m_ok == 0ull) continue;
+                GS_COUNT(5, 1); GS_COUNT(6, __popcll(m_ok));
                 float u = 0.f, dch = 0.f;
-                if (ok) {
-                    const float rcp1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
+                    const float om = 1.0f - alpha;
+                    const float rcp1ma = __builtin_amdgcn_rcpf(om);
                     T = T * rcp1ma;
                     const float c0 = c.x, c1 = c.y, c2 = c.z;
-                    ac0 = last_alpha * lc0 + (1.f - last_alpha) * ac0; lc0 = c0;
-                    ac1 = last_alpha * lc1 + (1.f - last_alpha) * ac1; lc1 = c1;
-                    ac2 = last_alpha * lc2 + (1.f - last_alpha) * ac2; lc2 = c2;
                     float dL_dalpha = (c0 - ac0) * dp0 + (c1 - ac1) * dp1 + (c2 - ac2) * dp2;
-                    last_alpha = alpha;
+                    // backward.cu:505-507's accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec, evaluated HERE for the
+                    // next contributor instead of there from a saved (last_alpha, last_color): same operands, same result, and
+                    // four register moves per pair fewer (the first contributor sees 0 either way)
+                    ac0 = alpha * c0 + om * ac0;
+                    ac1 = alpha * c1 + om * ac1;
+                    ac2 = alpha * c2 + om * ac2;
                     dL_dalpha *= T;
                     dL_dalpha += tfbg * rcp1ma;
                     dch = alpha * T; u = G * dL_dalpha;
