@@ -174,7 +174,10 @@ typedef struct gsrast_options {
     int backward_phase;       /* backward: 0 (default) everything; 1 = the blend backward only (fills the gradient records and, with
                                  sh_grad_factors, writes the factors: all a multi-GPU caller needs to START its exchange); 2 = the
                                  per-Gaussian backward only (the rest of the outputs).  1 then 2 on the same arguments == 0 */
-    int reserved[4];          /* must be zero */
+    int depth_sort;           /* forward: 0 (default) bucket depth sort -- two launches: Gaussians into ~P/256 depth buckets, one LDS sort per
+                                 bucket; a scene whose depths pile up in one bucket is detected on the device and re-sorted by the radix
+                                 passes; 1 = always the LSD radix sort (3-4 passes of three launches).  Same order either way */
+    int reserved[3];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one fork / join event pair per device); contexts

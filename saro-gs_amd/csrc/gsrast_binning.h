@@ -373,6 +373,221 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Bucket depth sort: the default order-by-depth of the P Gaussians for the run-compressed binning (the LSD radix sort above is the
+// fallback and serves the instance-level binning).
+// An LSD radix pass costs three dependent launches, the scan that follows three more, and at 1e6 Gaussians all of them are launch /
+// latency bound (sort 85-110 us + scan 23 us for 16 MB of keys).  Three launches do the same job:
+//   depth_bucket_scatter_kernel  every visible Gaussian goes to bucket floor((z - zmin) * NB / (zmax - zmin)) -- monotone in z;
+//       NB ~ P / 256 buckets keep a few hundred elements each.  No histogram, no scan: a bucket owns a fixed slab of (key, index)
+//       slots, a workgroup ranks its 2048 elements per bucket with LDS atomics and reserves slab space with ONE returning global
+//       atomic per non-empty bucket.  Counters and slabs are kept PER XCD (workgroup b runs on XCD b mod 8; each XCD has its own
+//       L2): with one counter set all eight L2s fight over the same 128 cache lines and the atomics alone cost 15 us.
+//   depth_bucket_sort_kernel     one workgroup per bucket: collects the bucket's eight sub-slabs, sorts them in LDS on the 64-bit
+//       composite (depth bits << 32 | index) -- a total order, so the result does not depend on the arrival order and ties fall in
+//       index order exactly as under the stable radix sort -- and writes, IN THE BUCKET'S OWN SLOT RANGE, the sorted ids and the
+//       inclusive scan of their tile-rectangle widths, plus the bucket's totals.  Nothing here needs a prefix over buckets.
+//   depth_bucket_scan_kernel     one workgroup: exclusive scan of the buckets' width totals (-> first column run of each bucket, Q),
+//       sum of their tile counts (-> num_rendered), the overflow verdict.
+// emit_column_runs_kernel then runs one workgroup per bucket.  Culled Gaussians (key ~0) are never touched.
+// zmin / zmax come from preprocess_fwd_kernel (per-block minima / maxima, reduced by every scatter workgroup).  A scene whose depths
+// pile up (more Gaussians in one bucket than its slab holds) raises a flag the host reads back with the instance counts; the
+// forward then repeats the sort with the radix passes and the context uses those for its next calls (gsrast_forward).
+constexpr int BK_CAP = GSRAST_BK_CAP;    // slots per bucket = the largest bucket the LDS sort takes
+constexpr int BK_XCD = 8;                // counter / slab sets
+constexpr int BK_CAPX = BK_CAP / BK_XCD; // slots per (bucket, XCD) sub-slab
+constexpr int BK_MAX_BUCKETS = 8192;
+constexpr int BK_ITEMS = 8;              // elements per lane of the scatter kernel
+__device__ __forceinline__ uint32_t depth_bucket_of(uint32_t key, float zmin, float scale, uint32_t nb)
+{
+    const float t = (__uint_as_float(key) - zmin) * scale;        // monotone in the key: subtraction, product and truncation all are
+    const uint32_t d = (uint32_t)t;                               // (t >= 0; a NaN or huge product saturates / clamps below)
+    return d < nb ? d : nb - 1u;
+}
+
+__global__ void __launch_bounds__(256)
+depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ block_zrange, uint32_t nzblk,
+                            uint32_t nb, uint32_t* __restrict__ gcount /* [8][nb]: per-XCD bucket counts (zeroed by preprocess_fwd) */,
+                            uint2* __restrict__ slab /* [nb][8][BK_CAPX] */)
+{
+    __shared__ uint32_t cnt[BK_MAX_BUCKETS];
+    __shared__ uint32_t s_mm[2];
+    const unsigned lane = lane_id();
+    const uint32_t xcd = blockIdx.x & (BK_XCD - 1);
+    if (threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; }
+    for (uint32_t k = threadIdx.x; k < nb; k += 256) cnt[k] = 0u;
+    __syncthreads();
+    {
+        // eight independent 16-byte loads per lane and round (a plain strided loop waits one memory round trip per element)
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        const uint4* zr = reinterpret_cast<const uint4*>(block_zrange);     // two blocks per load; the array is padded to an even count
+        const uint32_t n4 = (nzblk + 1) / 2;
+        for (uint32_t q0 = threadIdx.x; q0 < n4; q0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t q = q0 + u * 256; v[u] = q < n4 ? zr[q] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { lo = min(lo, min(v[u].x, v[u].z)); hi = max(hi, max(v[u].y, v[u].w)); }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
+        if (lane == 0) { atomicMin(&s_mm[0], lo); atomicMax(&s_mm[1], hi); }
+    }
+    const uint32_t base = blockIdx.x * (256 * BK_ITEMS);
+    uint32_t key[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) { const uint32_t i = base + r * 256 + threadIdx.x; key[r] = i < n ? keys[i] : 0xFFFFFFFFu; }
+    __syncthreads();
+    const float zmin = __uint_as_float(s_mm[0]), zmax = __uint_as_float(s_mm[1]);
+    const float scale = zmax > zmin ? (float)nb / (zmax - zmin) : 0.0f;
+    uint32_t dg[BK_ITEMS], lr[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) {
+        dg[r] = 0u; lr[r] = 0u;
+        if (key[r] != 0xFFFFFFFFu) { dg[r] = depth_bucket_of(key[r], zmin, scale, nb); lr[r] = atomicAdd(&cnt[dg[r]], 1u); }
+    }
+    __syncthreads();
+    // one returning global atomic per non-empty bucket of this workgroup, sixteen in flight per lane (issued back to back: a loop
+    // that stores each result before it asks for the next waits a full memory round trip per bucket)
+    uint32_t* gc = gcount + (size_t)xcd * nb;
+    for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 16) {
+        uint32_t c[16], g[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const uint32_t k = k0 + u * 256; c[u] = k < nb ? cnt[k] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) { g[u] = 0u; if (c[u]) g[u] = atomicAdd(&gc[k0 + u * 256], c[u]); }
+#pragma unroll
+        for (int u = 0; u < 16; u++) { if (c[u]) cnt[k0 + u * 256] = g[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) {
+        if (key[r] != 0xFFFFFFFFu) {
+            const uint32_t pos = cnt[dg[r]] + lr[r];
+            if (pos < (uint32_t)BK_CAPX) slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint2(key[r], base + r * 256 + threadIdx.x);
+        }
+    }
+}
+
+// 128-thread exclusive scan of per-thread totals; *total = block sum
+__device__ __forceinline__ uint32_t block128_excl_scan(uint32_t v, uint32_t* total)
+{
+    __shared__ uint32_t wsum2[2];
+    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) wsum2[wave] = inc;
+    __syncthreads();
+    const uint32_t s0 = wsum2[0], s1 = wsum2[1];
+    __syncthreads();
+    *total = s0 + s1;
+    return (wave ? s0 : 0u) + inc - v;
+}
+
+__global__ void __launch_bounds__(128)
+depth_bucket_sort_kernel(const uint2* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb,
+                         const uint2* __restrict__ gather_rect, const uint32_t* __restrict__ tiles /* [P]: the reference's tile counts (-> num_rendered) */,
+                         uint32_t* __restrict__ border /* [nb][BK_CAP]: sorted Gaussian ids of each bucket */,
+                         uint32_t* __restrict__ bwincl /* [nb][BK_CAP]: inclusive scan of their rectangle widths inside the bucket */,
+                         uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */)
+{
+    __shared__ unsigned long long sk[BK_CAP];
+    __shared__ uint32_t s_cx[BK_XCD + 1];
+    const uint32_t b = blockIdx.x, t0 = threadIdx.x;
+    if (t0 == 0) {
+        uint32_t acc = 0, over = 0;
+        for (int x = 0; x < BK_XCD; x++) {
+            const uint32_t c = gcount[(size_t)x * nb + b];
+            over |= c > (uint32_t)BK_CAPX ? 1u : 0u;
+            s_cx[x] = acc; acc += c < (uint32_t)BK_CAPX ? c : (uint32_t)BK_CAPX;
+        }
+        s_cx[BK_XCD] = acc | (over << 31);
+    }
+    __syncthreads();
+    const uint32_t n = s_cx[BK_XCD] & 0x7FFFFFFFu, over = s_cx[BK_XCD] >> 31;
+    uint32_t m = 2; while (m < n) m <<= 1;
+    if (n) {
+        // lane t of sub-slab x: 16 lanes per sub-slab and round, all eight sub-slabs at once
+        const uint32_t x = t0 >> 4, l = t0 & 15u;
+        const uint32_t c0 = s_cx[x], c1 = s_cx[x + 1] & 0x7FFFFFFFu;
+        for (uint32_t t = l; t < c1 - c0; t += 16) {
+            const uint2 e = slab[((size_t)b * BK_XCD + x) * BK_CAPX + t];
+            sk[c0 + t] = ((unsigned long long)e.x << 32) | e.y;
+        }
+        for (uint32_t t = n + t0; t < m; t += 128) sk[t] = ~0ull;
+    }
+    __syncthreads();
+    if (n > 1) {
+        for (uint32_t k = 2; k <= m; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = t0; t < (m >> 1); t += 128) {
+                    const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
+                    const unsigned long long a = sk[i], c = sk[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { sk[i] = c; sk[l] = a; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // widths, their inclusive scan in sorted order, tile total: thread t owns the E consecutive elements [t*E, t*E + E)
+    const uint32_t E = (m + 127) / 128;          // <= BK_CAP / 128
+    uint32_t g[BK_CAP / 128], w[BK_CAP / 128], wsum = 0, tsum = 0;
+#pragma unroll
+    for (int e = 0; e < BK_CAP / 128; e++) {
+        const uint32_t t = t0 * E + e;
+        g[e] = 0u; w[e] = 0u;
+        if ((uint32_t)e < E && t < n) {
+            g[e] = (uint32_t)sk[t];
+            const uint2 rc = gather_rect[g[e]];       // the (possibly clipped) rectangle the column runs come from
+            w[e] = (rc.y & 0xFFFFu) - (rc.x & 0xFFFFu);
+            tsum += tiles[g[e]];
+        }
+        wsum += w[e];
+    }
+    uint32_t wtot, ttot;
+    uint32_t run = block128_excl_scan(wsum, &wtot);
+    (void)block128_excl_scan(tsum, &ttot);
+#pragma unroll
+    for (int e = 0; e < BK_CAP / 128; e++) {
+        const uint32_t t = t0 * E + e;
+        run += w[e];
+        if ((uint32_t)e < E && t < n) { border[(size_t)b * BK_CAP + t] = g[e]; bwincl[(size_t)b * BK_CAP + t] = run; }
+    }
+    if (t0 == 0) binfo[b] = make_uint4(n, wtot, ttot, over);
+}
+
+// One workgroup: bases[b] = column runs of the buckets in front of b; totals {num_rendered lo, Q, -, num_rendered hi}; overflow verdict.
+__global__ void __launch_bounds__(256)
+depth_bucket_scan_kernel(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ bbase,
+                         uint32_t* __restrict__ scalars /* [0] R lo, [1] Q, [3] R hi, [11] overflow */)
+{
+    __shared__ unsigned long long s_t[256];
+    __shared__ uint32_t s_w[BK_MAX_BUCKETS];
+    uint32_t over = 0;
+    unsigned long long tsum = 0;
+    for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 8) {       // coalesced, eight independent loads per lane and round
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * 256; v[u] = k < nb ? binfo[k] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * 256; if (k < nb) s_w[k] = v[u].y; tsum += v[u].z; over |= v[u].w; }
+    }
+    __syncthreads();
+    const uint32_t per = (nb + 255) / 256;       // consecutive buckets per thread (nb <= 8192: at most 32)
+    uint32_t wsum = 0;
+    for (uint32_t e = 0; e < per; e++) { const uint32_t k = threadIdx.x * per + e; if (k < nb) wsum += s_w[k]; }
+    uint32_t wtot;
+    uint32_t run = block_excl_scan(wsum, &wtot);
+    for (uint32_t e = 0; e < per; e++) {
+        const uint32_t k = threadIdx.x * per + e;
+        if (k < nb) { bbase[k] = run; run += s_w[k]; }
+    }
+    s_t[threadIdx.x] = tsum;
+    over = __syncthreads_or((int)over) ? 1u : 0u;
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) s_t[threadIdx.x] += s_t[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) { scalars[0] = (uint32_t)s_t[0]; scalars[1] = wtot; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Instance emission (reference duplicateWithKeys, rasterizer_impl.cu:70-111), in depth order.
 // order[j] = Gaussian at depth rank j; offsets = inclusive scan of tiles[order[.]].
 // The 64 Gaussians of a wave own one contiguous output range; the wave walks that range 64 slots
@@ -485,20 +700,31 @@ __device__ __forceinline__ double sqrt_newton(double x)
 __global__ void __launch_bounds__(256)
 emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ woffsets /* incl. scan of widths */,
                         const float4* __restrict__ binrec, int W, int H, int cull, uint32_t capQ,
-                        uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals)
+                        uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals,
+                        // bucket depth sort (binfo != null): one workgroup per bucket; `order` / `woffsets` are the buckets' own slot
+                        // ranges [nb][BK_CAP] (sorted ids, inclusive width scan inside the bucket), bbase the buckets' first runs
+                        const uint4* __restrict__ binfo = nullptr, const uint32_t* __restrict__ bbase = nullptr)
 {
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
     // per-Gaussian ellipse terms (fp64): det, 2tc, b, 1/c, dy_max, dx_top;  mode 0 = keep the column, 1 = clip, 2 = empty
     __shared__ double s_det[4][64], s_t2c[4][64], s_b[4][64], s_invc[4][64], s_dymax[4][64], s_dxtop[4][64];
     __shared__ float s_mx[4][64], s_my[4][64];
     __shared__ uint32_t s_mode[4][64];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t nloc = 0, run0 = 0, nchunks = 1;
+    if (binfo) {
+        const uint4 bi = binfo[blockIdx.x];
+        nloc = bi.x; run0 = bbase[blockIdx.x]; nchunks = (nloc + 255u) / 256u;
+        order += (size_t)blockIdx.x * BK_CAP; woffsets += (size_t)blockIdx.x * BK_CAP; P = (int)nloc;
+    }
+    for (uint32_t chunk = 0; chunk < nchunks; chunk++) {
+    if (chunk) __syncthreads();
+    const int j = binfo ? (int)(chunk * 256u + threadIdx.x) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     uint32_t g = 0, w = 0, incl, x0 = 0, yh = 0;
     if (j < P) {
         g = order[j];
-        incl = woffsets[j];
-        const uint32_t prev = j > 0 ? woffsets[j - 1] : 0u;
+        incl = run0 + woffsets[j];
+        const uint32_t prev = j > 0 ? run0 + woffsets[j - 1] : run0;
         w = incl - prev;                         // culled Gaussians (sorted last, width 0) never touch binrec
         uint2 rc = make_uint2(0u, 0u);
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
@@ -533,7 +759,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
             s_mx[wave][lane] = mx; s_my[wave][lane] = my; s_mode[wave][lane] = mode;
         }
     } else {
-        incl = P > 0 ? woffsets[P - 1] : 0u;
+        incl = P > 0 ? run0 + woffsets[P - 1] : run0;
     }
     const uint32_t e = incl - w;
     const uint32_t wstart = __shfl(e, 0, 64);
@@ -576,6 +802,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         run_keys[wstart + o] = (uint16_t)x;
         run_vals[wstart + o] = make_uint2(s_g[wave][sidx], yhv);
     }
+    } // chunk
 }
 
 // Per-block histogram over tile rows of the instances of RUNS_PER_BLOCK consecutive (x-sorted) runs:

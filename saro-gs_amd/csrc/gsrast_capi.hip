@@ -41,21 +41,21 @@ std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0};      // process-wid
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
 // threads driving different streams / devices with different options cannot disturb each other.
 struct DefaultOptions {
-    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1};
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0};
 } g_def;
 gsrast_options snapshot_defaults()
 {
     gsrast_options o{};
     o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
     o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
-    o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream;
+    o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream; o.depth_sort = g_def.depth_sort;
     return o;
 }
 bool options_valid(const gsrast_options& o)
 {
     auto ppl_ok = [](int v) { return v == 0 || v == 1 || v == 2 || v == 4; };
     return o.exp_mode >= 0 && o.exp_mode <= 2 && (o.binning == 0 || o.binning == 1) && ppl_ok(o.fwd_pixels_per_lane) && ppl_ok(o.bwd_pixels_per_lane) &&
-           o.backward_phase >= 0 && o.backward_phase <= 2;
+           o.backward_phase >= 0 && o.backward_phase <= 2 && (o.depth_sort == 0 || o.depth_sort == 1);
 }
 
 int fail(int code, const char* what, hipError_t e = hipSuccess)
@@ -257,15 +257,34 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // These hints (and the counts of the last call) belong to a gsrast_context: one per caller that renders a sequence of similar
 // views.  The reference-shaped entry points use a context private to the calling host thread.
 } // namespace
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
 struct gsrast_context {
     std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0};
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
+    std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
     std::mutex mu;
 };
 namespace {
+// The context's side stream on the current device (created on first use, lowest priority: its bandwidth-heavy kernels should fill
+// the gaps the critical path leaves, not compete with it for compute units).  nullptr if it cannot be had.
+SideStream* side_stream_of(gsrast_context* ctx)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SideStream& x = ctx->side[device];
+    if (!x.stream) {
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, prio_least) != hipSuccess) { x.stream = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &x;
+}
 gsrast_context* thread_context()
 {   // deliberately leaked at thread exit (a few words): see Readback above for why nothing here has a destructor
     thread_local gsrast_context* c = new gsrast_context();
@@ -412,6 +431,7 @@ void gsrast_context_destroy(gsrast_context* c)
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
         if (x.join) (void)hipEventDestroy(x.join);
+        if (x.join2) (void)hipEventDestroy(x.join2);
     }
     delete c;
 }
@@ -422,6 +442,7 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "last_instances")) return (int)c->last_R.load();   // num_rendered / column runs of the context's last forward call
     if (!strcmp(name, "last_runs")) return (int)c->last_Q.load();
     if (!strcmp(name, "redo_count")) return c->redo_count.load();
+    if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
     return GSRAST_E_ARG;
 }
 
@@ -440,6 +461,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "sh_grad_factors")) { g_def.sh_grad_factors = value ? 1 : 0; return 0; }
     if (!strcmp(name, "speculative")) { g_def.speculative = value ? 1 : 0; return 0; }
     if (!strcmp(name, "side_stream")) { g_def.side_stream = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "depth_sort")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.depth_sort = value; return 0; }
     if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -462,9 +484,10 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "binning")) return g_def.binning.load();
     if (!strcmp(name, "tile_clip")) return g_def.tile_clip.load();
     if (!strcmp(name, "sh_grad_factors")) return g_def.sh_grad_factors.load();
-    if (!strcmp(name, "last_instances") || !strcmp(name, "last_runs") || !strcmp(name, "redo_count")) return gsrast_context_query(nullptr, name);
+    if (!strcmp(name, "last_instances") || !strcmp(name, "last_runs") || !strcmp(name, "redo_count") || !strcmp(name, "bucket_skip")) return gsrast_context_query(nullptr, name);
     if (!strcmp(name, "speculative")) return g_def.speculative.load();
     if (!strcmp(name, "side_stream")) return g_def.side_stream.load();
+    if (!strcmp(name, "depth_sort")) return g_def.depth_sort.load();
     if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
@@ -585,54 +608,73 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
     const bool runbin = o.binning == 0 && cam.gy <= 256 && T <= 65536u;
     const bool buckets_ok = T <= BUCKET_MAX_TILES;      // launch order of the blend kernels from work buckets (u16 tile ids)
+    // Depth order of the Gaussians: bucket sort (two launches, gsrast_binning.h) unless the caller or the context's recent history
+    // says radix sort
+    const bool bucket_sort = runbin && o.depth_sort == 0 && (size_t)P >= BUCKET_SORT_MIN_P && ctx->bucket_skip.load() == 0;
+    const uint32_t nbk = depth_buckets_host((size_t)P);
     // Colour half of the per-Gaussian forward (SH -> RGB: most of its bytes) on the context's side stream, forked off the
     // caller's stream here and joined in front of the blend: it overlaps the geometry kernel, the depth sort and the binning.
     SideStream* side = nullptr;
     hipStream_t cs = s;
-    if (o.side_stream) {
-        int device = 0;
-        GS_HIP(hipGetDevice(&device));
-        if (device >= 0 && device < 32) {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            SideStream& x = ctx->side[device];
-            if (!x.stream) {
-                // lowest priority: its one bandwidth-heavy kernel should fill the gaps the latency-bound sort kernels leave, not
-                // compete with them for compute units
-                int prio_least = 0, prio_greatest = 0;
-                (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-                GS_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, prio_least));
-                GS_HIP(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
-                GS_HIP(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
-            }
-            side = &x;
+    if (o.side_stream) side = side_stream_of(ctx);
+    // Where it forks matters little: its 200 MB of traffic stretches whatever latency-bound kernel runs beside it by about as much as
+    // it hides (measured: beside the geometry kernel + depth sort +55 us, beside the run emission + run sort +45 / +65 us, beside the
+    // LDS-bound run_scatter_rows it starves itself and delays the blend) -- it forks at entry, which was the best of those by ~20 us.
+    // The 64 B / Gaussian zero-fill of the backward's gradient records follows on the side stream, under the VALU-bound forward blend.
+    bool color_launched = false;
+    auto launch_color = [&]() -> int {
+        if (color_launched) return GSRAST_OK;
+        color_launched = true;
+        if (side) {
+            GS_HIP(hipEventRecord(side->fork, s));             // the inputs (and the buffers just handed out) are ordered on s
+            GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+            cs = side->stream;
         }
-    }
-    if (side) {
-        GS_HIP(hipEventRecord(side->fork, s));                 // the inputs (and the buffers just handed out) are ordered on s
-        GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-        cs = side->stream;
-    }
-    {
-        ProfScope ps(K_COLOR, cs);
-        preprocess_color_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, cs>>>(
-            P, D, M, means3D, colors_precomp ? nullptr : shs, colors_precomp, cam_pos, rec2, at<unsigned char>(geom, GL.clamped),
-            at<float4>(geom, GL.grec));
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
-    }
-    if (side) GS_HIP(hipEventRecord(side->join, side->stream));
+        {
+            ProfScope ps(K_COLOR, cs);
+            preprocess_color_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, cs>>>(
+                P, D, M, means3D, colors_precomp ? nullptr : shs, colors_precomp, cam_pos, rec2, at<unsigned char>(geom, GL.clamped),
+                side ? nullptr : at<float4>(geom, GL.grec));
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
+        }
+        if (side) {
+            GS_HIP(hipEventRecord(side->join, side->stream));
+            GS_HIP(hipMemsetAsync(at<float>(geom, GL.grec), 0, (size_t)P * GREC * sizeof(float), side->stream));
+            GS_HIP(hipEventRecord(side->join2, side->stream));
+        }
+        return GSRAST_OK;
+    };
+    { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
         preprocess_fwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
             P, means3D, scales, rotations, opacities, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
             tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
-            (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt));
+            (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt),
+            bucket_sort ? at<uint32_t>(geom, GL.zrange) : nullptr, at<uint32_t>(geom, GL.bk_count), bucket_sort ? (int)nbk * BK_XCD : 0);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
     const bool assume_short = adaptive_sort && g_sort_hint.load() != 0 && ctx->depth_short.load() != 0;
-    auto sort_and_scan = [&](bool assume) -> int {
-        {
+    const uint32_t* order = vA;     // the radix-sorted sequence ends in A under every pass count; the bucket sort leaves (kA, vA) alone
+    bool bucketed = false;          // the order in force comes from the bucket sort (per-bucket slot ranges) rather than `order`
+    auto sort_and_scan = [&](bool assume, bool buckets) -> int {
+        bucketed = buckets;
+        if (buckets) {      // three launches instead of the radix passes and the scan (gsrast_binning.h)
+            uint32_t* gcount = at<uint32_t>(geom, GL.bk_count);
+            uint2* slab = at<uint2>(geom, GL.bk_slab);
+            {   ProfScope ps(K_SORT_DEPTH, s);
+                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + 255) / 256), nbk, gcount, slab);
+                GS_LAUNCHED("depth_bucket_scatter");
+                depth_bucket_sort_kernel<<<nbk, 128, 0, s>>>(slab, gcount, nbk, rect, tiles, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info));
+                GS_LAUNCHED("depth_bucket_sort"); }
+            ProfScope ps(K_SCAN_TILES, s);
+            depth_bucket_scan_kernel<<<1, 256, 0, s>>>(at<uint4>(geom, GL.bk_info), nbk, at<uint32_t>(geom, GL.bk_base), scalars);
+            GS_LAUNCHED("depth_bucket_scan");
+            return GSRAST_OK;
+        } else {
+            order = vA;
             ProfScope ps(K_SORT_DEPTH, s);
             // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
             const SortAdapt<uint32_t, uint32_t> ad{ at<uint32_t>(geom, GL.keyC), at<uint32_t>(geom, GL.valC), at<uint32_t>(geom, GL.sort_minmax), scalars + 8, assume };
@@ -650,8 +692,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         }
         return rc;
     };
-    { int rc = sort_and_scan(assume_short); if (rc != GSRAST_OK) return rc; }
-    const uint32_t* order = vA; // the sorted sequence ends in A under every pass count
+    { int rc = sort_and_scan(assume_short, bucket_sort); if (rc != GSRAST_OK) return rc; }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
     // reference rasterizer_impl.cu:311 (the run-compressed path writes every tile's range itself, empty ones included)
@@ -686,8 +727,12 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         const uint32_t* Q_dev = counts_dev ? counts_dev + 1 : nullptr;
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
-            emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
-                                                                   o.tile_clip, capQ_, rkA, rvA);
+            if (bucketed)
+                emit_column_runs_kernel<<<nbk, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
+                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
+            else
+                emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
+                                                                       o.tile_clip, capQ_, rkA, rvA);
             GS_LAUNCHED("emit_column_runs"); }
         const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
         {   ProfScope ps(K_SORT_TILE, s);
@@ -707,6 +752,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         return GSRAST_OK;
     };
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built) -> int {
+        { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }  // the other binning scheme / nothing to bin: not forked yet
         if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));       // the colours (rec2) are the blend's input
         ProfScope ps(K_BLEND_FWD, s);
         uint32_t grid = ((T + 7) / 8) * 8;
@@ -733,6 +779,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
         }
         GS_LAUNCHED("blend_fwd");
+        if (side) GS_HIP(hipStreamWaitEvent(s, side->join2, 0));      // the gradient records are zero before anything after this forward
         return GSRAST_OK;
     };
 
@@ -752,10 +799,21 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     }
     { int rc = read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
     bool sort_redone = false;
-    if (adaptive_sort) {
+    if (!bucket_sort && o.depth_sort == 0 && ctx->bucket_skip.load() > 0) ctx->bucket_skip--;
+    if (bucket_sort) {
+        if (counts[11] != 0) {      // more Gaussians at (nearly) one depth than a bucket holds: sort again with the radix passes, and
+            ctx->redo_count++;      // start with those for a while (everything enqueued so far used a wrong order, as below)
+            ctx->bucket_skip = 16;
+            int rc = sort_and_scan(false, false);
+            if (rc == GSRAST_OK) rc = read_u32(scalars, s, counts, 12);
+            if (rc != GSRAST_OK) return rc;
+            sort_redone = true;
+            if (adaptive_sort) ctx->depth_short = counts[8] <= 24u ? 1 : 0;
+        }
+    } else if (adaptive_sort) {
         if (assume_short && counts[10] != 0) {      // the scene's depth range widened: sort again with all four passes, then as after
             ctx->redo_count++;                      // an undersized speculative launch (everything enqueued so far used a wrong order)
-            int rc = sort_and_scan(false);
+            int rc = sort_and_scan(false, false);
             if (rc == GSRAST_OK) rc = read_u32(scalars, s, counts, 12);
             if (rc != GSRAST_OK) return rc;
             sort_redone = true;
@@ -1207,6 +1265,23 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
     float* grec = at<float>(geom, GL.grec);
     const bool do_blend = o.backward_phase != 2, do_geom = o.backward_phase != 1;
     if (do_blend && !o.grads_zeroed) GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
+    // What the per-Gaussian backward needs of the SH coefficients -- d(colour)/d(view direction), 36 B instead of 12*M -- depends on
+    // nothing the blend backward produces: evaluated on the side stream of the calling thread's context WHILE the VALU-bound blend
+    // backward runs, joined in front of preprocess_bwd (or at the end of phase 1 of a two-phase backward).
+    SideStream* side = nullptr;
+    if (do_blend && use_sh && D > 0) {
+        if (o.side_stream && R > 0) side = side_stream_of(thread_context());
+        hipStream_t ds = s;
+        if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); ds = side->stream; }
+        // two waves per compute unit, grid-stride: enough loads in flight for ~1.5 TB/s, few enough not to push the blend kernel's
+        // workgroups off the chip (an unthrottled launch slowed the blend backward by 20 %, this one by 2 %)
+        const int grid = side ? std::min((P + 63) / 64, 512) : (P + 63) / 64;
+        sh_dir_derivs_kernel<<<grid, 64, 0, ds>>>(P, D, M, means3D, shs, campos, radii,
+                                                  at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "sh_dir_derivs", e);
+        if (side) GS_HIP(hipEventRecord(side->join, side->stream));
+    }
     if (do_blend && R > 0) {
         ProfScope ps(K_BLEND_BWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;
@@ -1244,11 +1319,13 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
         sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh);
         GS_LAUNCHED("sh_factor");
     }
+    if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));
     if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
         preprocess_bwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
             P, D, M, means3D, radii, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
+            at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC),
             use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, reinterpret_cast<const float4*>(grec),
             dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, (use_sh && o.sh_grad_factors) ? 1 : 0);
         GS_LAUNCHED("preprocess_bwd");

@@ -29,14 +29,32 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
 //   scalars  u32[64]     [0] = num_rendered ... [8] = significant bits of the depth keys (adaptive pass count of the depth sort)
 //   keyC/valC u32[P] x2  third buffer pair of the depth sort, sort_minmax u32[2 nblk]: per-block key minimum / maximum
+//   shdA/B   float4[P] x2, shdC f32[P]   backward only: d(colour)/d(view direction) {dx[3], dy[3], dz[3]} (sh_dir_derivs_kernel, on a side
+//                        stream beside the blend backward), so that the per-Gaussian backward reads 36 B instead of 12*M
+//   zrange   u32[2 ceil(P/256)]  per-block minimum / maximum depth key (preprocess_fwd); the bucket depth sort (gsrast_binning.h, NB ~ P/256
+//                        buckets of CAP slots): bk_count u32[8][NB], bk_slab uint2[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
+//                        u32[NB][CAP] (sorted ids, inclusive width scan inside the bucket), bk_info uint4[NB], bk_base u32[NB]
 //   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
     size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, total;
+        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
+constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is one or two self-scanned radix passes anyway
+#ifndef GSRAST_BK_TARGET
+#define GSRAST_BK_TARGET 256      // Gaussians per depth bucket, roughly
+#endif
+#ifndef GSRAST_BK_CAP
+#define GSRAST_BK_CAP 1024        // slots per bucket
+#endif
+static inline uint32_t depth_buckets_host(size_t P)     // buckets of the depth sort: ~P / 256, a power of two in [256, 8192] (gsrast_binning.h)
+{
+    uint32_t nb = 256;
+    while ((size_t)nb * GSRAST_BK_TARGET < P && nb < 8192u) nb <<= 1;
+    return nb;
+}
 // Binning (per instance), replaces BinningState (rasterizer_impl.h:56-65):
 //   valA/B u32[C] x2  Gaussian id ping-pong (valA at offset 0 = the final point_list)
 //   keyA/B u32[C] x2  tile id ping-pong (16-bit ids up to 65 536 tiles), hist u32[256*nblk(C)], scan_tmp
@@ -106,6 +124,16 @@ static inline GeomLayout geom_layout(size_t P)
     L.grec = take(Pp * GREC * 4);
     L.keyC = take(Pp * 4); L.valC = take(Pp * 4);                               // third buffer pair of the adaptive depth sort
     L.sort_minmax = take(2 * rs_blocks_n(Pp, GSRAST_DEPTH_ITEMS) * 4);
+    L.shdA = take(Pp * 16); L.shdB = take(Pp * 16); L.shdC = take(Pp * 4);
+    // bucket depth sort (gsrast_binning.h): per-block depth ranges of preprocess_fwd (256 Gaussians per block), bucket counters, slabs
+    L.zrange = take(((Pp + 255) / 256 + 1) * 8);
+    {
+        const size_t nb = Pp >= BUCKET_SORT_MIN_P ? depth_buckets_host(Pp) : 0;
+        L.bk_count = take(nb * 8 * 4);                       // [8 XCDs][nb]
+        L.bk_slab = take(nb * GSRAST_BK_CAP * 8);            // [nb][8][CAP / 8] (key, id)
+        L.bk_order = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl = take(nb * GSRAST_BK_CAP * 4);
+        L.bk_info = take(nb * 16); L.bk_base = take(nb * 4);
+    }
     L.total = o + 256;
     return L;
 }

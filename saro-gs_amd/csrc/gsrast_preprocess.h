@@ -168,6 +168,48 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float pos[3], const flo
 }
 
 
+// d(colour)/d(view direction), 9 numbers {dx[c], dy[c], dz[c]} (backward.cu:78-127 dRGBdx / dRGBdy / dRGBdz): a function of the
+// coefficients and the direction only -- of nothing the blend backward produces.  sh_dir_derivs_kernel evaluates it on a side stream
+// WHILE the (VALU-bound) blend backward runs and stores the nine floats (36 B); the per-Gaussian backward, which is on the critical
+// path and bandwidth-bound, then reads those instead of the 12*M-byte coefficient block -- same expressions, same operands, same bits.
+#define SHV(k, c) sh[(k) * 3 + (c)]
+__device__ __forceinline__ void sh_dir_derivs(int deg, float x, float y, float z, const float* __restrict__ sh,
+                                              float dx[3], float dy[3], float dz[3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; c++) { dx[c] = 0.0f; dy[c] = 0.0f; dz[c] = 0.0f; }
+    if (deg > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { dx[c] = -kSH1 * SHV(3, c); dy[c] = -kSH1 * SHV(1, c); dz[c] = kSH1 * SHV(2, c); }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dx[c] += kSH2[0] * y * SHV(4, c) + kSH2[2] * 2.0f * -x * SHV(6, c) + kSH2[3] * z * SHV(7, c) + kSH2[4] * 2.0f * x * SHV(8, c);
+                dy[c] += kSH2[0] * x * SHV(4, c) + kSH2[1] * z * SHV(5, c) + kSH2[2] * 2.0f * -y * SHV(6, c) + kSH2[4] * 2.0f * -y * SHV(8, c);
+                dz[c] += kSH2[1] * y * SHV(5, c) + kSH2[2] * 2.0f * 2.0f * z * SHV(6, c) + kSH2[3] * x * SHV(7, c);
+            }
+            if (deg > 2) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dx[c] += (kSH3[0] * SHV(9, c) * 3.0f * 2.0f * xy + kSH3[1] * SHV(10, c) * yz +
+                              kSH3[2] * SHV(11, c) * -2.0f * xy + kSH3[3] * SHV(12, c) * -3.0f * 2.0f * xz +
+                              kSH3[4] * SHV(13, c) * (-3.0f * xx + 4.0f * zz - yy) +
+                              kSH3[5] * SHV(14, c) * 2.0f * xz + kSH3[6] * SHV(15, c) * 3.0f * (xx - yy));
+                    dy[c] += (kSH3[0] * SHV(9, c) * 3.0f * (xx - yy) + kSH3[1] * SHV(10, c) * xz +
+                              kSH3[2] * SHV(11, c) * (-3.0f * yy + 4.0f * zz - xx) +
+                              kSH3[3] * SHV(12, c) * -3.0f * 2.0f * yz + kSH3[4] * SHV(13, c) * -2.0f * xy +
+                              kSH3[5] * SHV(14, c) * -2.0f * yz + kSH3[6] * SHV(15, c) * -3.0f * 2.0f * xy);
+                    dz[c] += (kSH3[1] * SHV(10, c) * xy + kSH3[2] * SHV(11, c) * 4.0f * 2.0f * yz +
+                              kSH3[3] * SHV(12, c) * 3.0f * (2.0f * zz - xx - yy) +
+                              kSH3[4] * SHV(13, c) * 4.0f * 2.0f * xz + kSH3[5] * SHV(14, c) * (xx - yy));
+                }
+            }
+        }
+    }
+}
+#undef SHV
+
 // -------------------------------------------------------------------------------------------
 // SH coefficients are [P][M][3] AoS: one lane's block is M*12 bytes at a stride of M*12 bytes, the
 // worst case for per-lane loads.  The workgroup therefore moves its PP_THREADS consecutive blocks
@@ -231,11 +273,11 @@ __global__ void __launch_bounds__(PP_THREADS)
 preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                         const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
                         float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
-                        float4* __restrict__ grec4 /* [P][4]: the backward's gradient records, zero-filled here, off the critical path */)
+                        float4* __restrict__ grec4 /* [P][4] or null: the backward's gradient records, zero-filled here when there is no side stream to do it */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
-    {   // this workgroup's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
+    if (grec4) {   // this workgroup's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
         const size_t q0 = (size_t)blockIdx.x * PP_THREADS * 4, q1 = (size_t)P * 4;
 #pragma unroll
         for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -271,9 +313,13 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
                       uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val,
                       int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */,
-                      uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */)
+                      uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */,
+                      uint32_t* __restrict__ block_zrange /* [gridDim.x][2] or null: minimum / maximum depth key of this block's visible
+                                                             Gaussians, for the bucket depth sort (gsrast_binning.h); {~0, 0} if it has none */,
+                      uint32_t* __restrict__ zero_words, int n_zero_words /* that sort's counters: zeroed here, spread over the blocks */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // Every per-Gaussian input is requested up front: loads issued where they are first used (inside the visibility / area
     // branches) put three more memory round trips into a latency-bound kernel.  Clamped index: lanes past P load a valid
@@ -287,9 +333,9 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
         q_in = reinterpret_cast<const float4*>(rotations)[ic];
     }
     const float op_in = opacities[ic];
-    if (i >= P) return;
     const Cam cam = load_cam(cam_args);
     int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
+    if (i < P) {
 
     float ph[4], pv[3];
     xform4x4(p, cam.proj, ph);
@@ -371,6 +417,20 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     }
     radii[i] = rad_out; tiles[i] = ntiles; rect[i] = rc;
     sort_key[i] = key; sort_val[i] = (uint32_t)i;
+    } // i < P
+    if (block_zrange) {     // depth range of the block's visible Gaussians (positive floats order like their bits; culled: key = ~0)
+        __shared__ uint32_t s_lo[4], s_hi[4];
+        uint32_t lo = key, hi = key == 0xFFFFFFFFu ? 0u : key;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            block_zrange[2 * blockIdx.x] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+            block_zrange[2 * blockIdx.x + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+            if (blockIdx.x == gridDim.x - 1 && (gridDim.x & 1u)) { block_zrange[2 * gridDim.x] = 0xFFFFFFFFu; block_zrange[2 * gridDim.x + 1] = 0u; }   // read in pairs
+        }
+    }
 }
 
 // K0: reference rasterizer_impl.cu:54-66
@@ -395,8 +455,9 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 // The multi-GPU exchange moves g (returned in g_out) instead of the 48 products (gsrast_sh_grad_combine).
 template <bool FACTORS = false>
 __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const float campos[3],
-                                            const float* __restrict__ sh, unsigned cl, const float dcol[3],
-                                            float dmean[3], float* __restrict__ dsh, float* g_out = nullptr)
+                                            const float dx[3], const float dy[3], const float dz[3] /* sh_dir_derivs */,
+                                            unsigned cl, const float dcol[3],
+                                            float dmean[3], float* __restrict__ dsh)
 {
     const float o0 = pos[0] - campos[0], o1 = pos[1] - campos[1], o2 = pos[2] - campos[2];
     const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
@@ -404,50 +465,24 @@ __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const f
     float g[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) g[c] = dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f);
-    if (FACTORS) { g_out[0] = g[0]; g_out[1] = g[1]; g_out[2] = g[2]; }
-    float dx[3] = { 0, 0, 0 }, dy[3] = { 0, 0, 0 }, dz[3] = { 0, 0, 0 };
-#define SHV(k, c) sh[(k) * 3 + (c)]
 #define PUT(k, w) { if (!FACTORS) { const float w_ = (w); dsh[(k) * 3 + 0] = w_ * g[0]; dsh[(k) * 3 + 1] = w_ * g[1]; dsh[(k) * 3 + 2] = w_ * g[2]; } }
     PUT(0, kSH0);
     if (deg > 0) {
         PUT(1, -kSH1 * y); PUT(2, kSH1 * z); PUT(3, -kSH1 * x);
-#pragma unroll
-        for (int c = 0; c < 3; c++) { dx[c] = -kSH1 * SHV(3, c); dy[c] = -kSH1 * SHV(1, c); dz[c] = kSH1 * SHV(2, c); }
         if (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             PUT(4, kSH2[0] * xy); PUT(5, kSH2[1] * yz); PUT(6, kSH2[2] * (2.0f * zz - xx - yy));
             PUT(7, kSH2[3] * xz); PUT(8, kSH2[4] * (xx - yy));
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                dx[c] += kSH2[0] * y * SHV(4, c) + kSH2[2] * 2.0f * -x * SHV(6, c) + kSH2[3] * z * SHV(7, c) + kSH2[4] * 2.0f * x * SHV(8, c);
-                dy[c] += kSH2[0] * x * SHV(4, c) + kSH2[1] * z * SHV(5, c) + kSH2[2] * 2.0f * -y * SHV(6, c) + kSH2[4] * 2.0f * -y * SHV(8, c);
-                dz[c] += kSH2[1] * y * SHV(5, c) + kSH2[2] * 2.0f * 2.0f * z * SHV(6, c) + kSH2[3] * x * SHV(7, c);
-            }
             if (deg > 2) {
                 PUT(9, kSH3[0] * y * (3.0f * xx - yy)); PUT(10, kSH3[1] * xy * z);
                 PUT(11, kSH3[2] * y * (4.0f * zz - xx - yy));
                 PUT(12, kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
                 PUT(13, kSH3[4] * x * (4.0f * zz - xx - yy)); PUT(14, kSH3[5] * z * (xx - yy));
                 PUT(15, kSH3[6] * x * (xx - 3.0f * yy));
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    dx[c] += (kSH3[0] * SHV(9, c) * 3.0f * 2.0f * xy + kSH3[1] * SHV(10, c) * yz +
-                              kSH3[2] * SHV(11, c) * -2.0f * xy + kSH3[3] * SHV(12, c) * -3.0f * 2.0f * xz +
-                              kSH3[4] * SHV(13, c) * (-3.0f * xx + 4.0f * zz - yy) +
-                              kSH3[5] * SHV(14, c) * 2.0f * xz + kSH3[6] * SHV(15, c) * 3.0f * (xx - yy));
-                    dy[c] += (kSH3[0] * SHV(9, c) * 3.0f * (xx - yy) + kSH3[1] * SHV(10, c) * xz +
-                              kSH3[2] * SHV(11, c) * (-3.0f * yy + 4.0f * zz - xx) +
-                              kSH3[3] * SHV(12, c) * -3.0f * 2.0f * yz + kSH3[4] * SHV(13, c) * -2.0f * xy +
-                              kSH3[5] * SHV(14, c) * -2.0f * yz + kSH3[6] * SHV(15, c) * -3.0f * 2.0f * xy);
-                    dz[c] += (kSH3[1] * SHV(10, c) * xy + kSH3[2] * SHV(11, c) * 4.0f * 2.0f * yz +
-                              kSH3[3] * SHV(12, c) * 3.0f * (2.0f * zz - xx - yy) +
-                              kSH3[4] * SHV(13, c) * 4.0f * 2.0f * xz + kSH3[5] * SHV(14, c) * (xx - yy));
-                }
             }
         }
     }
 #undef PUT
-#undef SHV
     const float dd0 = dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2];
     const float dd1 = dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2];
     const float dd2 = dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2];
@@ -476,11 +511,48 @@ sh_factor_kernel(int P, const int* __restrict__ radii, const unsigned char* __re
         g_out[3 * (size_t)i + c] = live ? dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f) : 0.0f;
 }
 
+// d(colour)/d(view direction) of every visible Gaussian (sh_dir_derivs above), for preprocess_bwd_kernel.  Launched by
+// gsrast_backward on the context's side stream beside the blend backward: no LDS and few registers, so that its waves fit into the
+// register space the blend kernel's five waves per SIMD leave free; a lane reads its 12*M-byte coefficient block with 16-byte loads.
+__global__ void __launch_bounds__(64)
+sh_dir_derivs_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                     const float* __restrict__ campos_dev, const int* __restrict__ radii,
+                     float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC)
+{
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < P; i += gridDim.x * 64) {
+    if (radii[i] <= 0) continue;
+    const float o0 = means3D[3 * i] - campos_dev[0], o1 = means3D[3 * i + 1] - campos_dev[1], o2 = means3D[3 * i + 2] - campos_dev[2];
+    const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+    const float x = o0 / len, y = o1 / len, z = o2 / len;
+    const int ncoef = (D + 1) * (D + 1);
+    float dx[3], dy[3], dz[3];
+    const float* row = shs + (size_t)i * M * 3;
+    if (((M * 3) & 3) == 0 && ((uintptr_t)shs & 15) == 0 && ncoef * 3 <= PP_SH_MAX) {
+        float v[PP_SH_MAX];
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+        for (int q = 0; q < PP_SH_MAX / 4; q++) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q * 4 < ncoef * 3) t = row4[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        sh_dir_derivs(D, x, y, z, v, dx, dy, dz);
+    } else {
+        sh_dir_derivs(D, x, y, z, row, dx, dy, dz);
+    }
+    shdA[i] = make_float4(dx[0], dx[1], dx[2], dy[0]);
+    shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
+    shdC[i] = dz[2];
+    }
+}
+
 // K6 + K7 fused.  Every output row is written exactly once (zeros for culled Gaussians), so the
 // caller does not have to zero-fill the five output arrays.  dL/dsh leaves through LDS (coalesced).
 __global__ void __launch_bounds__(PP_THREADS)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
-                      const float* __restrict__ shs, const unsigned char* __restrict__ clamped,
+                      const float* __restrict__ shs /* only its presence matters: the coefficients are not read */,
+                      const unsigned char* __restrict__ clamped,
+                      const float4* __restrict__ shdA, const float4* __restrict__ shdB, const float* __restrict__ shdC /* sh_dir_derivs_kernel's output */,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ cov3D /* internal or precomp */, CamArgs cam_args,
                       const float4* __restrict__ grec /* [P][4]: the blend backward's gradient records (GeomLayout::grec) */,
@@ -514,8 +586,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const float g2x = gr0.x, g2y = gr0.y;
     const float dcol[3] = { gr1.z, gr1.w, gr2.x };
     unsigned char clamped_in = 0;
-    if (shs) clamped_in = clamped[ic];                      // uniform
-    if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
+    float4 sdA = make_float4(0.f, 0.f, 0.f, 0.f), sdB = sdA; float sdC = 0.0f;
+    if (shs) {                                              // uniform
+        clamped_in = clamped[ic];
+        if (D > 0) { sdA = shdA[ic]; sdB = shdB[ic]; sdC = shdC[ic]; }
+    }
     const Cam cam = load_cam(cam_args);
     const bool live = i < P && radius_in > 0;
     if (i < P) {    // the screen-space gradients leave in the reference's arrays (rasterize_points.cu:150-158), written once
@@ -613,19 +688,15 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     dmean[1] += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
     dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
     if (shs) {
-        if (sh_factors) {
-            float gf[3];     // the factor itself left with sh_factor_kernel, right after the blend backward
-            sh_backward<true>(D, mean, cam.campos, staged ? my_lds : shs + (size_t)i * M * 3, clamped_in, dcol, dmean, nullptr, gf);
+        const float ddx[3] = { sdA.x, sdA.y, sdA.z }, ddy[3] = { sdA.w, sdB.x, sdB.y }, ddz[3] = { sdB.z, sdB.w, sdC };
+        if (sh_factors) {    // the factor itself left with sh_factor_kernel, right after the blend backward
+            sh_backward<true>(D, mean, cam.campos, ddx, ddy, ddz, clamped_in, dcol, dmean, nullptr);
         } else if (staged) {
-            // the lane's coefficients move LDS -> registers first: its LDS row is then reused for dL/dsh
-            float shv[PP_SH_MAX];
-#pragma unroll
-            for (int k = 0; k < PP_SH_MAX; k++) shv[k] = k < ncoef * 3 ? my_lds[k] : 0.0f;
-            sh_backward(D, mean, cam.campos, shv, clamped_in, dcol, dmean, my_lds);
+            sh_backward(D, mean, cam.campos, ddx, ddy, ddz, clamped_in, dcol, dmean, my_lds);
             for (int k = ncoef * 3; k < M * 3; k++) my_lds[k] = 0.0f;
         } else {
             float* dsh = dL_dsh + (size_t)i * M * 3;
-            sh_backward(D, mean, cam.campos, shs + (size_t)i * M * 3, clamped_in, dcol, dmean, dsh);
+            sh_backward(D, mean, cam.campos, ddx, ddy, ddz, clamped_in, dcol, dmean, dsh);
             for (int k = ncoef * 3; k < M * 3; k++) dsh[k] = 0.0f;
         }
     }

@@ -239,9 +239,10 @@ def test_extreme_aspect_ratios_on_the_run_path(W, H, orc, scenes, rast, gpu):
             assert (err <= 1e-5 + 1e-3 * np.abs(ref)).all(), (k, float(err.max()))
 
 
+@pytest.mark.parametrize("depth_sort", [1, 0], ids=["radix", "buckets"])
 @pytest.mark.parametrize("radius,short", [(4.0, True), (9.0, True), (2.6, False), (1.5, False)],
                          ids=["depths_1p7_to_6p3_three_passes", "depths_cross_8_three_passes", "wide_range_four_passes", "near_plane_four_passes"])
-def test_adaptive_depth_sort_pass_count(radius, short, orc, scenes, rast, gpu):
+def test_adaptive_depth_sort_pass_count(radius, short, depth_sort, orc, scenes, rast, gpu):
     """The depth sort of > 131072 Gaussians decides ON THE DEVICE whether its fourth 8-bit pass is needed: digits of passes 2-4
     are taken from key - base (base = smallest visible key, low byte cleared), and a key span below 2^24 is sorted after three
     passes -- also when the depths straddle a power of two (camera distance 4: 1.7 .. 6.3; distance 9: across 8).  Wide depth
@@ -251,7 +252,11 @@ def test_adaptive_depth_sort_pass_count(radius, short, orc, scenes, rast, gpu):
     sc = scenes.synth(P, 5)
     cam = scenes.camera(1, 7, W, H, radius=radius)
     o32 = orc.render(sc, cam)
-    h = run_hip(rast, sc, cam, gpu, tile_clip=0)
+    rast._C.set_option("depth_sort", depth_sort)      # 1: the radix passes this test is about; 0: the default bucket sort on the same depth ranges
+    try:
+        h = run_hip(rast, sc, cam, gpu, tile_clip=0)
+    finally:
+        rast._C.set_option("depth_sort", 0)
     d = o32["depths"][o32["radii"] > 0].view(np.uint32).astype(np.int64)
     assert ((d.max() - (d.min() & ~0xFF)) < (1 << 24)) == short           # the regime this case is meant to exercise
     assert h["R"] == o32["R"]
@@ -271,15 +276,84 @@ def test_depth_sort_pass_hint_follows_the_scene(orc, scenes, rast, gpu):
     _C = rast._C
     want = {}
     redo0 = None
-    for step, radius in enumerate([4.0, 4.0, 2.6, 2.6, 4.0]):
-        cam = scenes.camera(2, 7, W, H, radius=radius)
-        if radius not in want:
-            want[radius] = orc.render(sc, cam)
-        o32 = want[radius]
-        if step == 1:
-            redo0 = _C.get_option("redo_count")
-        h = run_hip(rast, sc, cam, gpu, tile_clip=0)            # two forwards per call (state export + autograd module)
-        np.testing.assert_array_equal(h["point_list"], o32["point_list"], err_msg=f"step {step}")
-        np.testing.assert_array_equal(h["ranges"], o32["ranges"])
-        np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
-    assert _C.get_option("redo_count") - redo0 == 1
+    _C.set_option("depth_sort", 1)         # the radix sort (the default bucket sort has no pass count)
+    try:
+        for step, radius in enumerate([4.0, 4.0, 2.6, 2.6, 4.0]):
+            cam = scenes.camera(2, 7, W, H, radius=radius)
+            if radius not in want:
+                want[radius] = orc.render(sc, cam)
+            o32 = want[radius]
+            if step == 1:
+                redo0 = _C.get_option("redo_count")
+            h = run_hip(rast, sc, cam, gpu, tile_clip=0)            # two forwards per call (state export + autograd module)
+            np.testing.assert_array_equal(h["point_list"], o32["point_list"], err_msg=f"step {step}")
+            np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+            np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+        assert _C.get_option("redo_count") - redo0 == 1
+    finally:
+        _C.set_option("depth_sort", 0)
+
+
+def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu):
+    """The default depth sort puts the Gaussians into ~P/256 depth buckets of fixed capacity.  A scene whose depths pile up -- here
+    three thin sheets facing the camera, 20 000 Gaussians at (nearly) one depth each -- overflows a bucket: the device reports it
+    with the instance counts, the forward repeats the sort with the radix passes (one redo) and the context goes straight to
+    those for its next calls.  Every forward equals the oracle entry by entry; equal depths fall in index order."""
+    from gpu_harness import run_hip
+    P, W, H = 60_000, 480, 360
+    sc = scenes.synth(P, 9)
+    cam = scenes.camera(0, 5, W, H)
+    # flatten the cloud onto three planes perpendicular to the viewing direction (view matrix row 2 = the depth axis)
+    V = np.asarray(cam["viewmatrix"], dtype=np.float64).reshape(4, 4)       # stored transposed: V[c][r]
+    axis = V[:3, 2] / np.linalg.norm(V[:3, 2])
+    m = sc["means3D"].astype(np.float64)
+    layer = (np.arange(P) % 3 - 1) * 0.4
+    m = m - np.outer(m @ axis, axis) + np.outer(layer, axis)
+    sc = dict(sc); sc["means3D"] = m.astype(np.float32)
+    o32 = orc.render(sc, cam)
+    nvis = int((o32["radii"] > 0).sum())
+    assert nvis > 30_000 and np.unique(o32["depths"][o32["radii"] > 0]).size < nvis // 20      # many exactly equal depth keys
+    _C = rast._C
+    assert _C.get_option("depth_sort") == 0
+    redo0 = _C.get_option("redo_count")
+    try:
+        for step in range(2):
+            h = run_hip(rast, sc, cam, gpu, tile_clip=0)            # two forwards per call
+            assert h["R"] == o32["R"]
+            np.testing.assert_array_equal(h["keys_sorted"], o32["keys_sorted"], err_msg=f"step {step}")
+            np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+            np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+            np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+            if step == 0:
+                assert _C.get_option("redo_count") - redo0 == 1, "the first forward must have re-sorted"
+                assert _C.get_option("bucket_skip") > 0
+        assert _C.get_option("redo_count") - redo0 == 1, "later forwards start with the radix sort"
+    finally:
+        # let the context forget: an ordinary scene, until the bucket sort is tried (and kept) again
+        sc2 = scenes.synth(P, 10)
+        for _ in range(12):
+            if _C.get_option("bucket_skip") == 0:
+                break
+            run_hip(rast, sc2, cam, gpu, tile_clip=0)
+        assert _C.get_option("bucket_skip") == 0
+
+
+def test_bucket_depth_sort_ties_fall_in_index_order(orc, scenes, rast, gpu):
+    """Every Gaussian twice (same mean, different appearance): all depth keys come in equal pairs.  The bucket sort orders a bucket by
+    (depth bits, index), so the lists equal the oracle's stable 64-bit key sort entry by entry -- and no bucket overflows."""
+    from gpu_harness import run_hip
+    P, W, H = 30_000, 400, 300
+    a, b = scenes.synth(P, 11), scenes.synth(P, 12)
+    sc = {k: (np.concatenate([a[k], b[k]], axis=0) if isinstance(a[k], np.ndarray) and a[k].shape[:1] == (P,) else a[k]) for k in a}
+    sc["means3D"] = np.concatenate([a["means3D"], a["means3D"]], axis=0)
+    cam = scenes.camera(3, 8, W, H)
+    o32 = orc.render(sc, cam)
+    _C = rast._C
+    redo0 = _C.get_option("redo_count")
+    h = run_hip(rast, sc, cam, gpu, tile_clip=0)
+    assert _C.get_option("redo_count") == redo0 and _C.get_option("bucket_skip") == 0
+    assert h["R"] == o32["R"]
+    np.testing.assert_array_equal(h["keys_sorted"], o32["keys_sorted"])
+    np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+    np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
