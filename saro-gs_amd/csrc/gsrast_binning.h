@@ -405,9 +405,12 @@ __device__ __forceinline__ uint32_t depth_bucket_of(uint32_t key, float zmin, fl
 }
 
 __global__ void __launch_bounds__(256)
-depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ block_zrange, uint32_t nzblk,
+depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                            uint32_t n, const uint32_t* __restrict__ block_zrange, uint32_t nzblk,
                             uint32_t nb, uint32_t* __restrict__ gcount /* [8][nb]: per-XCD bucket counts (zeroed by preprocess_fwd) */,
-                            uint2* __restrict__ slab /* [nb][8][BK_CAPX] */)
+                            uint4* __restrict__ slab /* [nb][8][BK_CAPX]: {depth key, id, rectangle width, tile count} -- what the sort kernel
+                                                        needs of a Gaussian travels with it (gathering rect / tiles by id there cost 15 us) */,
+                            float* __restrict__ zparam /* [2]: zmin, scale -- for the sort kernel */)
 {
     __shared__ uint32_t cnt[BK_MAX_BUCKETS];
     __shared__ uint32_t s_mm[2];
@@ -439,6 +442,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, uint32_t n, const
     __syncthreads();
     const float zmin = __uint_as_float(s_mm[0]), zmax = __uint_as_float(s_mm[1]);
     const float scale = zmax > zmin ? (float)nb / (zmax - zmin) : 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { zparam[0] = zmin; zparam[1] = scale; }
     uint32_t dg[BK_ITEMS], lr[BK_ITEMS];
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
@@ -459,100 +463,141 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, uint32_t n, const
         for (int u = 0; u < 16; u++) { if (c[u]) cnt[k0 + u * 256] = g[u]; }
     }
     __syncthreads();
+    uint2 rc[BK_ITEMS]; uint32_t tl[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) {      // coalesced, requested together (culled Gaussians have rect = tiles = 0)
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        rc[r] = make_uint2(0u, 0u); tl[r] = 0u;
+        if (i < n) { rc[r] = rect[i]; tl[r] = tiles[i]; }
+    }
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
         if (key[r] != 0xFFFFFFFFu) {
             const uint32_t pos = cnt[dg[r]] + lr[r];
-            if (pos < (uint32_t)BK_CAPX) slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint2(key[r], base + r * 256 + threadIdx.x);
+            if (pos < (uint32_t)BK_CAPX)
+                slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, (rc[r].y & 0xFFFFu) - (rc[r].x & 0xFFFFu), tl[r]);
         }
     }
 }
 
-// 128-thread exclusive scan of per-thread totals; *total = block sum
-__device__ __forceinline__ uint32_t block128_excl_scan(uint32_t v, uint32_t* total)
+// One WAVE per bucket, no workgroup barrier anywhere: everything a bucket needs is wave-synchronous (LDS operations of one wave
+// execute in order; wave_sync() only keeps the compiler from moving them across each other).
+// The sort inside a bucket is a second bucket pass in LDS, not a comparison network (a bitonic sort of 256-512 64-bit composites in
+// LDS measured 10-15 us per bucket, dependent LDS round trips all the way): the bucket's depth interval is cut into BK_SUB
+// sub-intervals (again monotone in z), an LDS counter per sub-interval hands out arrival ranks, a scan of the counters gives each
+// sub-interval its place, and an element's final position is its sub-interval's start + the number of smaller (depth bits, index)
+// composites among the one to three elements that share it.  Correct for any distribution (a sub-interval holding k elements costs
+// k^2 comparisons -- scenes with massive depth ties overflow the slabs and take the radix path anyway).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+constexpr int BK_SUB = 256;
+constexpr int BK_WAVES = 2;              // buckets per workgroup
+
+__device__ __forceinline__ uint4 bucket_element(const uint4* __restrict__ slab, uint32_t b, const uint32_t (&start)[BK_XCD + 1], uint32_t e)
+{   // element e of the bucket in arrival order = element (e - start[x]) of sub-slab x
+    uint32_t x = 0, s0 = 0;
+#pragma unroll
+    for (int q = 1; q < BK_XCD; q++) { const bool ge = e >= start[q]; x += ge ? 1u : 0u; s0 = ge ? start[q] : s0; }
+    return slab[((size_t)b * BK_XCD + x) * BK_CAPX + (e - s0)];
+}
+__device__ __forceinline__ uint32_t depth_sub_bucket(uint32_t key, float zmin, float scale, uint32_t b)
 {
-    __shared__ uint32_t wsum2[2];
-    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t inc = wave_incl_scan(v);
-    if (lane == 63) wsum2[wave] = inc;
-    __syncthreads();
-    const uint32_t s0 = wsum2[0], s1 = wsum2[1];
-    __syncthreads();
-    *total = s0 + s1;
-    return (wave ? s0 : 0u) + inc - v;
+    const float t = (__uint_as_float(key) - zmin) * scale - (float)b;      // in [0, 1) except in the clamped last bucket
+    const uint32_t d = (uint32_t)(t * (float)BK_SUB);
+    return d < (uint32_t)BK_SUB ? d : (uint32_t)BK_SUB - 1u;
 }
 
-__global__ void __launch_bounds__(128)
-depth_bucket_sort_kernel(const uint2* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb,
-                         const uint2* __restrict__ gather_rect, const uint32_t* __restrict__ tiles /* [P]: the reference's tile counts (-> num_rendered) */,
+__global__ void __launch_bounds__(64 * BK_WAVES)
+depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb, const float* __restrict__ zparam,
                          uint32_t* __restrict__ border /* [nb][BK_CAP]: sorted Gaussian ids of each bucket */,
                          uint32_t* __restrict__ bwincl /* [nb][BK_CAP]: inclusive scan of their rectangle widths inside the bucket */,
                          uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */)
 {
-    __shared__ unsigned long long sk[BK_CAP];
-    __shared__ uint32_t s_cx[BK_XCD + 1];
-    const uint32_t b = blockIdx.x, t0 = threadIdx.x;
-    if (t0 == 0) {
-        uint32_t acc = 0, over = 0;
-        for (int x = 0; x < BK_XCD; x++) {
-            const uint32_t c = gcount[(size_t)x * nb + b];
-            over |= c > (uint32_t)BK_CAPX ? 1u : 0u;
-            s_cx[x] = acc; acc += c < (uint32_t)BK_CAPX ? c : (uint32_t)BK_CAPX;
-        }
-        s_cx[BK_XCD] = acc | (over << 31);
+    __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
+    __shared__ uint32_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order
+    __shared__ uint16_t s_wid[BK_WAVES][BK_CAP];                // widths, grouped like s_grp
+    __shared__ uint32_t s_cnt[BK_WAVES][BK_SUB + 1];
+    const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * BK_WAVES + wave;
+    if (b >= nb) return;
+    unsigned long long* grp = s_grp[wave];
+    uint32_t* aux = s_aux[wave];
+    uint16_t* wid = s_wid[wave];
+    uint32_t* cnt = s_cnt[wave];
+    const float zmin = zparam[0], scale = zparam[1];
+    // the eight sub-slab counts: lanes 0-7 load, an 8-lane inclusive scan gives the sub-slabs' first positions in the bucket
+    uint32_t c = lane < (unsigned)BK_XCD ? gcount[(size_t)lane * nb + b] : 0u;
+    const uint32_t over = __ballot(c > (uint32_t)BK_CAPX) != 0ull ? 1u : 0u;
+    c = c < (uint32_t)BK_CAPX ? c : (uint32_t)BK_CAPX;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < BK_XCD; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= (unsigned)d) inc += t; }
+    uint32_t start[BK_XCD + 1];
+    start[0] = 0u;
+#pragma unroll
+    for (int x = 0; x < BK_XCD; x++) start[x + 1] = __builtin_amdgcn_readlane(inc, x);
+    const uint32_t n = start[BK_XCD];
+    for (uint32_t k = lane; k <= (uint32_t)BK_SUB; k += 64) cnt[k] = 0u;
+    wave_sync();
+    // 1. arrival rank inside the sub-interval; the tile counts are only summed
+    uint32_t tsum = 0;
+    for (uint32_t e0 = lane; e0 < n; e0 += 64 * 4) {
+        uint4 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; kv[u] = e < n ? bucket_element(slab, b, start, e) : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; if (e < n) { aux[e] = atomicAdd(&cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)], 1u); tsum += kv[u].w; } }
     }
-    __syncthreads();
-    const uint32_t n = s_cx[BK_XCD] & 0x7FFFFFFFu, over = s_cx[BK_XCD] >> 31;
-    uint32_t m = 2; while (m < n) m <<= 1;
-    if (n) {
-        // lane t of sub-slab x: 16 lanes per sub-slab and round, all eight sub-slabs at once
-        const uint32_t x = t0 >> 4, l = t0 & 15u;
-        const uint32_t c0 = s_cx[x], c1 = s_cx[x + 1] & 0x7FFFFFFFu;
-        for (uint32_t t = l; t < c1 - c0; t += 16) {
-            const uint2 e = slab[((size_t)b * BK_XCD + x) * BK_CAPX + t];
-            sk[c0 + t] = ((unsigned long long)e.x << 32) | e.y;
-        }
-        for (uint32_t t = n + t0; t < m; t += 128) sk[t] = ~0ull;
+    wave_sync();
+    // 2. exclusive scan of the BK_SUB counters in place (lane owns four consecutive ones); cnt[BK_SUB] = n
+    {
+        uint32_t v[BK_SUB / 64], sum = 0;
+#pragma unroll
+        for (int q = 0; q < BK_SUB / 64; q++) { v[q] = cnt[lane * (BK_SUB / 64) + q]; sum += v[q]; }
+        uint32_t run = wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int q = 0; q < BK_SUB / 64; q++) { cnt[lane * (BK_SUB / 64) + q] = run; run += v[q]; }
+        if (lane == 63) cnt[BK_SUB] = run;
     }
-    __syncthreads();
-    if (n > 1) {
-        for (uint32_t k = 2; k <= m; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = t0; t < (m >> 1); t += 128) {
-                    const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
-                    const unsigned long long a = sk[i], c = sk[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { sk[i] = c; sk[l] = a; }
-                }
-                __syncthreads();
+    wave_sync();
+    // 3. group by sub-interval (the slab is read again: L2)
+    for (uint32_t e0 = lane; e0 < n; e0 += 64 * 4) {
+        uint4 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; kv[u] = e < n ? bucket_element(slab, b, start, e) : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = e0 + u * 64;
+            if (e < n) {
+                const uint32_t slot = cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)] + aux[e];
+                grp[slot] = ((unsigned long long)kv[u].x << 32) | kv[u].y;
+                wid[slot] = (uint16_t)kv[u].z;
             }
         }
     }
-    // widths, their inclusive scan in sorted order, tile total: thread t owns the E consecutive elements [t*E, t*E + E)
-    const uint32_t E = (m + 127) / 128;          // <= BK_CAP / 128
-    uint32_t g[BK_CAP / 128], w[BK_CAP / 128], wsum = 0, tsum = 0;
-#pragma unroll
-    for (int e = 0; e < BK_CAP / 128; e++) {
-        const uint32_t t = t0 * E + e;
-        g[e] = 0u; w[e] = 0u;
-        if ((uint32_t)e < E && t < n) {
-            g[e] = (uint32_t)sk[t];
-            const uint2 rc = gather_rect[g[e]];       // the (possibly clipped) rectangle the column runs come from
-            w[e] = (rc.y & 0xFFFFu) - (rc.x & 0xFFFFu);
-            tsum += tiles[g[e]];
-        }
-        wsum += w[e];
+    wave_sync();
+    // 4. final position = start of the group + smaller composites inside it; the id goes out, the width into LDS at that position
+    for (uint32_t e = lane; e < n; e += 64) {
+        const unsigned long long me = grp[e];
+        const uint32_t d2 = depth_sub_bucket((uint32_t)(me >> 32), zmin, scale, b);
+        const uint32_t s0 = cnt[d2], s1 = cnt[d2 + 1];
+        uint32_t r = 0;
+        for (uint32_t q = s0; q < s1; q++) r += grp[q] < me ? 1u : 0u;
+        border[(size_t)b * BK_CAP + s0 + r] = (uint32_t)me;
+        aux[s0 + r] = wid[e];                                   // (possibly clipped) rectangle width = column runs
     }
-    uint32_t wtot, ttot;
-    uint32_t run = block128_excl_scan(wsum, &wtot);
-    (void)block128_excl_scan(tsum, &ttot);
+    wave_sync();
+    // 5. inclusive scan of the widths in sorted order: lane t owns the E consecutive elements [t*E, t*E + E)
+    const uint32_t E = (n + 63) / 64;            // <= BK_CAP / 64
+    uint32_t wsum = 0;
+    for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) wsum += aux[t]; }
+    uint32_t run = wave_incl_scan(wsum) - wsum;
+    const uint32_t wtot = __shfl(run + wsum, 63, 64);
 #pragma unroll
-    for (int e = 0; e < BK_CAP / 128; e++) {
-        const uint32_t t = t0 * E + e;
-        run += w[e];
-        if ((uint32_t)e < E && t < n) { border[(size_t)b * BK_CAP + t] = g[e]; bwincl[(size_t)b * BK_CAP + t] = run; }
-    }
-    if (t0 == 0) binfo[b] = make_uint4(n, wtot, ttot, over);
+    for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
+    for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) { run += aux[t]; aux[t] = run; } }
+    wave_sync();
+    for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
+    if (lane == 0) binfo[b] = make_uint4(n, wtot, tsum, over);
 }
 
 // One workgroup: bases[b] = column runs of the buckets in front of b; totals {num_rendered lo, Q, -, num_rendered hi}; overflow verdict.

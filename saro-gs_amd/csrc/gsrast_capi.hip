@@ -663,11 +663,11 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         bucketed = buckets;
         if (buckets) {      // three launches instead of the radix passes and the scan (gsrast_binning.h)
             uint32_t* gcount = at<uint32_t>(geom, GL.bk_count);
-            uint2* slab = at<uint2>(geom, GL.bk_slab);
+            uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
-                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + 255) / 256), nbk, gcount, slab);
+                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + 255) / 256), nbk, gcount, slab, at<float>(geom, GL.bk_param));
                 GS_LAUNCHED("depth_bucket_scatter");
-                depth_bucket_sort_kernel<<<nbk, 128, 0, s>>>(slab, gcount, nbk, rect, tiles, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info));
+                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info));
                 GS_LAUNCHED("depth_bucket_sort"); }
             ProfScope ps(K_SCAN_TILES, s);
             depth_bucket_scan_kernel<<<1, 256, 0, s>>>(at<uint4>(geom, GL.bk_info), nbk, at<uint32_t>(geom, GL.bk_base), scalars);

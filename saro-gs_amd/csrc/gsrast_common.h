@@ -32,14 +32,14 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   shdA/B   float4[P] x2, shdC f32[P]   backward only: d(colour)/d(view direction) {dx[3], dy[3], dz[3]} (sh_dir_derivs_kernel, on a side
 //                        stream beside the blend backward), so that the per-Gaussian backward reads 36 B instead of 12*M
 //   zrange   u32[2 ceil(P/256)]  per-block minimum / maximum depth key (preprocess_fwd); the bucket depth sort (gsrast_binning.h, NB ~ P/256
-//                        buckets of CAP slots): bk_count u32[8][NB], bk_slab uint2[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
+//                        buckets of CAP slots): bk_count u32[8][NB], bk_slab uint4[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
 //                        u32[NB][CAP] (sorted ids, inclusive width scan inside the bucket), bk_info uint4[NB], bk_base u32[NB]
 //   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
     size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, total;
+        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, bk_param, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
 constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is one or two self-scanned radix passes anyway
@@ -130,9 +130,9 @@ static inline GeomLayout geom_layout(size_t P)
     {
         const size_t nb = Pp >= BUCKET_SORT_MIN_P ? depth_buckets_host(Pp) : 0;
         L.bk_count = take(nb * 8 * 4);                       // [8 XCDs][nb]
-        L.bk_slab = take(nb * GSRAST_BK_CAP * 8);            // [nb][8][CAP / 8] (key, id)
+        L.bk_slab = take(nb * GSRAST_BK_CAP * 16);           // [nb][8][CAP / 8] {key, id, width, tiles}
         L.bk_order = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl = take(nb * GSRAST_BK_CAP * 4);
-        L.bk_info = take(nb * 16); L.bk_base = take(nb * 4);
+        L.bk_info = take(nb * 16); L.bk_base = take(nb * 4); L.bk_param = take(16);
     }
     L.total = o + 256;
     return L;

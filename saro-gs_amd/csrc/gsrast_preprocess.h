@@ -276,17 +276,21 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
                         float4* __restrict__ grec4 /* [P][4] or null: the backward's gradient records, zero-filled here when there is no side stream to do it */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
-    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
-    if (grec4) {   // this workgroup's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
-        const size_t q0 = (size_t)blockIdx.x * PP_THREADS * 4, q1 = (size_t)P * 4;
+    const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
+    const int nblocks = (P + PP_THREADS - 1) / PP_THREADS;
+    // grid-stride over blocks of PP_THREADS Gaussians.  (A grid of 64 ... 1024 workgroups on the side stream was measured: the
+    // kernel gets 2-8x longer and the stretch of its neighbours moves from kernel to kernel, the step time stays the same.)
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int i = blk * PP_THREADS + threadIdx.x;
+    if (grec4) {   // this block's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
+        const size_t q0 = (size_t)blk * PP_THREADS * 4, q1 = (size_t)P * 4;
 #pragma unroll
         for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
-    const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
     const int ic = i < P ? i : P - 1;
     const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };       // requested before the staging barrier
-    if (staged) { stage_sh_in(shs, P, M, blockIdx.x * PP_THREADS, sh_lds); __syncthreads(); }
-    if (i >= P) return;
+    if (staged) { if (blk != (int)blockIdx.x) __syncthreads(); stage_sh_in(shs, P, M, blk * PP_THREADS, sh_lds); __syncthreads(); }
+    if (i < P) {
     float col[3];
     unsigned cl = 0;
     if (!colors_precomp) {
@@ -301,6 +305,8 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
     }
     rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
     clamped[i] = (unsigned char)cl;
+    }
+    } // blk
 }
 
 // K1 forward, geometry half.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
