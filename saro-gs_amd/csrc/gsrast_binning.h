@@ -510,7 +510,8 @@ __global__ void __launch_bounds__(64 * BK_WAVES)
 depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb, const float* __restrict__ zparam,
                          uint32_t* __restrict__ border /* [nb][BK_CAP]: sorted Gaussian ids of each bucket */,
                          uint32_t* __restrict__ bwincl /* [nb][BK_CAP]: inclusive scan of their rectangle widths inside the bucket */,
-                         uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */)
+                         uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */,
+                         uint32_t* __restrict__ bwsum /* [nb]: column runs again, compact -- every emission workgroup sums the ones in front of it */)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
     __shared__ uint32_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order
@@ -597,39 +598,34 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) { run += aux[t]; aux[t] = run; } }
     wave_sync();
     for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
-    if (lane == 0) binfo[b] = make_uint4(n, wtot, tsum, over);
+    if (lane == 0) { binfo[b] = make_uint4(n, wtot, tsum, over); bwsum[b] = wtot; }
 }
 
-// One workgroup: bases[b] = column runs of the buckets in front of b; totals {num_rendered lo, Q, -, num_rendered hi}; overflow verdict.
-__global__ void __launch_bounds__(256)
-depth_bucket_scan_kernel(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ bbase,
-                         uint32_t* __restrict__ scalars /* [0] R lo, [1] Q, [3] R hi, [11] overflow */)
+// Totals of the buckets: {num_rendered lo, Q, -, num_rendered hi} and the overflow verdict into `scalars` -- by the last workgroup of
+// the bucketed run emission (below), or, when the host needs the counts BEFORE it can launch that (no capacity hint yet), by this
+// one-workgroup kernel.
+__device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars)
 {
     __shared__ unsigned long long s_t[256];
-    __shared__ uint32_t s_w[BK_MAX_BUCKETS];
-    uint32_t over = 0;
+    __shared__ uint32_t s_q[256];
+    uint32_t over = 0, q = 0;
     unsigned long long tsum = 0;
     for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 8) {       // coalesced, eight independent loads per lane and round
         uint4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * 256; v[u] = k < nb ? binfo[k] : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * 256; if (k < nb) s_w[k] = v[u].y; tsum += v[u].z; over |= v[u].w; }
+        for (int u = 0; u < 8; u++) { q += v[u].y; tsum += v[u].z; over |= v[u].w; }
     }
-    __syncthreads();
-    const uint32_t per = (nb + 255) / 256;       // consecutive buckets per thread (nb <= 8192: at most 32)
-    uint32_t wsum = 0;
-    for (uint32_t e = 0; e < per; e++) { const uint32_t k = threadIdx.x * per + e; if (k < nb) wsum += s_w[k]; }
-    uint32_t wtot;
-    uint32_t run = block_excl_scan(wsum, &wtot);
-    for (uint32_t e = 0; e < per; e++) {
-        const uint32_t k = threadIdx.x * per + e;
-        if (k < nb) { bbase[k] = run; run += s_w[k]; }
-    }
-    s_t[threadIdx.x] = tsum;
+    s_t[threadIdx.x] = tsum; s_q[threadIdx.x] = q;
     over = __syncthreads_or((int)over) ? 1u : 0u;
-    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) s_t[threadIdx.x] += s_t[threadIdx.x + st]; __syncthreads(); }
-    if (threadIdx.x == 0) { scalars[0] = (uint32_t)s_t[0]; scalars[1] = wtot; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over; }
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t[threadIdx.x] += s_t[threadIdx.x + st]; s_q[threadIdx.x] += s_q[threadIdx.x + st]; } __syncthreads(); }
+    if (threadIdx.x == 0) { scalars[0] = (uint32_t)s_t[0]; scalars[1] = s_q[0]; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over; }
+}
+__global__ void __launch_bounds__(256)
+depth_bucket_scan_kernel(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars /* [0] R lo, [1] Q, [3] R hi, [11] overflow */)
+{
+    depth_bucket_totals(binfo, nb, scalars);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -748,7 +744,8 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                         uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals,
                         // bucket depth sort (binfo != null): one workgroup per bucket; `order` / `woffsets` are the buckets' own slot
                         // ranges [nb][BK_CAP] (sorted ids, inclusive width scan inside the bucket), bbase the buckets' first runs
-                        const uint4* __restrict__ binfo = nullptr, const uint32_t* __restrict__ bbase = nullptr)
+                        const uint4* __restrict__ binfo = nullptr, const uint32_t* __restrict__ bwsum = nullptr, uint32_t nbuckets = 0,
+                        uint32_t* __restrict__ scalars = nullptr /* the last workgroup leaves the totals here (depth_bucket_totals) */)
 {
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
     // per-Gaussian ellipse terms (fp64): det, 2tc, b, 1/c, dy_max, dx_top;  mode 0 = keep the column, 1 = clip, 2 = empty
@@ -758,8 +755,29 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t nloc = 0, run0 = 0, nchunks = 1;
     if (binfo) {
-        const uint4 bi = binfo[blockIdx.x];
-        nloc = bi.x; run0 = bbase[blockIdx.x]; nchunks = (nloc + 255u) / 256u;
+        // first column run of this bucket = runs of the buckets in front of it: independent 16-byte loads of the compact totals
+        __shared__ uint32_t s_run0[4];
+        uint32_t part = 0;
+        const uint4* w4 = reinterpret_cast<const uint4*>(bwsum);
+        const uint32_t b = blockIdx.x, n4 = (b + 3) / 4;
+        for (uint32_t q0 = threadIdx.x; q0 < n4; q0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t q = q0 + u * 256; v[u] = q < n4 ? w4[q] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t k = 4 * (q0 + u * 256);
+                part += (k < b ? v[u].x : 0u) + (k + 1 < b ? v[u].y : 0u) + (k + 2 < b ? v[u].z : 0u) + (k + 3 < b ? v[u].w : 0u);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_run0[wave] = part;
+        const uint4 bi = binfo[b];
+        __syncthreads();
+        run0 = s_run0[0] + s_run0[1] + s_run0[2] + s_run0[3];
+        if (scalars && b + 1 == nbuckets) depth_bucket_totals(binfo, nbuckets, scalars);
+        nloc = bi.x; nchunks = (nloc + 255u) / 256u;
         order += (size_t)blockIdx.x * BK_CAP; woffsets += (size_t)blockIdx.x * BK_CAP; P = (int)nloc;
     }
     for (uint32_t chunk = 0; chunk < nchunks; chunk++) {

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -648,7 +649,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
-        preprocess_fwd_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+        preprocess_fwd_kernel<<<(P + PF_THREADS - 1) / PF_THREADS, PF_THREADS, 0, s>>>(
             P, means3D, scales, rotations, opacities, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
             tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
             (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt),
@@ -659,19 +660,18 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     const bool assume_short = adaptive_sort && g_sort_hint.load() != 0 && ctx->depth_short.load() != 0;
     const uint32_t* order = vA;     // the radix-sorted sequence ends in A under every pass count; the bucket sort leaves (kA, vA) alone
     bool bucketed = false;          // the order in force comes from the bucket sort (per-bucket slot ranges) rather than `order`
+    bool totals_pending = false;    // ... and nobody has summed the buckets' totals (R, Q, overflow verdict) into `scalars` yet
     auto sort_and_scan = [&](bool assume, bool buckets) -> int {
-        bucketed = buckets;
+        bucketed = buckets; totals_pending = false;
         if (buckets) {      // three launches instead of the radix passes and the scan (gsrast_binning.h)
             uint32_t* gcount = at<uint32_t>(geom, GL.bk_count);
             uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
-                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + 255) / 256), nbk, gcount, slab, at<float>(geom, GL.bk_param));
+                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + PF_THREADS - 1) / PF_THREADS), nbk, gcount, slab, at<float>(geom, GL.bk_param));
                 GS_LAUNCHED("depth_bucket_scatter");
-                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info));
+                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
                 GS_LAUNCHED("depth_bucket_sort"); }
-            ProfScope ps(K_SCAN_TILES, s);
-            depth_bucket_scan_kernel<<<1, 256, 0, s>>>(at<uint4>(geom, GL.bk_info), nbk, at<uint32_t>(geom, GL.bk_base), scalars);
-            GS_LAUNCHED("depth_bucket_scan");
+            totals_pending = true;      // by the run emission's last workgroup, or by launch_bucket_totals() if the host needs them first
             return GSRAST_OK;
         } else {
             order = vA;
@@ -716,7 +716,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     // ---- the rest of the forward as two re-launchable pieces ----
     // run-compressed binning; nQ / capR are either exact counts (counts_dev == nullptr) or capacities with the real
     // counts read on the device (speculative launch: grids and histogram strides follow the capacities)
-    auto launch_run_binning = [&](char* binb, uint32_t capR_, uint32_t capQ_, uint32_t nQ, const uint32_t* counts_dev) -> int {
+    auto launch_run_binning = [&](char* binb, uint32_t capR_, uint32_t capQ_, uint32_t nQ, const uint32_t* counts_dev, const std::function<int()>& after_emit = nullptr) -> int {
         const RunBinLayout RL = runbin_layout((size_t)capR_, (size_t)capQ_);
         uint16_t *rkA = at<uint16_t>(binb, RL.rkeyA), *rkB = at<uint16_t>(binb, RL.rkeyB);
         uint2 *rvA = at<uint2>(binb, RL.rvalA), *rvB = at<uint2>(binb, RL.rvalB);
@@ -729,11 +729,13 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         {   ProfScope ps(K_EMIT, s);
             if (bucketed)
                 emit_column_runs_kernel<<<nbk, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
-                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
+                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars);
             else
                 emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
                                                                        o.tile_clip, capQ_, rkA, rvA);
             GS_LAUNCHED("emit_column_runs"); }
+        if (bucketed) totals_pending = false;
+        if (after_emit) { int rc = after_emit(); if (rc != GSRAST_OK) return rc; }
         const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
         {   ProfScope ps(K_SORT_TILE, s);
             int rc = radix_sort<uint16_t, uint2, GSRAST_RUN_SORT_ITEMS>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev);   // runs by column
@@ -787,13 +789,23 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     //  [9] key base, [10] "three sort passes were assumed and were not enough"}
     uint32_t counts[12] = { 0 };
     Readback* rb = nullptr;
-    { int rc = read_u32_begin(scalars, s, 12, &rb); if (rc != GSRAST_OK) return rc; }
+    const bool speculative = runbin && bin != nullptr && o.speculative != 0;
+    auto begin_readback = [&]() -> int { return read_u32_begin(scalars, s, 12, &rb); };
+    if (!(speculative && totals_pending)) {       // (with the bucket sort the totals come out of the speculative run emission: read back right behind it)
+        if (totals_pending) {
+            ProfScope ps(K_SCAN_TILES, s);
+            depth_bucket_scan_kernel<<<1, 256, 0, s>>>(at<uint4>(geom, GL.bk_info), nbk, scalars);
+            GS_LAUNCHED("depth_bucket_scan");
+            totals_pending = false;
+        }
+        int rc = begin_readback(); if (rc != GSRAST_OK) return rc;
+    }
     // Speculative launch: with a buffer sized from the previous call, binning and blend are enqueued BEFORE the host knows
     // R and Q (the kernels read the counts on the device), so the GPU never idles on the read-back.  If the counts turn
     // out not to fit, the device published empty ranges and the two pieces are simply launched again with exact sizes.
-    const bool speculative = runbin && bin != nullptr && o.speculative != 0;
     if (speculative) {
-        int rc = launch_run_binning(bin, cap, capQ, capQ, scalars);
+        const bool late = totals_pending;
+        int rc = launch_run_binning(bin, cap, capQ, capQ, scalars, late ? std::function<int()>(begin_readback) : std::function<int()>());
         if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true);
         if (rc != GSRAST_OK) return rc;
     }

@@ -33,7 +33,7 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //                        stream beside the blend backward), so that the per-Gaussian backward reads 36 B instead of 12*M
 //   zrange   u32[2 ceil(P/256)]  per-block minimum / maximum depth key (preprocess_fwd); the bucket depth sort (gsrast_binning.h, NB ~ P/256
 //                        buckets of CAP slots): bk_count u32[8][NB], bk_slab uint4[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
-//                        u32[NB][CAP] (sorted ids, inclusive width scan inside the bucket), bk_info uint4[NB], bk_base u32[NB]
+//                        u32[NB][CAP] (sorted ids, inclusive width scan inside the bucket), bk_info uint4[NB], bk_base u32[NB] (compact column-run totals)
 //   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads

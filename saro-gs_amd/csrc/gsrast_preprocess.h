@@ -310,7 +310,11 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
 }
 
 // K1 forward, geometry half.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
-__global__ void __launch_bounds__(256)
+#ifndef GSRAST_PF_THREADS
+#define GSRAST_PF_THREADS 256      // (1024-thread blocks shorten the depth-range reduction of the bucket scatter by 2 us, but beside the colour kernel they wait for whole-CU wave slots: 43 -> 107 us)
+#endif
+constexpr int PF_THREADS = GSRAST_PF_THREADS;
+__global__ void __launch_bounds__(PF_THREADS)
 preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ cov3D_precomp, CamArgs cam_args, int* __restrict__ radii,
@@ -425,15 +429,18 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     sort_key[i] = key; sort_val[i] = (uint32_t)i;
     } // i < P
     if (block_zrange) {     // depth range of the block's visible Gaussians (positive floats order like their bits; culled: key = ~0)
-        __shared__ uint32_t s_lo[4], s_hi[4];
+        __shared__ uint32_t s_lo[PF_THREADS / 64], s_hi[PF_THREADS / 64];
         uint32_t lo = key, hi = key == 0xFFFFFFFFu ? 0u : key;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
         if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            block_zrange[2 * blockIdx.x] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-            block_zrange[2 * blockIdx.x + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+            uint32_t blo = s_lo[0], bhi = s_hi[0];
+#pragma unroll
+            for (int w = 1; w < PF_THREADS / 64; w++) { blo = min(blo, s_lo[w]); bhi = max(bhi, s_hi[w]); }
+            block_zrange[2 * blockIdx.x] = blo;
+            block_zrange[2 * blockIdx.x + 1] = bhi;
             if (blockIdx.x == gridDim.x - 1 && (gridDim.x & 1u)) { block_zrange[2 * gridDim.x] = 0xFFFFFFFFu; block_zrange[2 * gridDim.x + 1] = 0u; }   // read in pairs
         }
     }
