@@ -242,21 +242,29 @@ def stage_table(_C, wl, st, P, deg, H):
     Rl, Q = st["R_listed"], st["Q"]
     passes_t = 2 if T > 256 else 1
     run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
+    bucket_sort = run_binning and _C.get_option("depth_sort") == 0 and P >= 32768
     alg = {
         "preprocess_fwd": P * (44 + 24) + Pv * 92,                # geometry half: in 44 B, out radii / tiles / rect / sort pair 24 B + 92 B per visible Gaussian
         "preprocess_color": P * (12 + 12 * C + 17),               # colour half (side stream, overlapped with sort + binning): means + SH in, rec2 + clamp flags out
-        "sort_depth": P * 20 * 4,
-        "scan_tiles": P * 12 if run_binning else P * 24,
+        # bucket depth sort (default): scatter reads key + rect + tiles (16 B), writes a 16-B slab element; the sort kernel reads it
+        # (twice, the second time from L2) and writes id + width scan (8 B) -- per visible Gaussian; radix passes: 20 B x 4
+        "sort_depth": (P * 16 + Pv * 40) if bucket_sort else P * 20 * 4,
+        "scan_tiles": (0 if bucket_sort else P * 12) if run_binning else P * 24,   # bucket sort: totals by the run emission's last workgroup
         # run-compressed: Q column runs of 10 B emitted, sorted by column (one pass), expanded once into Rl instances
         "emit_instances": (P * 40 + Q * 10) if run_binning else (P * 24 + R * 6),
         "sort_tile": (Q * 22 + Q * 16 + Rl * 4) if run_binning else R * 14 * passes_t,
         "tile_ranges": T * 8 if run_binning else R * 2 + T * 8,
         "blend_fwd": Re * 44 + N * 24,
         "blend_bwd": N * 20 + Re * 76,
-        "preprocess_bwd": P * (24 * C + 173 + 64 + 28),       # + the gradient record read + dL/dmean2D, dL/dopacity, dL/dcolor written
+        # in: mean 12, radius 4, scale 12, rotation 16, gradient record 64, clamp flags 1, colour / direction derivatives 36;
+        # out: dL/dmean2D 12, dL/dopacity 4, dL/dmean3D 12, dL/dsh 12 C, dL/dscale 12, dL/drot 16  (the SH block is not read any more)
+        "preprocess_bwd": P * (12 * C + 201),
+        "sh_dir_derivs": Pv * (12 * C + 12 + 36) + P * 4,       # side stream, beside the blend backward: SH + mean in, 36 B out
     }
     per_kernel = {}
     for name, nbytes in alg.items():
+        if name not in pk:
+            continue
         ms = pk[name][0] / max(pk[name][1], 1)
         per_kernel[name] = {"ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
                             "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,

@@ -167,7 +167,10 @@ typedef struct gsrast_options {
     int bwd_pixels_per_lane;  /* 0 auto (default), 1 / 2 / 4 */
     int sh_grad_factors;      /* backward: dL_dsh receives the [P][3] factor, see gsrast_sh_grad_combine */
     int side_stream;          /* 1 (default) forward: the colour kernel (SH -> RGB) runs on a stream of the context, forked off
-                                 `stream` at entry and joined in front of the blend, beside the depth sort and the binning;
+                                 `stream` at entry and joined in front of the blend, beside the depth sort and the binning, and the
+                                 zero-fill of the gradient records follows on it under the blend (joined before the call returns);
+                                 backward: the SH view-direction derivatives are evaluated on the calling thread's context stream
+                                 beside the blend backward, joined in front of the per-Gaussian backward.
                                  0 = everything on `stream` */
     int grads_zeroed;         /* backward: 1 = no backward has run on this forward's geometry buffer yet (the forward leaves the
                                  gradient records zero), so the 64 B / Gaussian zero-fill is skipped; 0 (default) = fill */
@@ -175,18 +178,20 @@ typedef struct gsrast_options {
                                  sh_grad_factors, writes the factors: all a multi-GPU caller needs to START its exchange); 2 = the
                                  per-Gaussian backward only (the rest of the outputs).  1 then 2 on the same arguments == 0 */
     int depth_sort;           /* forward: 0 (default) bucket depth sort -- two launches: Gaussians into ~P/256 depth buckets, one LDS sort per
-                                 bucket; a scene whose depths pile up in one bucket is detected on the device and re-sorted by the radix
-                                 passes; 1 = always the LSD radix sort (3-4 passes of three launches).  Same order either way */
+                                 bucket (run-compressed binning, P >= 32768); a scene whose depths pile up in one bucket is detected on
+                                 the device and re-sorted by the radix passes, which the context then uses for its next 16 calls
+                                 ("bucket_skip"); 1 = always the LSD radix sort (3-4 passes of three launches).  Same order either way */
     int reserved[3];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
-/* A context may be used by one host thread at a time (it owns one side stream and one fork / join event pair per device); contexts
+/* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device); contexts
  * are independent of each other.  Destroy it only after the calls that used it have returned. */
 typedef struct gsrast_context gsrast_context;
 gsrast_context* gsrast_context_create(void);
 void gsrast_context_destroy(gsrast_context* ctx);
 /* "last_instances" (num_rendered), "last_runs" (column runs) of the context's last forward call, "redo_count"
- * (speculative launches that had to be repeated); ctx NULL = the calling thread's context. */
+ * (speculative launches / depth sorts that had to be repeated), "bucket_skip" (forwards that will still go straight to the radix
+ * depth sort after a bucket overflow); ctx NULL = the calling thread's context. */
 int gsrast_context_query(const gsrast_context* ctx, const char* name);
 int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
                       gsrast_alloc_fn geometry_alloc, void* geometry_ctx,

@@ -76,10 +76,10 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 // ---- per-kernel device timing (option "profile") -------------------------------------------
 enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
-                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_COUNT };
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_COUNT };
 const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
                                             "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
-                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color" };
+                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color", "sh_dir_derivs" };
 struct Pending { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<Pending> g_pending;
@@ -1288,10 +1288,13 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
         // two waves per compute unit, grid-stride: enough loads in flight for ~1.5 TB/s, few enough not to push the blend kernel's
         // workgroups off the chip (an unthrottled launch slowed the blend backward by 20 %, this one by 2 %)
         const int grid = side ? std::min((P + 63) / 64, 512) : (P + 63) / 64;
-        sh_dir_derivs_kernel<<<grid, 64, 0, ds>>>(P, D, M, means3D, shs, campos, radii,
-                                                  at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC));
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "sh_dir_derivs", e);
+        {
+            ProfScope ps(K_SH_DERIVS, ds);
+            sh_dir_derivs_kernel<<<grid, 64, 0, ds>>>(P, D, M, means3D, shs, campos, radii,
+                                                      at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC));
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "sh_dir_derivs", e);
+        }
         if (side) GS_HIP(hipEventRecord(side->join, side->stream));
     }
     if (do_blend && R > 0) {

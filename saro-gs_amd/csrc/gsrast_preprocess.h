@@ -227,12 +227,23 @@ __device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int P
     const int nfl = ng * row;
     const float* src = shs + (size_t)base * row;
     if ((row & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        // All of a lane's (at most PP_SH_MAX / 4 = 12) 16-byte loads are requested before the first LDS store: written as a
+        // plain loop the compiler emitted load / wait / store per element -- twelve serial memory round trips per workgroup.
+        // (Also measured: a 52-float row stride with 16-byte LDS stores and row reads, conflict-free both ways on paper -- the
+        // kernel went from 72 to 121 us alone, 119 VGPRs and a spilled row.)
         const float4* src4 = reinterpret_cast<const float4*>(src);
-        for (int q = threadIdx.x; q * 4 < nfl; q += PP_THREADS) {
-            const float4 v = src4[q];
-            const int f = q * 4, g = f / row, c = f - g * row;
-            float* d = lds + g * PP_SH_STRIDE + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        const int n4 = nfl >> 2;
+        float4 v[PP_SH_MAX / 4];
+#pragma unroll
+        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; if (q < n4) v[u] = src4[q]; }
+#pragma unroll
+        for (int u = 0; u < PP_SH_MAX / 4; u++) {
+            const int q = threadIdx.x + u * PP_THREADS;
+            if (q < n4) {
+                const int f = q * 4, g = f / row, c = f - g * row;
+                float* d = lds + g * PP_SH_STRIDE + c;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
         }
     } else {
         for (int f = threadIdx.x; f < nfl; f += PP_THREADS) {
