@@ -272,6 +272,33 @@ def stage_table(_C, wl, st, P, deg, H):
     return per_kernel, pk
 
 
+def in_flight_row(rast, scenes, P, W, H, deg, dev, steps, warmup, lanes=2):
+    """views/s with `lanes` views in flight: view k of the batch runs forward + backward on stream k % lanes.  `steps` rounds of
+    `lanes` views each are timed, after `warmup` rounds; also the same views one after the other on one stream."""
+    wls = [Workload(rast, scenes, P, W, H, deg, k, 8, dev) for k in range(lanes)]
+    streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+
+    def rounds(n, use_streams):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            for k, wl in enumerate(wls):
+                if use_streams:
+                    with torch.cuda.stream(streams[k]):
+                        wl.step()
+                else:
+                    wl.step()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    rounds(warmup, False); rounds(warmup, True)
+    t_seq = rounds(steps, False)
+    t_par = rounds(steps, True)
+    return {"views_per_s": round(lanes * steps / t_par, 1), "views_per_s_one_stream_same_loop": round(lanes * steps / t_seq, 1),
+            "lanes": lanes, "rounds": steps, "warmup_rounds": warmup,
+            "note": "throughput of a batch loop with two views in flight (distributed_step(views_in_flight=2)); `value` above is one view at a time"}
+
+
 def measure_point(rast, scenes, vp, P, W, H, deg, dev, steps, warmup, full=False, kind="cube"):
     """One more workload with the headline's protocol (same steps / warm-up).  full: also the roofline object and the stage table."""
     _C = rast._C
@@ -890,6 +917,13 @@ def main():
         m = measure_point(rast, scenes, vp, P, W, H, deg, dev, a.steps, a.warmup, full=True, kind="shell")
         result["shell_scene_1080p"] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup", "config", "per_stage")}
         result["shell_scene_1080p"]["blend_bwd_ms"] = m["roofline"]["avg_launch_ms"]
+        # NOT the headline protocol: two views of a batch in flight on two streams of the one GPU (what
+        # view_parallel.distributed_step(views_in_flight=2) does when a rank renders several views of the reference's batch loop,
+        # train.py:198-226): one view's latency-bound binning runs under the other's VALU-bound blend kernels
+        try:
+            result["two_views_in_flight_1080p"] = in_flight_row(rast, scenes, P, W, H, deg, dev, a.steps, a.warmup)
+        except Exception as e:      # noqa: BLE001
+            result["two_views_in_flight_1080p"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

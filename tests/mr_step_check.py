@@ -62,7 +62,13 @@ def main():
 
     raw = make_raw()
     bucket = vp.StepBucket(raw)
-    stats = vp.distributed_step(bucket, list(range(V)), lambda k: render_loss(raw, k))
+    in_flight = int(os.environ.get("GSRAST_TEST_IN_FLIGHT", "1"))      # > 1: this rank's views alternate between that many streams
+    stats = vp.distributed_step(bucket, list(range(V)), lambda k: render_loss(raw, k), views_in_flight=in_flight)
+    if in_flight > 1:       # and again: the lanes' partial caches start from zero each step
+        first = {n: raw[n].grad.clone() for n in want}
+        stats = vp.distributed_step(bucket, list(range(V)), lambda k: render_loss(raw, k), views_in_flight=in_flight)
+        for n in want:
+            assert float((first[n] - raw[n].grad).abs().max()) <= 1e-6 + 1e-3 * float(first[n].abs().max()), n
     torch.cuda.synchronize()
     worst = 0.0
     for n in want:

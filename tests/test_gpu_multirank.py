@@ -46,6 +46,27 @@ def test_distributed_step_equals_reference_batch_loop_on_the_real_chain():
     assert sorted(r for r, _ in reports) == ["0", "1"] and all(ok == "True" for _, ok in reports), out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_distributed_step_with_two_views_in_flight_on_the_real_chain(ranks):
+    """The same check with each rank's views alternating between two streams (distributed_step(views_in_flight=2)): one process
+    rendering all four views, and two ranks rendering two each."""
+    env = dict(os.environ, GSRAST_TEST_IN_FLIGHT="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ranks == 1:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.join("tests", "mr_step_check.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    else:
+        os.environ["GSRAST_TEST_IN_FLIGHT"] = "2"
+        try:
+            out = _torchrun([os.path.join("tests", "mr_step_check.py")])
+        finally:
+            del os.environ["GSRAST_TEST_IN_FLIGHT"]
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    import re
+    reports = re.findall(r"STEP_CHECK rank (\d+) worst \S+ stats_ok (True|False)", out.stdout)
+    assert len(reports) == ranks and all(ok == "True" for _, ok in reports), out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("exchange", ["factors", "allreduce"])
 def test_bench_two_ranks(exchange):
     out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "100000", "--exchange", exchange,

@@ -150,7 +150,7 @@ def _reference_loop(model, views):
     return grads, dict(visibility_count=count, visibility_filter=vfilter, radii=radii, viewspace_point_grad=g.unsqueeze(1), loss=loss_last / len(views))
 
 
-def _step_worker(rank, world, port, out_dir, n_views):
+def _step_worker(rank, world, port, out_dir, n_views, in_flight=1):
     for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -160,8 +160,8 @@ def _step_worker(rank, world, port, out_dir, n_views):
     torch.manual_seed(0)
     model = _DynamicStageModel(257, 11)                    # replicated parameters: same seed on every rank
     bucket = vp.StepBucket(model.leaves())
-    stats = vp.distributed_step(bucket, list(range(n_views)), model.render_loss)
-    stats2 = vp.distributed_step(bucket, list(range(n_views)), model.render_loss)      # a second step starts from a clean cache
+    stats = vp.distributed_step(bucket, list(range(n_views)), model.render_loss, views_in_flight=in_flight)
+    stats2 = vp.distributed_step(bucket, list(range(n_views)), model.render_loss, views_in_flight=in_flight)      # a second step starts from a clean cache
     for k in ("viewspace_point_grad", "radii", "visibility_count"):
         assert torch.equal(stats[k], stats2[k])
     if rank == 0:
@@ -188,6 +188,25 @@ def test_distributed_step_equals_the_reference_batch_loop(tmp_path, n_views):
     s = got["stats"]
     np.testing.assert_array_equal(s["visibility_count"].numpy(), want_s["visibility_count"].numpy().astype(np.float32))
     np.testing.assert_array_equal(s["visibility_filter"].numpy(), want_s["visibility_filter"].numpy())
+    np.testing.assert_array_equal(s["radii"].numpy(), want_s["radii"].numpy().astype(np.float32))
+    np.testing.assert_allclose(s["viewspace_point_grad"].numpy(), want_s["viewspace_point_grad"].numpy(), rtol=2e-5, atol=1e-9)
+    assert abs(float(s["loss"]) - want_s["loss"]) < 1e-5
+
+
+@pytest.mark.parametrize("n_views,in_flight", [(5, 2), (6, 3)], ids=["five_views_two_in_flight", "six_views_three_in_flight"])
+def test_distributed_step_with_views_in_flight(tmp_path, n_views, in_flight):
+    """Several views per rank, alternating between lanes (streams on a GPU; on the CPU the lanes only keep separate partial caches and
+    take their gradients with autograd.grad): same gradients and statistics as the reference's sequential loop."""
+    world = 2
+    mp.spawn(_step_worker, args=(world, _free_port(), str(tmp_path), n_views, in_flight), nprocs=world, join=True)
+    got = torch.load(tmp_path / "step.pt")
+    model = _DynamicStageModel(257, 11)
+    want_g, want_s = _reference_loop(model, list(range(n_views)))
+    assert set(got["grads"]) == set(want_g)
+    for n in want_g:
+        np.testing.assert_allclose(got["grads"][n].numpy(), want_g[n].numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
+    s = got["stats"]
+    np.testing.assert_array_equal(s["visibility_count"].numpy(), want_s["visibility_count"].numpy().astype(np.float32))
     np.testing.assert_array_equal(s["radii"].numpy(), want_s["radii"].numpy().astype(np.float32))
     np.testing.assert_allclose(s["viewspace_point_grad"].numpy(), want_s["viewspace_point_grad"].numpy(), rtol=2e-5, atol=1e-9)
     assert abs(float(s["loss"]) - want_s["loss"]) < 1e-5
