@@ -357,3 +357,50 @@ def test_bucket_depth_sort_ties_fall_in_index_order(orc, scenes, rast, gpu):
     np.testing.assert_array_equal(h["point_list"], o32["point_list"])
     np.testing.assert_array_equal(h["ranges"], o32["ranges"])
     np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+
+
+def test_bucket_depth_sort_edge_populations(orc, scenes, rast, gpu):
+    """Bucket-sort path (P >= 32768) with nothing visible, with one visible Gaussian, and with all visible Gaussians at exactly one depth
+    among culled ones: outputs equal the oracle; an empty scene renders the background."""
+    from gpu_harness import run_hip
+    P, W, H = 40_000, 160, 120
+    cam = scenes.camera(0, 3, W, H)
+    base = scenes.synth(P, 21)
+    far = np.array(cam["campos"], np.float32) * 3.0                     # behind the camera (it looks at the origin)
+    for nvis in (0, 1, 5000):
+        sc = dict(base)
+        m = np.tile(far, (P, 1)).astype(np.float32)
+        m[:nvis] = base["means3D"][:nvis]
+        sc["means3D"] = m
+        o32 = orc.render(sc, cam)
+        assert int((o32["radii"] > 0).sum()) in ((0,) if nvis == 0 else range(1, nvis + 1))
+        h = run_hip(rast, sc, cam, gpu, tile_clip=0)
+        assert h["R"] == o32["R"]
+        np.testing.assert_array_equal(h["radii"], o32["radii"])
+        np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+        np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+        np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+    assert rast._C.get_option("bucket_skip") == 0
+
+
+def test_bucket_depth_sort_with_an_undersized_speculative_launch(orc, scenes, rast, gpu):
+    """The bucket sort leaves the instance counts to the run emission of the speculative launch.  A view with far more instances than
+    the context's capacity hint: the emission is bounded by the capacity, the counts still come out right, the launch is repeated with
+    exact sizes (one redo) and the lists equal the oracle's; then a small view inside the oversized capacity."""
+    from gpu_harness import run_hip
+    _C = rast._C
+    W, H = 320, 240
+    seq = [(40_000, 0.5, 9.0), (60_000, 2.0, 4.0), (40_000, 0.5, 9.0)]       # (P, scale multiplier, camera distance)
+    redo0 = _C.get_option("redo_count")
+    for n, (P, sm, radius) in enumerate(seq):
+        sc = scenes.synth(P, 31 + n, scale_mul=sm)
+        cam = scenes.camera(n, 5, W, H, radius=radius)
+        o32 = orc.render(sc, cam)
+        for clip in (0, 1):
+            h = run_hip(rast, sc, cam, gpu, tile_clip=clip)
+            assert h["R"] == o32["R"], (n, clip)
+            if clip == 0:
+                np.testing.assert_array_equal(h["point_list"], o32["point_list"])
+                np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+            np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+    assert _C.get_option("redo_count") - redo0 >= 1 and _C.get_option("bucket_skip") == 0
