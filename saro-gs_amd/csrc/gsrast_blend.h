@@ -169,6 +169,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     constexpr float FAR = 1.0e15f;
     float pxa = inside ? pxf : FAR;
     uint64_t alive = __ballot(inside);
+    uint64_t m_above = alive;                     // lanes whose T is still above 0.5 (median-depth test below)
 
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
@@ -221,9 +222,17 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     C0 = __builtin_fmaf(c.x * alpha, T, C0);
                     C1 = __builtin_fmaf(c.y * alpha, T, C1);
                     C2 = __builtin_fmaf(c.z * alpha, T, C2);
-                    Dm = (T > 0.5f && test_T < 0.5f) ? b.z : Dm;
                     T = test_T;
                     last = base + j + 1;
+                }
+                // median depth (forward.cu:368-372: the Gaussian that takes T across 0.5).  T only falls, so the lanes still above
+                // 0.5 are a shrinking scalar mask: once a pixel is at or below 0.5 the test costs it nothing (it was two compares
+                // and a select per pair), and in an occluded scene that is most of the list.
+                if (m_above & m_upd) {
+                    const uint64_t m_here = m_above & m_upd;
+                    const uint64_t m_cross = m_here & __builtin_amdgcn_ballot_w64(test_T < 0.5f);
+                    Dm = __builtin_amdgcn_inverse_ballot_w64(m_cross) ? b.z : Dm;
+                    m_above &= ~(m_here & __builtin_amdgcn_ballot_w64(!(test_T > 0.5f)));      // T == 0.5 exactly: never crosses (T > 0.5 fails from then on)
                 }
 #ifdef GSRAST_DEBUG_COUNTERS
                 if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(m_upd)); if (m_upd) atomicAdd(&g_dbg[3], 1ull); }
