@@ -449,6 +449,14 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         dg[r] = 0u; lr[r] = 0u;
         if (key[r] != 0xFFFFFFFFu) { dg[r] = depth_bucket_of(key[r], zmin, scale, nb); lr[r] = atomicAdd(&cnt[dg[r]], 1u); }
     }
+    // what travels with the element: coalesced, requested here so that the loads pass under the atomics' round trip below
+    uint2 rc[BK_ITEMS]; uint32_t tl[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) {      // (culled Gaussians have rect = tiles = 0)
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        rc[r] = make_uint2(0u, 0u); tl[r] = 0u;
+        if (i < n) { rc[r] = rect[i]; tl[r] = tiles[i]; }
+    }
     __syncthreads();
     // one returning global atomic per non-empty bucket of this workgroup, sixteen in flight per lane (issued back to back: a loop
     // that stores each result before it asks for the next waits a full memory round trip per bucket)
@@ -463,13 +471,6 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         for (int u = 0; u < 16; u++) { if (c[u]) cnt[k0 + u * 256] = g[u]; }
     }
     __syncthreads();
-    uint2 rc[BK_ITEMS]; uint32_t tl[BK_ITEMS];
-#pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {      // coalesced, requested together (culled Gaussians have rect = tiles = 0)
-        const uint32_t i = base + r * 256 + threadIdx.x;
-        rc[r] = make_uint2(0u, 0u); tl[r] = 0u;
-        if (i < n) { rc[r] = rect[i]; tl[r] = tiles[i]; }
-    }
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
         if (key[r] != 0xFFFFFFFFu) {
@@ -754,12 +755,17 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
     __shared__ uint32_t s_mode[4][64];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t nloc = 0, run0 = 0, nchunks = 1;
+    uint32_t pre_g = 0, pre_w = 0, pre_wm = 0;
     if (binfo) {
         // first column run of this bucket = runs of the buckets in front of it: independent 16-byte loads of the compact totals
         __shared__ uint32_t s_run0[4];
         uint32_t part = 0;
         const uint4* w4 = reinterpret_cast<const uint4*>(bwsum);
         const uint32_t b = blockIdx.x, n4 = (b + 3) / 4;
+        order += (size_t)b * BK_CAP; woffsets += (size_t)b * BK_CAP;
+        // the first chunk's ids and width scans are requested now (slots past the bucket's count hold stale values, never used):
+        // their round trip passes under the prefix sum's instead of behind it
+        pre_g = order[threadIdx.x]; pre_w = woffsets[threadIdx.x]; pre_wm = threadIdx.x ? woffsets[threadIdx.x - 1] : 0u;
         for (uint32_t q0 = threadIdx.x; q0 < n4; q0 += 256 * 8) {
             uint4 v[8];
 #pragma unroll
@@ -778,16 +784,17 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         run0 = s_run0[0] + s_run0[1] + s_run0[2] + s_run0[3];
         if (scalars && b + 1 == nbuckets) depth_bucket_totals(binfo, nbuckets, scalars);
         nloc = bi.x; nchunks = (nloc + 255u) / 256u;
-        order += (size_t)blockIdx.x * BK_CAP; woffsets += (size_t)blockIdx.x * BK_CAP; P = (int)nloc;
+        P = (int)nloc;
     }
     for (uint32_t chunk = 0; chunk < nchunks; chunk++) {
     if (chunk) __syncthreads();
     const int j = binfo ? (int)(chunk * 256u + threadIdx.x) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     uint32_t g = 0, w = 0, incl, x0 = 0, yh = 0;
     if (j < P) {
-        g = order[j];
-        incl = run0 + woffsets[j];
-        const uint32_t prev = j > 0 ? run0 + woffsets[j - 1] : run0;
+        const bool pre = binfo && chunk == 0;
+        g = pre ? pre_g : order[j];
+        incl = run0 + (pre ? pre_w : woffsets[j]);
+        const uint32_t prev = j > 0 ? run0 + (pre ? pre_wm : woffsets[j - 1]) : run0;
         w = incl - prev;                         // culled Gaussians (sorted last, width 0) never touch binrec
         uint2 rc = make_uint2(0u, 0u);
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
