@@ -11,9 +11,9 @@ from test_gpu_parity import _check_forward_exact, _check_grads
 pytestmark = pytest.mark.gpu
 
 
-def _config(seed):
+def _config(seed, large=False):
     rng = np.random.default_rng(1000 + seed)
-    P = int(rng.choice([1, 2, 5, 17, 64, 300, 1000, 3000]))
+    P = int(rng.choice([33000, 40001, 65536, 90000])) if large else int(rng.choice([1, 2, 5, 17, 64, 300, 1000, 3000]))
     W = int(rng.choice([16, 17, 31, 48, 64, 97, 160, 203, 320]))
     H = int(rng.choice([5, 16, 33, 48, 83, 112, 240]))
     deg = int(rng.integers(0, 4))
@@ -24,9 +24,19 @@ def _config(seed):
                 cam=(int(rng.integers(0, 7)), 7), big_grad=bool(rng.random() < 0.5), rng=rng)
 
 
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_configuration_at_bucket_sort_sizes(seed, orc, scenes, rast, gpu):
+    """The same sweep at Gaussian counts that take the bucket depth sort (P >= 32768) -- the context carries its capacity hints from
+    one random configuration to the next, so undersized speculative launches and their repeats are part of it."""
+    _run_configuration(seed, _config(seed, large=True), orc, scenes, rast, gpu)
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_random_configuration(seed, orc, scenes, rast, gpu):
-    c = _config(seed)
+    _run_configuration(seed, _config(seed), orc, scenes, rast, gpu)
+
+
+def _run_configuration(seed, c, orc, scenes, rast, gpu):
     rng = c["rng"]
     P, W, H = c["P"], c["W"], c["H"]
     sc = scenes.synth(P, 2000 + seed, sh_degree=c["deg"], scale_mul=c["scale_mul"])
@@ -63,4 +73,9 @@ def test_random_configuration(seed, orc, scenes, rast, gpu):
             np.testing.assert_array_equal(bits(h["out_depth"]), bits(o32["out_depth"]))
         else:
             _check_forward_exact(o32, h, clipped=bool(clip))
-        _check_grads(o64, o32, h, names, strict=not c["big_grad"], conditioning=c["aniso"] > 10.0)
+        # dL/dcov3D amplifies the rounding of the conic gradient by (focal / depth)^2 ~ 1e4: with tens of thousands of sub-pixel
+        # Gaussians the fp32 oracle itself misses the absolute bar there, so the large cases hold it to the fp32 oracle's own error
+        # (likewise tens of thousands of image-sized or 10:1 Gaussians: thousands of contributors per pixel; tools/fuzz_one.py prints
+        # the HIP and the fp32-oracle errors side by side -- the HIP path is the more accurate of the two on every tensor there)
+        hard = P > 30000 and (c["use_cov"] or c["aniso"] >= 10.0 or c["scale_mul"] >= 8.0)
+        _check_grads(o64, o32, h, names, strict=not c["big_grad"], conditioning=c["aniso"] > 10.0 or hard)
