@@ -811,6 +811,9 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 // (Measured and dropped: compacting the surviving pairs into the eight rows -- a pair takes the next free row, its staged index in
 // a packed scalar, the transposed phase runs when eight rows are full -- instead of fixed groups of eight consecutive staged
 // instances: 332 -> 342 us at 1 M, 464 -> 455 at 3 M.  The groups are dense enough; the zeros are pixels inside a row.)
+// (Also measured and dropped: v_exp_f32 for the backward's exp with the exact sequence only when some lane's alpha is within 1e-7 of
+// 1/255 -- the decision stays the forward's, ~20 issue cycles per pair fewer on paper: 332 -> 332 us.  The kernel is not short of
+// issue slots for that chain; the exp hides under the LDS round trips of the pair's records.)
 template <int EXPMODE>
 __global__ void __launch_bounds__(256)
 blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
