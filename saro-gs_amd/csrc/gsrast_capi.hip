@@ -282,7 +282,14 @@ SideStream* side_stream_of(gsrast_context* ctx)
         if (hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, prio_least) != hipSuccess) { x.stream = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
+            hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) != hipSuccess) {
+            if (x.fork) (void)hipEventDestroy(x.fork);          // all or nothing: the next call tries again
+            if (x.join) (void)hipEventDestroy(x.join);
+            if (x.join2) (void)hipEventDestroy(x.join2);
+            (void)hipStreamDestroy(x.stream);
+            x = SideStream{};
+            return nullptr;
+        }
     }
     return &x;
 }
