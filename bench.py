@@ -785,16 +785,40 @@ def hexplane_row(dev, P):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves -- the same command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one process per GPU, rendezvous on 127.0.0.1) -- and pass
+    rank 0's JSON line and the exit code through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     import view_parallel as vp
-    rank, local, world = vp.init_from_env()
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != a.gpus:     # never print a line whose n_gpus differs from what was asked for
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world_env} rank(s) (WORLD_SIZE); refusing to run", file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
     # GSRAST_SINGLE_DEVICE=1: every rank on cuda:0 (only to exercise the N>1 path on a 1-GPU box, with gloo)
     single = os.environ.get("GSRAST_SINGLE_DEVICE") == "1"
+    if a.gpus > 1 and not single and torch.cuda.device_count() < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} device(s) are visible; refusing to run", file=sys.stderr)
+        raise SystemExit(2)
+    rank, local, world = vp.init_from_env()
+    assert world == a.gpus
     dev = torch.device("cuda", local if (world > 1 and not single) else 0)
     torch.cuda.set_device(dev)
     import diff_gaussian_rasterization_ch3 as rast

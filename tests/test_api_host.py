@@ -89,3 +89,20 @@ def test_state_arena_is_freed_by_refcounting_not_by_the_cyclic_gc():
         assert arena_ref() is None and buf_ref() is None     # gone without gc.collect()
     finally:
         gc.enable()
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """bench.py never prints a line whose n_gpus differs from --gpus: a launcher that started another number of ranks is refused
+    with a non-zero exit code (checked before anything touches a GPU, so this runs on the CPU box)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "refusing" in out.stderr and '{"metric"' not in out.stdout
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and '{"metric"' not in out.stdout

@@ -74,3 +74,32 @@ def test_bench_two_ranks(exchange):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d, _ = json.JSONDecoder().raw_decode(out.stdout[out.stdout.rfind('{"metric"'):])
     assert d["n_gpus"] == 2 and d["config"]["views_per_step"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with no torchrun environment -- the command the driver's scaling step runs -- starts two ranks
+    itself and prints ONE JSON line with n_gpus = 2 (both ranks on cuda:0 over gloo here: this box has one GPU)."""
+    env = dict(os.environ, GSRAST_DIST_BACKEND="gloo", GSRAST_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "100000"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["views_per_step"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 3
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """Without GSRAST_SINGLE_DEVICE a 1-GPU box cannot run --gpus 2: non-zero exit code, no JSON line (never n_gpus != --gpus)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GSRAST_SINGLE_DEVICE", "GSRAST_DIST_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "50000"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert '{"metric"' not in out.stdout
