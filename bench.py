@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--gaussians", type=int, default=1_000_000, help="headline #Gaussians at 1920x1080")
+    ap.add_argument("--gaussians", type=int, default=3_000_000, help="headline #Gaussians at 1920x1080 (BASELINE.json configs[4]: the 3 M stress)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
@@ -189,41 +189,81 @@ def _profile_json(name):
         return None
 
 
-def roofline_of(st, bwd_ms, P):
-    """The contract's roofline object for blend_bwd_cull_kernel: algorithmic bytes (N*20 + R_eff*40 + R_eff*36 per
-    launch) / its mean launch duration (HIP events on the launch stream, this run) / 8 TB/s.  `traffic` and `valu` are NOT
-    measured in this run: they are the per-launch PMC counters of the committed rocprofv3 passes (profiles/pmc_blend_bwd*.json
-    with the same number of Gaussians, collected by tools/collect_profiles.sh), priced with the measured issue costs of
-    profiles/r02_valu_calib.json / r02_valu_mix.json."""
+def roofline_of(st, bwd_ms, P, exp2=None):
+    """The roofline object of the dominant kernel, blend_bwd_cull_t_kernel.
+
+    The kernel is VALU-issue bound, so `bound` says "valu" and the binding pair is `valu.achieved / valu.peak` in
+    wave64 instructions per second; the contract's HBM pair stays in `achieved / peak / frac` (ALGORITHMIC bytes, SURVEY.md 8d:
+    N*20 + R_eff*40 + R_eff*36 per launch, / this run's mean launch duration / 8 TB/s).  `provenance` says for every field whether
+    it was measured in this run (HIP events on the launch stream inside the timed region) or read from the committed rocprofv3 PMC
+    passes of the same workload (profiles/pmc_blend_bwd*.json, tools/collect_profiles.sh)."""
     bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
     achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
     traffic, valu, src = None, None, None
-    for name in ("pmc_blend_bwd.json", "pmc_blend_bwd_3M.json"):
+    for name in ("pmc_blend_bwd_3M.json", "pmc_blend_bwd.json"):
         pj = _profile_json(name)
-        if pj and pj.get("gaussians", 1_000_000 if name == "pmc_blend_bwd.json" else 3_000_000) == P:
+        if pj and pj.get("gaussians", 3_000_000 if "3M" in name else 1_000_000) == P:
             traffic, src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
             vi = pj.get("valu_wave_insts_per_launch")
-            mix, cal = _profile_json("r02_valu_mix.json"), _profile_json("r02_valu_calib.json")
+            mix = _profile_json("r03_valu_mix.json") or _profile_json("r02_valu_mix.json")
+            cal = _profile_json("r02_valu_calib.json")
             if vi and bwd_ms > 0 and mix and cal:
                 cyc = mix["kernels"]["blend_bwd_cull_t_kernel"]["avg_cycles_per_valu_inst"]
                 fma = max(r["wave_insts_per_s"] for r in cal["results"] if r["op"] == "v_fma_f32")
                 rate = vi / (bwd_ms * 1e-3)
-                valu = {"wave_insts_per_launch": vi, "wave_insts_per_s": round(rate, 1),
+                peak = 1024 * 2.4e9 / cyc           # wave64 instructions/s the chip can issue at this kernel's mix
+                valu = {"achieved": round(rate, 1), "peak": round(peak, 1), "unit": "wave64 instructions/s",
+                        "issue_slot_frac": round(rate / peak, 3),
+                        "wave_insts_per_launch": vi, "avg_cycles_per_inst": cyc,
                         "frac_of_measured_v_fma_f32_rate": round(rate / fma, 3),
-                        "avg_cycles_per_inst": cyc, "issue_slot_frac": round(vi * cyc / (1024 * 2.4e9 * bwd_ms * 1e-3), 3),
-                        "note": "SQ_INSTS_VALU per launch (committed rocprofv3 pass) x the kernel's static instruction mix priced with the "
-                                "MEASURED issue cost of each class (full-rate fma/mul/add 2.4 cycles per wave64 instruction and SIMD, "
-                                "half-rate dpp/cmp/cndmask/min/cvt/ldexp 4.1, quarter-rate rcp/exp 8.1: tools/valu_calib.hip) / "
-                                "(1024 SIMDs x 2.4 GHz x this run's launch duration)",
-                        "source": [src, "profiles/r02_valu_calib.json", "profiles/r02_valu_mix.json"]}
+                        "profile_launch_ms": pj.get("avg_launch_ms"),
+                        "note": "SQ_INSTS_VALU per launch (committed rocprofv3 pass) / this run's launch duration, against 1024 SIMDs x 2.4 GHz / "
+                                "the kernel's static instruction mix priced with the MEASURED issue cost of each class (full-rate fma/mul/add "
+                                "2.4 cycles per wave64 instruction and SIMD, half-rate dpp/cmp/cndmask/min/cvt/ldexp 4.1, quarter-rate rcp/exp "
+                                "8.1: tools/valu_calib.hip, tools/valu_mix.py)"}
             break
-    return {"kernel": "blend_bwd_cull_t_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": (src + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, committed; not measured in this run)") if src else None,
-            "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": round(bwd_ms, 4),
-            "note": "VALU-issue-bound kernel (valu.issue_slot_frac): see DESIGN.md 4; pair-evaluations/s is the telling rate",
-            "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
-            "valu": valu}
+    out = {"kernel": "blend_bwd_cull_t_kernel", "bound": "valu" if valu else "hbm",
+           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_ratio": round(traffic / bwd_bytes, 3) if traffic else None,
+           "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": round(bwd_ms, 4),
+           "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
+           "valu": valu,
+           "provenance": {"avg_launch_ms / achieved / frac / gpairs_per_s": "measured in this run (HIP events on the launch stream, timed region)",
+                          "algorithmic_bytes_per_launch": "SURVEY.md 8d formula with this run's measured R_eff (tile_clip=0 lists)",
+                          "traffic / traffic_ratio": (src + ": rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 units per MI355X_MICROARCH.md), committed pass, not this run") if src else None,
+                          "valu.wave_insts_per_launch": (src + ": SQ_INSTS_VALU per launch, committed pass, not this run") if src else None,
+                          "valu.avg_cycles_per_inst": "profiles/r0x_valu_mix.json over profiles/r02_valu_calib.json (measured issue costs)"},
+           "note": "VALU-issue-bound kernel: valu.issue_slot_frac is the binding fraction; frac is the HBM fraction the contract asks for (small by construction)"}
+    if exp2:
+        out["exp_mode_2"] = exp2
+    return out
+
+
+def exp_mode2_row(_C, wl, dev, kid):
+    """Both blend kernels with exp_mode 2 (v_exp_f32, within a few ulp of mode 0: north_star's 1e-5 bar, not the bit-exact one)
+    next to the default's fixed-sequence exp: event-bracketed launches of a separate, untimed pass."""
+    cur = _C.get_option("exp_mode")
+    res = {}
+    for mode in (cur, 2):
+        _C.set_option("exp_mode", mode)
+        for _ in range(3):
+            wl.step(None, 1)
+        torch.cuda.synchronize(dev)
+        _C.profile_reset()
+        _C.set_option("profile", (1 << kid["blend_bwd"]) | (1 << kid["blend_fwd"]))
+        t0 = time.perf_counter()
+        for _ in range(10):
+            wl.step(None, 1)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 10 * 1e3
+        pk = _C.profile_read()
+        _C.set_option("profile", 0)
+        res[f"exp_mode_{mode}"] = {"blend_fwd_ms": round(pk["blend_fwd"][0] / max(pk["blend_fwd"][1], 1), 4),
+                                   "blend_bwd_ms": round(pk["blend_bwd"][0] / max(pk["blend_bwd"][1], 1), 4),
+                                   "ms_per_step_with_both_bracketed": round(dt, 4)}
+    _C.set_option("exp_mode", cur)
+    res["note"] = "mode 2 = hardware v_exp_f32; outputs within 1e-5 of mode 0 (tests/test_gpu_parity.py::test_other_exp_modes_within_tolerance); the headline runs the mode in config.exp_mode"
+    return res
 
 
 def stage_table(_C, wl, st, P, deg, H):
@@ -572,109 +612,6 @@ def iteration_row(rast, scenes, dev, P, W, H, deg):
             "pieces": "activate_gaussians -> GaussianRasterizer -> l1_dssim_loss -> backward -> GaussianAdam.step"}
 
 
-def dynamic_iteration_row(rast, scenes, dev, P, W, H, deg):
-    """A whole DYNAMIC-stage training iteration with every built row in place (scene/saro_gaussian.py:779-847 get_deformation
-    + train.py:190-250, one view): residual field (fused_hexplane) -> lifespan / motion / rotation+scale / SH MLPs (torch.nn,
-    fp32, the reference's layer shapes :104-110 with deform_hidden_dim 128, time encoding 4) -> activation epilogue with the
-    residuals -> rasterizer -> L1 + D-SSIM -> backward -> fused Adam (Gaussian groups) + torch Adam (MLPs, planes).
-    Field shape: configs/dnerf (64^3 x 128 frames, 32 features, one scale).  Also the cost of the MLP part alone, the next
-    piece this iteration is bound by."""
-    import itertools
-    import torch.nn as nn
-    import fused_adam, fused_epilogue, fused_hexplane, fused_loss
-    sc = scenes.synth(P, 0, sh_degree=deg)
-    cam = scenes.camera(0, 1, W, H)
-    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
-    rs = rast.GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]), scale_modifier=1.0,
-        viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
-    raster = rast.GaussianRasterizer(rs)
-    g = torch.Generator(device="cpu").manual_seed(0)
-    raw = dict(xyz=t(sc["means3D"]), rotation=t(sc["rotations"]), scaling=torch.log(t(sc["scales"])),
-               opacity=torch.logit(t(sc["opacities"]).clamp(1e-4, 1 - 1e-4)), f_dc=t(sc["shs"][:, :1]), f_rest=t(sc["shs"][:, 1:]),
-               temporal_pos=torch.rand((P, 1), generator=g).to(dev))
-    raw = {k: v.requires_grad_(True) for k, v in raw.items()}
-    reso, C, Hd, nfreq = [64, 64, 64, 128], 32, 128, 4
-    coo = list(itertools.combinations(range(4), 2))
-    grids = [(0.1 * torch.randn((1, C, reso[b], reso[a]), generator=g)).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-             for (a, b) in coo]
-    emb = 1 + 2 * nfreq
-    mlp = lambda i, o: nn.Sequential(nn.Linear(i, Hd), nn.ReLU(), nn.Linear(Hd, Hd), nn.ReLU(), nn.Linear(Hd, o)).to(dev)  # noqa: E731
-    motion_mlp, rot_mlp, shs_mlp = mlp(C + emb, 3), mlp(C + emb, 7), mlp(C + emb, 48)
-    opacity_mlp = nn.Sequential(nn.Linear(C, Hd), nn.ReLU(), nn.Linear(Hd, Hd // 2), nn.ReLU(), nn.Linear(Hd // 2, 1), nn.Sigmoid()).to(dev)
-    for m in (motion_mlp, rot_mlp, shs_mlp):
-        nn.init.zeros_(m[-1].weight); nn.init.zeros_(m[-1].bias)      # residuals start at zero: the scene stays in view
-    lo, hi = raw["xyz"].detach().min(0).values, raw["xyz"].detach().max(0).values
-    base_scale = (hi - lo) / torch.tensor(reso[:3], device=dev, dtype=torch.float32)
-    freqs = (2.0 ** torch.arange(nfreq, device=dev, dtype=torch.float32))[None]
-    inv = torch.ones(P, 1, device=dev)
-    lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3, temporal_pos=1e-4)
-    opt_g = fused_adam.GaussianAdam([{"params": [raw[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in raw], eps=1e-15)
-    net_params = [p_ for m in (motion_mlp, rot_mlp, shs_mlp, opacity_mlp) for p_ in m.parameters()]
-    opt_n = torch.optim.Adam([{"params": net_params, "lr": 1.6e-4}, {"params": grids, "lr": 1.6e-3}], eps=1e-15, fused=True)
-    gt = torch.rand(3, H, W, device=dev)
-    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
-    timestamp = 0.37
-
-    def field():
-        with torch.no_grad():                                                     # hexplane.py:253-260, :237-249; inputs detached (:780)
-            pts = torch.cat(((raw["xyz"] - hi) / (lo - hi), raw["temporal_pos"] * (reso[3] / (reso[3] - 1.0))), dim=1)
-            sc_ = torch.exp(raw["scaling"]).clamp(min=base_scale / 2, max=base_scale / 2 * reso[0])
-            levels = torch.cat((torch.log2(2 * sc_ / base_scale), torch.zeros((P, 1), device=dev)), dim=1)
-        return fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
-
-    def heads(feat):
-        lifespan = 1 - opacity_mlp(feat)
-        lifespan = (1 - 1.0 / reso[3]) * lifespan + 1.0 / reso[3]
-        distance = timestamp - raw["temporal_pos"]
-        trbf = torch.exp(-4 * (distance / lifespan) ** 2)
-        with torch.no_grad():
-            x = distance * freqs
-            te = torch.cat((distance, torch.sin(x), torch.cos(x)), dim=1)
-        df = torch.cat((feat, te), dim=1)
-        return motion_mlp(df), rot_mlp(df), trbf, shs_mlp(df).reshape(-1, 16, 3)
-
-    def step():
-        mres, rres, trbf, sres = heads(field())
-        motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(
-            raw["xyz"], raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"],
-            motion_residual=mres, rot_residual=rres, trbfoutput=trbf, shs_residual=sres)
-        color, _, _ = raster(means3D=motion, means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
-        loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
-        opt_g.zero_grad(); opt_n.zero_grad(); m2.grad = None
-        loss.backward()
-        opt_g.step(); opt_n.step()
-
-    feat_fixed = field().detach()
-
-    def heads_only():
-        outs = heads(feat_fixed)
-        for p_ in net_params: p_.grad = None
-        raw["temporal_pos"].grad = None
-        sum(o.sum() for o in outs).backward()
-
-    def tm(fn, n=10):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3
-
-    ms_torch, ms_heads_torch = tm(step), tm(heads_only)
-    import fused_mlp
-    for m in (motion_mlp, rot_mlp, shs_mlp, opacity_mlp):
-        fused_mlp.convert_heads(m)            # same parameters; weight / bias gradients by gsrast_linear_wgrad (split-K, fp32 MFMA)
-    ms, ms_heads = tm(step), tm(heads_only)
-    return {"ms": round(ms, 3), "iterations_per_s": round(1e3 / ms, 1), "mlp_heads_fwd_bwd_alone_ms": round(ms_heads, 3),
-            "with_plain_nn_linear_heads_ms": round(ms_torch, 3), "plain_nn_linear_heads_alone_ms": round(ms_heads_torch, 3),
-            "gaussians": P, "image": [H, W], "field": "64x64x64x128, 32 features, 1 scale",
-            "pieces": "interpolate_ms_features -> MLP heads (fp32; fused_mlp.SplitKLinear) -> activate_gaussians(residuals) -> GaussianRasterizer -> "
-                      "l1_dssim_loss -> backward -> GaussianAdam.step + torch Adam(fused) for MLPs / planes"}
-
-
 def knn_row(dev, P):
     """"Next" row (second item): simple_knn.distCUDA2 for P points (the reference's random-init
     cube, dataset_readers.py:526), next to an exact k-d tree 3-NN on all host cores (scipy cKDTree, fp64)."""
@@ -778,7 +715,6 @@ def hexplane_row(dev, P):
                 fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
             torch.cuda.synchronize(dev)
             res["forward_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
-        res["gather_GBps_forward"] = round(P * 6 * 8 * C * 4 / (res["forward_ms"] * 1e-3) / 1e9, 1)
         res["points"] = P
         out[tag] = res
         del grids
@@ -886,9 +822,10 @@ def main():
     _C.set_option("profile", 0)
 
     st = wl.stats()
-    per_kernel, pk = (None, None)
+    per_kernel, pk, exp2 = (None, None, None)
     if world == 1:
         per_kernel, pk = stage_table(_C, wl, st, P, deg, H)
+        exp2 = exp_mode2_row(_C, wl, dev, kid)
     result = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
@@ -901,14 +838,14 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
+            "config": {"workload": f"BASELINE configs[4] stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
                                    + ((" + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
                                        if a.exchange == "factors" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
                        "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],
                        "blended_pairs_fwd": st["pairs_fwd"]},
-            "roofline": roofline_of(st, bwd_ms, P),
+            "roofline": roofline_of(st, bwd_ms, P, exp2),
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,
@@ -925,10 +862,10 @@ def main():
             if p == P:
                 sweep[str(p)] = {"views_per_s": result["value"], "ms_per_step": result["ms_per_step"], "steps": a.steps, "warmup": a.warmup}
                 continue
-            full = p == 3_000_000           # BASELINE.json configs[4]: the 3 M stress gets its own roofline object and stage table
+            full = p == 1_000_000           # the 1 M point (rounds 1-2's headline) keeps its own roofline object and stage table
             m = measure_point(rast, scenes, vp, p, W, H, deg, dev, a.steps, a.warmup, full=full)
             if full:
-                result["cfg5_3M_1080p"] = m
+                result["sweep_1M_1080p"] = m
             sweep[str(p)] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup")}
         result["sweep_1080p"] = sweep
         # the other single-GPU shapes BASELINE.json names (synthetic stand-ins): informational, same protocol
@@ -938,7 +875,7 @@ def main():
         result["baseline_configs"] = other
         # a second occlusion regime (scenes.synth_shell: a surface, R_eff ~ R) at the headline's size: the binning / culling / launch
         # order choices are not tuned to the cube's early termination alone
-        m = measure_point(rast, scenes, vp, P, W, H, deg, dev, a.steps, a.warmup, full=True, kind="shell")
+        m = measure_point(rast, scenes, vp, 1_000_000, W, H, deg, dev, a.steps, a.warmup, full=True, kind="shell")
         result["shell_scene_1080p"] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup", "config", "per_stage")}
         result["shell_scene_1080p"]["blend_bwd_ms"] = m["roofline"]["avg_launch_ms"]
         # NOT the headline protocol: two views of a batch in flight on two streams of the one GPU (what
@@ -950,6 +887,7 @@ def main():
             result["two_views_in_flight_1080p"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        P_headline, P = P, min(P, 1_000_000)      # the SURVEY 8f rows are quoted at 1 M Gaussians (rounds 1-2), whatever the headline
         try:
             result["next_rows"] = loss_row(dev, H, W)
         except Exception as e:
@@ -971,15 +909,12 @@ def main():
         except Exception as e:      # noqa: BLE001
             result["next_rows"]["hexplane_field_fwd_bwd"] = {"error": str(e)}
         try:
-            result["next_rows"]["dynamic_stage_training_iteration"] = dynamic_iteration_row(rast, scenes, dev, P, W, H, deg)
-        except Exception as e:      # noqa: BLE001
-            result["next_rows"]["dynamic_stage_training_iteration"] = {"error": str(e)}
-        try:
             result["next_rows"]["static_stage_training_iteration"] = iteration_row(rast, scenes, dev, P, W, H, deg)
         except Exception as e:
             result["next_rows"]["static_stage_training_iteration"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
+            P = P_headline
             try:
                 result["cpu_baseline"] = cpu_baseline(scenes, P, W, H, deg, a.cpu_budget_s)
             except Exception as e:  # the baseline is reported, never required for the GPU number

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define GSRAST_ABI_VERSION 1
+#define GSRAST_ABI_VERSION 2   /* 2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
+                                    reference); options.forward_only; gsrast_forward_raw / gsrast_backward_raw */
 #define GSRAST_TILE_X 16 /* reference config.h:16 */
 #define GSRAST_TILE_Y 16 /* reference config.h:17 */
 
@@ -181,7 +182,11 @@ typedef struct gsrast_options {
                                  bucket (run-compressed binning, P >= 32768); a scene whose depths pile up in one bucket is detected on
                                  the device and re-sorted by the radix passes, which the context then uses for its next 16 calls
                                  ("bucket_skip"); 1 = always the LSD radix sort (3-4 passes of three launches).  Same order either way */
-    int reserved[3];          /* must be zero */
+    int forward_only;         /* forward: 1 = no backward will follow on this call's state (evaluation / torch.no_grad()): the colour kernel
+                                 does not store d(colour)/d(view direction) (36 B / Gaussian) for the backward.  A backward on such a
+                                 state must be given forward_only = 1 as well; it then evaluates those derivatives itself
+                                 (sh_dir_derivs_kernel, re-reading the SH blocks).  0 (default) = the forward prepares them */
+    int reserved[2];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device); contexts

@@ -42,7 +42,7 @@ std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0};      // process-wid
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
 // threads driving different streams / devices with different options cannot disturb each other.
 struct DefaultOptions {
-    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0};
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0};
 } g_def;
 gsrast_options snapshot_defaults()
 {
@@ -50,6 +50,7 @@ gsrast_options snapshot_defaults()
     o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
     o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
     o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream; o.depth_sort = g_def.depth_sort;
+    o.forward_only = g_def.forward_only;
     return o;
 }
 bool options_valid(const gsrast_options& o)
@@ -470,6 +471,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "speculative")) { g_def.speculative = value ? 1 : 0; return 0; }
     if (!strcmp(name, "side_stream")) { g_def.side_stream = value ? 1 : 0; return 0; }
     if (!strcmp(name, "depth_sort")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.depth_sort = value; return 0; }
+    if (!strcmp(name, "forward_only")) { g_def.forward_only = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -496,6 +498,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "speculative")) return g_def.speculative.load();
     if (!strcmp(name, "side_stream")) return g_def.side_stream.load();
     if (!strcmp(name, "depth_sort")) return g_def.depth_sort.load();
+    if (!strcmp(name, "forward_only")) return g_def.forward_only.load();
     if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
@@ -640,9 +643,24 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         }
         {
             ProfScope ps(K_COLOR, cs);
-            preprocess_color_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, cs>>>(
-                P, D, M, means3D, colors_precomp ? nullptr : shs, colors_precomp, cam_pos, rec2, at<unsigned char>(geom, GL.clamped),
-                side ? nullptr : at<float4>(geom, GL.grec));
+            // persistent workgroups (six 25-KB workgroups fit a compute unit), each walks its blocks with the next one's loads in flight
+            const int nblocks = (P + PP_THREADS - 1) / PP_THREADS;
+            const int grid = std::min(nblocks, COLOR_GRID);
+            // d(colour)/d(view direction) for the backward (36 B / Gaussian), unless the caller said that no backward will follow
+            const bool want_shd = shs && !colors_precomp && D > 0 && !o.forward_only;
+            float4* sA = want_shd ? at<float4>(geom, GL.shdA) : nullptr;
+            float4* sB = want_shd ? at<float4>(geom, GL.shdB) : nullptr;
+            float* sC = want_shd ? at<float>(geom, GL.shdC) : nullptr;
+            const float* sh_in = colors_precomp ? nullptr : shs;
+            unsigned char* cl = at<unsigned char>(geom, GL.clamped);
+            float4* gz = side ? nullptr : at<float4>(geom, GL.grec);
+            const bool staged = sh_in && M * 3 <= PP_SH_MAX && ((M * 3) & 3) == 0 && ((uintptr_t)sh_in & 15) == 0;
+            if (staged && M * 3 == PP_SH_MAX)
+                preprocess_color_kernel<PP_SH_MAX><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, cam_pos, rec2, cl, gz, sA, sB, sC);
+            else if (staged)
+                preprocess_color_kernel<0><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, cam_pos, rec2, cl, gz, sA, sB, sC);
+            else
+                preprocess_color_direct_kernel<<<(P + 255) / 256, 256, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, cam_pos, rec2, cl, gz, sA, sB, sC);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
         }
@@ -1287,8 +1305,11 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
     // What the per-Gaussian backward needs of the SH coefficients -- d(colour)/d(view direction), 36 B instead of 12*M -- depends on
     // nothing the blend backward produces: evaluated on the side stream of the calling thread's context WHILE the VALU-bound blend
     // backward runs, joined in front of preprocess_bwd (or at the end of phase 1 of a two-phase backward).
+    // Round 3: the forward's colour kernel leaves those nine floats per Gaussian while it has the coefficient block in LDS
+    // (preprocess_color_kernel), so this kernel only runs for a state whose forward was told that no backward would follow
+    // (options.forward_only, passed to both calls by a caller that changed its mind).
     SideStream* side = nullptr;
-    if (do_blend && use_sh && D > 0) {
+    if (do_blend && use_sh && D > 0 && o.forward_only) {
         if (o.side_stream && R > 0) side = side_stream_of(thread_context());
         hipStream_t ds = s;
         if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); ds = side->stream; }

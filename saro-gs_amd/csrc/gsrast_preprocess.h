@@ -217,41 +217,13 @@ __device__ __forceinline__ void sh_dir_derivs(int deg, float x, float y, float z
 // reads that follow), and the backward writes dL/dsh back the same way.
 constexpr int PP_THREADS = 128;
 constexpr int PP_SH_MAX = 48;                   // (3+1)^2 coefficients x 3 channels
+#ifndef GSRAST_COLOR_GRID
+#define GSRAST_COLOR_GRID 1536              // persistent workgroups of the colour kernel: 256 compute units x the six that fit one (LDS)
+#endif
+constexpr int COLOR_GRID = GSRAST_COLOR_GRID;
 constexpr int PP_SH_STRIDE = PP_SH_MAX + 1;     // +1: conflict-free per-lane reads.  25 KB of LDS per workgroup = 6 workgroups per CU;
                                                 // both kernels are latency-bound at that occupancy (4 per CU: +17 %, 3: +40 %)
 
-__device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int P, int M, int base, float* lds)
-{
-    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
-    const int row = M * 3;
-    const int nfl = ng * row;
-    const float* src = shs + (size_t)base * row;
-    if ((row & 3) == 0 && ((uintptr_t)src & 15) == 0) {
-        // All of a lane's (at most PP_SH_MAX / 4 = 12) 16-byte loads are requested before the first LDS store: written as a
-        // plain loop the compiler emitted load / wait / store per element -- twelve serial memory round trips per workgroup.
-        // (Also measured: a 52-float row stride with 16-byte LDS stores and row reads, conflict-free both ways on paper -- the
-        // kernel went from 72 to 121 us alone, 119 VGPRs and a spilled row.)
-        const float4* src4 = reinterpret_cast<const float4*>(src);
-        const int n4 = nfl >> 2;
-        float4 v[PP_SH_MAX / 4];
-#pragma unroll
-        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; if (q < n4) v[u] = src4[q]; }
-#pragma unroll
-        for (int u = 0; u < PP_SH_MAX / 4; u++) {
-            const int q = threadIdx.x + u * PP_THREADS;
-            if (q < n4) {
-                const int f = q * 4, g = f / row, c = f - g * row;
-                float* d = lds + g * PP_SH_STRIDE + c;
-                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
-            }
-        }
-    } else {
-        for (int f = threadIdx.x; f < nfl; f += PP_THREADS) {
-            const int g = f / row, c = f - g * row;
-            lds[g * PP_SH_STRIDE + c] = src[f];
-        }
-    }
-}
 __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P, int M, int base, const float* lds)
 {
     const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
@@ -278,46 +250,146 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P,
 // caller's colors_precomp, into rec2.  It depends on nothing the geometry half produces -- so gsrast_forward runs it on a
 // low-priority side stream, beside the geometry kernel, the depth sort and the binning (all latency-bound), and joins it in
 // front of the blend, the first kernel to read a colour.  Evaluated for every Gaussian (a culled one is never read).
-// (A grid-stride version limited to 2-4 workgroups per CU was measured: no better -- the sort kernels it runs beside slow
-// down by the memory latency under load, not by a lack of wave slots.)
+//
+// Round 3: (i) while a Gaussian's coefficient block sits in LDS the kernel also evaluates d(colour)/d(view direction)
+// (backward.cu:78-127 dRGBdx / dy / dz, sh_dir_derivs above) and stores the nine floats (shdA / shdB / shdC, 36 B) for
+// preprocess_bwd_kernel -- round 2 re-read the 12*M-byte blocks for that in the backward (sh_dir_derivs_kernel, as long as the
+// blend backward itself at 3 M Gaussians); (ii) PERSISTENT workgroups with a register double buffer: a workgroup requests the
+// NEXT block's twelve 16-byte loads per lane right after it has parked the current block in LDS, so the loads travel under the
+// barrier, the SH evaluation and the stores -- the one-block-per-workgroup form had its bytes in flight only during the first
+// third of a workgroup's life (3.1 TB/s alone, with six 25-KB workgroups per CU).
+// ROW: floats per SH row known at compile time (48 for the reference's M = 16), 0 = runtime (other M, or unaligned input).
+// Loads are unconditional with clamped indices (a short last block re-reads its last 16 bytes): no branch around a load, so the
+// compiler never has to drain the loads in flight at a join.
+template <int ROW>
+__device__ __forceinline__ void color_load_block(const float* __restrict__ shs, int P, int row, int blk, float4 (&v)[PP_SH_MAX / 4])
+{
+    const int base = blk * PP_THREADS;
+    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
+    const int r = ROW ? ROW : row;
+    const int n4 = (ng * r) >> 2;
+    const float4* src4 = reinterpret_cast<const float4*>(shs + (size_t)base * r);
+#pragma unroll
+    for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = src4[q < n4 ? q : n4 - 1]; }
+}
+template <int ROW>
+__device__ __forceinline__ void color_park_block(int P, int row, int blk, const float4 (&v)[PP_SH_MAX / 4], float* lds)
+{
+    const int base = blk * PP_THREADS;
+    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
+    const int r = ROW ? ROW : row;
+    const int n4 = (ng * r) >> 2;
+#pragma unroll
+    for (int u = 0; u < PP_SH_MAX / 4; u++) {
+        const int q = threadIdx.x + u * PP_THREADS;
+        if (q < n4) {
+            const int f = q * 4, g = f / r, c = f - g * r;
+            float* d = lds + g * PP_SH_STRIDE + c;
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+    }
+}
+
+// SH rows through LDS: M * 3 <= PP_SH_MAX floats per row, a multiple of four, 16-byte aligned base (checked by the host).
+template <int ROW>
 __global__ void __launch_bounds__(PP_THREADS)
 preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
-                        const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
+                        const float* __restrict__ campos_dev,
                         float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
-                        float4* __restrict__ grec4 /* [P][4] or null: the backward's gradient records, zero-filled here when there is no side stream to do it */)
+                        float4* __restrict__ grec4 /* [P][4] or null: the backward's gradient records, zero-filled here when there is no side stream to do it */,
+                        float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC /* null: no backward will follow (or D = 0) */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
-    const bool staged = shs && !colors_precomp && M * 3 <= PP_SH_MAX;
     const int nblocks = (P + PP_THREADS - 1) / PP_THREADS;
-    // grid-stride over blocks of PP_THREADS Gaussians.  (A grid of 64 ... 1024 workgroups on the side stream was measured: the
-    // kernel gets 2-8x longer and the stretch of its neighbours moves from kernel to kernel, the step time stays the same.)
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int i = blk * PP_THREADS + threadIdx.x;
-    if (grec4) {   // this block's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
-        const size_t q0 = (size_t)blk * PP_THREADS * 4, q1 = (size_t)P * 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    const int row = M * 3;
+    const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
+    float4 v[PP_SH_MAX / 4];
+    float pn[3];
+    int blk = blockIdx.x;           // the host launches at most nblocks workgroups
+    {   // (the mean first: the loop copies it out of the prefetch registers at its end, and loads return in order)
+        const int i0 = blk * PP_THREADS + threadIdx.x, ic0 = i0 < P ? i0 : P - 1;
+        pn[0] = means3D[3 * ic0]; pn[1] = means3D[3 * ic0 + 1]; pn[2] = means3D[3 * ic0 + 2];
+        color_load_block<ROW>(shs, P, row, blk, v);
     }
-    const int ic = i < P ? i : P - 1;
-    const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };       // requested before the staging barrier
-    if (staged) { if (blk != (int)blockIdx.x) __syncthreads(); stage_sh_in(shs, P, M, blk * PP_THREADS, sh_lds); __syncthreads(); }
-    if (i < P) {
+    for (; blk < nblocks; blk += gridDim.x) {
+        const int i = blk * PP_THREADS + threadIdx.x;
+        if (grec4) {   // this block's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
+            const size_t q0 = (size_t)blk * PP_THREADS * 4, q1 = (size_t)P * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+        const float p[3] = { pn[0], pn[1], pn[2] };
+        if (blk != (int)blockIdx.x) __syncthreads();          // the previous block's rows have been read
+        color_park_block<ROW>(P, row, blk, v, sh_lds);
+        {   // the next block's loads leave now and travel under everything below (the last round re-reads its own block: harmless)
+            const int nb = blk + (int)gridDim.x < nblocks ? blk + (int)gridDim.x : blk;
+            const int i1 = nb * PP_THREADS + threadIdx.x, ic1 = i1 < P ? i1 : P - 1;
+            pn[0] = means3D[3 * ic1]; pn[1] = means3D[3 * ic1 + 1]; pn[2] = means3D[3 * ic1 + 2];
+            color_load_block<ROW>(shs, P, row, nb, v);
+        }
+        __syncthreads();
+        if (i < P) {
+            const float* my_sh = sh_lds + threadIdx.x * PP_SH_STRIDE;
+            float col[3];
+            unsigned cl = 0;
+            sh_to_rgb(D, p, campos, my_sh, col);
+#pragma unroll
+            for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
+            if (shdA) {    // same expressions on the same operands as sh_dir_derivs_kernel: the same bits
+                const float o0 = p[0] - campos[0], o1 = p[1] - campos[1], o2 = p[2] - campos[2];
+                const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+                const float x = o0 / len, y = o1 / len, z = o2 / len;
+                float dx[3], dy[3], dz[3];
+                sh_dir_derivs(D, x, y, z, my_sh, dx, dy, dz);
+                shdA[i] = make_float4(dx[0], dx[1], dx[2], dy[0]);
+                shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
+                shdC[i] = dz[2];
+            }
+            rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+            clamped[i] = (unsigned char)cl;
+        }
+    }
+}
+
+// The same without LDS staging: colors_precomp, or SH rows the staged kernel does not take (more than 16 coefficients, rows
+// that are not a multiple of 16 bytes, an unaligned base).  One lane per Gaussian, rows read in place.
+__global__ void __launch_bounds__(256)
+preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                               const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
+                               float4* __restrict__ rec2, unsigned char* __restrict__ clamped, float4* __restrict__ grec4,
+                               float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    if (grec4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) grec4[4 * (size_t)i + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float col[3];
     unsigned cl = 0;
     if (!colors_precomp) {
+        const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
         const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
-        const float* my_sh = staged ? sh_lds + threadIdx.x * PP_SH_STRIDE : shs + (size_t)i * M * 3;
+        const float* my_sh = shs + (size_t)i * M * 3;
         sh_to_rgb(D, p, campos, my_sh, col);
 #pragma unroll
         for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
+        if (shdA) {
+            const float o0 = p[0] - campos[0], o1 = p[1] - campos[1], o2 = p[2] - campos[2];
+            const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+            const float x = o0 / len, y = o1 / len, z = o2 / len;
+            float dx[3], dy[3], dz[3];
+            sh_dir_derivs(D, x, y, z, my_sh, dx, dy, dz);
+            shdA[i] = make_float4(dx[0], dx[1], dx[2], dy[0]);
+            shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
+            shdC[i] = dz[2];
+        }
     } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
     }
     rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
     clamped[i] = (unsigned char)cl;
-    }
-    } // blk
 }
 
 // K1 forward, geometry half.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.

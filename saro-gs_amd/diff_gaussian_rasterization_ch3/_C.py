@@ -22,6 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsrast_hip.so")
 
 NUM_CHANNELS = 3  # reference config.h:15
+ABI_VERSION = 2   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib: Optional[C.CDLL] = None
@@ -46,13 +47,13 @@ class OptionsStruct(C.Structure):
     _fields_ = [("exp_mode", C.c_int), ("binning", C.c_int), ("tile_clip", C.c_int), ("cull", C.c_int), ("lpt", C.c_int),
                 ("speculative", C.c_int), ("fwd_pixels_per_lane", C.c_int), ("bwd_pixels_per_lane", C.c_int),
                 ("sh_grad_factors", C.c_int), ("side_stream", C.c_int), ("grads_zeroed", C.c_int), ("backward_phase", C.c_int), ("depth_sort", C.c_int),
-                ("reserved", C.c_int * 3)]
+                ("forward_only", C.c_int), ("reserved", C.c_int * 2)]
 
 
 # Per-call options are kept PER HOST THREAD on the Python side and travel with every call (gsrast_forward_ex /
 # gsrast_backward_ex): two threads rendering on two streams with different options never see each other's settings.
-PER_CALL_OPTIONS = ("exp_mode", "binning", "tile_clip", "cull", "lpt", "speculative", "fwd_pixels_per_lane", "bwd_pixels_per_lane", "side_stream", "depth_sort")
-_OPTION_DEFAULTS = dict(exp_mode=0, binning=0, tile_clip=1, cull=1, lpt=1, speculative=1, fwd_pixels_per_lane=0, bwd_pixels_per_lane=0, side_stream=1, depth_sort=0)
+PER_CALL_OPTIONS = ("exp_mode", "binning", "tile_clip", "cull", "lpt", "speculative", "fwd_pixels_per_lane", "bwd_pixels_per_lane", "side_stream", "depth_sort", "forward_only")
+_OPTION_DEFAULTS = dict(exp_mode=0, binning=0, tile_clip=1, cull=1, lpt=1, speculative=1, fwd_pixels_per_lane=0, bwd_pixels_per_lane=0, side_stream=1, depth_sort=0, forward_only=0)
 _OPTION_RANGE = dict(exp_mode=(0, 1, 2), binning=(0, 1), depth_sort=(0, 1), fwd_pixels_per_lane=(0, 1, 2, 4), bwd_pixels_per_lane=(0, 1, 2, 4))
 _tls = threading.local()
 
@@ -71,10 +72,11 @@ def current_options() -> dict:
 
 
 def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None, grads_zeroed: bool = False,
-                    backward_phase: int = 0) -> OptionsStruct:
+                    backward_phase: int = 0, forward_only: bool = False) -> OptionsStruct:
     o = OptionsStruct()
     for k, v in (_thread_options() if options is None else options).items():
         setattr(o, k, int(v))
+    o.forward_only = int(bool(forward_only) or bool(o.forward_only))
     o.sh_grad_factors = int(bool(sh_grad_factors))
     o.grads_zeroed = int(bool(grads_zeroed))
     o.backward_phase = int(backward_phase)
@@ -171,7 +173,7 @@ def lib() -> C.CDLL:
     L.gsrast_linear_wgrad.argtypes = [ci, ci, ci, vp, vp, vp, vp, ci, vp]
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
-    if L.gsrast_abi_version() != 1:
+    if L.gsrast_abi_version() != ABI_VERSION:
         raise ImportError("libgsrast_hip.so: ABI version mismatch")
     _lib = L
     return L
@@ -311,11 +313,12 @@ class _Arena:
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                        image_width, sh, degree, campos, prefiltered
+                        image_width, sh, degree, campos, prefiltered, *, forward_only: bool = False
                         ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Forward.  Mirrors RasterizeGaussiansCUDA (rasterize_points.cu:35-115): returns
     ``(num_rendered, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
-    out_depth[1,H,W])``."""
+    out_depth[1,H,W])``.  `forward_only` (not in the reference): no backward will follow on the returned state (the autograd
+    node passes it when no input requires a gradient): the library skips what it only prepares for the backward."""
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:56-58
     dev = _require_gpu(means3D)
@@ -335,7 +338,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             rendered = L.gsrast_forward_ex(
-                None, C.byref(_options_struct()),       # context: the calling thread's own (capacity hints of the speculative launch)
+                None, C.byref(_options_struct(forward_only=forward_only)),       # context: the calling thread's own (capacity hints of the speculative launch)
                 arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
                 P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),

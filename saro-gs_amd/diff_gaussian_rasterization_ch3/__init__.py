@@ -67,10 +67,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered, color, radii, geom_buf, bin_buf, img_buf, depth = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-            rs.sh_degree, rs.campos, rs.prefiltered)
+            rs.sh_degree, rs.campos, rs.prefiltered, forward_only=not any(ctx.needs_input_grad))
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.gs_options = _C.current_options()      # the backward runs on autograd's thread: it must use THIS thread's options
+        ctx.gs_options["forward_only"] = int(not any(ctx.needs_input_grad))   # (a backward then cannot happen; kept consistent anyway)
         ctx.gs_backwards = 0                       # backwards run on this state (retain_graph): only the first finds zeroed records
         # opacities are not saved: the state buffer keeps them next to the conic (REF:84)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,

@@ -811,3 +811,60 @@ def test_two_phase_backward_factor_ready_hook(scenes, rast, gpu):
         assert ((a - b).abs() <= 1e-6 + 1e-4 * a.abs()).all(), what
     fac = arena.factor[: 3 * P].reshape(P, 3)
     assert fac.abs().max() > 0 and not fac[radii == 0].any()
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_direction_derivatives_from_the_forward_equal_the_backward_kernel(deg, scenes, rast, gpu):
+    """Round 3: the forward's colour kernel stores d(colour)/d(view direction) (backward.cu:78-127) for the backward while the SH
+    block is in LDS.  options.forward_only = 1 on both calls selects round 2's route (the backward re-reads the SH blocks in
+    sh_dir_derivs_kernel): same expressions on the same operands -- the gradients agree to the run-to-run noise of the blend
+    backward's float atomics (the bar of test_second_backward_on_the_same_forward_state)."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H = 6000, 176, 128
+    sc = scenes.synth(P, 301 + deg, sh_degree=deg)
+    cam = scenes.camera(2, 5, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    g = t(scenes.upstream_grad(H, W, 302))
+    e = torch.empty(0)
+    res = []
+    for fo in (0, 1):
+        _C.set_option("forward_only", fo)
+        try:
+            R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+                rs.bg, t(sc["means3D"]), e, t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), 1.0, e, rs.viewmatrix, rs.projmatrix,
+                rs.tanfovx, rs.tanfovy, H, W, t(sc["shs"]), deg, rs.campos, False)
+            grads = _C.rasterize_gaussians_backward(
+                rs.bg, t(sc["means3D"]), radii, e, t(sc["scales"]), t(sc["rotations"]), 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                rs.tanfovy, g, t(sc["shs"]), deg, rs.campos, gb, R, bb, ib, first_backward=True)
+        finally:
+            _C.set_option("forward_only", 0)
+        torch.cuda.synchronize()
+        res.append((color, [x.clone() for x in grads]))
+    assert torch.equal(res[0][0], res[1][0])
+    assert float(res[0][1][3].abs().max()) > 0
+    for a, b in zip(res[0][1], res[1][1]):
+        assert ((a - b).abs() <= 1e-7 + 1e-4 * a.abs()).all()
+
+
+def test_no_grad_forward_skips_the_backward_preparation(orc, scenes, rast, gpu):
+    """Evaluation (torch.no_grad(), or no input requiring a gradient): the autograd node tells the library that no backward follows
+    (options.forward_only); outputs are bit-identical to the training-mode forward."""
+    import torch
+    from conftest import settings_from
+    P, W, H = 4000, 160, 112
+    sc = scenes.synth(P, 311)
+    cam = scenes.camera(0, 3, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    kw = dict(means3D=t(sc["means3D"]), means2D=torch.zeros((P, 3), device=gpu), opacities=t(sc["opacities"]), shs=t(sc["shs"]),
+              scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    with torch.no_grad():
+        c0, r0, d0 = rast.GaussianRasterizer(rs)(**kw)
+    kw["means3D"] = kw["means3D"].clone().requires_grad_(True)
+    c1, r1, d1 = rast.GaussianRasterizer(rs)(**kw)
+    assert torch.equal(c0, c1.detach()) and torch.equal(r0, r1) and torch.equal(d0, d1)
+    o = orc.render(sc, cam, None)
+    assert np.array_equal(bits(c0.cpu().numpy()), bits(o["out_color"]))
