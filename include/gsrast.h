@@ -276,6 +276,53 @@ int gsrast_activate_backward(int P, const float* rotation, const float* rot_res,
                              float* d_rotation, float* d_scaling, float* d_rot_res, float* d_opacity_logit, float* d_trbf,
                              void* stream);
 
+/* ---- rank 3 as SURVEY.md 8f wrote it: the epilogue FUSED INTO the per-Gaussian kernels (K1 / K7) ----
+ * gsrast_forward_raw / gsrast_backward_raw are gsrast_forward_ex / gsrast_backward_ex taking the model's RAW leaves
+ * (scene/saro_gaussian.py:306-319: _xyz, _rotation, _scaling, _opacity, _features_dc, _features_rest) and the optional deformation
+ * residuals of get_deformation (:807-847) instead of activated attributes: the activations above run in registers inside
+ * preprocess_fwd / preprocess_color, the chain rule inside preprocess_bwd, and the [P][M][3] coefficient tensor
+ * (cat(dc, rest) + residual: 192 B / Gaussian written by the model and re-read by the rasterizer, and back) is never materialised.
+ * The rasterizer's outputs and state are bit-identical to gsrast_activate_forward followed by gsrast_forward_ex.
+ * The reference-shaped entry points are untouched; this pair is additional.  M in {4, 16}; rotation, features_dc, features_rest,
+ * shs_res and the matching gradient arrays 16-byte aligned.  NULL = absent optional residual. */
+typedef struct gsrast_raw_inputs {
+    const float* xyz;             /* [P][3]  _xyz */
+    const float* motion_res;      /* [P][3]  or NULL: means3D = xyz + motion_res */
+    const float* rotation;        /* [P][4]  _rotation (not normalised) */
+    const float* rot_res;         /* [P][7]  or NULL: [:, :4] added to rotation, [:, 4:] to scaling, before the activations */
+    const float* scaling;         /* [P][3]  _scaling (log scale) */
+    const float* opacity_logit;   /* [P]     _opacity */
+    const float* trbf;            /* [P]     or NULL: opacity = sigmoid(logit) * trbf */
+    const float* features_dc;     /* [P][1][3] */
+    const float* features_rest;   /* [P][M-1][3] */
+    const float* shs_res;         /* [P][M][3] or NULL */
+} gsrast_raw_inputs;
+typedef struct gsrast_raw_grads {   /* every array is fully overwritten */
+    float* dL_dmean2D;            /* [P][3]  screen-space gradient (densification statistic), .z = 0 */
+    float* d_xyz;                 /* [P][3]  = the gradient of motion_res too */
+    float* d_rotation;            /* [P][4] */
+    float* d_scaling;             /* [P][3] */
+    float* d_rot_res;             /* [P][7]  or NULL ({d_rotation, d_scaling} side by side) */
+    float* d_opacity_logit;       /* [P] */
+    float* d_trbf;                /* [P]     or NULL */
+    float* d_features_dc;         /* [P][1][3]    } or both NULL when d_shs_res is given (its rows are [dc | rest]) */
+    float* d_features_rest;       /* [P][M-1][3]  } */
+    float* d_shs_res;             /* [P][M][3] or NULL; requires shs_res */
+} gsrast_raw_grads;
+int gsrast_forward_raw(gsrast_context* ctx, const gsrast_options* options,
+                       gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
+                       gsrast_alloc_fn binning_alloc, void* binning_ctx,
+                       gsrast_alloc_fn image_alloc, void* image_ctx,
+                       int P, int D, int M, const float* background, int width, int height,
+                       const gsrast_raw_inputs* inputs, float scale_modifier,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, float* out_color, float* out_depth, int* radii, void* stream);
+int gsrast_backward_raw(const gsrast_options* options, int P, int D, int M, int R, const float* background, int width, int height,
+                        const gsrast_raw_inputs* inputs, float scale_modifier,
+                        const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                        const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                        const float* dL_dpix, const gsrast_raw_grads* grads, void* stream);
+
 /* ---- "next" row, rank 4 (third item): Adam step of the per-Gaussian parameter groups with a PER-ROW learning rate ----
  * Replaces torch.optim.Adam(l, lr=0.0, eps=1e-15, fused=True) for the groups of scene/saro_gaussian.py:306-323 whose
  * 'lr' update_learning_rate (:345-398) sets to lr * inv_intergral, a [P,1] tensor.  One launch for up to 8 groups:

@@ -565,16 +565,24 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
                              radii, stream);
 }
 
-int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
+// The forward behind gsrast_forward_ex (rawin == nullptr) and gsrast_forward_raw (rawin: means3D / opacities / scales / rotations
+// are then the model's raw leaves, shs a non-null placeholder; the per-Gaussian kernels run as their RAW instantiations).
+static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                       gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_alloc_fn binning_alloc,
                       void* binning_ctx, gsrast_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
                       const float* background, int width, int height, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales,
                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
                       const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream)
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream,
+                      const gsrast_raw_inputs* rawin)
 {
-    (void)prefiltered; // the reference only traps when a prefiltered point is culled (auxiliary.h:156-160)
+    (void)prefiltered;
+    RawArgs raw{};
+    if (rawin) {
+        raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
+        raw.features_dc = rawin->features_dc; raw.features_rest = rawin->features_rest; raw.shs_res = rawin->shs_res;
+    } // the reference only traps when a prefiltered point is culled (auxiliary.h:156-160)
     const gsrast_options o = options ? *options : snapshot_defaults();
     if (!options_valid(o)) return fail(GSRAST_E_ARG, "forward: bad option value");
     if (!ctx) ctx = thread_context();
@@ -633,6 +641,14 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     // LDS-bound run_scatter_rows it starves itself and delays the blend) -- it forks at entry, which was the best of those by ~20 us.
     // The 64 B / Gaussian zero-fill of the backward's gradient records follows on the side stream, under the VALU-bound forward blend.
     bool color_launched = false;
+    // Every exit after the fork must order the caller's stream behind the side stream: the colour kernel and the zero-fill write
+    // into the geometry buffer, which the caller is free to release (on `s`) as soon as this function has returned -- an error
+    // return (allocation failure, overflow, a failed launch) included: those drain the side stream.  The normal path enqueues the
+    // two waits itself (in front of / behind the blend) and disarms the guard.
+    struct SideJoinGuard {
+        SideStream*& side; hipStream_t s; bool& launched; bool joined = false;
+        ~SideJoinGuard() { if (launched && side && !joined) (void)hipStreamSynchronize(side->stream); }    // error path: cost is irrelevant
+    } side_guard{ side, s, color_launched };
     auto launch_color = [&]() -> int {
         if (color_launched) return GSRAST_OK;
         color_launched = true;
@@ -643,9 +659,6 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         }
         {
             ProfScope ps(K_COLOR, cs);
-            // persistent workgroups (six 25-KB workgroups fit a compute unit), each walks its blocks with the next one's loads in flight
-            const int nblocks = (P + PP_THREADS - 1) / PP_THREADS;
-            const int grid = std::min(nblocks, COLOR_GRID);
             // d(colour)/d(view direction) for the backward (36 B / Gaussian), unless the caller said that no backward will follow
             const bool want_shd = shs && !colors_precomp && D > 0 && !o.forward_only;
             float4* sA = want_shd ? at<float4>(geom, GL.shdA) : nullptr;
@@ -655,10 +668,14 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
             unsigned char* cl = at<unsigned char>(geom, GL.clamped);
             float4* gz = side ? nullptr : at<float4>(geom, GL.grec);
             const bool staged = sh_in && M * 3 <= PP_SH_MAX && ((M * 3) & 3) == 0 && ((uintptr_t)sh_in & 15) == 0;
-            if (staged && M * 3 == PP_SH_MAX)
-                preprocess_color_kernel<PP_SH_MAX><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, cam_pos, rec2, cl, gz, sA, sB, sC);
+            const int grid = (P + PP_THREADS - 1) / PP_THREADS;
+            if (rawin) {        // (gsrast_forward_raw has checked M and the alignment of the three SH arrays)
+                if (M * 3 == PP_SH_MAX) preprocess_color_kernel<PP_SH_MAX, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
+                else preprocess_color_kernel<0, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
+            } else if (staged && M * 3 == PP_SH_MAX)
+                preprocess_color_kernel<PP_SH_MAX, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
             else if (staged)
-                preprocess_color_kernel<0><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, cam_pos, rec2, cl, gz, sA, sB, sC);
+                preprocess_color_kernel<0, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
             else
                 preprocess_color_direct_kernel<<<(P + 255) / 256, 256, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, cam_pos, rec2, cl, gz, sA, sB, sC);
             hipError_t e = hipGetLastError();
@@ -674,11 +691,18 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
-        preprocess_fwd_kernel<<<(P + PF_THREADS - 1) / PF_THREADS, PF_THREADS, 0, s>>>(
-            P, means3D, scales, rotations, opacities, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
-            tiles, rect, at<float4>(geom, GL.binrec), kA, vA,
-            (runbin && o.tile_clip) ? 1 : 0, at<uint32_t>(img, IL.bucket_cnt),
-            bucket_sort ? at<uint32_t>(geom, GL.zrange) : nullptr, at<uint32_t>(geom, GL.bk_count), bucket_sort ? (int)nbk * BK_XCD : 0);
+        const int pf_grid = (P + PF_THREADS - 1) / PF_THREADS;
+        const int clip = (runbin && o.tile_clip) ? 1 : 0;
+        uint32_t* zr = bucket_sort ? at<uint32_t>(geom, GL.zrange) : nullptr;
+        const int nzero = bucket_sort ? (int)nbk * BK_XCD : 0;
+        if (rawin)
+            preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
+                P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
+                tiles, rect, at<float4>(geom, GL.binrec), kA, vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
+        else
+            preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
+                P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
+                tiles, rect, at<float4>(geom, GL.binrec), kA, vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -806,7 +830,7 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
         default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
         }
         GS_LAUNCHED("blend_fwd");
-        if (side) GS_HIP(hipStreamWaitEvent(s, side->join2, 0));      // the gradient records are zero before anything after this forward
+        if (side) { GS_HIP(hipStreamWaitEvent(s, side->join2, 0)); side_guard.joined = true; }      // the gradient records are zero before anything after this forward
         return GSRAST_OK;
     };
 
@@ -919,6 +943,42 @@ int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
     }
     { int rc = launch_blend(plist, runbin && R > 0 && Q > 0); if (rc != GSRAST_OK) return rc; }
     return (int)R;
+}
+
+int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
+                      gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_alloc_fn binning_alloc,
+                      void* binning_ctx, gsrast_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                      const float* background, int width, int height, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales,
+                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream)
+{
+    return forward_impl(ctx, options, geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, stream, nullptr);
+}
+
+static const char* raw_inputs_check(int P, int M, const gsrast_raw_inputs* in)
+{
+    if (!in) return "raw: NULL inputs";
+    if (P == 0) return nullptr;
+    if (!in->xyz || !in->rotation || !in->scaling || !in->opacity_logit || !in->features_dc || (M > 1 && !in->features_rest)) return "raw: NULL required input";
+    if (M < 1 || M * 3 > PP_SH_MAX || ((M * 3) & 3)) return "raw: M must be 4 or 16 (SH rows of a multiple of 16 bytes, at most 16 coefficients)";
+    if (((uintptr_t)in->rotation | (uintptr_t)in->features_dc | (uintptr_t)in->features_rest | (uintptr_t)in->shs_res) & 15) return "raw: rotation / features_dc / features_rest / shs_res must be 16-byte aligned";
+    return nullptr;
+}
+
+int gsrast_forward_raw(gsrast_context* ctx, const gsrast_options* options,
+                       gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_alloc_fn binning_alloc, void* binning_ctx,
+                       gsrast_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width, int height,
+                       const gsrast_raw_inputs* in, float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, float* out_color, float* out_depth, int* radii, void* stream)
+{
+    if (const char* e = raw_inputs_check(P, M, in)) return fail(GSRAST_E_ARG, e);
+    return forward_impl(ctx, options, geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M, background, width, height,
+                        in->xyz, in->features_dc /* "there are SH coefficients" */, nullptr, in->opacity_logit, in->scaling, scale_modifier, in->rotation, nullptr,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, radii, stream, in);
 }
 
 int gsrast_activate_forward(int P, int M, const float* xyz, const float* motion_res, const float* rotation,
@@ -1263,14 +1323,22 @@ int gsrast_backward(int P, int D, int M, int R, const float* background, int wid
                               dL_dscale, dL_drot, stream);
 }
 
-int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R, const float* background, int width, int height,
+static int backward_impl(const gsrast_options* options, int P, int D, int M, int R, const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                        float scale_modifier, const float* rotations, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                        float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
                        const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream)
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
+                       const gsrast_raw_inputs* rawin, const gsrast_raw_grads* rawout)
 {
+    RawArgs raw{}; RawGrads rawg{};
+    if (rawin) {
+        raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
+        raw.features_dc = rawin->features_dc; raw.features_rest = rawin->features_rest; raw.shs_res = rawin->shs_res;
+        rawg.d_rot_res = rawout->d_rot_res; rawg.d_trbf = rawout->d_trbf; rawg.d_dc = rawout->d_features_dc; rawg.d_rest = rawout->d_features_rest;
+        rawg.d_shs_res = rawout->d_shs_res;
+    }
     const gsrast_options o = options ? *options : snapshot_defaults();
     if (!options_valid(o)) return fail(GSRAST_E_ARG, "backward: bad option value");
     hipStream_t s = (hipStream_t)stream;
@@ -1310,6 +1378,7 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
     // (options.forward_only, passed to both calls by a caller that changed its mind).
     SideStream* side = nullptr;
     if (do_blend && use_sh && D > 0 && o.forward_only) {
+        if (rawin) return fail(GSRAST_E_ARG, "backward_raw: the forward was run with forward_only");
         if (o.side_stream && R > 0) side = side_stream_of(thread_context());
         hipStream_t ds = s;
         if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); ds = side->stream; }
@@ -1366,14 +1435,56 @@ int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R
     if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
-        preprocess_bwd_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
-            P, D, M, means3D, radii, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
+        if (rawin)
+        preprocess_bwd_kernel<true><<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
+            P, D, M, means3D, radii, raw, rawg, shs, at<unsigned char>(geom, GL.clamped),
+            at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC),
+            scales, rotations, cov, cam, reinterpret_cast<const float4*>(grec),
+            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0);
+        else
+        preprocess_bwd_kernel<false><<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
+            P, D, M, means3D, radii, raw, rawg, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
             at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC),
             use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, reinterpret_cast<const float4*>(grec),
             dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, (use_sh && o.sh_grad_factors) ? 1 : 0);
         GS_LAUNCHED("preprocess_bwd");
     }
     return GSRAST_OK;
+}
+
+int gsrast_backward_ex(const gsrast_options* options, int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                       float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                       const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream)
+{
+    return backward_impl(options, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D,
+                         dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, stream, nullptr, nullptr);
+}
+
+int gsrast_backward_raw(const gsrast_options* options, int P, int D, int M, int R, const float* background, int width, int height,
+                        const gsrast_raw_inputs* in, float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* campos,
+                        float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                        const float* dL_dpix, const gsrast_raw_grads* out, void* stream)
+{
+    if (const char* e = raw_inputs_check(P, M, in)) return fail(GSRAST_E_ARG, e);
+    if (!out) return fail(GSRAST_E_ARG, "backward_raw: NULL gradient set");
+    if (P == 0) return GSRAST_OK;
+    if (!out->dL_dmean2D || !out->d_xyz || !out->d_rotation || !out->d_scaling || !out->d_opacity_logit) return fail(GSRAST_E_ARG, "backward_raw: NULL required gradient output");
+    if ((in->rot_res != nullptr) != (out->d_rot_res != nullptr) && in->rot_res == nullptr) return fail(GSRAST_E_ARG, "backward_raw: d_rot_res without rot_res");
+    if (out->d_shs_res ? !in->shs_res : (!out->d_features_dc || (M > 1 && !out->d_features_rest)))
+        return fail(GSRAST_E_ARG, "backward_raw: give d_features_dc + d_features_rest, or (with shs_res) d_shs_res whose rows hold both");
+    if (((uintptr_t)out->d_rotation | (uintptr_t)out->d_features_dc | (uintptr_t)out->d_features_rest | (uintptr_t)out->d_shs_res) & 15)
+        return fail(GSRAST_E_ARG, "backward_raw: d_rotation / d_features_dc / d_features_rest / d_shs_res must be 16-byte aligned");
+    gsrast_options o = options ? *options : snapshot_defaults();
+    o.sh_grad_factors = 0;      // the factor exchange needs the rasterizer's own dL/dsh layout
+    float* sh_marker = out->d_shs_res ? out->d_shs_res : out->d_features_dc;
+    return backward_impl(&o, P, D, M, R, background, width, height, in->xyz, in->features_dc, nullptr, in->scaling, scale_modifier, in->rotation, nullptr,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, out->dL_dmean2D,
+                         nullptr, out->d_opacity_logit, nullptr, out->d_xyz, nullptr, sh_marker, out->d_scaling, out->d_rotation, stream, in, out);
 }
 
 int gsrast_debug_export(int P, int R, int width, int height, const char* geom_buffer, const char* binning_buffer,

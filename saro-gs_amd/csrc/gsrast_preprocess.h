@@ -48,6 +48,50 @@ __device__ __forceinline__ Cam load_cam(const CamArgs& a)
     return c;
 }
 
+// ---- raw-parameter entry points (gsrast_forward_raw / gsrast_backward_raw) ------------------------------
+// SaRO-GS hands the rasterizer ACTIVATED attributes: exp(_scaling), normalize(_rotation), sigmoid(_opacity) * trbf,
+// cat(_features_dc, _features_rest) + residuals (scene/saro_gaussian.py:807-847, activations :39-47) -- a [P,16,3] tensor written
+// by the model and re-read here, and the reverse in the backward.  With RAW = true the per-Gaussian kernels take the model's
+// leaves (and the optional deformation residuals) themselves and apply the activations in registers; the backward applies the
+// chain rule and writes the gradients of the leaves.  The expressions are epilogue_small_fwd / _bwd_kernel's (gsrast_epilogue.h),
+// operation for operation, so the rasterizer sees bit-identical inputs either way.
+struct RawArgs {
+    const float* motion_res;     // [P][3] or null   motion = xyz + motion_res
+    const float* rot_res;        // [P][7] or null   rot = normalize(rotation + [:, :4]), scale = exp(scaling + [:, 4:])
+    const float* trbf;           // [P] or null      opacity = sigmoid(logit) * trbf
+    const float* opacity_logit;  // [P]              (the backward needs it again; the forward gets it as `opacities`)
+    const float* features_dc;    // [P][3]
+    const float* features_rest;  // [P][(M-1)*3]     shs = cat(dc, rest) + shs_res
+    const float* shs_res;        // [P][M*3] or null
+};
+struct RawGrads {
+    float* d_rot_res;            // [P][7] or null
+    float* d_trbf;               // [P] or null
+    float* d_dc;                 // [P][3]           (null when d_shs_res is given: the caller slices that)
+    float* d_rest;               // [P][(M-1)*3]     ( " )
+    float* d_shs_res;            // [P][M*3] or null
+};
+__device__ __forceinline__ void raw_mean(const RawArgs& r, int i, float p[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = p[k] + (r.motion_res ? r.motion_res[3 * (size_t)i + k] : 0.0f);
+}
+// in: q = _rotation row, s = _scaling row.  out: q = normalised quaternion, s = exp(.), x = rotation + residual (what was normalised)
+__device__ __forceinline__ void raw_rot_scale(const RawArgs& r, int i, float4& q, float s[3], float4& x)
+{
+    if (r.rot_res) {
+        const float* rr = r.rot_res + 7 * (size_t)i;
+        q.x += rr[0]; q.y += rr[1]; q.z += rr[2]; q.w += rr[3];
+        s[0] += rr[4]; s[1] += rr[5]; s[2] += rr[6];
+    }
+    x = q;
+    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);     // F.normalize, eps 1e-12
+    q = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+#pragma unroll
+    for (int k = 0; k < 3; k++) s[k] = expf(s[k]);
+}
+__device__ __forceinline__ float raw_sigmoid(float logit) { return 1.0f / (1.0f + expf(-logit)); }
+
 struct M3 { float m[3][3]; };  // m[c][r], column-major like the reference's glm::mat3
 
 __device__ __forceinline__ void xform4x3(const float p[3], const float* M, float o[3])
@@ -217,10 +261,6 @@ __device__ __forceinline__ void sh_dir_derivs(int deg, float x, float y, float z
 // reads that follow), and the backward writes dL/dsh back the same way.
 constexpr int PP_THREADS = 128;
 constexpr int PP_SH_MAX = 48;                   // (3+1)^2 coefficients x 3 channels
-#ifndef GSRAST_COLOR_GRID
-#define GSRAST_COLOR_GRID 1536              // persistent workgroups of the colour kernel: 256 compute units x the six that fit one (LDS)
-#endif
-constexpr int COLOR_GRID = GSRAST_COLOR_GRID;
 constexpr int PP_SH_STRIDE = PP_SH_MAX + 1;     // +1: conflict-free per-lane reads.  25 KB of LDS per workgroup = 6 workgroups per CU;
                                                 // both kernels are latency-bound at that occupancy (4 per CU: +17 %, 3: +40 %)
 
@@ -245,109 +285,171 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P,
     }
 }
 
+// RAW: the rows of dL/dsh leave as the gradients of the model's two SH leaves, d_dc [P][3] and d_rest [P][row-3] (both blocks
+// start 16-byte aligned: 128 rows), whole float4s coalesced, the last block's odd floats one by one.
+__device__ __forceinline__ void stage_sh_out_split(float* __restrict__ d_dc, float* __restrict__ d_rest, int P, int row, int base, const float* lds)
+{
+    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
+    const int rrow = row - 3;
+    if (rrow > 0) {
+        const int nfr = ng * rrow, n4r = nfr >> 2;
+        float* dst = d_rest + (size_t)base * rrow;
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+        for (int q = threadIdx.x; q < n4r; q += PP_THREADS) {
+            float e4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int f = q * 4 + e, g = f / rrow, c = f - g * rrow; e4[e] = lds[g * PP_SH_STRIDE + 3 + c]; }
+            dst4[q] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        }
+        if ((int)threadIdx.x < (nfr & 3)) { const int f = n4r * 4 + threadIdx.x, g = f / rrow, c = f - g * rrow; dst[f] = lds[g * PP_SH_STRIDE + 3 + c]; }
+    }
+    {
+        const int nfd = ng * 3, n4d = nfd >> 2;
+        float* dst = d_dc + (size_t)base * 3;
+        if ((int)threadIdx.x < n4d) {
+            float e4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int f = threadIdx.x * 4 + e, g = f / 3, c = f - g * 3; e4[e] = lds[g * PP_SH_STRIDE + c]; }
+            reinterpret_cast<float4*>(dst)[threadIdx.x] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        }
+        if ((int)threadIdx.x < (nfd & 3)) { const int f = n4d * 4 + threadIdx.x, g = f / 3, c = f - g * 3; dst[f] = lds[g * PP_SH_STRIDE + c]; }
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // K1 forward, colour half (forward.cu:20-71 computeColorFromSH, the colour lines of :237-246): SH -> RGB + clamp flags, or the
 // caller's colors_precomp, into rec2.  It depends on nothing the geometry half produces -- so gsrast_forward runs it on a
 // low-priority side stream, beside the geometry kernel, the depth sort and the binning (all latency-bound), and joins it in
 // front of the blend, the first kernel to read a colour.  Evaluated for every Gaussian (a culled one is never read).
 //
-// Round 3: (i) while a Gaussian's coefficient block sits in LDS the kernel also evaluates d(colour)/d(view direction)
+// Round 3: while a Gaussian's coefficient block sits in LDS the kernel also evaluates d(colour)/d(view direction)
 // (backward.cu:78-127 dRGBdx / dy / dz, sh_dir_derivs above) and stores the nine floats (shdA / shdB / shdC, 36 B) for
 // preprocess_bwd_kernel -- round 2 re-read the 12*M-byte blocks for that in the backward (sh_dir_derivs_kernel, as long as the
-// blend backward itself at 3 M Gaussians); (ii) PERSISTENT workgroups with a register double buffer: a workgroup requests the
-// NEXT block's twelve 16-byte loads per lane right after it has parked the current block in LDS, so the loads travel under the
-// barrier, the SH evaluation and the stores -- the one-block-per-workgroup form had its bytes in flight only during the first
-// third of a workgroup's life (3.1 TB/s alone, with six 25-KB workgroups per CU).
-// ROW: floats per SH row known at compile time (48 for the reference's M = 16), 0 = runtime (other M, or unaligned input).
-// Loads are unconditional with clamped indices (a short last block re-reads its last 16 bytes): no branch around a load, so the
-// compiler never has to drain the loads in flight at a join.
-template <int ROW>
-__device__ __forceinline__ void color_load_block(const float* __restrict__ shs, int P, int row, int blk, float4 (&v)[PP_SH_MAX / 4])
+// blend backward itself at 3 M Gaussians).
+// The block's rows enter LDS (row stride PP_SH_STRIDE floats) through coalesced 16-byte loads; loads are unconditional with
+// clamped indices (a short last block re-reads its last 16 bytes) and all of a lane's loads are requested before the first LDS
+// store.  ROW: floats per SH row known at compile time (48 for the reference's M = 16), 0 = runtime.
+// RAW: the rows are cat(features_dc [P][3], features_rest [P][row-3]) + shs_res [P][row] (RawArgs), assembled in LDS: dc and rest are
+// parked first, then the residual is added in place by the lane that loaded it (one add per element, like the model's `+`).
+template <int ROW, bool RAW>
+__device__ __forceinline__ void color_stage_rows(const float* __restrict__ shs, const RawArgs& raw, int P, int row_rt, int blk, float* lds)
 {
     const int base = blk * PP_THREADS;
     const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
-    const int r = ROW ? ROW : row;
-    const int n4 = (ng * r) >> 2;
-    const float4* src4 = reinterpret_cast<const float4*>(shs + (size_t)base * r);
+    const int row = ROW ? ROW : row_rt;
+    if (!RAW) {
+        const int n4 = (ng * row) >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(shs + (size_t)base * row);
+        float4 v[PP_SH_MAX / 4];
 #pragma unroll
-    for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = src4[q < n4 ? q : n4 - 1]; }
-}
-template <int ROW>
-__device__ __forceinline__ void color_park_block(int P, int row, int blk, const float4 (&v)[PP_SH_MAX / 4], float* lds)
-{
-    const int base = blk * PP_THREADS;
-    const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
-    const int r = ROW ? ROW : row;
-    const int n4 = (ng * r) >> 2;
+        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = src4[q < n4 ? q : n4 - 1]; }
 #pragma unroll
-    for (int u = 0; u < PP_SH_MAX / 4; u++) {
-        const int q = threadIdx.x + u * PP_THREADS;
-        if (q < n4) {
-            const int f = q * 4, g = f / r, c = f - g * r;
-            float* d = lds + g * PP_SH_STRIDE + c;
-            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        for (int u = 0; u < PP_SH_MAX / 4; u++) {
+            const int q = threadIdx.x + u * PP_THREADS;
+            if (q < n4) {
+                const int f = q * 4, g = f / row, c = f - g * row;
+                float* d = lds + g * PP_SH_STRIDE + c;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
+        }
+        return;
+    }
+    // RAW.  rest: ng * (row - 3) floats from a 16-byte aligned start (128 rows are a multiple of 16 bytes whatever the row length);
+    // whole float4s with coalesced loads, the at most three floats behind them (last block only) one by one.
+    const int rrow = row - 3;
+    const int nfr = ng * rrow, n4r = nfr >> 2;
+    const float* rsrc = raw.features_rest + (size_t)base * rrow;
+    const float4* rsrc4 = reinterpret_cast<const float4*>(rsrc);
+    const int nfd = ng * 3, n4d = nfd >> 2;
+    const float* dsrc = raw.features_dc + (size_t)base * 3;
+    const int n4s = (ng * row) >> 2;                               // residual: whole rows of a multiple of four floats
+    const float4* ssrc4 = reinterpret_cast<const float4*>(raw.shs_res ? raw.shs_res + (size_t)base * row : raw.features_rest);
+    float4 v[PP_SH_MAX / 4], vs[PP_SH_MAX / 4], vd;
+#pragma unroll
+    for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = n4r > 0 ? rsrc4[q < n4r ? q : n4r - 1] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    vd = n4d > 0 ? reinterpret_cast<const float4*>(dsrc)[(int)threadIdx.x < n4d ? (int)threadIdx.x : n4d - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (raw.shs_res) {
+#pragma unroll
+        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; vs[u] = ssrc4[q < n4s ? q : n4s - 1]; }
+    }
+    if (rrow > 0) {
+#pragma unroll
+        for (int u = 0; u < PP_SH_MAX / 4; u++) {
+            const int q = threadIdx.x + u * PP_THREADS;
+            if (q < n4r) {
+                const float e4[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const int f = q * 4 + e, g = f / rrow, c = f - g * rrow; lds[g * PP_SH_STRIDE + 3 + c] = e4[e]; }
+            }
+        }
+        if ((int)threadIdx.x < (nfr & 3)) { const int f = n4r * 4 + threadIdx.x, g = f / rrow, c = f - g * rrow; lds[g * PP_SH_STRIDE + 3 + c] = rsrc[f]; }
+    }
+    if ((int)threadIdx.x < n4d) {
+        const float e4[4] = { vd.x, vd.y, vd.z, vd.w };
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int f = threadIdx.x * 4 + e, g = f / 3, c = f - g * 3; lds[g * PP_SH_STRIDE + c] = e4[e]; }
+    }
+    if ((int)threadIdx.x < (nfd & 3)) { const int f = n4d * 4 + threadIdx.x, g = f / 3, c = f - g * 3; lds[g * PP_SH_STRIDE + c] = dsrc[f]; }
+    if (raw.shs_res) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PP_SH_MAX / 4; u++) {
+            const int q = threadIdx.x + u * PP_THREADS;
+            if (q < n4s) {
+                const int f = q * 4, g = f / row, c = f - g * row;
+                float* d = lds + g * PP_SH_STRIDE + c;
+                d[0] = d[0] + vs[u].x; d[1] = d[1] + vs[u].y; d[2] = d[2] + vs[u].z; d[3] = d[3] + vs[u].w;
+            }
         }
     }
 }
 
-// SH rows through LDS: M * 3 <= PP_SH_MAX floats per row, a multiple of four, 16-byte aligned base (checked by the host).
-template <int ROW>
+// SH rows through LDS: M * 3 <= PP_SH_MAX floats per row, a multiple of four, 16-byte aligned bases (checked by the host).
+// One workgroup per block of PP_THREADS Gaussians.  (Round 3 also measured PERSISTENT workgroups that request the next block's
+// loads before they evaluate the current one -- 1536 / 1024 / 768 / 512 workgroups: the kernel alone stayed at 198-203 us for
+// 3 M Gaussians, 80 us for 1 M, and beside the geometry kernel its 134 VGPRs x 3 waves per SIMD left that kernel no room
+// (157 -> 264 us).  More bytes in flight do not help: ~37 MB are in flight either way.)
+template <int ROW, bool RAW>
 __global__ void __launch_bounds__(PP_THREADS)
-preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs, RawArgs raw,
                         const float* __restrict__ campos_dev,
                         float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
                         float4* __restrict__ grec4 /* [P][4] or null: the backward's gradient records, zero-filled here when there is no side stream to do it */,
                         float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC /* null: no backward will follow (or D = 0) */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
-    const int nblocks = (P + PP_THREADS - 1) / PP_THREADS;
-    const int row = M * 3;
-    const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
-    float4 v[PP_SH_MAX / 4];
-    float pn[3];
-    int blk = blockIdx.x;           // the host launches at most nblocks workgroups
-    {   // (the mean first: the loop copies it out of the prefetch registers at its end, and loads return in order)
-        const int i0 = blk * PP_THREADS + threadIdx.x, ic0 = i0 < P ? i0 : P - 1;
-        pn[0] = means3D[3 * ic0]; pn[1] = means3D[3 * ic0 + 1]; pn[2] = means3D[3 * ic0 + 2];
-        color_load_block<ROW>(shs, P, row, blk, v);
+    const int blk = blockIdx.x;
+    const int i = blk * PP_THREADS + threadIdx.x;
+    if (grec4) {   // this block's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
+        const size_t q0 = (size_t)blk * PP_THREADS * 4, q1 = (size_t)P * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
-    for (; blk < nblocks; blk += gridDim.x) {
-        const int i = blk * PP_THREADS + threadIdx.x;
-        if (grec4) {   // this block's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
-            const size_t q0 = (size_t)blk * PP_THREADS * 4, q1 = (size_t)P * 4;
+    const int ic = i < P ? i : P - 1;
+    float p[3] = { means3D[3 * (size_t)ic], means3D[3 * (size_t)ic + 1], means3D[3 * (size_t)ic + 2] };       // requested before the staging barrier
+    if (RAW) raw_mean(raw, ic, p);
+    const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
+    color_stage_rows<ROW, RAW>(shs, raw, P, M * 3, blk, sh_lds);
+    __syncthreads();
+    if (i < P) {
+        const float* my_sh = sh_lds + threadIdx.x * PP_SH_STRIDE;
+        float col[3];
+        unsigned cl = 0;
+        sh_to_rgb(D, p, campos, my_sh, col);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const size_t q = q0 + (size_t)k * PP_THREADS + threadIdx.x; if (q < q1) grec4[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
+        if (shdA) {    // same expressions on the same operands as sh_dir_derivs_kernel: the same bits
+            const float o0 = p[0] - campos[0], o1 = p[1] - campos[1], o2 = p[2] - campos[2];
+            const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+            const float x = o0 / len, y = o1 / len, z = o2 / len;
+            float dx[3], dy[3], dz[3];
+            sh_dir_derivs(D, x, y, z, my_sh, dx, dy, dz);
+            shdA[i] = make_float4(dx[0], dx[1], dx[2], dy[0]);
+            shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
+            shdC[i] = dz[2];
         }
-        const float p[3] = { pn[0], pn[1], pn[2] };
-        if (blk != (int)blockIdx.x) __syncthreads();          // the previous block's rows have been read
-        color_park_block<ROW>(P, row, blk, v, sh_lds);
-        {   // the next block's loads leave now and travel under everything below (the last round re-reads its own block: harmless)
-            const int nb = blk + (int)gridDim.x < nblocks ? blk + (int)gridDim.x : blk;
-            const int i1 = nb * PP_THREADS + threadIdx.x, ic1 = i1 < P ? i1 : P - 1;
-            pn[0] = means3D[3 * ic1]; pn[1] = means3D[3 * ic1 + 1]; pn[2] = means3D[3 * ic1 + 2];
-            color_load_block<ROW>(shs, P, row, nb, v);
-        }
-        __syncthreads();
-        if (i < P) {
-            const float* my_sh = sh_lds + threadIdx.x * PP_SH_STRIDE;
-            float col[3];
-            unsigned cl = 0;
-            sh_to_rgb(D, p, campos, my_sh, col);
-#pragma unroll
-            for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
-            if (shdA) {    // same expressions on the same operands as sh_dir_derivs_kernel: the same bits
-                const float o0 = p[0] - campos[0], o1 = p[1] - campos[1], o2 = p[2] - campos[2];
-                const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
-                const float x = o0 / len, y = o1 / len, z = o2 / len;
-                float dx[3], dy[3], dz[3];
-                sh_dir_derivs(D, x, y, z, my_sh, dx, dy, dz);
-                shdA[i] = make_float4(dx[0], dx[1], dx[2], dy[0]);
-                shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
-                shdC[i] = dz[2];
-            }
-            rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
-            clamped[i] = (unsigned char)cl;
-        }
+        rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+        clamped[i] = (unsigned char)cl;
     }
 }
 
@@ -397,9 +499,12 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
 #define GSRAST_PF_THREADS 256      // (1024-thread blocks shorten the depth-range reduction of the bucket scatter by 2 us, but beside the colour kernel they wait for whole-CU wave slots: 43 -> 107 us)
 #endif
 constexpr int PF_THREADS = GSRAST_PF_THREADS;
+// RAW (gsrast_forward_raw): means3D / scales / rotations / opacities are the model's _xyz / _scaling / _rotation / _opacity leaves
+// and `raw` carries the optional residuals; the activations happen right behind the loads (RawArgs above).
+template <bool RAW>
 __global__ void __launch_bounds__(PF_THREADS)
 preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ scales,
-                      const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ rotations, const float* __restrict__ opacities, RawArgs raw,
                       const float* __restrict__ cov3D_precomp, CamArgs cam_args, int* __restrict__ radii,
                       float* __restrict__ depths, float4* __restrict__ rec0, float4* __restrict__ rec1,
                       float* __restrict__ cov3D,
@@ -418,14 +523,21 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     // branches) put three more memory round trips into a latency-bound kernel.  Clamped index: lanes past P load a valid
     // element and never use it.
     const int ic = i < P ? i : P - 1;
-    const float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
+    float p[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
     float s_in[3] = { 0.f, 0.f, 0.f };
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!cov3D_precomp) {                                   // uniform
         s_in[0] = scales[3 * ic]; s_in[1] = scales[3 * ic + 1]; s_in[2] = scales[3 * ic + 2];
         q_in = reinterpret_cast<const float4*>(rotations)[ic];
     }
-    const float op_in = opacities[ic];
+    float op_in = opacities[ic];
+    if (RAW) {
+        raw_mean(raw, ic, p);
+        float4 x_unused;
+        raw_rot_scale(raw, ic, q_in, s_in, x_unused);
+        const float sg = raw_sigmoid(op_in);
+        op_in = raw.trbf ? sg * raw.trbf[ic] : sg;
+    }
     const Cam cam = load_cam(cam_args);
     int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
     if (i < P) {
@@ -644,8 +756,12 @@ sh_dir_derivs_kernel(int P, int D, int M, const float* __restrict__ means3D, con
 
 // K6 + K7 fused.  Every output row is written exactly once (zeros for culled Gaussians), so the
 // caller does not have to zero-fill the five output arrays.  dL/dsh leaves through LDS (coalesced).
+// RAW (gsrast_backward_raw): means3D / scales / rotations are the model's leaves as in preprocess_fwd_kernel<true>; the chain rule
+// through the activations (epilogue_small_bwd_kernel's expressions) is applied before the stores: dL_dmeans3D = d_xyz (= d_motion_res),
+// dL_dscale = d_scaling, dL_drot = d_rotation, dL_dopacity = d_opacity_logit, plus RawGrads (d_rot_res, d_trbf, the SH leaves).
+template <bool RAW>
 __global__ void __launch_bounds__(PP_THREADS)
-preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
+preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii, RawArgs raw, RawGrads rawg,
                       const float* __restrict__ shs /* only its presence matters: the coefficients are not read */,
                       const unsigned char* __restrict__ clamped,
                       const float4* __restrict__ shdA, const float4* __restrict__ shdB, const float* __restrict__ shdC /* sh_dir_derivs_kernel's output */,
@@ -668,12 +784,20 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // to sit behind the staging barrier, the radius test and each other -- five memory round trips in a latency-bound kernel
     const int ic = i < P ? i : P - 1;
     const int radius_in = radii[ic];
-    const float mean[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
+    float mean[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
     float s[3] = { 0.f, 0.f, 0.f };
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scales) {                                           // uniform
         s[0] = scales[3 * ic]; s[1] = scales[3 * ic + 1]; s[2] = scales[3 * ic + 2];
         q_in = reinterpret_cast<const float4*>(rotations)[ic];
+    }
+    float4 raw_x = make_float4(0.f, 0.f, 0.f, 0.f);        // RAW: rotation + residual, before normalisation
+    float raw_sg = 0.0f, raw_tb = 1.0f;                     // RAW: sigmoid(logit), trbf
+    if (RAW) {
+        raw_mean(raw, ic, mean);
+        raw_rot_scale(raw, ic, q_in, s, raw_x);
+        raw_sg = raw_sigmoid(raw.opacity_logit[ic]);
+        raw_tb = raw.trbf ? raw.trbf[ic] : 1.0f;
     }
     // the Gaussian's gradient record: {dL/dmean2D.x, .y, dL/dconic a, b | c, dL/dopacity, dL/dr, dL/dg | dL/db, ...} -- three 16-byte
     // loads from one 64-byte line (zero for a Gaussian no tile listed)
@@ -691,6 +815,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool live = i < P && radius_in > 0;
     if (i < P) {    // the screen-space gradients leave in the reference's arrays (rasterize_points.cu:150-158), written once
         dL_dmean2D[3 * (size_t)i] = g2x; dL_dmean2D[3 * (size_t)i + 1] = g2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+        if (RAW) {      // d(opacity logit) = d_opacity * trbf * s (1 - s),  d(trbf) = d_opacity * s
+            const float go = gr1.y;
+            dL_dopacity[i] = go * raw_tb * raw_sg * (1.0f - raw_sg);
+            if (rawg.d_trbf) rawg.d_trbf[i] = go * raw_sg;
+        } else
         dL_dopacity[i] = gr1.y;
         if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = dcol[0]; dL_dcolor[3 * (size_t)i + 1] = dcol[1]; dL_dcolor[3 * (size_t)i + 2] = dcol[2]; }
         if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[i] = dcon;
@@ -711,6 +840,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
             for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)i + k] = 0.0f;
             reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RAW && rawg.d_rot_res) { float* o = rawg.d_rot_res + 7 * (size_t)i; for (int k = 0; k < 7; k++) o[k] = 0.0f; }
         }
     }
     if (live) {
@@ -819,6 +949,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         float ds[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) ds[k] = R.m[0][k] * dM.m[0][k] + R.m[1][k] * dM.m[1][k] + R.m[2][k] * dM.m[2][k];
+        if (RAW) {      // d(scaling + residual) = d_scale * scale
+#pragma unroll
+            for (int k = 0; k < 3; k++) ds[k] = ds[k] * s[k];
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)i + k] = ds[k];
 #define D_(cc, rr) (dM.m[rr][cc] * sm[cc])
@@ -829,10 +963,30 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         dq.z = 2.0f * x * (D_(1, 0) + D_(0, 1)) + 2.0f * r * (D_(2, 0) - D_(0, 2)) + 2.0f * z * (D_(1, 2) + D_(2, 1)) - 4.0f * y * (D_(2, 2) + D_(0, 0));
         dq.w = 2.0f * r * (D_(0, 1) - D_(1, 0)) + 2.0f * x * (D_(2, 0) + D_(0, 2)) + 2.0f * y * (D_(1, 2) + D_(2, 1)) - 4.0f * z * (D_(1, 1) + D_(0, 0));
 #undef D_
+        if (RAW) {      // d(rotation + residual) = (g - y <y, g>) / |x|,  y = x / |x|  (|x| < eps: the clamp is not differentiated)
+            const float4 g = dq;
+            const float nn = sqrtf(raw_x.x * raw_x.x + raw_x.y * raw_x.y + raw_x.z * raw_x.z + raw_x.w * raw_x.w);
+            if (nn >= 1e-12f) {
+                const float inv = 1.0f / nn;
+                const float4 yv = make_float4(raw_x.x * inv, raw_x.y * inv, raw_x.z * inv, raw_x.w * inv);
+                const float dot = yv.x * g.x + yv.y * g.y + yv.z * g.z + yv.w * g.w;
+                dq = make_float4((g.x - yv.x * dot) * inv, (g.y - yv.y * dot) * inv, (g.z - yv.z * dot) * inv, (g.w - yv.w * dot) * inv);
+            } else {
+                dq = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+            }
+            if (rawg.d_rot_res) {
+                float* o = rawg.d_rot_res + 7 * (size_t)i;
+                o[0] = dq.x; o[1] = dq.y; o[2] = dq.z; o[3] = dq.w; o[4] = ds[0]; o[5] = ds[1]; o[6] = ds[2];
+            }
+        }
         reinterpret_cast<float4*>(dL_drot)[i] = dq;
     }
     } // live
-    if (staged && !sh_factors) { __syncthreads(); stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds); }
+    if (staged && !sh_factors) {
+        __syncthreads();
+        if (RAW && !rawg.d_shs_res) stage_sh_out_split(rawg.d_dc, rawg.d_rest, P, M * 3, blockIdx.x * PP_THREADS, sh_lds);
+        else stage_sh_out(RAW ? rawg.d_shs_res : dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
+    }
 }
 
 // dL/dsh of a batch of N views from the N per-view factors (see sh_backward<FACTORS>):

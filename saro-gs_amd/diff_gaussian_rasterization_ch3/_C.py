@@ -38,7 +38,7 @@ EXPORTS = (
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward", "gsrast_linear_wgrad",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query",
-    "gsrast_forward_ex", "gsrast_backward_ex",
+    "gsrast_forward_ex", "gsrast_backward_ex", "gsrast_forward_raw", "gsrast_backward_raw",
 )
 
 
@@ -83,6 +83,18 @@ def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = Non
     return o
 
 
+class RawInputsStruct(C.Structure):
+    """gsrast_raw_inputs (include/gsrast.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("xyz", "motion_res", "rotation", "rot_res", "scaling", "opacity_logit", "trbf",
+                                          "features_dc", "features_rest", "shs_res")]
+
+
+class RawGradsStruct(C.Structure):
+    """gsrast_raw_grads (include/gsrast.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("dL_dmean2D", "d_xyz", "d_rotation", "d_scaling", "d_rot_res", "d_opacity_logit", "d_trbf",
+                                          "d_features_dc", "d_features_rest", "d_shs_res")]
+
+
 class AdamGroupStruct(C.Structure):
     """gsrast_adam_group (include/gsrast.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
@@ -116,6 +128,12 @@ def lib() -> C.CDLL:
     L.gsrast_forward_ex.argtypes = [vp, C.POINTER(OptionsStruct)] + L.gsrast_forward.argtypes
     L.gsrast_backward_ex.restype = ci
     L.gsrast_backward_ex.argtypes = [C.POINTER(OptionsStruct)] + L.gsrast_backward.argtypes
+    L.gsrast_forward_raw.restype = ci
+    L.gsrast_forward_raw.argtypes = [vp, C.POINTER(OptionsStruct), _ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci,
+                                     C.POINTER(RawInputsStruct), cf, vp, vp, vp, cf, cf, vp, vp, vp, vp]
+    L.gsrast_backward_raw.restype = ci
+    L.gsrast_backward_raw.argtypes = [C.POINTER(OptionsStruct), ci, ci, ci, ci, vp, ci, ci, C.POINTER(RawInputsStruct), cf, vp, vp, vp, cf, cf,
+                                      vp, vp, vp, vp, vp, C.POINTER(RawGradsStruct), vp]
     L.gsrast_options_init.restype = None
     L.gsrast_options_init.argtypes = [C.POINTER(OptionsStruct)]
     L.gsrast_context_create.restype = vp
@@ -435,6 +453,111 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         if rc != 0:
             raise _err(rc, "gsrast_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+# ---- raw-parameter entry points (include/gsrast.h: gsrast_forward_raw / gsrast_backward_raw; no counterpart in the reference's _C) ----
+RAW_NAMES = ("xyz", "motion_res", "rotation", "rot_res", "scaling", "opacity_logit", "trbf", "features_dc", "features_rest", "shs_res")
+
+
+def _raw_struct(raw: dict, dev: torch.device, P: int):
+    """raw: name -> tensor or None (RAW_NAMES).  Returns (struct, the contiguous tensors it points into, M)."""
+    keep = {}
+    for n in RAW_NAMES:
+        t = raw.get(n)
+        if t is not None and t.numel() == 0 and P != 0:
+            t = None
+        keep[n] = None if t is None else _dev_f32(t, n, dev)
+    for n in ("xyz", "rotation", "scaling", "opacity_logit", "features_dc", "features_rest"):
+        if keep[n] is None:
+            raise RuntimeError(f"rasterize_gaussians_raw: {n} is required")
+    if keep["xyz"].ndim != 2 or keep["xyz"].shape[1] != 3:
+        raise RuntimeError("xyz must have dimensions (num_points, 3)")
+    M = 1 + int(keep["features_rest"].shape[1])
+    shapes = dict(motion_res=(P, 3), rotation=(P, 4), rot_res=(P, 7), scaling=(P, 3), features_dc=(P, 1, 3), features_rest=(P, M - 1, 3),
+                  shs_res=(P, M, 3))
+    for n, shp in shapes.items():
+        if keep[n] is not None and tuple(keep[n].shape) != shp:
+            raise RuntimeError(f"rasterize_gaussians_raw: {n} must be {list(shp)} (got {list(keep[n].shape)})")
+    for n in ("opacity_logit", "trbf"):
+        if keep[n] is not None and keep[n].numel() != P:
+            raise RuntimeError(f"rasterize_gaussians_raw: {n} must hold one value per Gaussian")
+    st = RawInputsStruct(**{n: _ptr(keep[n]) for n in RAW_NAMES})
+    return st, keep, M
+
+
+def rasterize_gaussians_raw(background, raw: dict, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
+                            degree, campos, *, forward_only: bool = False):
+    """rasterize_gaussians taking the model's raw leaves + optional residuals (`raw`: RAW_NAMES -> tensor / None); the activations
+    of scene/saro_gaussian.py:39-47, :807-847 run inside the per-Gaussian kernels.  Same return tuple."""
+    dev = _require_gpu(raw["xyz"])
+    L = lib()
+    P, H, W = int(raw["xyz"].shape[0]), int(image_height), int(image_width)
+    st, keep, M = _raw_struct(raw, dev, P)
+    f = lambda t, n: _dev_f32(t, n, dev)  # noqa: E731
+    background, viewmatrix, projmatrix, campos = f(background, "bg"), f(viewmatrix, "viewmatrix"), f(projmatrix, "projmatrix"), f(campos, "campos")
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    arena = _Arena(dev)
+    try:
+        with torch.cuda.device(dev):
+            rendered = L.gsrast_forward_raw(
+                None, C.byref(_options_struct(forward_only=forward_only)),
+                arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
+                P, int(degree), M, _ptr(background), W, H, C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                float(tan_fovx), float(tan_fovy), out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii),
+                torch.cuda.current_stream(dev).cuda_stream)
+        if rendered < 0:
+            raise _err(rendered, "gsrast_forward_raw")
+        return rendered, out_color, radii, arena.tensor(0), arena.tensor(1), arena.tensor(2), out_depth
+    finally:
+        arena.close()
+
+
+def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, *, options: Optional[dict] = None,
+                                     first_backward: bool = False) -> dict:
+    """Gradients of the raw leaves: dict with dL_dmeans2D [P,3], xyz (= motion_res), rotation, scaling, opacity_logit [P,1], features_dc,
+    features_rest, and -- when the residual was given -- rot_res [P,7], trbf [P,1], shs_res [P,M,3] (features_dc / features_rest are then
+    views of shs_res: the rows hold both)."""
+    dev = _require_gpu(raw["xyz"])
+    L = lib()
+    P = int(raw["xyz"].shape[0])
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    st, keep, M = _raw_struct(raw, dev, P)
+    f = lambda t, n: _dev_f32(t, n, dev)  # noqa: E731
+    background, viewmatrix, projmatrix, campos = f(background, "bg"), f(viewmatrix, "viewmatrix"), f(projmatrix, "projmatrix"), f(campos, "campos")
+    dL_dout_color = f(dL_dout_color, "dL_dout_color")
+    o = dict(dtype=torch.float32, device=dev)
+    g = dict(dL_dmeans2D=torch.empty((P, 3), **o), xyz=torch.empty((P, 3), **o), rotation=torch.empty((P, 4), **o), scaling=torch.empty((P, 3), **o),
+             opacity_logit=torch.empty((P, 1), **o))
+    if keep["rot_res"] is not None:
+        g["rot_res"] = torch.empty((P, 7), **o)
+    if keep["trbf"] is not None:
+        g["trbf"] = torch.empty((P, 1), **o)
+    if keep["shs_res"] is not None:
+        g["shs_res"] = torch.empty((P, M, 3), **o)
+        g["features_dc"], g["features_rest"] = g["shs_res"][:, :1, :], g["shs_res"][:, 1:, :]
+        p_dc = p_rest = None
+    else:
+        g["features_dc"], g["features_rest"] = torch.empty((P, 1, 3), **o), torch.empty((P, M - 1, 3), **o)
+        p_dc, p_rest = g["features_dc"].data_ptr(), _ptr(g["features_rest"])
+    gs = RawGradsStruct(dL_dmean2D=g["dL_dmeans2D"].data_ptr(), d_xyz=g["xyz"].data_ptr(), d_rotation=g["rotation"].data_ptr(),
+                        d_scaling=g["scaling"].data_ptr(), d_rot_res=_ptr(g.get("rot_res")), d_opacity_logit=g["opacity_logit"].data_ptr(),
+                        d_trbf=_ptr(g.get("trbf")), d_features_dc=p_dc, d_features_rest=p_rest, d_shs_res=_ptr(g.get("shs_res")))
+    if P != 0:
+        radii_c = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = L.gsrast_backward_raw(
+                C.byref(_options_struct(options=options, grads_zeroed=first_backward)), P, int(degree), M, int(R), _ptr(background), W, H,
+                C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                _ptr(radii_c), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color), C.byref(gs),
+                torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise _err(rc, "gsrast_backward_raw")
+    if keep["motion_res"] is not None:
+        g["motion_res"] = g["xyz"]
+    return g
 
 
 def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Tensor, n_views: int, scale: float) -> torch.Tensor:

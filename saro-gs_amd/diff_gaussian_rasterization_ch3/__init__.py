@@ -141,3 +141,63 @@ class GaussianRasterizer(nn.Module):
             rotations if rotations is not None else empty,
             cov3D_precomp if have_cov else empty,
             self.raster_settings)
+
+
+# ---- raw-parameter module (no counterpart in the reference: SURVEY.md 8f rank 3 as written -- the activation / deformation epilogue
+# of scene/saro_gaussian.py:807-847 fused into the per-Gaussian kernels) -------------------------------------------------------------
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Inputs in _C.RAW_NAMES order (absent residuals: None) + means2D (the gradient sink of REF:42) + the settings."""
+
+    @staticmethod
+    def forward(ctx, means2D, raster_settings, *raw_tensors):
+        rs = raster_settings
+        raw = dict(zip(_C.RAW_NAMES, raw_tensors))
+        forward_only = not any(ctx.needs_input_grad)
+        num_rendered, color, radii, geom_buf, bin_buf, img_buf, depth = _C.rasterize_gaussians_raw(
+            rs.bg, raw, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
+            rs.sh_degree, rs.campos, forward_only=forward_only)
+        ctx.raster_settings, ctx.num_rendered = rs, num_rendered
+        ctx.gs_options = _C.current_options()
+        ctx.gs_options["forward_only"] = int(forward_only)
+        ctx.gs_backwards = 0
+        ctx.present = tuple(t is not None for t in raw_tensors)
+        ctx.save_for_backward(*[t for t in raw_tensors if t is not None], radii, geom_buf, bin_buf, img_buf)
+        ctx.mark_non_differentiable(radii, depth)
+        ctx.set_materialize_grads(False)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
+        rs = ctx.raster_settings
+        saved = list(ctx.saved_tensors)
+        img_buf, bin_buf, geom_buf, radii = saved.pop(), saved.pop(), saved.pop(), saved.pop()
+        it = iter(saved)
+        raw = {n: (next(it) if here else None) for n, here in zip(_C.RAW_NAMES, ctx.present)}
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((_C.NUM_CHANNELS, rs.image_height, rs.image_width), device=radii.device)
+        g = _C.rasterize_gaussians_raw_backward(
+            rs.bg, raw, radii, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree,
+            rs.campos, geom_buf, ctx.num_rendered, bin_buf, img_buf, options=ctx.gs_options, first_backward=ctx.gs_backwards == 0)
+        ctx.gs_backwards += 1
+        shapes = {n: (None if raw[n] is None else raw[n].shape) for n in _C.RAW_NAMES}
+        grads = tuple(None if raw[n] is None else g[n].reshape(shapes[n]) if g[n].is_contiguous() else g[n] for n in _C.RAW_NAMES)
+        return (g["dL_dmeans2D"], None) + grads
+
+
+class GaussianRasterizerRaw(nn.Module):
+    """GaussianRasterizer for callers that hold SaRO-GS's RAW parameters: forward(xyz, means2D, rotation, scaling, opacity, features_dc,
+    features_rest, motion_residual=None, rot_residual=None, trbfoutput=None, shs_residual=None) renders
+    means3D = xyz + motion_residual, rotations = normalize(rotation + rot_residual[:, :4]), scales = exp(scaling + rot_residual[:, 4:]),
+    opacities = sigmoid(opacity) * trbfoutput, shs = cat(features_dc, features_rest) + shs_residual (scene/saro_gaussian.py:807-847) --
+    outputs bit-identical to fused_epilogue.activate_gaussians followed by GaussianRasterizer, without the activated tensors ever
+    being written.  Gradients flow to every tensor given."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, xyz, means2D, rotation, scaling, opacity, features_dc, features_rest, motion_residual=None, rot_residual=None,
+                trbfoutput=None, shs_residual=None):
+        raw = dict(xyz=xyz, motion_res=motion_residual, rotation=rotation, rot_res=rot_residual, scaling=scaling, opacity_logit=opacity,
+                   trbf=trbfoutput, features_dc=features_dc, features_rest=features_rest, shs_res=shs_residual)
+        return _RasterizeGaussiansRaw.apply(means2D, self.raster_settings, *[raw[n] for n in _C.RAW_NAMES])

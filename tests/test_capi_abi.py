@@ -28,7 +28,8 @@ def test_header_and_library_agree(rast, L):
     for n in names:
         assert hasattr(raw, n), f"{n} declared in gsrast.h but not exported"
     assert sorted(rast._C.EXPORTS) == names
-    assert L.gsrast_abi_version() == 1
+    assert L.gsrast_abi_version() == rast._C.ABI_VERSION == 2
+    assert re.search(r"#define GSRAST_ABI_VERSION 2\b", open(HEADER).read())
 
 
 def test_no_torch_or_cxx_types_in_the_boundary():
@@ -101,3 +102,31 @@ def test_widened_rows_reject_bad_arguments_without_a_device(rast, L):
     assert L.gsrast_linear_wgrad(10, 129, 8, None, None, None, None, 0, None) == -1
     assert L.gsrast_linear_wgrad(10, 8, 0, None, None, None, None, 0, None) == -1
     assert L.gsrast_linear_wgrad(10, 8, 8, None, None, None, None, 0, None) == -1      # NULL dW
+
+
+def test_raw_entry_points_reject_bad_arguments_before_any_device_work(L, rast):
+    """gsrast_forward_raw / gsrast_backward_raw validate their pointer sets on the host (no GPU needed for the refusals)."""
+    _C = rast._C
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+    cb = ALLOC(lambda ctx, n: None)
+    one = C.c_void_p(16)
+    opts = _C.OptionsStruct()
+    L.gsrast_options_init(C.byref(opts))
+    assert opts.forward_only == 0 and opts.tile_clip == 1
+    ins = _C.RawInputsStruct()
+    rc = L.gsrast_forward_raw(None, C.byref(opts), cb, None, cb, None, cb, None, 10, 3, 16, one, 64, 64, C.byref(ins), 1.0, one, one, one, 1.0, 1.0, one, one, one, None)
+    assert rc < 0 and b"raw" in L.gsrast_last_error()
+    ok = dict(xyz=16, rotation=16, scaling=16, opacity_logit=16, features_dc=16, features_rest=16)
+    ins = _C.RawInputsStruct(**ok)
+    rc = L.gsrast_forward_raw(None, C.byref(opts), cb, None, cb, None, cb, None, 10, 3, 9, one, 64, 64, C.byref(ins), 1.0, one, one, one, 1.0, 1.0, one, one, one, None)
+    assert rc < 0 and b"M must be" in L.gsrast_last_error()
+    ins = _C.RawInputsStruct(**dict(ok, features_rest=20))
+    rc = L.gsrast_forward_raw(None, C.byref(opts), cb, None, cb, None, cb, None, 10, 3, 16, one, 64, 64, C.byref(ins), 1.0, one, one, one, 1.0, 1.0, one, one, one, None)
+    assert rc < 0 and b"aligned" in L.gsrast_last_error()
+    ins = _C.RawInputsStruct(**ok)
+    gr = _C.RawGradsStruct()
+    rc = L.gsrast_backward_raw(C.byref(opts), 10, 3, 16, 5, one, 64, 64, C.byref(ins), 1.0, one, one, one, 1.0, 1.0, one, one, one, one, one, C.byref(gr), None)
+    assert rc < 0 and b"NULL required gradient" in L.gsrast_last_error()
+    gr = _C.RawGradsStruct(dL_dmean2D=16, d_xyz=16, d_rotation=16, d_scaling=16, d_opacity_logit=16, d_shs_res=16)
+    rc = L.gsrast_backward_raw(C.byref(opts), 10, 3, 16, 5, one, 64, 64, C.byref(ins), 1.0, one, one, one, 1.0, 1.0, one, one, one, one, one, C.byref(gr), None)
+    assert rc < 0 and b"d_shs_res" in L.gsrast_last_error()

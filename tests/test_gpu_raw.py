@@ -1,0 +1,165 @@
+"""-m gpu: the raw-parameter entry points (include/gsrast.h: gsrast_forward_raw / gsrast_backward_raw, module GaussianRasterizerRaw) --
+SURVEY.md 8f rank 3 as written: the activation / deformation epilogue of scene/saro_gaussian.py:807-847 (activations :39-47) fused
+into the per-Gaussian kernels, the [P,16,3] coefficient tensor never materialised.
+
+Bars, in all 16 present / absent combinations of the four residuals:
+  * rasterizer outputs BIT-IDENTICAL to fused_epilogue.activate_gaussians -> GaussianRasterizer (the unchanged drop-in path);
+  * against  epilogue_oracle o gsrast_oracle : the forward bit-exact on the oracle's rendering of the activated attributes, every raw
+    gradient within 1e-5 abs (+1e-4 relative) of  epilogue_oracle.backward( f64 rasterizer oracle )."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import settings_from
+from gpu_harness import bits
+
+pytestmark = pytest.mark.gpu
+
+COMBOS = [dict(zip(("motion_res", "rot_res", "trbf", "shs_res"), c)) for c in itertools.product((True, False), repeat=4)]
+ATOL, RTOL = 1e-5, 1e-4
+
+
+def _raw_scene(scenes, P, seed, M, deg):
+    """Raw leaves whose activations give a scene like scenes.synth, plus small residuals."""
+    sc = scenes.synth(P, seed, sh_degree=deg)
+    rng = np.random.default_rng(seed + 1000)
+    shs = sc["shs"][:, :M].astype(np.float32)
+    raw = dict(
+        xyz=sc["means3D"], motion_res=0.01 * rng.normal(size=(P, 3)),
+        rotation=sc["rotations"] * rng.uniform(0.5, 2.0, size=(P, 1)), rot_res=np.concatenate([0.05 * rng.normal(size=(P, 4)), 0.1 * rng.normal(size=(P, 3))], 1),
+        scaling=np.log(sc["scales"]), opacity=np.log(sc["opacities"].clip(1e-4, 1 - 1e-4) / (1 - sc["opacities"].clip(1e-4, 1 - 1e-4))),
+        trbf=rng.uniform(0.3, 1.0, size=(P, 1)), f_dc=shs[:, :1], f_rest=shs[:, 1:], shs_res=0.03 * rng.normal(size=(P, M, 3)))
+    raw["rotation"][0] = 0.0; raw["rot_res"][0, :4] = 0.0          # a zero quaternion: normalize clamps at eps
+    return sc, {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in raw.items()}
+
+
+def _tensors(raw, use, dev):
+    t = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in raw.items()}
+    kw = dict(motion_residual=t["motion_res"] if use["motion_res"] else None, rot_residual=t["rot_res"] if use["rot_res"] else None,
+              trbfoutput=t["trbf"] if use["trbf"] else None, shs_residual=t["shs_res"] if use["shs_res"] else None)
+    return t, kw
+
+
+@pytest.mark.parametrize("use", COMBOS, ids=["".join("1" if v else "0" for v in c.values()) for c in COMBOS])
+def test_raw_rasterizer_against_epilogue_then_rasterizer_and_the_oracles(use, orc, scenes, rast, gpu):
+    from oracle import epilogue_oracle as eo
+    import fused_epilogue
+    P, W, H, M, deg = 3000, 160, 112, 16, 3
+    sc, raw = _raw_scene(scenes, P, 401, M, deg)
+    cam = scenes.camera(1, 4, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    g_np = scenes.upstream_grad(H, W, 402)
+    g = torch.from_numpy(g_np).to(gpu)
+
+    # (a) the fused path
+    ta, kwa = _tensors(raw, use, gpu)
+    m2a = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    ca, ra, da = rast.GaussianRasterizerRaw(rs)(ta["xyz"], m2a, ta["rotation"], ta["scaling"], ta["opacity"], ta["f_dc"], ta["f_rest"], **kwa)
+    ca.backward(g)
+    # (b) the drop-in path behind the standalone epilogue
+    tb, kwb = _tensors(raw, use, gpu)
+    m2b = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(tb["xyz"], tb["rotation"], tb["scaling"], tb["opacity"], tb["f_dc"], tb["f_rest"], **kwb)
+    cb, rb, db = rast.GaussianRasterizer(rs)(means3D=motion, means2D=m2b, opacities=opa, shs=shs, scales=scale, rotations=rot)
+    cb.backward(g)
+    torch.cuda.synchronize()
+    assert torch.equal(ca, cb) and torch.equal(ra, rb) and torch.equal(da, db), "raw path must render bit-identically to epilogue -> rasterizer"
+    assert int((ra > 0).sum()) > P // 2
+    names = ["xyz", "rotation", "scaling", "opacity", "f_dc", "f_rest"] + [k for k in ("motion_res", "rot_res", "trbf", "shs_res") if use[k]]
+    for k in names:
+        a, b = ta[k].grad, tb[k].grad
+        assert a is not None and a.shape == ta[k].shape, k
+        sl = slice(1, None) if k in ("rotation", "rot_res") else slice(None)     # row 0: x / eps, 1e12-scaled
+        assert ((a[sl] - b[sl]).abs() <= 2e-7 + 1e-4 * b[sl].abs()).all(), (k, float((a[sl] - b[sl]).abs().max()))
+    for k in ("motion_res", "rot_res", "trbf", "shs_res"):
+        if not use[k]:
+            assert ta[k].grad is None
+    assert ((m2a.grad - m2b.grad).abs() <= 2e-7 + 1e-4 * m2b.grad.abs()).all()
+
+    # (c) epilogue_oracle o gsrast_oracle.  The rasterizer oracle renders the ACTIVATED attributes the device produced (fp32; the
+    # standalone epilogue is itself checked against epilogue_oracle in test_epilogue.py) so that no 1-ulp input difference flips a
+    # radius; the chain back to the raw leaves is epilogue_oracle.backward in fp64.
+    act = dict(sc)
+    act.update(means3D=motion.detach().cpu().numpy(), rotations=rot.detach().cpu().numpy(), scales=scale.detach().cpu().numpy(),
+               opacities=opa.detach().cpu().numpy(), shs=shs.detach().cpu().numpy())
+    eo_f = eo.forward(raw["xyz"], raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"],
+                      motion_res=raw["motion_res"] if use["motion_res"] else None, rot_res=raw["rot_res"] if use["rot_res"] else None,
+                      trbf=raw["trbf"] if use["trbf"] else None, shs_res=raw["shs_res"] if use["shs_res"] else None)
+    np.testing.assert_allclose(act["scales"], eo_f["scale"], rtol=3e-6)
+    np.testing.assert_allclose(act["shs"], eo_f["shs"], rtol=3e-6, atol=1e-7)
+    o32 = orc.render(act, cam, g_np)
+    o64 = orc.render(act, cam, g_np, f64=True)
+    assert np.array_equal(ra.cpu().numpy(), o32["radii"])
+    assert np.array_equal(bits(ca.detach().cpu().numpy()), bits(o32["out_color"]))
+    assert np.array_equal(bits(da.detach().cpu().numpy()), bits(o32["out_depth"]))
+    b64 = eo.backward(raw["rotation"], raw["scaling"], raw["opacity"], raw["rot_res"] if use["rot_res"] else None,
+                      raw["trbf"] if use["trbf"] else None, o64["dL_drotations"], o64["dL_dscales"], o64["dL_dopacity"].reshape(P, 1))
+    want = dict(xyz=o64["dL_dmeans3D"], rotation=b64["rotation"], scaling=b64["scaling"], opacity=b64["logit"].reshape(P, 1),
+                f_dc=o64["dL_dsh"][:, :1], f_rest=o64["dL_dsh"][:, 1:])
+    if use["motion_res"]:
+        want["motion_res"] = o64["dL_dmeans3D"]
+    if use["rot_res"]:
+        want["rot_res"] = np.concatenate([b64["rotation"], b64["scaling"]], 1)
+    if use["trbf"]:
+        want["trbf"] = b64["trbf"].reshape(P, 1)
+    if use["shs_res"]:
+        want["shs_res"] = o64["dL_dsh"]
+    for k, w in want.items():
+        got = ta[k].grad.cpu().numpy().astype(np.float64).reshape(w.shape)
+        sl = slice(1, None) if k in ("rotation", "rot_res") else slice(None)
+        err = np.abs(got[sl] - w[sl])
+        assert (err <= ATOL + RTOL * np.abs(w[sl])).all(), (k, float(err.max()))
+    err = np.abs(m2a.grad.cpu().numpy() - o64["dL_dmeans2D"])
+    assert (err <= ATOL + RTOL * np.abs(o64["dL_dmeans2D"])).all()
+
+
+@pytest.mark.parametrize("P,M,deg", [(1, 16, 3), (127, 16, 2), (129, 16, 3), (1001, 4, 1), (130, 4, 0)])
+def test_raw_rasterizer_ragged_sizes_and_short_rows(P, M, deg, scenes, rast, gpu):
+    """Blocks that end inside a 16-byte group of features_dc / features_rest (P not a multiple of 4), a single Gaussian, M = 4."""
+    import fused_epilogue
+    W, H = 96, 64
+    sc, raw = _raw_scene(scenes, P, 411 + P, M, deg)
+    raw["rotation"][0] = [1.0, 0.1, 0.0, 0.2]
+    cam = scenes.camera(0, 3, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    g = torch.from_numpy(scenes.upstream_grad(H, W, 412)).to(gpu)
+    for use in (COMBOS[0], COMBOS[-1]):
+        ta, kwa = _tensors(raw, use, gpu)
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        ca, ra, da = rast.GaussianRasterizerRaw(rs)(ta["xyz"], m2, ta["rotation"], ta["scaling"], ta["opacity"], ta["f_dc"], ta["f_rest"], **kwa)
+        ca.backward(g)
+        tb, kwb = _tensors(raw, use, gpu)
+        m2b = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        act = fused_epilogue.activate_gaussians(tb["xyz"], tb["rotation"], tb["scaling"], tb["opacity"], tb["f_dc"], tb["f_rest"], **kwb)
+        cb, rb, db = rast.GaussianRasterizer(rs)(means3D=act[0], means2D=m2b, opacities=act[3], shs=act[4], scales=act[2], rotations=act[1])
+        cb.backward(g)
+        assert torch.equal(ca, cb) and torch.equal(ra, rb) and torch.equal(da, db)
+        for k in ta:
+            if ta[k].grad is None:
+                assert tb[k].grad is None, k
+                continue
+            a, b = ta[k].grad, tb[k].grad
+            assert ((a - b).abs() <= 2e-7 + 1e-4 * b.abs()).all(), (k, float((a - b).abs().max()))
+
+
+def test_raw_entry_points_reject_bad_arguments(scenes, rast, gpu):
+    P, W, H = 64, 48, 32
+    sc, raw = _raw_scene(scenes, P, 421, 16, 3)
+    cam = scenes.camera(0, 1, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    t, _ = _tensors(raw, COMBOS[-1], gpu)
+    m2 = torch.zeros((P, 3), device=gpu)
+    R = rast.GaussianRasterizerRaw(rs)
+    with pytest.raises(RuntimeError):       # M = 9 rows are not a multiple of 16 bytes: the fused path does not take them
+        R(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"][:, :8].contiguous())
+    with pytest.raises(RuntimeError):
+        R(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"], rot_residual=torch.zeros((P, 4), device=gpu))
+    with pytest.raises(RuntimeError):
+        R(t["xyz"].cpu(), m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"])
+    # evaluation: no gradient anywhere -> forward only, still the same picture
+    with torch.no_grad():
+        c0, r0, d0 = R(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"])
+    c1, r1, d1 = R(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"])
+    assert torch.equal(c0, c1.detach()) and torch.equal(r0, r1)
