@@ -77,6 +77,19 @@ def ref_python_vectors():
     print("wrote ref_python_vectors.npz")
 
 
+def ref_focal_vectors():
+    """fov2focal / focal2fov of the reference's OWN utils/graphics_utils.py:76-80: pins focal = size / (2 tan(fov / 2)), the relation
+    rasterizer_impl.cu:222-223 evaluates from tan_fov (focal_y = height / (2 tan_fovy)) and that scenes.camera / the oracle restate."""
+    gfx = _load("ref_graphics_utils", os.path.join(REF, "utils", "graphics_utils.py"))
+    rng = np.random.default_rng(77)
+    fov = rng.uniform(0.2, 2.4, size=64)
+    pix = rng.integers(16, 4096, size=64).astype(np.float64)
+    focal = np.array([gfx.fov2focal(f, p) for f, p in zip(fov, pix)], np.float64)
+    back = np.array([gfx.focal2fov(fc, p) for fc, p in zip(focal, pix)], np.float64)
+    np.savez_compressed(os.path.join(HERE, "ref_focal_vectors.npz"), fov=fov, pixels=pix, ref_fov2focal=focal, ref_focal2fov_of_that=back)
+    print("ref_focal_vectors.npz written")
+
+
 def oracle_scenes():
     import scenes
     from oracle import oracle as orc
@@ -225,8 +238,12 @@ def loss_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "focal":        # only the (round 3) focal fixture; the others stay as committed
+        ref_focal_vectors()
+        sys.exit(0)
     if os.path.isdir(REF):
         ref_python_vectors()
+        ref_focal_vectors()
     else:
         print("no /root/reference here: keeping the committed ref_python_vectors.npz")
     oracle_scenes()

@@ -1,0 +1,163 @@
+"""-m gpu: the drop-in API driven the way SaRO-GS's renderer drives it (tests/caller_train_render.py restates
+/root/reference/renderer/__init__.py:35-228), checked against the oracle; and the three reference-shaped C entry points
+(gsrast_forward / gsrast_backward / gsrast_mark_visible -- include/gsrast.h, replacing CudaRasterizer::Rasterizer::{forward, backward,
+markVisible}, rasterizer.h:24-83) driven through RAW ctypes with the test's own allocation callbacks."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_harness import bits
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-5, 1e-4
+
+
+def _oracle_inputs(pc, cam):
+    """The activated attributes exactly as the caller hands them to the rasterizer (same fp32 bits), for the oracle."""
+    n = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    sc = dict(means3D=n(pc.get_xyz), scales=n(pc.get_scaling), rotations=n(pc.get_rotation), opacities=n(pc.get_opacity),
+              shs=n(pc.get_features), sh_degree=pc.active_sh_degree, bg=np.zeros(3, np.float32))
+    return sc
+
+
+def test_train_render_caller_matches_the_oracle(orc, scenes, rast, gpu):
+    import caller_train_render as crt
+    P, W, H = 6000, 208, 144
+    scene = scenes.synth(P, 501)
+    cam = scenes.camera(2, 7, W, H)
+    vc = crt.TinyCamera(cam)
+    pc = crt.TinyGaussians(scene, gpu, sh_degree=3)
+    bg = torch.tensor([0.0, 0.0, 0.0], device=gpu)
+    pkg = crt.train_render(vc, pc, bg)
+    vsp = pkg["viewspace_points"]
+    assert not vsp.is_leaf and vsp.requires_grad                  # zeros(requires_grad) + 0, as the reference builds it
+    g_np = scenes.upstream_grad(H, W, 502)
+    (pkg["render"] * torch.from_numpy(g_np).to(gpu)).sum().backward()        # d loss / d render = g
+    assert vsp.grad is not None and vsp.grad.shape == (P, 3)     # retain_grad() on the non-leaf worked through the autograd node
+    # oracle on the same activated attributes; tanfov as the caller computed it
+    ocam = dict(cam, tanfovx=math.tan(vc.FoVx * 0.5), tanfovy=math.tan(vc.FoVy * 0.5))
+    sc = _oracle_inputs(pc, cam)
+    o32 = orc.render(sc, ocam, g_np)
+    o64 = orc.render(sc, ocam, g_np, f64=True)
+    assert np.array_equal(pkg["radii"].cpu().numpy(), o32["radii"])
+    assert np.array_equal(pkg["visibility_filter"].cpu().numpy(), o32["radii"] > 0)
+    assert np.array_equal(bits(pkg["render"].detach().cpu().numpy()), bits(o32["out_color"]))
+    # train.py:212 -- torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1), the densification statistic
+    got = torch.norm(vsp.grad[:, :2], dim=-1).cpu().numpy().astype(np.float64)
+    want = np.linalg.norm(o64["dL_dmeans2D"][:, :2], axis=1)
+    assert (np.abs(got - want) <= ATOL + RTOL * want).all()
+    assert float(vsp.grad[:, 2].abs().max()) == 0.0
+    # gradients reached the RAW leaves through torch's activations
+    for name in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+        gr = getattr(pc, name).grad
+        assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().max()) > 0, name
+    np.testing.assert_allclose(pc._xyz.grad.cpu().numpy(), o64["dL_dmeans3D"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(pc._features_rest.grad.cpu().numpy(), o64["dL_dsh"][:, 1:], rtol=RTOL, atol=ATOL)
+
+
+def test_test_render_caller_with_depth_and_segment_pass(orc, scenes, rast, gpu):
+    import caller_train_render as crt
+    P, W, H = 4000, 160, 128
+    scene = scenes.synth(P, 511)
+    cam = scenes.camera(0, 5, W, H)
+    vc = crt.TinyCamera(cam)
+    pc = crt.TinyGaussians(scene, gpu, sh_degree=2)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=gpu)
+    with torch.no_grad():
+        res = crt.test_render(vc, pc, bg, require_segment=True)
+    ocam = dict(cam, tanfovx=math.tan(vc.FoVx * 0.5), tanfovy=math.tan(vc.FoVy * 0.5))
+    sc = _oracle_inputs(pc, cam)
+    sc["bg"] = np.ones(3, np.float32)
+    o = orc.render(sc, ocam)
+    assert np.array_equal(bits(res["render"].cpu().numpy()), bits(o["out_color"]))
+    assert np.array_equal(bits(res["depth"].cpu().numpy()), bits(o["out_depth"]))
+    assert res["depth"].shape == (1, H, W) and res["opacity"].shape == (P, 1)
+    assert np.array_equal(res["visibility_filter"].cpu().numpy(), o["radii"] > 0)
+    seg_cols = pc.get_lifespan.detach().expand(-1, 3)
+    assert not seg_cols.is_contiguous()                             # the reference hands over this stride-0 view
+    oseg = orc.render(sc, ocam, colors_precomp=seg_cols.cpu().numpy().copy())
+    assert np.array_equal(bits(res["segment_render"].cpu().numpy()), bits(oseg["out_color"]))
+
+
+# ---- the reference-shaped C entry points, raw ctypes, the test's own allocator -----------------------------------------------------
+class _Buffers:
+    """Allocation callbacks as a C caller would write them: three growing device buffers (torch only supplies the memory)."""
+
+    def __init__(self, dev):
+        self.dev, self.held, self.calls = dev, [None, None, None], [0, 0, 0]
+        self.FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+        self.cbs = [self.FN(self._make(k)) for k in range(3)]
+
+    def _make(self, k):
+        def alloc(_ctx, nbytes):
+            self.calls[k] += 1
+            self.held[k] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.dev)
+            p = self.held[k].data_ptr()
+            return (p + 255) & ~255
+        return alloc
+
+    def ptr(self, k):
+        return (self.held[k].data_ptr() + 255) & ~255 if self.held[k] is not None else None
+
+
+def test_reference_shaped_entry_points_through_raw_ctypes(orc, scenes, rast, gpu):
+    L = C.CDLL(rast._C.LIB_PATH)            # a fresh handle: no argtypes from the binding, everything spelled out here
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.gsrast_forward.restype = ci
+    L.gsrast_forward.argtypes = [vp] * 6 + [ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp]
+    L.gsrast_backward.restype = ci
+    L.gsrast_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf] + [vp] * 15
+    L.gsrast_mark_visible.restype = ci
+    L.gsrast_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    L.gsrast_last_error.restype = C.c_char_p
+    P, W, H, D, M = 5000, 176, 120, 3, 16
+    sc = scenes.synth(P, 521)
+    cam = scenes.camera(3, 8, W, H)
+    g_np = scenes.upstream_grad(H, W, 522)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    d = {k: t(sc[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations", "bg")}
+    view, proj, campos, dpix = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["campos"]), t(g_np)
+    color = torch.full((3, H, W), -1.0, device=gpu); depth = torch.full((1, H, W), -1.0, device=gpu)
+    radii = torch.full((P,), -1, dtype=torch.int32, device=gpu)
+    bufs = _Buffers(gpu)
+    stream = torch.cuda.current_stream(gpu).cuda_stream
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    cb = [C.cast(f, vp) for f in bufs.cbs]
+    R = L.gsrast_forward(cb[0], None, cb[1], None, cb[2], None, P, D, M, p(d["bg"]), W, H, p(d["means3D"]), p(d["shs"]), None, p(d["opacities"]),
+                         p(d["scales"]), 1.0, p(d["rotations"]), None, p(view), p(proj), p(campos), cam["tanfovx"], cam["tanfovy"], 0,
+                         p(color), p(depth), p(radii), stream)
+    assert R > 0, L.gsrast_last_error()
+    assert all(c >= 1 for c in bufs.calls)
+    o32 = orc.render(sc, cam, g_np)
+    o64 = orc.render(sc, cam, g_np, f64=True)
+    torch.cuda.synchronize()
+    assert R == o32["R"]                                            # num_rendered keeps the reference's meaning
+    assert np.array_equal(radii.cpu().numpy(), o32["radii"])
+    assert np.array_equal(bits(color.cpu().numpy()), bits(o32["out_color"]))
+    assert np.array_equal(bits(depth.cpu().numpy()), bits(o32["out_depth"]))
+    # backward: every output array is OVERWRITTEN (ABI version 2) -- poison them first
+    z = lambda *s: torch.full(s, 7.0, device=gpu)  # noqa: E731
+    g = dict(mean2D=z(P, 3), conic=z(P, 4), opacity=z(P), color=z(P, 3), mean3D=z(P, 3), cov3D=z(P, 6), sh=z(P, M, 3), scale=z(P, 3), rot=z(P, 4))
+    rc = L.gsrast_backward(P, D, M, R, p(d["bg"]), W, H, p(d["means3D"]), p(d["shs"]), None, p(d["scales"]), 1.0, p(d["rotations"]), None,
+                           p(view), p(proj), p(campos), cam["tanfovx"], cam["tanfovy"], p(radii), bufs.ptr(0), bufs.ptr(1), bufs.ptr(2), p(dpix),
+                           p(g["mean2D"]), p(g["conic"]), p(g["opacity"]), p(g["color"]), p(g["mean3D"]), p(g["cov3D"]), p(g["sh"]), p(g["scale"]),
+                           p(g["rot"]), stream)
+    assert rc == 0, L.gsrast_last_error()
+    torch.cuda.synchronize()
+    for name, key in (("mean2D", "dL_dmeans2D"), ("opacity", "dL_dopacity"), ("mean3D", "dL_dmeans3D"), ("sh", "dL_dsh"), ("scale", "dL_dscales"),
+                      ("rot", "dL_drotations")):
+        got = g[name].cpu().numpy().astype(np.float64)
+        ref = o64[key].reshape(got.shape)
+        err = np.abs(got - ref)
+        assert (err <= ATOL + RTOL * np.abs(ref)).all(), (name, float(err.max()))
+    assert float(g["conic"][:, 2].abs().max()) == 0.0               # .z of dL_dconic is never written by the reference (backward.cu:549-551)
+    assert float(g["cov3D"].abs().max()) > 0
+    # markVisible (rasterizer.h:27-32)
+    present = torch.full((P,), 9, dtype=torch.uint8, device=gpu)
+    rc = L.gsrast_mark_visible(P, p(d["means3D"]), p(view), p(proj), p(present), stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(present.cpu().numpy().astype(bool), orc.mark_visible(sc["means3D"], cam["viewmatrix"], cam["projmatrix"]))

@@ -147,3 +147,30 @@ def test_loss_oracle_matches_reference_loss_utils():
         got = loss_oracle.l1_dssim(img, gt, lam)
         np.testing.assert_allclose(got, z[f"ref_{tag}_loss_l1_ssim"], rtol=0, atol=2e-6)      # the reference ran in fp32
         assert abs(got[0] - float(z[f"ref_{tag}_loss_f64"])) < 1e-9                           # ... and in fp64
+
+
+def test_focal_from_tan_fov_matches_reference_fov2focal(orc, scenes):
+    """rasterizer_impl.cu:222-223: focal = size / (2 tan_fov), with tan_fov = tan(0.5 FoV) (renderer/__init__.py:50-51) -- the
+    reference's own utils/graphics_utils.py fov2focal / focal2fov (tests/golden/ref_focal_vectors.npz).  Checked on the quantity the
+    oracle derives from it: a Gaussian's screen-space covariance, cov2D = (focal s / z)^2 + 0.3 on the optical axis."""
+    import math
+    import os
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_focal_vectors.npz"))
+    np.testing.assert_allclose(v["pixels"] / (2.0 * np.tan(0.5 * v["fov"])), v["ref_fov2focal"], rtol=1e-14)
+    np.testing.assert_allclose(v["ref_focal2fov_of_that"], v["fov"], rtol=1e-13)
+    for k in range(0, 64, 9):
+        fov, size = float(v["fov"][k]), int(v["pixels"][k]) | 1            # odd size: ndc 0 is a pixel centre
+        size = min(size, 257)
+        focal = size / (2.0 * math.tan(0.5 * fov))
+        np.testing.assert_allclose(focal, float(v["ref_fov2focal"][k]) * size / float(v["pixels"][k]), rtol=1e-12)
+        view = np.eye(4, dtype=np.float32)
+        proj = scenes.projection(0.01, 100.0, fov, fov)
+        cam = dict(image_height=size, image_width=size, tanfovx=math.tan(0.5 * fov), tanfovy=math.tan(0.5 * fov), viewmatrix=view,
+                   projmatrix=np.ascontiguousarray(view @ proj.T.astype(np.float32)), campos=np.zeros(3, np.float32), scale_modifier=1.0,
+                   prefiltered=False)
+        s, z = 0.05, 3.0
+        sc = dict(means3D=np.array([[0, 0, z]], np.float32), scales=np.full((1, 3), s, np.float32), rotations=np.array([[1, 0, 0, 0]], np.float32),
+                  opacities=np.full((1, 1), 0.5, np.float32), shs=np.zeros((1, 16, 3), np.float32), sh_degree=0, bg=np.zeros(3, np.float32))
+        o = orc.render(sc, cam, f64=True)
+        cov = (focal * s / z) ** 2 + 0.3
+        np.testing.assert_allclose(o["conic_opacity"][0, 0], 1.0 / cov, rtol=1e-5)
