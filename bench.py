@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=3_000_000, help="headline #Gaussians at 1920x1080 (BASELINE.json configs[4]: the 3 M stress)")
+    ap.add_argument("--scene", choices=("cube", "shell"), default="cube", help="cube: scenes.synth (SURVEY 8d, the headline); shell: scenes.synth_shell (profiling runs)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
@@ -794,7 +795,7 @@ def main():
         _C.set_option("binning", a.binning)
 
     P, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
-    wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev)
+    wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1), dev=dev, kind=a.scene)
     bucket = None
     if world > 1:
         # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the backward writes
@@ -837,8 +838,9 @@ def main():
     per_kernel, pk, exp2 = (None, None, None)
     if world == 1:
         per_kernel, pk = stage_table(_C, wl, st, P, deg, H)
-        exp2 = exp_mode2_row(_C, wl, dev, kid)
+        exp2 = None if os.environ.get("BENCH_NO_EXP2") else exp_mode2_row(_C, wl, dev, kid)
     result = None
+    scene_fn = "synth" if a.scene == "cube" else "synth_shell"
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt
@@ -850,7 +852,7 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4] stress-1080p: synth(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
+            "config": {"workload": f"BASELINE configs[4] stress-1080p: {scene_fn}(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
                                    + ((" + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
                                        if a.exchange == "factors" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,

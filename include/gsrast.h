@@ -137,6 +137,11 @@ int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, con
  * (GeometryState / BinningState / ImageState members, rasterizer_impl.h:30-65).  Any output
  * pointer may be NULL.  All pointers are device pointers.  keys_sorted is rebuilt as
  * (tile << 32) | depth_bits from the sorted instance list. */
+/* NOTE for consumers of the state buffers: with options.tile_clip = 1 (the default) the binning lists a Gaussian only in the tiles
+ * its alpha >= 1/255 ellipse reaches, so the instance list holds sum(ranges.y - ranges.x) <= num_rendered entries -- num_rendered (the
+ * return value of gsrast_forward) keeps the REFERENCE's meaning (tiles of the 3-sigma squares, rasterizer_impl.cu:277-282) and is then
+ * NOT the length of point_list / keys_sorted; size those arrays for num_rendered and read only the ranges.  With tile_clip = 0 the
+ * lists are the reference's literal ones and the two numbers coincide.  n_contrib indexes the list in force. */
 int gsrast_debug_export(int P, int R, int width, int height,
                         const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
                         float* depths, float* means2D /*[P][2]*/, float* cov3D /*[P][6]*/,
@@ -181,7 +186,7 @@ typedef struct gsrast_options {
     int depth_sort;           /* forward: 0 (default) bucket depth sort -- two launches: Gaussians into ~P/256 depth buckets, one LDS sort per
                                  bucket (run-compressed binning, P >= 32768); a scene whose depths pile up in one bucket is detected on
                                  the device and re-sorted by the radix passes, which the context then uses for its next 16 calls
-                                 ("bucket_skip"); 1 = always the LSD radix sort (3-4 passes of three launches).  Same order either way */
+                                 ("bucket_skip"; doubling with every further overflow, up to 4096); 1 = always the LSD radix sort (3-4 passes of three launches).  Same order either way */
     int forward_only;         /* forward: 1 = no backward will follow on this call's state (evaluation / torch.no_grad()): the colour kernel
                                  does not store d(colour)/d(view direction) (36 B / Gaussian) for the backward.  A backward on such a
                                  state must be given forward_only = 1 as well; it then evaluates those derivatives itself

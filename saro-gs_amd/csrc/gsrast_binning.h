@@ -201,7 +201,10 @@ radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __r
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) atomicAdd(&cnt[wave][((key[r] - base) >> shift) & mask], 1u);
     }
-    if (adapt & RA_MINMAX) {     // key 0xFFFFFFFF marks a culled Gaussian (preprocess_fwd_kernel): it sorts to the end under any pass count
+    if (adapt & RA_MINMAX) {     // key 0xFFFFFFFF marks a culled Gaussian (preprocess_fwd_kernel).  With four passes it sorts to the end; on the
+                                 // three-pass (short) path its digits come from the low 24 bits of (key - base) and it may land ANYWHERE in
+                                 // `order` -- harmless: no consumer relies on its place (emit_column_runs / emit_instances skip a Gaussian by
+                                 // its width / tile count of 0, never by its position); it is only excluded from the minimum / maximum here
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
@@ -245,6 +248,9 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
     }
     uint32_t* row = block_hist + (size_t)blockIdx.x * nblk;
     uint32_t carry = 0;
+    // (Measured and dropped, round 3: requesting the next round's eight values before this round is scanned.  On gfx9 loads and stores
+    // share vmcnt and the compiler must drain the counter when both kinds are outstanding, so every round still waits for the previous
+    // round's stores: 26.0 -> 26.0 us for the ~20 000-entry rows of the tile-row pass at 3 M Gaussians.)
     for (uint32_t c0 = 0; c0 < nblk; c0 += 256 * 8) {
         const uint32_t base = c0 + threadIdx.x * 8;
         uint32_t v[8], sum = 0;
@@ -795,7 +801,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         g = pre ? pre_g : order[j];
         incl = run0 + (pre ? pre_w : woffsets[j]);
         const uint32_t prev = j > 0 ? run0 + (pre ? pre_wm : woffsets[j - 1]) : run0;
-        w = incl - prev;                         // culled Gaussians (sorted last, width 0) never touch binrec
+        w = incl - prev;                         // culled Gaussians (width 0, wherever the depth sort left them) never touch binrec
         uint2 rc = make_uint2(0u, 0u);
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
         if (w != 0u) {

@@ -130,7 +130,8 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
                       uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
                       uint32_t* __restrict__ bucket_cnt /* fwd [8][64] | bwd [64], or null */, uint16_t* __restrict__ bucket_list /* fwd [8][64][Tg] | bwd [64][T] */,
-                      int order_from_buckets)
+                      int order_from_buckets,
+                      float4* __restrict__ zero4 /* or null */, uint32_t n_zero4 /* the backward's gradient records (GeomLayout::grec), zero-filled here */)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
     __shared__ float4 s0[FB];
@@ -139,6 +140,15 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_tile;
 
+    // The 64 B / Gaussian zero-fill of the gradient records, spread over the workgroups of this VALU-bound kernel: a few 16-byte stores
+    // per lane that nobody waits for.  (Round 2: a memset on the side stream behind the colour kernel, joined behind this kernel --
+    // one more cross-stream wait, 10-20 us of idle queue in front of the backward's first kernel.)  Every workgroup of the launch does
+    // its slice, also the ones that find no tile below.
+    if (zero4) {
+        const uint32_t per = (n_zero4 + gridDim.x - 1) / gridDim.x;
+        const uint32_t q0 = blockIdx.x * per, q1 = min(n_zero4, q0 + per);
+        for (uint32_t q = q0 + threadIdx.x; q < q1; q += 256u) zero4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (!order_from_buckets && blockIdx.x >= ntiles) return;
     // heaviest tiles first, per XCD group
     const uint32_t Tg = xcd_group_tiles((uint32_t)gx, ntiles);

@@ -36,7 +36,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0};      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0};      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -265,6 +265,7 @@ struct gsrast_context {
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
+    std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
     std::mutex mu;
 };
@@ -317,7 +318,7 @@ template <typename T> T* at(char* base, size_t off) { return reinterpret_cast<T*
 template <typename T> const T* at(const char* base, size_t off) { return reinterpret_cast<const T*>(base + off); }
 
 __global__ void __launch_bounds__(256)
-export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __restrict__ rec0,
+export_geom_kernel(int P, const float4* __restrict__ rec0,
                    const float4* __restrict__ rec1, const float4* __restrict__ rec2,
                    const float* __restrict__ cov3D_in, const unsigned char* __restrict__ clamped_in,
                    const uint32_t* __restrict__ tiles_in, float* depths, float* means2D, float* cov3D,
@@ -327,7 +328,7 @@ export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __r
     if (i >= P) return;
     const bool vis = tiles_in[i] != 0;
     const float4 a = rec0[i], b = rec1[i], c = rec2[i];
-    if (depths) depths[i] = vis ? depths_in[i] : 0.0f;
+    if (depths) depths[i] = vis ? b.z : 0.0f;
     if (means2D) { means2D[2 * i] = vis ? a.x : 0.f; means2D[2 * i + 1] = vis ? a.y : 0.f; }
     if (cov3D) for (int k = 0; k < 6; k++) cov3D[6 * i + k] = cov3D_in[6 * i + k];
     if (conic_opacity) {
@@ -342,15 +343,21 @@ export_geom_kernel(int P, const float* __restrict__ depths_in, const float4* __r
     if (tiles) tiles[i] = tiles_in[i];
 }
 
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
 // one workgroup per tile: the 64-bit keys of the reference, rebuilt from the tile's range
 __global__ void __launch_bounds__(256)
 export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals_sorted,
-                   const float* __restrict__ depths, uint64_t* keys, uint32_t* point_list)
+                   const float4* __restrict__ rec1 /* .z = depth */, uint64_t* keys, uint32_t* point_list)
 {
     const uint2 r = ranges[blockIdx.x];
     for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) {
         const uint32_t g = vals_sorted[i];
-        if (keys) keys[i] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__float_as_uint(depths[g]);
+        if (keys) keys[i] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__float_as_uint(rec1[g].z);
         if (point_list) point_list[i] = g;
     }
 }
@@ -373,6 +380,7 @@ struct BlendArgs {
     const uint2* ranges; const uint32_t* plist; const uint32_t* order; int W, H, gx; uint32_t T; const float4 *r0, *r1, *r2; const float* bg;
     float *oc, *od, *fT; uint32_t *nc, *tm;                       // forward outputs (fT / nc / tm: inputs of backward)
     const float* dpix; float* grec;                              // backward
+    float4* zero4 = nullptr; uint32_t n_zero4 = 0;               // forward (culling kernel): the gradient records to zero-fill
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -411,7 +419,7 @@ template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
     blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
-                                                     a.bcnt, a.blist, a.from_buckets);
+                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -461,6 +469,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "exp_mode")) { if (value < 0 || value > 2) return GSRAST_E_ARG; g_def.exp_mode = value; return 0; }
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
     if (!strcmp(name, "sort_hint")) { g_sort_hint = value ? 1 : 0; return 0; }
@@ -488,6 +497,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "exp_mode")) return g_def.exp_mode.load();
     if (!strcmp(name, "profile")) return g_profile.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
+    if (!strcmp(name, "debug_state")) return g_debug_state.load();
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
     if (!strcmp(name, "bwd_pixels_per_lane")) return g_def.bwd_ppl.load();
     if (!strcmp(name, "cull")) return g_def.cull.load();
@@ -612,7 +622,6 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     char* img = (char*)image_alloc(image_ctx, IL.total);
     if (!img) return fail(GSRAST_E_ALLOC, "forward: image allocation failed");
 
-    float* depths = at<float>(geom, GL.depths);
     float4* rec0 = at<float4>(geom, GL.rec0); float4* rec1 = at<float4>(geom, GL.rec1); float4* rec2 = at<float4>(geom, GL.rec2);
     uint32_t* tiles = at<uint32_t>(geom, GL.tiles);
     uint2* rect = at<uint2>(geom, GL.rect);
@@ -639,7 +648,14 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // Where it forks matters little: its 200 MB of traffic stretches whatever latency-bound kernel runs beside it by about as much as
     // it hides (measured: beside the geometry kernel + depth sort +55 us, beside the run emission + run sort +45 / +65 us, beside the
     // LDS-bound run_scatter_rows it starves itself and delays the blend) -- it forks at entry, which was the best of those by ~20 us.
+    // Round 3 (colour kernel now 162 us alone at 3 M, geometry kernel 68): forking BEHIND the geometry kernel, so that the two
+    // bandwidth-bound kernels do not share the HBM and only the atomic-/latency-bound depth sort runs beside the colours, three
+    // alternating runs each: 3 M 581 -> 559 views/s, 2 M 750 -> 736, 1 M 1033 -> 1016, 0.5 M equal -- the bucket scatter's returning
+    // atomics suffer more from the colour kernel's traffic (179 -> 271 us at 3 M) than the geometry kernel does.
     // The 64 B / Gaussian zero-fill of the backward's gradient records follows on the side stream, under the VALU-bound forward blend.
+    // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
+    // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
+    const bool zero_in_blend = o.cull != 0 && o.fwd_pixels_per_lane == 0 && (size_t)P * 4 <= 0xFFFFFFFFull;
     bool color_launched = false;
     // Every exit after the fork must order the caller's stream behind the side stream: the colour kernel and the zero-fill write
     // into the geometry buffer, which the caller is free to release (on `s`) as soon as this function has returned -- an error
@@ -666,7 +682,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             float* sC = want_shd ? at<float>(geom, GL.shdC) : nullptr;
             const float* sh_in = colors_precomp ? nullptr : shs;
             unsigned char* cl = at<unsigned char>(geom, GL.clamped);
-            float4* gz = side ? nullptr : at<float4>(geom, GL.grec);
+            float4* gz = (side || zero_in_blend) ? nullptr : at<float4>(geom, GL.grec);
             const bool staged = sh_in && M * 3 <= PP_SH_MAX && ((M * 3) & 3) == 0 && ((uintptr_t)sh_in & 15) == 0;
             const int grid = (P + PP_THREADS - 1) / PP_THREADS;
             if (rawin) {        // (gsrast_forward_raw has checked M and the alignment of the three SH arrays)
@@ -683,8 +699,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         }
         if (side) {
             GS_HIP(hipEventRecord(side->join, side->stream));
-            GS_HIP(hipMemsetAsync(at<float>(geom, GL.grec), 0, (size_t)P * GREC * sizeof(float), side->stream));
-            GS_HIP(hipEventRecord(side->join2, side->stream));
+            if (!zero_in_blend) {
+                GS_HIP(hipMemsetAsync(at<float>(geom, GL.grec), 0, (size_t)P * GREC * sizeof(float), side->stream));
+                GS_HIP(hipEventRecord(side->join2, side->stream));
+            }
         }
         return GSRAST_OK;
     };
@@ -692,17 +710,18 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
         const int pf_grid = (P + PF_THREADS - 1) / PF_THREADS;
+        float* cov_dbg = g_debug_state.load() ? at<float>(geom, GL.cov3D) : nullptr;     // 24 B / Gaussian nobody but gsrast_debug_export reads
         const int clip = (runbin && o.tile_clip) ? 1 : 0;
         uint32_t* zr = bucket_sort ? at<uint32_t>(geom, GL.zrange) : nullptr;
         const int nzero = bucket_sort ? (int)nbk * BK_XCD : 0;
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
-                P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
-                tiles, rect, at<float4>(geom, GL.binrec), kA, vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
+                P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
-                P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, depths, rec0, rec1, at<float>(geom, GL.cov3D),
-                tiles, rect, at<float4>(geom, GL.binrec), kA, vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
+                P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -725,6 +744,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         } else {
             order = vA;
             ProfScope ps(K_SORT_DEPTH, s);
+            if (bucket_sort) {      // the geometry kernel left the values to the bucket sort (which overflowed): the identity, now
+                iota_kernel<<<(P + 255) / 256, 256, 0, s>>>(vA, (uint32_t)P);
+                GS_LAUNCHED("iota");
+            }
             // the last pass also writes rectangle widths (and, for the instance-level binning, tile counts) in depth order
             const SortAdapt<uint32_t, uint32_t> ad{ at<uint32_t>(geom, GL.keyC), at<uint32_t>(geom, GL.valC), at<uint32_t>(geom, GL.sort_minmax), scalars + 8, assume };
             int rc = radix_sort<uint32_t, uint32_t, GSRAST_DEPTH_ITEMS>(kA, vA, kB, vB, (uint32_t)P, 32, hist, scan_tmp, s, rect, runbin ? nullptr : offsets, woffsets, nullptr, &ad);
@@ -804,7 +827,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     };
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built) -> int {
         { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }  // the other binning scheme / nothing to bin: not forked yet
-        if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));       // the colours (rec2) are the blend's input
+        if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); if (zero_in_blend) side_guard.joined = true; }       // the colours (rec2) are the blend's input
         ProfScope ps(K_BLEND_FWD, s);
         uint32_t grid = ((T + 7) / 8) * 8;
         float* fT = at<float>(img, IL.final_T); uint32_t* nc = at<uint32_t>(img, IL.n_contrib);
@@ -814,6 +837,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
         const int ppl = pick_ppl(T, false, o);
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
+        if (zero_in_blend) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && o.lpt) {
             if (buckets_ok && fwd_lists_built) { ba.from_buckets = 1; grid = (uint32_t)(XCD_GROUPS * xcd_group_tiles_host((size_t)cam.gx, (size_t)cam.gy)); }   // the tile-range kernel already bucketed the tiles
@@ -830,7 +854,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         default: if (cull) launch_fwd_cull<2>(grid, s, ba); else dispatch_fwd<2>(ppl, grid, s, ba); break;
         }
         GS_LAUNCHED("blend_fwd");
-        if (side) { GS_HIP(hipStreamWaitEvent(s, side->join2, 0)); side_guard.joined = true; }      // the gradient records are zero before anything after this forward
+        if (side && !zero_in_blend) { GS_HIP(hipStreamWaitEvent(s, side->join2, 0)); side_guard.joined = true; }      // the gradient records are zero before anything after this forward
         return GSRAST_OK;
     };
 
@@ -862,9 +886,15 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     bool sort_redone = false;
     if (!bucket_sort && o.depth_sort == 0 && ctx->bucket_skip.load() > 0) ctx->bucket_skip--;
     if (bucket_sort) {
-        if (counts[11] != 0) {      // more Gaussians at (nearly) one depth than a bucket holds: sort again with the radix passes, and
+        if (counts[11] == 0 && ctx->bucket_backoff.load() > 0 && ++ctx->bucket_clean >= 64) { ctx->bucket_backoff = 0; ctx->bucket_clean = 0; }   // the scene changed: forget
+        if (counts[11] != 0) {
+            ctx->bucket_clean = 0;      // more Gaussians at (nearly) one depth than a bucket holds: sort again with the radix passes, and
             ctx->redo_count++;      // start with those for a while (everything enqueued so far used a wrong order, as below)
-            ctx->bucket_skip = 16;
+            // exponential back-off: 16 radix forwards after the first overflow, twice as many after each further one (a scene whose
+            // depths pile up for good pays the discarded speculative launch ever more rarely), capped at 4096
+            { const int prev = ctx->bucket_backoff.load(); const int next = prev <= 0 ? 16 : (prev >= 2048 ? 4096 : prev * 2);
+              ctx->bucket_backoff = next; ctx->bucket_skip = next; }
+            ctx->depth_short = 0;   // the radix path's pass-count hint is stale (not refreshed on the bucket path): assume four passes
             int rc = sort_and_scan(false, false);
             if (rc == GSRAST_OK) rc = read_u32(scalars, s, counts, 12);
             if (rc != GSRAST_OK) return rc;
@@ -1494,17 +1524,18 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
 {
     hipStream_t s = (hipStream_t)stream;
     if (P <= 0 || !geom_buffer) return fail(GSRAST_E_ARG, "debug_export: bad arguments");
+    if (cov3D && !g_debug_state.load()) return fail(GSRAST_E_ARG, "debug_export: cov3D is only kept by forwards run with gsrast_set_option(\"debug_state\", 1)");
     const GeomLayout GL = geom_layout((size_t)P);
     const ImgLayout IL = img_layout((size_t)width, (size_t)height);
     const uint32_t T = (uint32_t)((width + TILE_X - 1) / TILE_X) * (uint32_t)((height + TILE_Y - 1) / TILE_Y);
     export_geom_kernel<<<(P + 255) / 256, 256, 0, s>>>(
-        P, at<float>(geom_buffer, GL.depths), at<float4>(geom_buffer, GL.rec0), at<float4>(geom_buffer, GL.rec1),
+        P, at<float4>(geom_buffer, GL.rec0), at<float4>(geom_buffer, GL.rec1),
         at<float4>(geom_buffer, GL.rec2), at<float>(geom_buffer, GL.cov3D), at<unsigned char>(geom_buffer, GL.clamped),
         at<uint32_t>(geom_buffer, GL.tiles), depths, means2D, cov3D, conic_opacity, rgb, clamped, tiles_touched);
     GS_LAUNCHED("export_geom");
     if (R > 0 && binning_buffer && image_buffer && (keys_sorted || point_list)) {
         export_keys_kernel<<<T, 256, 0, s>>>(at<uint2>(image_buffer, IL.ranges), at<uint32_t>(binning_buffer, 0),
-                                             at<float>(geom_buffer, GL.depths), keys_sorted, point_list);
+                                             at<float4>(geom_buffer, GL.rec1), keys_sorted, point_list);
         GS_LAUNCHED("export_keys");
     }
     if (image_buffer) {

@@ -14,7 +14,7 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 // ---------------------------------------------------------------------------------------------
 // HBM layout of the three state buffers.  Every array starts on a 256-byte boundary.
 // Geometry (per Gaussian), replaces GeometryState (reference rasterizer_impl.h:30-45):
-//   depths   f32[P]      view-space z (also the low 32 key bits)
+//   (depth)              view-space z lives in rec1.z (also the low 32 key bits); there is no separate array
 //   rec0     float4[P]   {mean2D.x, mean2D.y, conic.x, conic.y}     \  gathered by the blend
 //   rec1     float4[P]   {conic.z, opacity, depth, skip_threshold}   > kernels, 48 B / instance
 //   rec2     float4[P]   {r, g, b, 0}   (colour kernel, side stream) /
@@ -38,7 +38,7 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
-    size_t depths, rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
+    size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
         hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, bk_param, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
@@ -112,7 +112,7 @@ static inline GeomLayout geom_layout(size_t P)
     GeomLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     size_t Pp = P ? P : 1;
-    L.depths = take(Pp * 4); L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16);
+    L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16);
     L.cov3D = take(Pp * 24); L.clamped = take(Pp); L.tiles = take(Pp * 4); L.rect = take(Pp * 8); L.binrec = take(Pp * 32);
     L.keyA = take(Pp * 4); L.keyB = take(Pp * 4); L.valA = take(Pp * 4); L.valB = take(Pp * 4);
     L.offsets = take(Pp * 4); L.woffsets = take(Pp * 4);

@@ -506,10 +506,10 @@ __global__ void __launch_bounds__(PF_THREADS)
 preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities, RawArgs raw,
                       const float* __restrict__ cov3D_precomp, CamArgs cam_args, int* __restrict__ radii,
-                      float* __restrict__ depths, float4* __restrict__ rec0, float4* __restrict__ rec1,
-                      float* __restrict__ cov3D,
+                      float4* __restrict__ rec0, float4* __restrict__ rec1,
+                      float* __restrict__ cov3D /* or null */,
                       uint32_t* __restrict__ tiles, uint2* __restrict__ rect, float4* __restrict__ binrec,
-                      uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val,
+                      uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val /* or null */,
                       int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */,
                       uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */,
                       uint32_t* __restrict__ block_zrange /* [gridDim.x][2] or null: minimum / maximum depth key of this block's visible
@@ -556,8 +556,10 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
             const float q[4] = { q_in.x, q_in.y, q_in.z, q_in.w };
             M3 Mm;
             cov3d_from_scale_rot(s_in, cam.scale_mod, q, c6, Mm);
+            if (cov3D) {       // only for gsrast_debug_export (option "debug_state"): the backward recomputes it from scale / rotation
 #pragma unroll
-            for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = c6[k];
+                for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = c6[k];
+            }
         }
         Cov2D cv;
         cov2d_eval(p, cam, c6, cv);
@@ -581,7 +583,6 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                 // with a 2% margin, so skipping the exp for such pairs never changes a decision.
                 // (clamped at -80 so that exp() is only ever evaluated on [-80, 0]: gs_exp<., BOUNDED>)
                 const float thr = op > 0.0f ? fmaxf(logf(1.0f / (255.0f * op)) - 0.02f, -80.0f) : 1.0f;
-                depths[i] = pv[2];
                 rec0[i] = make_float4(px, py, con0, con1);
                 rec1[i] = make_float4(con2, op, pv[2], thr);
                 rad_out = rad; ntiles = (uint32_t)area;
@@ -621,7 +622,8 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
         }
     }
     radii[i] = rad_out; tiles[i] = ntiles; rect[i] = rc;
-    sort_key[i] = key; sort_val[i] = (uint32_t)i;
+    sort_key[i] = key;
+    if (sort_val) sort_val[i] = (uint32_t)i;        // the radix depth sort's values; the bucket sort carries the index in its slab element
     } // i < P
     if (block_zrange) {     // depth range of the block's visible Gaussians (positive floats order like their bits; culled: key = ~0)
         __shared__ uint32_t s_lo[PF_THREADS / 64], s_hi[PF_THREADS / 64];

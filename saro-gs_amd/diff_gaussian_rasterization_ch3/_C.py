@@ -650,10 +650,14 @@ def debug_export(P: int, R: int, W: int, H: int, geomBuffer, binningBuffer, imag
         point_list=torch.zeros(max(R, 1), dtype=torch.int32, device=dev)[:R],
         ranges=torch.zeros((T, 2), dtype=torch.int32, device=dev),
         final_T=torch.zeros((H, W), **f32), n_contrib=torch.zeros((H, W), dtype=torch.int32, device=dev))
+    # cov3D is kept by the forward only under the process-wide option "debug_state" (24 B / Gaussian nothing else reads)
+    keep_cov = int(lib().gsrast_get_option(b"debug_state")) != 0
+    if not keep_cov:
+        del out["cov3D"]
     with torch.cuda.device(dev):
         rc = lib().gsrast_debug_export(
             P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), out["depths"].data_ptr(),
-            out["means2D"].data_ptr(), out["cov3D"].data_ptr(), out["conic_opacity"].data_ptr(),
+            out["means2D"].data_ptr(), out["cov3D"].data_ptr() if keep_cov else None, out["conic_opacity"].data_ptr(),
             out["rgb"].data_ptr(), out["clamped"].data_ptr(), out["tiles_touched"].data_ptr(),
             _ptr(out["keys_sorted"]), _ptr(out["point_list"]), out["ranges"].data_ptr(),
             out["final_T"].data_ptr(), out["n_contrib"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)

@@ -14,10 +14,12 @@ def run_hip(rast, scene, cam, device, dL_dcolor=None, colors_precomp=None, cov3D
     _C = rast._C
     _C.set_option("exp_mode", exp_mode)
     _C.set_option("tile_clip", tile_clip)
+    _C.set_option("debug_state", 1)         # the forward also keeps cov3D for debug_export (the product default does not store it)
     try:
         return _run_hip(rast, scene, cam, device, dL_dcolor, colors_precomp, cov3D_precomp)
     finally:
         _C.set_option("tile_clip", 1)
+        _C.set_option("debug_state", 0)
 
 
 def _run_hip(rast, scene, cam, device, dL_dcolor, colors_precomp, cov3D_precomp):

@@ -32,10 +32,14 @@ def _inputs(scenes, rast, P, W, H, dev, seed=0):
 
 def _forward_state(rast, rs, ten, P, W, H):
     e = torch.empty(0)
-    R, color, radii, gb, bb, ib, depth = rast._C.rasterize_gaussians(
-        rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix,
-        rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, ten["shs"], rs.sh_degree, rs.campos, False)
-    st = rast._C.debug_export(P, R, W, H, gb, bb, ib)
+    rast._C.set_option("debug_state", 1)        # keep cov3D for the export (not stored by default)
+    try:
+        R, color, radii, gb, bb, ib, depth = rast._C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, ten["shs"], rs.sh_degree, rs.campos, False)
+        st = rast._C.debug_export(P, R, W, H, gb, bb, ib)
+    finally:
+        rast._C.set_option("debug_state", 0)
     return R, color, radii, depth, st
 
 
@@ -331,7 +335,7 @@ def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu):
     finally:
         # let the context forget: an ordinary scene, until the bucket sort is tried (and kept) again
         sc2 = scenes.synth(P, 10)
-        for _ in range(12):
+        for _ in range(2100):       # 16 forwards after a first overflow; the pause doubles with every further one (capped at 4096)
             if _C.get_option("bucket_skip") == 0:
                 break
             run_hip(rast, sc2, cam, gpu, tile_clip=0)
