@@ -21,7 +21,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_$c.txt
   rm -rf $out/pmc_$c
 done
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o pmc -- python bench.py $extra --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_sq.err
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq -o pmc -- python bench.py $extra --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_sq.err
 f=$(ls $out/pmc_sq/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_SQ.txt
 rm -rf $out/pmc_sq
