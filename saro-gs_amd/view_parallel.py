@@ -193,7 +193,25 @@ class StepBucket:
             self.views.append(self.flat[o:o + p.numel()].view(p.shape))
             o += p.numel()
 
+    def matches(self, leaves: Dict[str, torch.Tensor]) -> bool:
+        """Is this bucket still the cache of `leaves` (the model's CURRENT parameters)?  Densification / pruning
+        (densify_and_prune -> replace_tensor_to_optimizer / cat_tensors_to_optimizer, scene/saro_gaussian.py:560-640, :700-760) replaces
+        the per-Gaussian parameters by NEW tensors with another P: the bucket then still points at the old ones, whose .grad no
+        backward fills any more.  The training loop checks after every densification step and rebuilds:
+            if not bucket.matches(model.leaves()): bucket = StepBucket(model.leaves())
+        on every rank alike (densification is deterministic on replicated parameters)."""
+        if list(leaves.keys()) != self.names:
+            return False
+        return all(q is p and tuple(q.shape) == tuple(v.shape) for q, p, v in zip(leaves.values(), self.leaves, self.views))
+
+    def stale(self) -> bool:
+        """A leaf was resized IN PLACE (p.data = ...) since the bucket was built: its cache view no longer fits."""
+        return any(tuple(p.shape) != tuple(v.shape) for p, v in zip(self.leaves, self.views))
+
     def zero(self) -> None:                     # zero_gradient_cache (saro_gaussian.py:249-264)
+        if self.stale():
+            raise RuntimeError("StepBucket: a leaf changed shape since the bucket was built (densification?): rebuild it with "
+                               "StepBucket(leaves) from the model's current parameters (see StepBucket.matches)")
         for p in self.leaves:                   # the previous step's .grad are views of this buffer: detach them first, or the
             p.grad = None                       # next backward would accumulate straight into the cache
         self.flat.zero_()

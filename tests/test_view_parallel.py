@@ -257,3 +257,67 @@ def test_overlapped_factor_all_gather_two_ranks(tmp_path):
     world = 2
     mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["True", "True"]
+
+
+# ---- densification between two steps: P changes, the bucket is rebuilt -----------------------------------------------------------
+def _densify(model, keep_every=3, clone_every=5):
+    """A deterministic stand-in for densify_and_prune (scene/saro_gaussian.py:700-760): prune every `keep_every`-th Gaussian, clone
+    every `clone_every`-th of the rest -- new Parameter objects with another P, as the reference's optimizer surgery leaves them."""
+    P = model._xyz.shape[0]
+    keep = torch.arange(P) % keep_every != 0
+    idx = torch.nonzero(keep)[:, 0]
+    idx = torch.cat([idx, idx[::clone_every]])
+    for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_temporal_pos"):
+        old = getattr(model, name)
+        setattr(model, name, torch.nn.Parameter(old.detach()[idx].clone()))
+    return int(idx.numel())
+
+
+def _densify_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import view_parallel as vp
+    torch.set_num_threads(1)
+    vp.init_from_env("gloo")
+    model = _DynamicStageModel(257, 11)
+    bucket = vp.StepBucket(model.leaves())
+    vp.distributed_step(bucket, [0, 1, 2, 3], model.render_loss)
+    assert bucket.matches(model.leaves())
+    P2 = _densify(model)                                    # the same surgery on every rank (replicated parameters)
+    assert P2 != 257 and not bucket.matches(model.leaves())  # new Parameter objects: the old bucket caches tensors nobody trains any more
+    # an in-place resize is caught by the step itself
+    old_leaf = bucket.leaves[0]
+    old_leaf.data = torch.zeros((5, 3))
+    try:
+        vp.distributed_step(bucket, [0, 1], model.render_loss)
+        raised = False
+    except RuntimeError as e:
+        raised = "rebuild" in str(e)
+    bucket = vp.StepBucket(model.leaves())
+    stats = vp.distributed_step(bucket, [4, 5, 6, 7], model.render_loss)
+    if rank == 0:
+        torch.save({"raised": raised, "P2": P2, "grads": {n: p.grad.clone() for n, p in model.leaves().items() if p.grad is not None},
+                    "stats": {k: v.clone() for k, v in stats.items()}}, os.path.join(out_dir, "densify.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_rebuilt_after_densification_changes_P(tmp_path):
+    """train.py:279-300: every densification interval the per-Gaussian parameters are replaced by tensors with another P.  The step
+    bucket detects it (refuses to run stale), is rebuilt from the new leaves, and the next distributed step equals the reference's
+    batch loop on the densified model."""
+    world = 2
+    mp.spawn(_densify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(tmp_path / "densify.pt")
+    assert got["raised"] is True
+    model = _DynamicStageModel(257, 11)
+    assert _densify(model) == got["P2"]
+    want_g, want_s = _reference_loop(model, [4, 5, 6, 7])
+    assert set(got["grads"]) == set(want_g)
+    for n in want_g:
+        assert got["grads"][n].shape == want_g[n].shape
+        np.testing.assert_allclose(got["grads"][n].numpy(), want_g[n].numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
+    np.testing.assert_array_equal(got["stats"]["radii"].numpy(), want_s["radii"].numpy().astype(np.float32))
+    np.testing.assert_allclose(got["stats"]["viewspace_point_grad"].numpy(), want_s["viewspace_point_grad"].numpy(), rtol=2e-5, atol=1e-9)
