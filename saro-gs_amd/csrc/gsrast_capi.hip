@@ -647,11 +647,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     if (o.side_stream) side = side_stream_of(ctx);
     // Where it forks matters little: its 200 MB of traffic stretches whatever latency-bound kernel runs beside it by about as much as
     // it hides (measured: beside the geometry kernel + depth sort +55 us, beside the run emission + run sort +45 / +65 us, beside the
-    // LDS-bound run_scatter_rows it starves itself and delays the blend) -- it forks at entry, which was the best of those by ~20 us.
-    // Round 3 (colour kernel now 162 us alone at 3 M, geometry kernel 68): forking BEHIND the geometry kernel, so that the two
-    // bandwidth-bound kernels do not share the HBM and only the atomic-/latency-bound depth sort runs beside the colours, three
-    // alternating runs each: 3 M 581 -> 559 views/s, 2 M 750 -> 736, 1 M 1033 -> 1016, 0.5 M equal -- the bucket scatter's returning
-    // atomics suffer more from the colour kernel's traffic (179 -> 271 us at 3 M) than the geometry kernel does.
+    // LDS-bound run_scatter_rows it starves itself and delays the blend) -- round 2 forked it at entry, the best of those by ~20 us.
+    // Round 3 (colour kernel now 162 us alone at 3 M, geometry kernel 68): it forks behind the depth sort -- see there.
     // The 64 B / Gaussian zero-fill of the backward's gradient records follows on the side stream, under the VALU-bound forward blend.
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
@@ -706,7 +703,6 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         }
         return GSRAST_OK;
     };
-    { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
         const int pf_grid = (P + PF_THREADS - 1) / PF_THREADS;
@@ -765,6 +761,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         return rc;
     };
     { int rc = sort_and_scan(assume_short, bucket_sort); if (rc != GSRAST_OK) return rc; }
+    // The colour kernel forks HERE, behind the geometry kernel and the depth sort (round 3; rounds 1-2: at entry): the geometry kernel
+    // is as bandwidth-bound as the colours are (running both at once is the sum of their times) and the bucket scatter's returning
+    // atomics are what the colour traffic hurts most (70 -> 150 us at 3 M); the gather-bound run emission and the run sort that now
+    // run beside it stretch less.  Two alternating runs each, views/s, entry -> here: 3 M 609 -> 619, 2 M 745 -> 753, 1 M 1059 -> 1082,
+    // 0.3 M 1504 -> 1551, 0.1 M 1878 -> 1894, shell 1 M 884 -> 917, cfg2 2692 -> 2787.  Behind the geometry kernel only: 3 M -3.8 %
+    // (the scatter beside the colours); behind the run emission: 3 M -4 % (the colours end after the binning, the blend waits).
+    { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
     // reference rasterizer_impl.cu:311 (the run-compressed path writes every tile's range itself, empty ones included)

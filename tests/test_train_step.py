@@ -9,7 +9,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_static_stage_iterations_reduce_the_loss(scenes, rast, gpu):
+@pytest.mark.parametrize("fused", [False, True], ids=["epilogue_then_rasterizer", "raw_entry_points"])
+def test_static_stage_iterations_reduce_the_loss(fused, scenes, rast, gpu):
+    """fused: the activations inside the rasterizer's per-Gaussian kernels (GaussianRasterizerRaw, round 3) instead of the standalone
+    epilogue in front of the drop-in module."""
     from conftest import settings_from
     import fused_adam
     import fused_epilogue
@@ -26,6 +29,9 @@ def test_static_stage_iterations_reduce_the_loss(scenes, rast, gpu):
                     f_rest=t(scene["shs"][:, 1:]))
 
     def render(raw):
+        if fused:
+            m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+            return rast.GaussianRasterizerRaw(rs)(raw["xyz"], m2, raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"])[0]
         motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(raw["xyz"], raw["rotation"], raw["scaling"], raw["opacity"],
                                                                           raw["f_dc"], raw["f_rest"])
         m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
