@@ -181,14 +181,32 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     uint64_t alive = __ballot(inside);
     uint64_t m_above = alive;                     // lanes whose T is still above 0.5 (median-depth test below)
 
+#ifdef GSRAST_FWD_PREFETCH
+    // Staging is software-pipelined as in the backward: the records of the NEXT batch (and the ids of the batch after that) are
+    // requested right behind the barrier that opens a batch, so the two dependent global latencies (point_list -> record) pass while
+    // the batch is blended.  A tile that saturates inside its first batch has fetched one batch it never uses (the memory system is
+    // idle under this VALU-bound kernel).
+    uint32_t id_cur = t < n ? point_list[range.x + t] : 0xFFFFFFFFu;
+    uint32_t id_next = FB + t < n ? point_list[range.x + FB + t] : 0xFFFFFFFFu;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+    if (id_cur != 0xFFFFFFFFu) { p0 = rec0[id_cur]; p1 = rec1[id_cur]; p2 = rec2[id_cur]; }
+#endif
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
         const uint32_t i = base + t;
+#ifdef GSRAST_FWD_PREFETCH
+        if (i < n) { s0[t] = p0; s1[t] = p1; s2[t] = p2; }
+        __syncthreads();
+        id_cur = id_next;
+        if (id_cur != 0xFFFFFFFFu) { p0 = rec0[id_cur]; p1 = rec1[id_cur]; p2 = rec2[id_cur]; }
+        id_next = base + 2u * FB + t < n ? point_list[range.x + base + 2u * FB + t] : 0xFFFFFFFFu;
+#else
         if (t < FB && i < n) {
             const uint32_t g = point_list[range.x + i];
             s0[t] = rec0[g]; s1[t] = rec1[g]; s2[t] = rec2[g];
         }
         __syncthreads();
+#endif
         const uint32_t cnt = (n - base) < FB ? (n - base) : FB;
         if (alive == 0ull) continue;                        // whole wave saturated: only helps staging
 #pragma unroll 1

@@ -412,7 +412,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # requested at all.
     dL_dmeans2D = torch.empty((P, 3), **opts)
     dL_dopacity = out("opacity", (P, 1), False)
-    dL_dcolors = torch.empty((P, NUM_CHANNELS), **opts)
+    # with SH colours dL_dcolors is an intermediate nobody reads (the node returns None for the absent colors_precomp input):
+    # not written -- an empty tensor in its place, like dL_dcov3D below (12 B / Gaussian of the bandwidth-bound per-Gaussian backward)
+    dL_dcolors = torch.empty((0, NUM_CHANNELS) if use_sh else (P, NUM_CHANNELS), **opts)
     dL_dmeans3D = out("means3D", (P, 3), False)
     # with scales / rotations dL_dcov3D is an intermediate nobody reads (the autograd node returns None for the absent
     # cov3D_precomp input): not computed, not written -- the binding returns an empty tensor in its place
@@ -439,7 +441,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
                     _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii_c),
                     _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color),
-                    dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                    dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), _ptr(dL_dcolors),
                     dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
                     dL_drotations.data_ptr(), stream)
 
