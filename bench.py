@@ -834,6 +834,16 @@ def main():
     prof = _C.profile_read()
     _C.set_option("profile", 0)
 
+    # the same protocol with the context's launch-order hints switched off (include/gsrast.h: options.no_order_hint): the bench repeats ONE
+    # camera pose, the best case for them; a pose seen for the first time is ordered by list length
+    no_hint = None
+    if world == 1:
+        _C.set_option("no_order_hint", 1)
+        try:
+            d0 = timed(wl, a.steps, a.warmup, None, 1, vp, dev)
+            no_hint = {"views_per_s": round(a.steps / d0, 3), "ms_per_step": round(d0 / a.steps * 1e3, 4), "steps": a.steps, "warmup": a.warmup}
+        finally:
+            _C.set_option("no_order_hint", 0)
     st = wl.stats()
     per_kernel, pk, exp2 = (None, None, None)
     if world == 1:
@@ -864,6 +874,10 @@ def main():
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,
             "host_step_ms": dict(HOST_STEPS), "preroll_steps": n_pre,
+            "launch_order_hint": {"headline": "on (library default): the context orders the forward blend of a camera pose it has rendered before by what "
+                                              "every tile consumed then; this bench repeats one pose per rank",
+                                  "switched_off": no_hint,
+                                  "note": "results never depend on it (tests/test_gpu_parity.py::test_launch_order_hints_never_change_a_result)"},
         }
 
     # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----

@@ -191,7 +191,12 @@ typedef struct gsrast_options {
                                  does not store d(colour)/d(view direction) (36 B / Gaussian) for the backward.  A backward on such a
                                  state must be given forward_only = 1 as well; it then evaluates those derivatives itself
                                  (sh_dir_derivs_kernel, re-reading the SH blocks).  0 (default) = the forward prepares them */
-    int reserved[2];          /* must be zero */
+    int no_order_hint;        /* forward: 1 = do not use / update the context's launch-order hints.  By default a context remembers, per device and
+                                 camera pose (hash of the view and projection matrices and the image size; 32 poses, least recently used
+                                 replaced; device memory, 2 B per tile and pose), how deep every tile's list was consumed the last time
+                                 that pose was rendered, and starts the forward blend's heaviest tiles first by it -- the list length, the
+                                 only estimate a first-seen pose has, is a poor one in occluded scenes.  Results never depend on it */
+    int reserved[1];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device); contexts

@@ -955,7 +955,9 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
                              uint32_t capR, int gx, int gy, const uint32_t* __restrict__ hist_scanned,
                              const uint32_t* __restrict__ digit_total, uint32_t nblk, uint2* __restrict__ ranges,
                              uint32_t* __restrict__ bucket_cnt /* forward launch order: [8][64] counts (zeroed), or null */,
-                             uint16_t* __restrict__ bucket_list /* [8][64][Tg] */)
+                             uint16_t* __restrict__ bucket_list /* [8][64][Tg] */,
+                             const HintTable* __restrict__ hints /* or null: what each tile of this camera pose consumed the last time (gsrast_common.h) */,
+                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */)
 {
     __shared__ int diff[257];
     __shared__ uint32_t lcnt[XCD_GROUPS * WORK_BUCKETS], lbase[XCD_GROUPS * WORK_BUCKETS];
@@ -983,6 +985,11 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
     if (y < (uint32_t)gy)
         ranges[y * (uint32_t)gx + x] = before1 > before0 ? make_uint2(row_base + before0, row_base + before1) : make_uint2(0u, 0u);
     work = before1 > before0 ? before1 - before0 : 0u;
+    // forward launch order: the prefix this tile consumed the last time this pose was rendered, if the context knows (never more than the list)
+    if (hints && hint_sel[1] && work && y < (uint32_t)gy) {
+        const uint32_t h = hint_work(hints, 0u)[(size_t)hint_sel[0] * ((uint32_t)gx * (uint32_t)gy) + y * (uint32_t)gx + x];
+        work = h < work ? (h ? h : 1u) : work;
+    }
     }
     if (bucket_cnt) {
         // forward launch order: append this column's tiles to the work buckets of their XCD group (tile row mod 8); one global

@@ -131,7 +131,9 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
                       uint32_t* __restrict__ bucket_cnt /* fwd [8][64] | bwd [64], or null */, uint16_t* __restrict__ bucket_list /* fwd [8][64][Tg] | bwd [64][T] */,
                       int order_from_buckets,
-                      float4* __restrict__ zero4 /* or null */, uint32_t n_zero4 /* the backward's gradient records (GeomLayout::grec), zero-filled here */)
+                      float4* __restrict__ zero4 /* or null */, uint32_t n_zero4 /* the backward's gradient records (GeomLayout::grec), zero-filled here */,
+                      HintTable* __restrict__ hints /* or null: the context's launch-order hints (gsrast_common.h); this view's slot receives every tile's consumed depth */,
+                      const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
     __shared__ float4 s0[FB];
@@ -181,32 +183,21 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     uint64_t alive = __ballot(inside);
     uint64_t m_above = alive;                     // lanes whose T is still above 0.5 (median-depth test below)
 
-#ifdef GSRAST_FWD_PREFETCH
-    // Staging is software-pipelined as in the backward: the records of the NEXT batch (and the ids of the batch after that) are
-    // requested right behind the barrier that opens a batch, so the two dependent global latencies (point_list -> record) pass while
-    // the batch is blended.  A tile that saturates inside its first batch has fetched one batch it never uses (the memory system is
-    // idle under this VALU-bound kernel).
-    uint32_t id_cur = t < n ? point_list[range.x + t] : 0xFFFFFFFFu;
-    uint32_t id_next = FB + t < n ? point_list[range.x + FB + t] : 0xFFFFFFFFu;
-    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
-    if (id_cur != 0xFFFFFFFFu) { p0 = rec0[id_cur]; p1 = rec1[id_cur]; p2 = rec2[id_cur]; }
-#endif
+    // (Measured and dropped, round 3: software-pipelined staging as in the backward -- the next batch's records requested behind the
+    // barrier that opens a batch.  -0.3 ... -1.2 % per step at 3 M / 1 M / shell: most tiles saturate inside their first batch and
+    // then have fetched 256 records for nothing; eight workgroups per CU hide the staging latency of the few heavy ones.
+    // Also measured and dropped: TWO PHASES -- every tile blends its first 256 entries, unfinished tiles park their per-pixel state
+    // and a second, persistent launch continues them heaviest-remaining-first (bit-identical outputs): blend_fwd 0.33 -> 0.37 ms at
+    // 3 M, 0.22 -> 0.26 at 1 M, 0.23 -> 0.36 on the shell scene.  The heavy tiles' serial chain of batches must run UNDER the bulk of
+    // the light tiles, not behind it: what helps is starting them first, i.e. knowing them -- see the launch-order hint below.)
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
         const uint32_t i = base + t;
-#ifdef GSRAST_FWD_PREFETCH
-        if (i < n) { s0[t] = p0; s1[t] = p1; s2[t] = p2; }
-        __syncthreads();
-        id_cur = id_next;
-        if (id_cur != 0xFFFFFFFFu) { p0 = rec0[id_cur]; p1 = rec1[id_cur]; p2 = rec2[id_cur]; }
-        id_next = base + 2u * FB + t < n ? point_list[range.x + base + 2u * FB + t] : 0xFFFFFFFFu;
-#else
         if (t < FB && i < n) {
             const uint32_t g = point_list[range.x + i];
             s0[t] = rec0[g]; s1[t] = rec1[g]; s2[t] = rec2[g];
         }
         __syncthreads();
-#endif
         const uint32_t cnt = (n - base) < FB ? (n - base) : FB;
         if (alive == 0ull) continue;                        // whole wave saturated: only helps staging
 #pragma unroll 1
@@ -291,6 +282,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __syncthreads();
     if (t == 0) {
         tile_max[tile] = s_max;
+        if (hints) hint_work(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
         // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
         if (bucket_cnt) bucket_append_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, tile, s_max);
     }

@@ -42,7 +42,7 @@ std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0};  
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
 // threads driving different streams / devices with different options cannot disturb each other.
 struct DefaultOptions {
-    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0};
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0}, no_order_hint{0};
 } g_def;
 gsrast_options snapshot_defaults()
 {
@@ -50,7 +50,7 @@ gsrast_options snapshot_defaults()
     o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
     o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
     o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream; o.depth_sort = g_def.depth_sort;
-    o.forward_only = g_def.forward_only;
+    o.forward_only = g_def.forward_only; o.no_order_hint = g_def.no_order_hint;
     return o;
 }
 bool options_valid(const gsrast_options& o)
@@ -267,6 +267,7 @@ struct gsrast_context {
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
     std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
+    struct Hints { HintTable* table = nullptr; uint32_t T = 0; } hints[32];   // per device: launch-order hints of the forward blend (gsrast_common.h), device memory
     std::mutex mu;
 };
 namespace {
@@ -294,6 +295,24 @@ SideStream* side_stream_of(gsrast_context* ctx)
         }
     }
     return &x;
+}
+// The context's hint table on the current device for a T-tile image (allocated on first use, cleared when T changes); nullptr if
+// it cannot be had -- the forward then orders its blend by list length, as a first-seen pose does.
+HintTable* hints_of(gsrast_context* ctx, uint32_t T, hipStream_t s)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto& h = ctx->hints[device];
+    if (h.table && h.T != T) {       // another image size: the estimates mean nothing (rare: drain, then start over)
+        (void)hipStreamSynchronize(s); (void)hipFree(h.table); h.table = nullptr;
+    }
+    if (!h.table) {
+        if (hipMalloc((void**)&h.table, hint_table_bytes(T)) != hipSuccess) { h.table = nullptr; return nullptr; }
+        h.T = T;
+        if (hipMemsetAsync(h.table, 0, sizeof(HintTable), s) != hipSuccess) { (void)hipFree(h.table); h.table = nullptr; return nullptr; }
+    }
+    return h.table;
 }
 gsrast_context* thread_context()
 {   // deliberately leaked at thread exit (a few words): see Readback above for why nothing here has a destructor
@@ -381,6 +400,7 @@ struct BlendArgs {
     float *oc, *od, *fT; uint32_t *nc, *tm;                       // forward outputs (fT / nc / tm: inputs of backward)
     const float* dpix; float* grec;                              // backward
     float4* zero4 = nullptr; uint32_t n_zero4 = 0;               // forward (culling kernel): the gradient records to zero-fill
+    HintTable* hints = nullptr; const uint32_t* hint_sel = nullptr;   // forward: the context's launch-order hints, this call's slot
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -419,7 +439,7 @@ template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
     blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
-                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4);
+                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -444,6 +464,7 @@ gsrast_context* gsrast_context_create(void) { return new (std::nothrow) gsrast_c
 void gsrast_context_destroy(gsrast_context* c)
 {
     if (!c) return;
+    for (auto& h : c->hints) if (h.table) (void)hipFree(h.table);
     for (SideStream& x : c->side) {
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
@@ -481,6 +502,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "side_stream")) { g_def.side_stream = value ? 1 : 0; return 0; }
     if (!strcmp(name, "depth_sort")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.depth_sort = value; return 0; }
     if (!strcmp(name, "forward_only")) { g_def.forward_only = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "no_order_hint")) { g_def.no_order_hint = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -509,6 +531,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "side_stream")) return g_def.side_stream.load();
     if (!strcmp(name, "depth_sort")) return g_def.depth_sort.load();
     if (!strcmp(name, "forward_only")) return g_def.forward_only.load();
+    if (!strcmp(name, "no_order_hint")) return g_def.no_order_hint.load();
     if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
@@ -650,6 +673,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // LDS-bound run_scatter_rows it starves itself and delays the blend) -- round 2 forked it at entry, the best of those by ~20 us.
     // Round 3 (colour kernel now 162 us alone at 3 M, geometry kernel 68): it forks behind the depth sort -- see there.
     // The 64 B / Gaussian zero-fill of the backward's gradient records follows on the side stream, under the VALU-bound forward blend.
+    // launch-order hints of the forward blend: per context, device and camera pose (gsrast_common.h); only with the work-bucket order
+    HintTable* hints = (runbin && buckets_ok && o.cull != 0 && o.lpt != 0 && o.fwd_pixels_per_lane == 0 && !o.no_order_hint) ? hints_of(ctx, T, s) : nullptr;
+    uint32_t* hint_sel = scalars + HINT_SEL;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
     const bool zero_in_blend = o.cull != 0 && o.fwd_pixels_per_lane == 0 && (size_t)P * 4 <= 0xFFFFFFFFull;
@@ -713,11 +739,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero);
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -824,7 +850,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             GS_LAUNCHED("run_scatter_rows"); }
         {   ProfScope ps(K_RANGES, s);
             tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges,
-                                                                buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list));
+                                                                buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel);
             GS_LAUNCHED("tile_ranges"); }
         return GSRAST_OK;
     };
@@ -841,6 +867,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const int ppl = pick_ppl(T, false, o);
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
         if (zero_in_blend) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
+        if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && o.lpt) {
             if (buckets_ok && fwd_lists_built) { ba.from_buckets = 1; grid = (uint32_t)(XCD_GROUPS * xcd_group_tiles_host((size_t)cam.gx, (size_t)cam.gy)); }   // the tile-range kernel already bucketed the tiles

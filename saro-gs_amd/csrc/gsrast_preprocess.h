@@ -514,9 +514,31 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */,
                       uint32_t* __restrict__ block_zrange /* [gridDim.x][2] or null: minimum / maximum depth key of this block's visible
                                                              Gaussians, for the bucket depth sort (gsrast_binning.h); {~0, 0} if it has none */,
-                      uint32_t* __restrict__ zero_words, int n_zero_words /* that sort's counters: zeroed here, spread over the blocks */)
+                      uint32_t* __restrict__ zero_words, int n_zero_words /* that sort's counters: zeroed here, spread over the blocks */,
+                      HintTable* __restrict__ hints /* or null: the context's launch-order hints of the forward blend (gsrast_common.h) */,
+                      uint32_t* __restrict__ hint_sel /* [2]: this call's slot and whether it held this pose already */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
+    if (hints && blockIdx.x == 0 && threadIdx.x == 0) {       // look this camera pose up; claim its slot, or the least recently used one
+        uint32_t h0 = 2166136261u, h1 = 0x9E3779B9u;
+        for (int k = 0; k < 16; k++) {
+            const uint32_t a = __float_as_uint(cam_args.view[k]), b = __float_as_uint(cam_args.proj[k]);
+            h0 = (h0 ^ a) * 16777619u; h0 = (h0 ^ b) * 16777619u;
+            h1 = (h1 + a) * 0x85EBCA6Bu; h1 ^= h1 >> 13; h1 = (h1 + b) * 0xC2B2AE35u; h1 ^= h1 >> 16;
+        }
+        h0 = (h0 ^ (uint32_t)cam_args.W) * 16777619u; h1 = (h1 + (uint32_t)cam_args.H) * 0x85EBCA6Bu;
+        h0 |= 1u;                                               // (0, 0) means "free"
+        const uint32_t now = hints->clock + 1u;
+        int slot = -1, lru = 0;
+        for (int k = 0; k < HINT_SLOTS; k++) {
+            if (hints->key[k][0] == h0 && hints->key[k][1] == h1) { slot = k; break; }
+            if (hints->stamp[k] < hints->stamp[lru]) lru = k;
+        }
+        const uint32_t found = slot >= 0 ? 1u : 0u;
+        if (slot < 0) { slot = lru; hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
+        hints->stamp[slot] = now; hints->clock = now;
+        hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
+    }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // Every per-Gaussian input is requested up front: loads issued where they are first used (inside the visibility / area

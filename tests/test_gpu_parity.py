@@ -868,3 +868,53 @@ def test_no_grad_forward_skips_the_backward_preparation(orc, scenes, rast, gpu):
     assert torch.equal(c0, c1.detach()) and torch.equal(r0, r1) and torch.equal(d0, d1)
     o = orc.render(sc, cam, None)
     assert np.array_equal(bits(c0.cpu().numpy()), bits(o["out_color"]))
+
+
+def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
+    """The context remembers, per camera pose, how deep every tile's list was consumed and orders the next forward blend of that pose
+    by it (include/gsrast.h: options.no_order_hint).  Only the launch order may depend on it: alternating poses, more poses than the
+    table has slots (least-recently-used replacement), another image size in between, and hints switched off all give bit-identical
+    outputs and state -- and the first render of every pose equals the oracle."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P = 40_000                      # the work-bucket launch order (and with it the hints) is in force on the run-compressed path
+    sc = scenes.synth(P, 601, scale_mul=0.7)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    e = torch.empty(0)
+
+    def render(cam, W, H):
+        rs = settings_from(rast, cam, sc, gpu)
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return R, color.clone(), depth.clone(), radii.clone(), st["n_contrib"].clone(), st["final_T"].clone()
+
+    def same(a, b):
+        return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+    W, H = 320, 240
+    cams = [scenes.camera(k, 40, W, H) for k in range(40)]          # 40 poses > 32 slots
+    first = {}
+    for k in (0, 1, 0, 1, 0):                                        # alternating: the third render of pose 0 runs by its own hint
+        out = render(cams[k], W, H)
+        if k in first:
+            assert same(out, first[k]), f"pose {k}: a hinted launch order changed a result"
+        first[k] = out
+    o = orc.render(sc, cams[0])
+    assert first[0][0] == o["R"] and np.array_equal(bits(first[0][1].cpu().numpy()), bits(o["out_color"]))
+    for k in range(2, 40):                                           # overflow the table: pose 0 and 1 are evicted
+        first[k] = render(cams[k], W, H)
+    other = render(scenes.camera(3, 7, 200, 152), 200, 152)          # another image size: the context starts a new table
+    assert same(render(scenes.camera(3, 7, 200, 152), 200, 152), other)
+    for k in (0, 1, 39, 20):
+        assert same(render(cams[k], W, H), first[k])
+        assert same(render(cams[k], W, H), first[k])
+    _C.set_option("no_order_hint", 1)
+    try:
+        for k in (0, 39):
+            assert same(render(cams[k], W, H), first[k])
+    finally:
+        _C.set_option("no_order_hint", 0)
