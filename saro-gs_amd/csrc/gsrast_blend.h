@@ -189,7 +189,10 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     // Also measured and dropped: TWO PHASES -- every tile blends its first 256 entries, unfinished tiles park their per-pixel state
     // and a second, persistent launch continues them heaviest-remaining-first (bit-identical outputs): blend_fwd 0.33 -> 0.37 ms at
     // 3 M, 0.22 -> 0.26 at 1 M, 0.23 -> 0.36 on the shell scene.  The heavy tiles' serial chain of batches must run UNDER the bulk of
-    // the light tiles, not behind it: what helps is starting them first, i.e. knowing them -- see the launch-order hint below.)
+    // the light tiles, not behind it: what helps is starting them first, i.e. knowing them -- see the launch-order hint below.
+    // And: TWO surviving instances per round (both alphas evaluated side by side for instruction-level parallelism in the heavy
+    // tiles' serial chain, updates applied in list order: bit-identical) -- -1.5 ... -2.7 % per step at every size: the second exp is
+    // wasted whenever one of the two fails its tests; s_setprio 3 / 1 for the first workgroups of the heaviest-first order: nothing.)
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
         const uint32_t i = base + t;
