@@ -213,66 +213,6 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 touch = strip_may_touch(a, b.x, b.w, sx0, sx1, sy0, sy1);
             }
             uint64_t mask = __ballot(touch);
-#ifdef GSRAST_FWD_DUAL
-            // TWO surviving instances per round.  A heavy tile is ONE serial chain per wave (the transmittance recurrence), and when the
-            // light tiles are gone its waves run nearly alone on their SIMDs: then the chain's own dependency latency -- LDS read,
-            // power, exp, alpha, tests -- sets the kernel's duration, not the issue rate.  Everything up to alpha is independent between
-            // instances; only the few instructions that touch T / C / the masks are serial.  So the second instance's alpha is
-            // evaluated beside the first's (twice the instruction-level parallelism) and the updates are applied in list order --
-            // the same operations on the same operands: bit-identical.
-#define GS_FWD_APPLY(J, B, CC, ALPHA, M_IN)                                                                                       \
-            {                                                                                                                      \
-                const float test_T = T * (1.0f - (ALPHA));                                                                         \
-                const uint64_t m_contrib = (M_IN) & __builtin_amdgcn_ballot_w64(!((ALPHA) < 1.0f / 255.0f));                       \
-                const uint64_t m_low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);                                              \
-                const uint64_t m_upd = m_contrib & ~m_low;                                                                         \
-                m_term = m_contrib & m_low;                                                                                        \
-                if (__builtin_amdgcn_inverse_ballot_w64(m_upd)) {                                                                  \
-                    C0 = __builtin_fmaf((CC).x * (ALPHA), T, C0);                                                                  \
-                    C1 = __builtin_fmaf((CC).y * (ALPHA), T, C1);                                                                  \
-                    C2 = __builtin_fmaf((CC).z * (ALPHA), T, C2);                                                                  \
-                    T = test_T;                                                                                                    \
-                    last = base + (J) + 1;                                                                                         \
-                }                                                                                                                  \
-                if (m_above & m_upd) {                                                                                             \
-                    const uint64_t m_here = m_above & m_upd;                                                                       \
-                    const uint64_t m_cross = m_here & __builtin_amdgcn_ballot_w64(test_T < 0.5f);                                  \
-                    Dm = __builtin_amdgcn_inverse_ballot_w64(m_cross) ? (B).z : Dm;                                                \
-                    m_above &= ~(m_here & __builtin_amdgcn_ballot_w64(!(test_T > 0.5f)));                                          \
-                }                                                                                                                  \
-                if (m_term) {                                                                                                      \
-                    pxa = __builtin_amdgcn_inverse_ballot_w64(m_term) ? FAR : pxa;                                                 \
-                    alive &= ~m_term;                                                                                              \
-                }                                                                                                                  \
-            }
-            while (mask) {
-                const uint32_t j0 = r * 64 + (uint32_t)__builtin_ctzll(mask);
-                mask &= mask - 1;
-                const bool two = mask != 0ull;
-                const uint32_t j1 = two ? r * 64 + (uint32_t)__builtin_ctzll(mask) : j0;
-                mask &= mask - 1;                                           // (0 & ~0 = 0 when there was no second one)
-                const float4 a0 = s0[j0], b0 = s1[j0], c0 = s2[j0];
-                const float4 a1 = s0[j1], b1 = s1[j1], c1 = s2[j1];
-                asm volatile("" :: "v"(b0.y), "v"(b0.z), "v"(c0.x), "v"(c0.w), "v"(b1.y), "v"(b1.z), "v"(c1.x), "v"(c1.w));
-                const float power0 = gs_power(a0.z, a0.w, b0.x, a0.x - pxa, a0.y - pyf);
-                const float power1 = gs_power(a1.z, a1.w, b1.x, a1.x - pxa, a1.y - pyf);
-                const uint64_t m_in0 = __builtin_amdgcn_ballot_w64(power0 <= 0.0f) & __builtin_amdgcn_ballot_w64(power0 >= b0.w);
-                uint64_t m_in1 = two ? (__builtin_amdgcn_ballot_w64(power1 <= 0.0f) & __builtin_amdgcn_ballot_w64(power1 >= b1.w)) : 0ull;
-                GS_COUNT(0, two ? 2 : 1);
-                if ((m_in0 | m_in1) == 0ull) continue;
-                float alpha0 = b0.y * gs_exp<EXPMODE, true>(power0);
-                float alpha1 = b1.y * gs_exp<EXPMODE, true>(power1);
-                alpha0 = alpha0 < 0.99f ? alpha0 : 0.99f;
-                alpha1 = alpha1 < 0.99f ? alpha1 : 0.99f;
-                uint64_t m_term = 0ull;
-                if (m_in0) GS_FWD_APPLY(j0, b0, c0, alpha0, m_in0)
-                if (alive == 0ull) { mask = 0; r = FB / 64u; continue; }        // wave saturated
-                m_in1 &= alive;          // a pixel that terminated at the first instance is parked: it would have failed the second's tests
-                if (m_in1) GS_FWD_APPLY(j1, b1, c1, alpha1, m_in1)
-                if (alive == 0ull) { mask = 0; r = FB / 64u; }
-            }
-#undef GS_FWD_APPLY
-#else
             while (mask) {
                 const uint32_t j = r * 64 + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1;
@@ -325,7 +265,6 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     if (alive == 0ull) { mask = 0; r = FB / 64u; }        // wave saturated
                 }
             }
-#endif
         }
     }
     if (inside) {
