@@ -199,8 +199,10 @@ typedef struct gsrast_options {
     int reserved[1];          /* must be zero */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
-/* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device); contexts
- * are independent of each other.  Destroy it only after the calls that used it have returned. */
+/* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device, and -- per
+ * device it has rendered on -- a few hundred KB of device memory: the launch-order hints of options.no_order_hint); contexts are
+ * independent of each other.  Destroy it only after the calls that used it have returned (gsrast_context_destroy frees the device
+ * memory, which waits for the device). */
 typedef struct gsrast_context gsrast_context;
 gsrast_context* gsrast_context_create(void);
 void gsrast_context_destroy(gsrast_context* ctx);
