@@ -611,7 +611,11 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
 // Totals of the buckets: {num_rendered lo, Q, -, num_rendered hi} and the overflow verdict into `scalars` -- by the last workgroup of
 // the bucketed run emission (below), or, when the host needs the counts BEFORE it can launch that (no capacity hint yet), by this
 // one-workgroup kernel.
-__device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars)
+// host_out (optional): 16 words of pinned, device-mapped host memory.  The totals are ALSO stored there, followed by a system-scope
+// fence and the call's sequence number in word 15: the host spins on that word instead of on a copy + event enqueued behind the
+// kernel (a D2H copy between two kernels costs ~14 us of queue: the copy itself and the dependent-launch gaps around it).
+__device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars,
+                                                    volatile uint32_t* host_out = nullptr, uint32_t host_seq = 0)
 {
     __shared__ unsigned long long s_t[256];
     __shared__ uint32_t s_q[256];
@@ -627,7 +631,16 @@ __device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ bi
     s_t[threadIdx.x] = tsum; s_q[threadIdx.x] = q;
     over = __syncthreads_or((int)over) ? 1u : 0u;
     for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t[threadIdx.x] += s_t[threadIdx.x + st]; s_q[threadIdx.x] += s_q[threadIdx.x + st]; } __syncthreads(); }
-    if (threadIdx.x == 0) { scalars[0] = (uint32_t)s_t[0]; scalars[1] = s_q[0]; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over; }
+    if (threadIdx.x == 0) {
+        scalars[0] = (uint32_t)s_t[0]; scalars[1] = s_q[0]; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over;
+        if (host_out) {
+            host_out[0] = (uint32_t)s_t[0]; host_out[1] = s_q[0]; host_out[2] = 0u; host_out[3] = (uint32_t)(s_t[0] >> 32);
+            for (int k = 4; k < 11; k++) host_out[k] = 0u;
+            host_out[11] = over;
+            __threadfence_system();
+            host_out[15] = host_seq;
+        }
+    }
 }
 __global__ void __launch_bounds__(256)
 depth_bucket_scan_kernel(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars /* [0] R lo, [1] Q, [3] R hi, [11] overflow */)
@@ -752,7 +765,8 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                         // bucket depth sort (binfo != null): one workgroup per bucket; `order` / `woffsets` are the buckets' own slot
                         // ranges [nb][BK_CAP] (sorted ids, inclusive width scan inside the bucket), bbase the buckets' first runs
                         const uint4* __restrict__ binfo = nullptr, const uint32_t* __restrict__ bwsum = nullptr, uint32_t nbuckets = 0,
-                        uint32_t* __restrict__ scalars = nullptr /* the last workgroup leaves the totals here (depth_bucket_totals) */)
+                        uint32_t* __restrict__ scalars = nullptr /* the last workgroup leaves the totals here (depth_bucket_totals) */,
+                        uint32_t* __restrict__ host_out = nullptr, uint32_t host_seq = 0 /* ... and in pinned host memory (see depth_bucket_totals) */)
 {
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
     // per-Gaussian ellipse terms (fp64): det, 2tc, b, 1/c, dy_max, dx_top;  mode 0 = keep the column, 1 = clip, 2 = empty
@@ -788,7 +802,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         const uint4 bi = binfo[b];
         __syncthreads();
         run0 = s_run0[0] + s_run0[1] + s_run0[2] + s_run0[3];
-        if (scalars && b + 1 == nbuckets) depth_bucket_totals(binfo, nbuckets, scalars);
+        if (scalars && b + 1 == nbuckets) depth_bucket_totals(binfo, nbuckets, scalars, host_out, host_seq);
         nloc = bi.x; nchunks = (nloc + 255u) / 256u;
         P = (int)nloc;
     }

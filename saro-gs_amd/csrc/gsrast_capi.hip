@@ -212,7 +212,9 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
 // (hipStreamSynchronize may sleep; the GPU is idle while we wait, so every microsecond counts).
 struct Readback {     // 64 pinned bytes + one event per (host thread, device); deliberately never freed: the destructor of a
     uint32_t* pinned = nullptr; hipEvent_t ev = nullptr;   // thread_local would call into the HIP runtime at thread / process exit,
-};                                                         // possibly after the runtime itself has been torn down
+    uint32_t* dev_alias = nullptr;                         // possibly after the runtime itself has been torn down
+    uint32_t seq = 0;       // dev_alias: the same 64 bytes as the device sees them (a kernel stores the counts there itself: read_flag_*)
+};
 constexpr int kMaxDevices = 32;
 thread_local Readback t_readback[kMaxDevices];     // one per (host thread, device): events belong to a device
 // begin: enqueue the copy + event; finish: spin until it landed.  Work enqueued between the two runs on the GPU while
@@ -225,8 +227,10 @@ int read_u32_begin(const uint32_t* dev, hipStream_t s, int nwords, Readback** ha
     if (device < 0 || device >= kMaxDevices) return GSRAST_OK;      // exotic topology: finish() does a blocking copy
     Readback& rb = t_readback[device];
     if (!rb.pinned) {
-        GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable));
+        GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable | hipHostMallocMapped));
         GS_HIP(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+        if (hipHostGetDevicePointer((void**)&rb.dev_alias, rb.pinned, 0) != hipSuccess) rb.dev_alias = nullptr;
+        rb.pinned[15] = 0u;
     }
     GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
     GS_HIP(hipEventRecord(rb.ev, s));
@@ -244,6 +248,42 @@ int read_u32_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t* 
     while ((e = hipEventQuery(rb->ev)) == hipErrorNotReady) { }
     if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "read_u32", e);
     for (int k = 0; k < nwords; k++) out[k] = rb->pinned[k];
+    return GSRAST_OK;
+}
+// The read-back without a copy: the producing kernel stores the (12) words into the pinned buffer itself and then the sequence number
+// into word 15 (depth_bucket_totals).  prepare: the buffer's device alias and this call's sequence number, or nullptr if mapped host
+// memory is not to be had (the caller then uses the copy).  finish: spin on word 15; should it not arrive within two seconds the stream
+// is drained and the counts are copied the slow way (a failed launch surfaces there).
+Readback* read_flag_prepare(uint32_t** dev_alias, uint32_t* seq)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return nullptr;
+    Readback& rb = t_readback[device];
+    if (!rb.pinned) {
+        if (hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { rb.pinned = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipHostGetDevicePointer((void**)&rb.dev_alias, rb.pinned, 0) != hipSuccess) rb.dev_alias = nullptr;
+        rb.pinned[15] = 0u;
+    }
+    if (!rb.dev_alias) return nullptr;
+    rb.seq = rb.seq + 1u ? rb.seq + 1u : 1u;
+    *dev_alias = rb.dev_alias; *seq = rb.seq;
+    return &rb;
+}
+int read_flag_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords)
+{
+    volatile uint32_t* p = rb->pinned;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1; p[15] != rb->seq; spins++) {
+        if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            GS_HIP(hipStreamSynchronize(s));
+            if (p[15] == rb->seq) break;
+            GS_HIP(hipMemcpy(out, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
+            return GSRAST_OK;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int k = 0; k < nwords; k++) out[k] = p[k];
     return GSRAST_OK;
 }
 int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
@@ -805,6 +845,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     auto grow = [](uint32_t v) { const uint64_t w = (uint64_t)v + v / 4 + 4096; return w > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)w; };
     uint32_t cap = 0, capQ = 0;
     char* bin = nullptr;
+    Readback* rb_flag = nullptr;                 // the counts arrive by the emission kernel's own store into pinned memory (no copy enqueued)
+    uint32_t* flag_alias = nullptr; uint32_t flag_seq = 0;
     static const bool trace = getenv("GSRAST_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     if (const uint32_t hint = ctx->R_hint.load()) {
@@ -830,7 +872,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         {   ProfScope ps(K_EMIT, s);
             if (bucketed)
                 emit_column_runs_kernel<<<nbk, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
-                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars);
+                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars,
+                                                            flag_alias, flag_seq);
             else
                 emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
                                                                        o.tile_clip, capQ_, rkA, rvA);
@@ -908,11 +951,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // out not to fit, the device published empty ranges and the two pieces are simply launched again with exact sizes.
     if (speculative) {
         const bool late = totals_pending;
-        int rc = launch_run_binning(bin, cap, capQ, capQ, scalars, late ? std::function<int()>(begin_readback) : std::function<int()>());
+        if (late) rb_flag = read_flag_prepare(&flag_alias, &flag_seq);
+        int rc = launch_run_binning(bin, cap, capQ, capQ, scalars, (late && !rb_flag) ? std::function<int()>(begin_readback) : std::function<int()>());
+        flag_alias = nullptr;                    // (a repeated emission below reads its counts back the ordinary way)
         if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true);
         if (rc != GSRAST_OK) return rc;
     }
-    { int rc = read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
+    { int rc = rb_flag ? read_flag_finish(rb_flag, scalars, s, counts, 12) : read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
     bool sort_redone = false;
     if (!bucket_sort && o.depth_sort == 0 && ctx->bucket_skip.load() > 0) ctx->bucket_skip--;
     if (bucket_sort) {
