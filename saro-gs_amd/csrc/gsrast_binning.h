@@ -615,7 +615,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
 // fence and the call's sequence number in word 15: the host spins on that word instead of on a copy + event enqueued behind the
 // kernel (a D2H copy between two kernels costs ~14 us of queue: the copy itself and the dependent-launch gaps around it).
 __device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars,
-                                                    volatile uint32_t* host_out = nullptr, uint32_t host_seq = 0)
+                                                    uint32_t* host_out = nullptr, uint32_t host_seq = 0)
 {
     __shared__ unsigned long long s_t[256];
     __shared__ uint32_t s_q[256];
@@ -633,12 +633,10 @@ __device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ bi
     for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t[threadIdx.x] += s_t[threadIdx.x + st]; s_q[threadIdx.x] += s_q[threadIdx.x + st]; } __syncthreads(); }
     if (threadIdx.x == 0) {
         scalars[0] = (uint32_t)s_t[0]; scalars[1] = s_q[0]; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over;
-        if (host_out) {
-            host_out[0] = (uint32_t)s_t[0]; host_out[1] = s_q[0]; host_out[2] = 0u; host_out[3] = (uint32_t)(s_t[0] >> 32);
-            for (int k = 4; k < 11; k++) host_out[k] = 0u;
-            host_out[11] = over;
+        if (host_out) {     // two stores to host memory: the four words the host reads on this path, then the flag
+            *reinterpret_cast<uint4*>(host_out) = make_uint4((uint32_t)s_t[0], s_q[0], over, (uint32_t)(s_t[0] >> 32));
             __threadfence_system();
-            host_out[15] = host_seq;
+            __hip_atomic_store(host_out + 15, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -781,7 +779,10 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         __shared__ uint32_t s_run0[4];
         uint32_t part = 0;
         const uint4* w4 = reinterpret_cast<const uint4*>(bwsum);
-        const uint32_t b = blockIdx.x, n4 = (b + 3) / 4;
+        // workgroup 0 only sums the buckets' totals (-> scalars, and the host): it is dispatched first, so its stores to host memory
+        // (slow: ~20 us) pass under the emission instead of behind it (as the last workgroup's job they made the kernel 22 us longer)
+        if (scalars && blockIdx.x == 0) { depth_bucket_totals(binfo, nbuckets, scalars, host_out, host_seq); return; }
+        const uint32_t b = scalars ? blockIdx.x - 1u : blockIdx.x, n4 = (b + 3) / 4;
         order += (size_t)b * BK_CAP; woffsets += (size_t)b * BK_CAP;
         // the first chunk's ids and width scans are requested now (slots past the bucket's count hold stale values, never used):
         // their round trip passes under the prefix sum's instead of behind it
@@ -802,7 +803,6 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         const uint4 bi = binfo[b];
         __syncthreads();
         run0 = s_run0[0] + s_run0[1] + s_run0[2] + s_run0[3];
-        if (scalars && b + 1 == nbuckets) depth_bucket_totals(binfo, nbuckets, scalars, host_out, host_seq);
         nloc = bi.x; nchunks = (nloc + 255u) / 256u;
         P = (int)nloc;
     }

@@ -283,7 +283,9 @@ int read_flag_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t*
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    for (int k = 0; k < nwords; k++) out[k] = p[k];
+    for (int k = 0; k < nwords; k++) out[k] = 0u;
+    out[0] = p[0]; out[1] = p[1]; out[3] = p[3];       // {R low, Q, overflow verdict, R high} (depth_bucket_totals)
+    if (nwords > 11) out[11] = p[2];
     return GSRAST_OK;
 }
 int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
@@ -871,7 +873,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
             if (bucketed)
-                emit_column_runs_kernel<<<nbk, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
+                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars,
                                                             flag_alias, flag_seq);
             else
