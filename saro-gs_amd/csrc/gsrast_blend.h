@@ -192,7 +192,10 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     // the light tiles, not behind it: what helps is starting them first, i.e. knowing them -- see the launch-order hint below.
     // And: TWO surviving instances per round (both alphas evaluated side by side for instruction-level parallelism in the heavy
     // tiles' serial chain, updates applied in list order: bit-identical) -- -1.5 ... -2.7 % per step at every size: the second exp is
-    // wasted whenever one of the two fails its tests; s_setprio 3 / 1 for the first workgroups of the heaviest-first order: nothing.)
+    // wasted whenever one of the two fails its tests; s_setprio 3 / 1 for the first workgroups of the heaviest-first order: nothing;
+    // DECOUPLED waves (every wave stages its own 64-instance batches with a register double buffer, no workgroup barrier in the
+    // loop, bit-identical): +0.3 ... +0.8 % on the cube at 0.1 / 1 / 3 M, -6.5 % on the shell scene, whose long consumed lists are then
+    // staged four times -- the barriers are not what the waves wait for.)
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
         const uint32_t i = base + t;
