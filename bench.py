@@ -619,7 +619,34 @@ def iteration_row(rast, scenes, dev, P, W, H, deg):
         return (time.perf_counter() - t0) / n * 1e3
 
     ms_f, ms_2, ms_e = tm(fused), tm(two_ops), tm(eager)
+    # the DYNAMIC stage's call shape: all four deformation residuals present (scene/saro_gaussian.py:807-847), rasterizer forward + backward
+    # only -- the raw entry points against the standalone epilogue in front of the drop-in rasterizer
+    g_ = torch.Generator(device="cpu").manual_seed(3)
+    res = dict(motion_residual=(0.01 * torch.randn((P, 3), generator=g_)).to(dev).requires_grad_(True),
+               rot_residual=(0.05 * torch.randn((P, 7), generator=g_)).to(dev).requires_grad_(True),
+               trbfoutput=torch.rand((P, 1), generator=g_).to(dev).requires_grad_(True),
+               shs_residual=(0.03 * torch.randn((P, 16, 3), generator=g_)).to(dev).requires_grad_(True))
+    gcol = torch.randn((3, H, W), generator=g_).to(dev) / (3.0 * H * W)
+
+    def clear():
+        for v in list(rc.values()) + list(ra.values()) + list(res.values()) + [m2]:
+            v.grad = None
+
+    def dyn_raw():
+        clear()
+        color, _, _ = raster_raw(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"], **res)
+        color.backward(gcol)
+
+    def dyn_two_ops():
+        clear()
+        motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(ra["xyz"], ra["rotation"], ra["scaling"], ra["opacity"], ra["f_dc"], ra["f_rest"], **res)
+        color, _, _ = raster(means3D=motion, means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
+        color.backward(gcol)
+
+    ms_dr, ms_d2 = tm(dyn_raw), tm(dyn_two_ops)
     return {"ms": round(ms_f, 4), "iterations_per_s": round(1e3 / ms_f, 1),
+            "dynamic_stage_call_all_residuals_fwd_bwd": {"raw_entry_points_ms": round(ms_dr, 4), "standalone_epilogue_then_rasterizer_ms": round(ms_d2, 4),
+                                                         "note": "rasterizer forward + backward with motion / rotation+scale / trbf / SH residuals given; no loss, no optimizer"},
             "standalone_epilogue_then_rasterizer_ms": round(ms_2, 4), "pytorch_pieces_around_same_rasterizer_ms": round(ms_e, 4),
             "speedup": round(ms_e / ms_f, 2), "gaussians": P, "image": [H, W],
             "pieces": "GaussianRasterizerRaw (activations inside the per-Gaussian kernels) -> l1_dssim_loss -> backward -> GaussianAdam.step"}

@@ -317,8 +317,8 @@ typedef struct gsrast_raw_grads {   /* every array is fully overwritten */
     float* d_rot_res;             /* [P][7]  or NULL ({d_rotation, d_scaling} side by side) */
     float* d_opacity_logit;       /* [P] */
     float* d_trbf;                /* [P]     or NULL */
-    float* d_features_dc;         /* [P][1][3]    } or both NULL when d_shs_res is given (its rows are [dc | rest]) */
-    float* d_features_rest;       /* [P][M-1][3]  } */
+    float* d_features_dc;         /* [P][1][3]    } may both be NULL when d_shs_res is given (its rows are [dc | rest]); given together with it, */
+    float* d_features_rest;       /* [P][M-1][3]  } the rows are written twice -- cheaper than slicing them out afterwards */
     float* d_shs_res;             /* [P][M][3] or NULL; requires shs_res */
 } gsrast_raw_grads;
 int gsrast_forward_raw(gsrast_context* ctx, const gsrast_options* options,

@@ -1582,8 +1582,9 @@ int gsrast_backward_raw(const gsrast_options* options, int P, int D, int M, int 
     if (P == 0) return GSRAST_OK;
     if (!out->dL_dmean2D || !out->d_xyz || !out->d_rotation || !out->d_scaling || !out->d_opacity_logit) return fail(GSRAST_E_ARG, "backward_raw: NULL required gradient output");
     if ((in->rot_res != nullptr) != (out->d_rot_res != nullptr) && in->rot_res == nullptr) return fail(GSRAST_E_ARG, "backward_raw: d_rot_res without rot_res");
-    if (out->d_shs_res ? !in->shs_res : (!out->d_features_dc || (M > 1 && !out->d_features_rest)))
-        return fail(GSRAST_E_ARG, "backward_raw: give d_features_dc + d_features_rest, or (with shs_res) d_shs_res whose rows hold both");
+    if (out->d_shs_res && !in->shs_res) return fail(GSRAST_E_ARG, "backward_raw: d_shs_res without shs_res");
+    if ((out->d_features_dc != nullptr) != (M > 1 ? out->d_features_rest != nullptr : out->d_features_dc != nullptr) || (!out->d_shs_res && !out->d_features_dc))
+        return fail(GSRAST_E_ARG, "backward_raw: give d_features_dc + d_features_rest and / or (with shs_res) d_shs_res, whose rows hold both");
     if (((uintptr_t)out->d_rotation | (uintptr_t)out->d_features_dc | (uintptr_t)out->d_features_rest | (uintptr_t)out->d_shs_res) & 15)
         return fail(GSRAST_E_ARG, "backward_raw: d_rotation / d_features_dc / d_features_rest / d_shs_res must be 16-byte aligned");
     gsrast_options o = options ? *options : snapshot_defaults();

@@ -67,7 +67,7 @@ struct RawArgs {
 struct RawGrads {
     float* d_rot_res;            // [P][7] or null
     float* d_trbf;               // [P] or null
-    float* d_dc;                 // [P][3]           (null when d_shs_res is given: the caller slices that)
+    float* d_dc;                 // [P][3]           (may be null when d_shs_res is given: the caller then slices that)
     float* d_rest;               // [P][(M-1)*3]     ( " )
     float* d_shs_res;            // [P][M*3] or null
 };
@@ -1008,8 +1008,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     } // live
     if (staged && !sh_factors) {
         __syncthreads();
-        if (RAW && !rawg.d_shs_res) stage_sh_out_split(rawg.d_dc, rawg.d_rest, P, M * 3, blockIdx.x * PP_THREADS, sh_lds);
-        else stage_sh_out(RAW ? rawg.d_shs_res : dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
+        if (RAW) {      // the rows leave as the gradient of shs_res (whole) and / or of the two SH leaves (split): whatever the caller gave
+            if (rawg.d_shs_res) stage_sh_out(rawg.d_shs_res, P, M, blockIdx.x * PP_THREADS, sh_lds);
+            if (rawg.d_dc) stage_sh_out_split(rawg.d_dc, rawg.d_rest, P, M * 3, blockIdx.x * PP_THREADS, sh_lds);
+        } else stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
     }
 }
 
