@@ -101,7 +101,15 @@ loss_reduce_kernel(const float2* __restrict__ partial, int n, float inv_count, f
 {
     __shared__ double r1[256], r2[256];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { a += (double)partial[i].x; b += (double)partial[i].y; }
+    // eight independent loads per round, added in index order (the plain loop waited one memory round trip per element: 25 us for the
+    // 24 480 partial sums of a 1080p image; the order of the additions -- and so the result -- is unchanged)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 256; v[u] = i < n ? partial[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 256; if (i < n) { a += (double)v[u].x; b += (double)v[u].y; } }
+    }
     r1[threadIdx.x] = a; r2[threadIdx.x] = b;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {

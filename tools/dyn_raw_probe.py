@@ -30,3 +30,20 @@ for _ in range(5): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30): step()
 torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / 30 * 1e3)
+if len(sys.argv) > 1 and sys.argv[1] == "static":
+    # the static-stage training iteration of bench.py's next_rows (raw rasterizer -> loss -> backward -> Adam), for a kernel trace
+    import fused_adam, fused_loss
+    gt = torch.rand(3, H, W, device=dev)
+    inv = torch.ones(P, 1, device=dev)
+    lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
+    opt = fused_adam.GaussianAdam([{"params": [raw[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in raw], eps=1e-15)
+    def it():
+        color, _, _ = R(raw["xyz"], m2, raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"])
+        loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
+        opt.zero_grad(); m2.grad = None
+        loss.backward()
+        opt.step()
+    for _ in range(5): it()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30): it()
+    torch.cuda.synchronize(); print("static iteration ms", (time.perf_counter() - t0) / 30 * 1e3)
