@@ -1,12 +1,15 @@
 // gsrast_capi.hip -- host orchestration + the C ABI declared in include/gsrast.h.
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics (see build.py).
 //
-// Launch plan (all on the caller's stream; one host sync to learn num_rendered, like the
-// reference's cudaMemcpy at rasterizer_impl.cu:282):
-//   forward : preprocess_fwd -> depth sort (4 x {hist, scan, scatter}) -> gather-scan of tiles
-//             -> [D2H num_rendered] -> emit -> tile sort (2 x {hist, scan, scatter}) -> ranges
-//             -> blend_fwd
-//   backward: blend_bwd -> preprocess_bwd (reference K6 + K7 fused)
+// Launch plan of the default path (every launch on the caller's stream except the colour kernel):
+//   forward : preprocess_fwd (geometry; claims the pose's launch-order hint slot) -> depth_bucket_scatter -> depth_bucket_sort
+//             -> [fork: preprocess_color on the context's side stream] -> emit_column_runs (workgroup 0: totals -> pinned host memory,
+//             the host spins on them while the rest is enqueued speculatively) -> run sort by column (hist, rowscan, scatter)
+//             -> run_hist_rows -> rowscan -> run_scatter_rows -> tile_ranges_from_runs -> [join] -> blend_fwd_cull (also zero-fills
+//             the gradient records, writes the pose's hints and the backward's launch order)
+//   backward: blend_bwd_cull_t -> preprocess_bwd (reference K6 + K7 fused; RAW: + the activations' chain rule)
+// Fallbacks: radix depth sort (+ scan) after a bucket overflow or with options.depth_sort = 1; instance-level binning with
+// options.binning = 1; repeated binning + blend with exact sizes when the speculative capacities did not fit.
 #include "../../include/gsrast.h"
 #include "gsrast_common.h"
 #include "gsrast_preprocess.h"

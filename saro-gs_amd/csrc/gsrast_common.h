@@ -29,8 +29,9 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   hist     u32[256*nblk(P)]   radix block histograms    scan_tmp u32[...]  scan partials
 //   scalars  u32[64]     [0] = num_rendered ... [8] = significant bits of the depth keys (adaptive pass count of the depth sort)
 //   keyC/valC u32[P] x2  third buffer pair of the depth sort, sort_minmax u32[2 nblk]: per-block key minimum / maximum
-//   shdA/B   float4[P] x2, shdC f32[P]   backward only: d(colour)/d(view direction) {dx[3], dy[3], dz[3]} (sh_dir_derivs_kernel, on a side
-//                        stream beside the blend backward), so that the per-Gaussian backward reads 36 B instead of 12*M
+//   shdA/B   float4[P] x2, shdC f32[P]   d(colour)/d(view direction) {dx[3], dy[3], dz[3]}, 36 B: written by the forward's colour kernel
+//                        while the SH block is in LDS (round 3; sh_dir_derivs_kernel in the backward for a forward_only state), so that the
+//                        per-Gaussian backward reads 36 B instead of 12*M
 //   zrange   u32[2 ceil(P/256)]  per-block minimum / maximum depth key (preprocess_fwd); the bucket depth sort (gsrast_binning.h, NB ~ P/256
 //                        buckets of CAP slots): bk_count u32[8][NB], bk_slab uint4[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
 //                        u32[NB][CAP] (sorted ids, inclusive width scan inside the bucket), bk_info uint4[NB], bk_base u32[NB] (compact column-run totals)

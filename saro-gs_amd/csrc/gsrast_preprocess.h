@@ -213,9 +213,10 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float pos[3], const flo
 
 
 // d(colour)/d(view direction), 9 numbers {dx[c], dy[c], dz[c]} (backward.cu:78-127 dRGBdx / dRGBdy / dRGBdz): a function of the
-// coefficients and the direction only -- of nothing the blend backward produces.  sh_dir_derivs_kernel evaluates it on a side stream
-// WHILE the (VALU-bound) blend backward runs and stores the nine floats (36 B); the per-Gaussian backward, which is on the critical
-// path and bandwidth-bound, then reads those instead of the 12*M-byte coefficient block -- same expressions, same operands, same bits.
+// coefficients and the direction only -- of nothing the blend backward produces.  The forward's colour kernel evaluates it while the
+// coefficient block is in LDS and stores the nine floats (36 B) (round 2, and still for a forward_only state: sh_dir_derivs_kernel on a
+// side stream beside the blend backward); the per-Gaussian backward, which is on the critical path and bandwidth-bound, then reads
+// those instead of the 12*M-byte coefficient block -- same expressions, same operands, same bits.
 #define SHV(k, c) sh[(k) * 3 + (c)]
 __device__ __forceinline__ void sh_dir_derivs(int deg, float x, float y, float z, const float* __restrict__ sh,
                                               float dx[3], float dy[3], float dz[3])
