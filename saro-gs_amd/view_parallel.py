@@ -289,7 +289,10 @@ def distributed_step(bucket: StepBucket, views: Sequence, render_loss_fn, batch:
     rank alternate between n streams, so that one view's binning (latency-bound) runs under the other's blend kernels (VALU-bound)
     -- measured on one MI355X at 1e6 Gaussians, 1080p: 1050 -> 1227 views/s with two views in flight (three: no better).  Each lane
     takes its gradients with torch.autograd.grad (nothing accumulates in the shared .grad fields) into its own partial cache; the
-    partial caches and statistics are summed before the collectives.  Same results up to fp32 summation order."""
+    partial caches and statistics are summed before the collectives.  Same results up to fp32 summation order.
+    Memory: every view in flight holds its own rasterizer state until its backward has run -- ~320-350 B per Gaussian of geometry
+    state (0.35 GB at 1e6 Gaussians, 0.95 GB at 3e6, gsrast_geometry_bytes), 4 B per listed instance + 20 B per column run of
+    binning state (0.1-0.3 GB) and 19 MB per 1080p image -- plus one partial gradient cache (the size of the bucket) per extra lane."""
     multi = dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if multi else 0
     world = dist.get_world_size() if multi else 1
