@@ -163,3 +163,18 @@ def test_raw_entry_points_reject_bad_arguments(scenes, rast, gpu):
         c0, r0, d0 = R(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"])
     c1, r1, d1 = R(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"])
     assert torch.equal(c0, c1.detach()) and torch.equal(r0, r1)
+
+
+def test_raw_rasterizer_with_no_gaussians(scenes, rast, gpu):
+    """P = 0 (rasterize_points.cu:81: nothing is rendered): zero image, empty radii, and a backward that returns empty gradients."""
+    W, H = 64, 48
+    sc = scenes.synth(4, 431)
+    cam = scenes.camera(0, 1, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    z = lambda *s: torch.zeros(s, device=gpu, requires_grad=True)  # noqa: E731
+    xyz, rot, scl, opa, dc, rest = z(0, 3), z(0, 4), z(0, 3), z(0, 1), z(0, 1, 3), z(0, 15, 3)
+    m2 = z(0, 3)
+    c, r, d = rast.GaussianRasterizerRaw(rs)(xyz, m2, rot, scl, opa, dc, rest)
+    assert c.shape == (3, H, W) and float(c.detach().abs().max()) == 0.0 and r.numel() == 0 and float(d.detach().abs().max()) == 0.0
+    c.sum().backward()
+    assert xyz.grad is not None and xyz.grad.shape == (0, 3)
