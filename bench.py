@@ -285,8 +285,8 @@ def stage_table(_C, wl, st, P, deg, H):
     run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
     bucket_sort = run_binning and _C.get_option("depth_sort") == 0 and P >= 32768
     alg = {
-        "preprocess_fwd": P * (44 + 24) + Pv * 92,                # geometry half: in 44 B, out radii / tiles / rect / sort pair 24 B + 92 B per visible Gaussian
-        "preprocess_color": P * (12 + 12 * C + 17),               # colour half (side stream, overlapped with sort + binning): means + SH in, rec2 + clamp flags out
+        "preprocess_fwd": P * (44 + 20) + Pv * 64,                # geometry half: in 44 B, out radii / tiles / rect / depth key 20 B + rec0, rec1, binrec 64 B per visible Gaussian (round 3: no cov3D / depth / sort value)
+        "preprocess_color": P * (12 + 12 * C + 17 + (36 if deg > 0 else 0)),   # colour half (side stream, beside the binning): means + SH in, rec2 + clamp flags + the 9 direction derivatives out
         # bucket depth sort (default): scatter reads key + rect + tiles (16 B), writes a 16-B slab element; the sort kernel reads it
         # (twice, the second time from L2) and writes id + width scan (8 B) -- per visible Gaussian; radix passes: 20 B x 4
         "sort_depth": (P * 16 + Pv * 40) if bucket_sort else P * 20 * 4,
