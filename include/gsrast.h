@@ -196,7 +196,9 @@ typedef struct gsrast_options {
                                  replaced; device memory, 2 B per tile and pose), how deep every tile's list was consumed the last time
                                  that pose was rendered, and starts the forward blend's heaviest tiles first by it -- the list length, the
                                  only estimate a first-seen pose has, is a poor one in occluded scenes.  Results never depend on it */
-    int reserved[1];          /* must be zero */
+    int dense_backward;       /* backward: 1 = the per-Gaussian backward reads every Gaussian's inputs (round 2's form).  0 (default): a
+                                 Gaussian whose gradient record is all zero (frustum-culled, or occluded: its gradient IS zero) gets its
+                                 zero rows written without its inputs being read */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device, and -- per

@@ -45,7 +45,7 @@ std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0};  
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
 // threads driving different streams / devices with different options cannot disturb each other.
 struct DefaultOptions {
-    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0}, no_order_hint{0};
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0}, no_order_hint{0}, dense_backward{0};
 } g_def;
 gsrast_options snapshot_defaults()
 {
@@ -53,14 +53,14 @@ gsrast_options snapshot_defaults()
     o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
     o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
     o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream; o.depth_sort = g_def.depth_sort;
-    o.forward_only = g_def.forward_only; o.no_order_hint = g_def.no_order_hint;
+    o.forward_only = g_def.forward_only; o.no_order_hint = g_def.no_order_hint; o.dense_backward = g_def.dense_backward;
     return o;
 }
 bool options_valid(const gsrast_options& o)
 {
     auto ppl_ok = [](int v) { return v == 0 || v == 1 || v == 2 || v == 4; };
     return o.exp_mode >= 0 && o.exp_mode <= 2 && (o.binning == 0 || o.binning == 1) && ppl_ok(o.fwd_pixels_per_lane) && ppl_ok(o.bwd_pixels_per_lane) &&
-           o.backward_phase >= 0 && o.backward_phase <= 2 && (o.depth_sort == 0 || o.depth_sort == 1);
+           o.backward_phase >= 0 && o.backward_phase <= 2 && (o.depth_sort == 0 || o.depth_sort == 1) && (o.dense_backward == 0 || o.dense_backward == 1);
 }
 
 int fail(int code, const char* what, hipError_t e = hipSuccess)
@@ -548,6 +548,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "depth_sort")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_def.depth_sort = value; return 0; }
     if (!strcmp(name, "forward_only")) { g_def.forward_only = value ? 1 : 0; return 0; }
     if (!strcmp(name, "no_order_hint")) { g_def.no_order_hint = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "dense_backward")) { g_def.dense_backward = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -577,6 +578,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "depth_sort")) return g_def.depth_sort.load();
     if (!strcmp(name, "forward_only")) return g_def.forward_only.load();
     if (!strcmp(name, "no_order_hint")) return g_def.no_order_hint.load();
+    if (!strcmp(name, "dense_backward")) return g_def.dense_backward.load();
     if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
@@ -1487,11 +1489,17 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // (preprocess_color_kernel), so this kernel only runs for a state whose forward was told that no backward would follow
     // (options.forward_only, passed to both calls by a caller that changed its mind).
     SideStream* side = nullptr;
+    struct BwdSideGuard {       // an error exit below must not leave side-stream work running on the caller's arrays
+        SideStream*& side; bool joined = false;
+        ~BwdSideGuard() { if (side && !joined) (void)hipStreamSynchronize(side->stream); }
+    } side_guard{ side };
     if (do_blend && use_sh && D > 0 && o.forward_only) {
         if (rawin) return fail(GSRAST_E_ARG, "backward_raw: the forward was run with forward_only");
-        if (o.side_stream && R > 0) side = side_stream_of(thread_context());
-        hipStream_t ds = s;
-        if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); ds = side->stream; }
+        if (o.side_stream && R > 0 && !side) {
+            side = side_stream_of(thread_context());
+            if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); }
+        }
+        hipStream_t ds = side ? side->stream : s;
         // two waves per compute unit, grid-stride: enough loads in flight for ~1.5 TB/s, few enough not to push the blend kernel's
         // workgroups off the chip (an unthrottled launch slowed the blend backward by 20 %, this one by 2 %)
         const int grid = side ? std::min((P + 63) / 64, 512) : (P + 63) / 64;
@@ -1541,22 +1549,22 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh);
         GS_LAUNCHED("sh_factor");
     }
-    if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));
+    if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
     if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
-        if (rawin)
-        preprocess_bwd_kernel<true><<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
-            P, D, M, means3D, radii, raw, rawg, shs, at<unsigned char>(geom, GL.clamped),
-            at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC),
-            scales, rotations, cov, cam, reinterpret_cast<const float4*>(grec),
-            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0);
-        else
-        preprocess_bwd_kernel<false><<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(
-            P, D, M, means3D, radii, raw, rawg, use_sh ? shs : nullptr, at<unsigned char>(geom, GL.clamped),
-            at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), at<float>(geom, GL.shdC),
-            use_sr ? scales : nullptr, use_sr ? rotations : nullptr, cov, cam, reinterpret_cast<const float4*>(grec),
-            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, (use_sh && o.sh_grad_factors) ? 1 : 0);
+        const int pb_grid = (P + PP_THREADS - 1) / PP_THREADS;
+        const float* sh_in = rawin ? shs : (use_sh ? shs : nullptr);
+        const float* sc_in = rawin ? scales : (use_sr ? scales : nullptr);
+        const float* ro_in = rawin ? rotations : (use_sr ? rotations : nullptr);
+        const int factors = (!rawin && use_sh && o.sh_grad_factors) ? 1 : 0;
+#define GS_PB_ARGS P, D, M, means3D, radii, raw, rawg, sh_in, at<unsigned char>(geom, GL.clamped), at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), \
+                   at<float>(geom, GL.shdC), sc_in, ro_in, cov, cam, reinterpret_cast<const float4*>(grec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,  \
+                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors
+        const bool skip = !o.dense_backward;        // Gaussians with an all-zero gradient record are not read
+        if (rawin) { if (skip) preprocess_bwd_kernel<true, true><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); else preprocess_bwd_kernel<true, false><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); }
+        else { if (skip) preprocess_bwd_kernel<false, true><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); else preprocess_bwd_kernel<false, false><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); }
+#undef GS_PB_ARGS
         GS_LAUNCHED("preprocess_bwd");
     }
     return GSRAST_OK;

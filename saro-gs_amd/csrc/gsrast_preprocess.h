@@ -784,12 +784,18 @@ sh_dir_derivs_kernel(int P, int D, int M, const float* __restrict__ means3D, con
 // RAW (gsrast_backward_raw): means3D / scales / rotations are the model's leaves as in preprocess_fwd_kernel<true>; the chain rule
 // through the activations (epilogue_small_bwd_kernel's expressions) is applied before the stores: dL_dmeans3D = d_xyz (= d_motion_res),
 // dL_dscale = d_scaling, dL_drot = d_rotation, dL_dopacity = d_opacity_logit, plus RawGrads (d_rot_res, d_trbf, the SH leaves).
-template <bool RAW>
+// SPARSE (round 3, the default): a Gaussian whose gradient record is all zero -- frustum-culled, or occluded: 83 % of the 3 M bench
+// scene -- is not READ: every output is linear in the record's nine sums, so its rows are exactly zero and are written as such without
+// its mean / scale / rotation / direction derivatives (80 of the 312 bytes the kernel moves per Gaussian; -28 us of 230 at 3 M, -19 us
+// at 1 M).  Measured and dropped: not writing those rows either, the arrays zero-filled by a kernel on the side stream under the blend
+// backward -- preprocess_bwd 229 -> 130 us at 3 M, but the fill's 700 MB slowed the VALU-bound blend backward by 45 us and the extra
+// launches cost the small scenes 10-50 us: no better than this at 3 M, worse everywhere else.
+template <bool RAW, bool SPARSE>
 __global__ void __launch_bounds__(PP_THREADS)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii, RawArgs raw, RawGrads rawg,
                       const float* __restrict__ shs /* only its presence matters: the coefficients are not read */,
                       const unsigned char* __restrict__ clamped,
-                      const float4* __restrict__ shdA, const float4* __restrict__ shdB, const float* __restrict__ shdC /* sh_dir_derivs_kernel's output */,
+                      const float4* __restrict__ shdA, const float4* __restrict__ shdB, const float* __restrict__ shdC /* the colour kernel's (or sh_dir_derivs_kernel's) output */,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ cov3D /* internal or precomp */, CamArgs cam_args,
                       const float4* __restrict__ grec /* [P][4]: the blend backward's gradient records (GeomLayout::grec) */,
@@ -806,44 +812,51 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool staged = shs && M * 3 <= PP_SH_MAX;
     float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
     // every per-Gaussian input is requested up front, before the SH rows are staged (see preprocess_fwd_kernel): the loads used
-    // to sit behind the staging barrier, the radius test and each other -- five memory round trips in a latency-bound kernel
+    // to sit behind the staging barrier, the radius test and each other -- five memory round trips in a latency-bound kernel.
+    // (SPARSE: the record and the radius first, the rest only for the Gaussians that need it.)
     const int ic = i < P ? i : P - 1;
     const int radius_in = radii[ic];
-    float mean[3] = { means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2] };
-    float s[3] = { 0.f, 0.f, 0.f };
-    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (scales) {                                           // uniform
-        s[0] = scales[3 * ic]; s[1] = scales[3 * ic + 1]; s[2] = scales[3 * ic + 2];
-        q_in = reinterpret_cast<const float4*>(rotations)[ic];
-    }
-    float4 raw_x = make_float4(0.f, 0.f, 0.f, 0.f);        // RAW: rotation + residual, before normalisation
-    float raw_sg = 0.0f, raw_tb = 1.0f;                     // RAW: sigmoid(logit), trbf
-    if (RAW) {
-        raw_mean(raw, ic, mean);
-        raw_rot_scale(raw, ic, q_in, s, raw_x);
-        raw_sg = raw_sigmoid(raw.opacity_logit[ic]);
-        raw_tb = raw.trbf ? raw.trbf[ic] : 1.0f;
-    }
     // the Gaussian's gradient record: {dL/dmean2D.x, .y, dL/dconic a, b | c, dL/dopacity, dL/dr, dL/dg | dL/db, ...} -- three 16-byte
     // loads from one 64-byte line (zero for a Gaussian no tile listed)
     const float4 gr0 = grec[4 * (size_t)ic], gr1 = grec[4 * (size_t)ic + 1], gr2 = grec[4 * (size_t)ic + 2];
+    bool touched = true;
+    if (SPARSE) touched = gr0.x != 0.f || gr0.y != 0.f || gr0.z != 0.f || gr0.w != 0.f || gr1.x != 0.f || gr1.y != 0.f || gr1.z != 0.f || gr1.w != 0.f || gr2.x != 0.f;
+    const bool live = i < P && radius_in > 0 && touched;
+    float mean[3] = { 0.f, 0.f, 0.f };
+    float s[3] = { 0.f, 0.f, 0.f };
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 raw_x = make_float4(0.f, 0.f, 0.f, 0.f);        // RAW: rotation + residual, before normalisation
+    float raw_sg = 0.0f, raw_tb = 1.0f;                     // RAW: sigmoid(logit), trbf
+    unsigned char clamped_in = 0;
+    float4 sdA = make_float4(0.f, 0.f, 0.f, 0.f), sdB = sdA; float sdC = 0.0f;
+    if (!SPARSE || live) {
+        mean[0] = means3D[3 * ic]; mean[1] = means3D[3 * ic + 1]; mean[2] = means3D[3 * ic + 2];
+        if (scales) {                                           // uniform
+            s[0] = scales[3 * ic]; s[1] = scales[3 * ic + 1]; s[2] = scales[3 * ic + 2];
+            q_in = reinterpret_cast<const float4*>(rotations)[ic];
+        }
+        if (RAW) {
+            raw_mean(raw, ic, mean);
+            raw_rot_scale(raw, ic, q_in, s, raw_x);
+            raw_sg = raw_sigmoid(raw.opacity_logit[ic]);
+            raw_tb = raw.trbf ? raw.trbf[ic] : 1.0f;
+        }
+        if (shs) {                                              // uniform
+            clamped_in = clamped[ic];
+            if (D > 0) { sdA = shdA[ic]; sdB = shdB[ic]; sdC = shdC[ic]; }
+        }
+    }
     const float4 dcon = make_float4(gr0.z, gr0.w, 0.0f, gr1.x);          // reference layout: .z is never written (backward.cu:549-551)
     const float g2x = gr0.x, g2y = gr0.y;
     const float dcol[3] = { gr1.z, gr1.w, gr2.x };
-    unsigned char clamped_in = 0;
-    float4 sdA = make_float4(0.f, 0.f, 0.f, 0.f), sdB = sdA; float sdC = 0.0f;
-    if (shs) {                                              // uniform
-        clamped_in = clamped[ic];
-        if (D > 0) { sdA = shdA[ic]; sdB = shdB[ic]; sdC = shdC[ic]; }
-    }
     const Cam cam = load_cam(cam_args);
-    const bool live = i < P && radius_in > 0;
     if (i < P) {    // the screen-space gradients leave in the reference's arrays (rasterize_points.cu:150-158), written once
         dL_dmean2D[3 * (size_t)i] = g2x; dL_dmean2D[3 * (size_t)i + 1] = g2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
         if (RAW) {      // d(opacity logit) = d_opacity * trbf * s (1 - s),  d(trbf) = d_opacity * s
             const float go = gr1.y;
-            dL_dopacity[i] = go * raw_tb * raw_sg * (1.0f - raw_sg);
-            if (rawg.d_trbf) rawg.d_trbf[i] = go * raw_sg;
+            const bool have = !SPARSE || live;          // (an untouched Gaussian has go = 0: zeros, without its logit)
+            dL_dopacity[i] = have ? go * raw_tb * raw_sg * (1.0f - raw_sg) : 0.0f;
+            if (rawg.d_trbf) rawg.d_trbf[i] = have ? go * raw_sg : 0.0f;
         } else
         dL_dopacity[i] = gr1.y;
         if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = dcol[0]; dL_dcolor[3 * (size_t)i + 1] = dcol[1]; dL_dcolor[3 * (size_t)i + 2] = dcol[2]; }

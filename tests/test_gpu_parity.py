@@ -87,8 +87,14 @@ def test_forward_backward_parity(name, P, W, H, deg, scale_mul, camkv, orc, scen
     orc.set_exp_mode(0)
     o32 = orc.render(sc, cam, g)
     o64 = orc.render(sc, cam, g, f64=True)
-    for clip in (0, 1):      # 0: the reference's literal lists; 1: the product default (row-clipped lists)
-        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, exp_mode=0, tile_clip=clip)
+    # clip 0: the reference's literal lists; 1: the product default (row-clipped lists).  dense 1: the per-Gaussian backward reads
+    # every Gaussian; 0 (default): the ones with an all-zero gradient record get their zeros without being read
+    for clip, dense in ((0, 0), (1, 0), (1, 1)):
+        rast._C.set_option("dense_backward", dense)
+        try:
+            h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, exp_mode=0, tile_clip=clip)
+        finally:
+            rast._C.set_option("dense_backward", 0)
         _check_forward_exact(o32, h, clipped=bool(clip))
         _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
 
@@ -918,3 +924,53 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
             assert same(render(cams[k], W, H), first[k])
     finally:
         _C.set_option("no_order_hint", 0)
+
+
+def _poison_allocator(gpu, nbytes=256 << 20):
+    """Fill the caching allocator's free blocks with NaN bit patterns, so that a torch.empty output that nobody writes is seen."""
+    import torch
+    t = [torch.full((nbytes // 16,), float("nan"), device=gpu) for _ in range(4)]
+    small = [torch.full((n,), float("nan"), device=gpu) for n in (3000, 12000, 24000, 48000, 96000, 192000) for _ in range(4)]
+    torch.cuda.synchronize()
+    del t, small
+
+
+@pytest.mark.parametrize("path", ["sh0", "sh3", "sh_M25", "colors_precomp", "cov3d_precomp"])
+def test_backward_writes_every_row_of_poisoned_outputs(path, orc, scenes, rast, gpu):
+    """The per-Gaussian backward does not read Gaussians whose gradient record is zero (options.dense_backward = 0, the default).
+    Same gradients as the dense form and as the oracle; rows of culled / unlisted Gaussians exactly zero although the output
+    arrays came out of the allocator full of NaNs."""
+    P, W, H = 4000, 160, 120
+    deg = {"sh0": 0, "sh3": 3, "sh_M25": 3}.get(path, 2)
+    sc = scenes.synth(P, 77, sh_degree=deg)
+    sc["means3D"][:500, 2] -= 40.0                       # behind the camera or far outside: culled
+    sc["means3D"][500:900, 0] += 60.0
+    kw = {}
+    if path == "sh_M25":
+        rng = np.random.default_rng(3)
+        sc["shs"] = np.concatenate([sc["shs"], rng.normal(size=(P, 9, 3)).astype(np.float32)], 1)
+    cam = scenes.camera(1, 4, W, H)
+    if path == "colors_precomp":
+        kw["colors_precomp"] = np.random.default_rng(4).uniform(0, 1, size=(P, 3)).astype(np.float32)
+    if path == "cov3d_precomp":
+        kw["cov3D_precomp"] = np.ascontiguousarray(orc.forward(sc, cam)["cov3D"]).astype(np.float32)
+    g = scenes.upstream_grad(H, W, 78) * (H * W)
+    o32 = orc.render(sc, cam, g, **kw)
+    o64 = orc.render(sc, cam, g, f64=True, **kw)
+    names = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity"]
+    names += ["dL_dcolors"] if path == "colors_precomp" else ["dL_dsh"]
+    names += ["dL_dcov3D"] if path == "cov3d_precomp" else ["dL_dscales", "dL_drotations"]
+    for dense in (0, 1):
+        rast._C.set_option("dense_backward", dense)
+        try:
+            _poison_allocator(gpu)
+            h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, **kw)
+        finally:
+            rast._C.set_option("dense_backward", 0)
+        for k in names:
+            assert np.isfinite(h[k]).all(), (dense, k)
+        _check_grads(o64, o32, h, names)
+        dead = np.asarray(h["radii"]) <= 0
+        assert dead.sum() >= 400
+        for k in names:
+            assert not np.asarray(h[k]).reshape(P, -1)[dead].any(), (dense, k)

@@ -53,11 +53,16 @@ def test_raw_rasterizer_against_epilogue_then_rasterizer_and_the_oracles(use, or
     g_np = scenes.upstream_grad(H, W, 402)
     g = torch.from_numpy(g_np).to(gpu)
 
-    # (a) the fused path
+    # (a) the fused path -- half of the combinations with the default per-Gaussian backward (Gaussians with a zero gradient record
+    # are not read), the other half with every Gaussian read
     ta, kwa = _tensors(raw, use, gpu)
     m2a = torch.zeros((P, 3), device=gpu, requires_grad=True)
-    ca, ra, da = rast.GaussianRasterizerRaw(rs)(ta["xyz"], m2a, ta["rotation"], ta["scaling"], ta["opacity"], ta["f_dc"], ta["f_rest"], **kwa)
-    ca.backward(g)
+    rast._C.set_option("dense_backward", 0 if (use["motion_res"] ^ use["shs_res"]) else 1)
+    try:
+        ca, ra, da = rast.GaussianRasterizerRaw(rs)(ta["xyz"], m2a, ta["rotation"], ta["scaling"], ta["opacity"], ta["f_dc"], ta["f_rest"], **kwa)
+        ca.backward(g)
+    finally:
+        rast._C.set_option("dense_backward", 0)
     # (b) the drop-in path behind the standalone epilogue
     tb, kwb = _tensors(raw, use, gpu)
     m2b = torch.zeros((P, 3), device=gpu, requires_grad=True)
@@ -125,11 +130,18 @@ def test_raw_rasterizer_ragged_sizes_and_short_rows(P, M, deg, scenes, rast, gpu
     cam = scenes.camera(0, 3, W, H)
     rs = settings_from(rast, cam, sc, gpu)
     g = torch.from_numpy(scenes.upstream_grad(H, W, 412)).to(gpu)
-    for use in (COMBOS[0], COMBOS[-1]):
+    for use, dense in ((COMBOS[0], 0), (COMBOS[-1], 0), (COMBOS[0], 1)):
         ta, kwa = _tensors(raw, use, gpu)
         m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
-        ca, ra, da = rast.GaussianRasterizerRaw(rs)(ta["xyz"], m2, ta["rotation"], ta["scaling"], ta["opacity"], ta["f_dc"], ta["f_rest"], **kwa)
-        ca.backward(g)
+        rast._C.set_option("dense_backward", dense)
+        try:
+            if not dense:       # the outputs come out of the allocator full of NaNs: rows of the Gaussians that are not read must still be zeros
+                junk = [torch.full((n,), float("nan"), device=gpu) for n in (P, 3 * P, 4 * P, 7 * P, 45 * P, 48 * P) for _ in range(3)]
+                del junk
+            ca, ra, da = rast.GaussianRasterizerRaw(rs)(ta["xyz"], m2, ta["rotation"], ta["scaling"], ta["opacity"], ta["f_dc"], ta["f_rest"], **kwa)
+            ca.backward(g)
+        finally:
+            rast._C.set_option("dense_backward", 0)
         tb, kwb = _tensors(raw, use, gpu)
         m2b = torch.zeros((P, 3), device=gpu, requires_grad=True)
         act = fused_epilogue.activate_gaussians(tb["xyz"], tb["rotation"], tb["scaling"], tb["opacity"], tb["f_dc"], tb["f_rest"], **kwb)
