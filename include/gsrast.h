@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSRAST_ABI_VERSION 2   /* 2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
+#define GSRAST_ABI_VERSION 3   /* 3: gsrast_options.no_list_cut (the struct grew).  2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
                                     reference); options.forward_only; gsrast_forward_raw / gsrast_backward_raw */
 #define GSRAST_TILE_X 16 /* reference config.h:16 */
 #define GSRAST_TILE_Y 16 /* reference config.h:17 */
@@ -199,6 +199,14 @@ typedef struct gsrast_options {
     int dense_backward;       /* backward: 1 = the per-Gaussian backward reads every Gaussian's inputs (round 2's form).  0 (default): a
                                  Gaussian whose gradient record is all zero (frustum-culled, or occluded: its gradient IS zero) gets its
                                  zero rows written without its inputs being read */
+    int no_list_cut;          /* forward: 1 = always bin every Gaussian.  0 (default): LIST CUT -- with the launch-order hints a context also
+                                 remembers, per pose and tile, a cut depth (that of the list entry twice as deep as the deepest one any pixel
+                                 of the tile consumed the last time; none for a tile whose pixels did not all saturate).  The next forward of
+                                 that pose gives column runs only to the Gaussians in front of the cut depth of some tile they cover -- in an
+                                 occluded scene a few per cent of them -- and VERIFIES the speculation on the device: a tile's list counts
+                                 as ending at its cut depth, and if some pixel of a cut tile is not saturated there, the whole binning and
+                                 blend run again over all Gaussians (enqueued behind the blend in any case, every kernel predicated on the
+                                 verdict).  Results never depend on it; needs tile_clip = 1, the bucket depth sort, at most 8192 tiles */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device, and -- per
@@ -208,7 +216,9 @@ void gsrast_options_init(gsrast_options* options);   /* fills in the built-in de
 typedef struct gsrast_context gsrast_context;
 gsrast_context* gsrast_context_create(void);
 void gsrast_context_destroy(gsrast_context* ctx);
-/* "last_instances" (num_rendered), "last_runs" (column runs) of the context's last forward call, "redo_count"
+/* "last_late" (Gaussians the list cut left without column runs in the context's last forward call), "cut_fallbacks" (forwards on the
+ * current device whose cut lists turned out too short and were redone from the full lists; this query waits for the device),
+ * "last_instances" (num_rendered), "last_runs" (column runs) of the context's last forward call, "redo_count"
  * (speculative launches / depth sorts that had to be repeated), "bucket_skip" (forwards that will still go straight to the radix
  * depth sort after a bucket overflow); ctx NULL = the calling thread's context. */
 int gsrast_context_query(const gsrast_context* ctx, const char* name);

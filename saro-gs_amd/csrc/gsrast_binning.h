@@ -176,10 +176,11 @@ __global__ void __launch_bounds__(RS_THREADS)
 radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
                   uint32_t* __restrict__ block_hist, uint32_t nblk,
                   const KeyT* __restrict__ keys_alt = nullptr, const uint32_t* __restrict__ sig = nullptr, int adapt = 0,
-                  uint32_t* __restrict__ block_minmax = nullptr)
+                  uint32_t* __restrict__ block_minmax = nullptr, const uint32_t* __restrict__ pred = nullptr /* predicated launch: returns unless *pred != 0 */)
 {
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t s_mm[2];
+    if (pred && *pred == 0u) return;
     const bool is_short = sort_is_short(sig, adapt);
     if ((adapt & RA_SKIP) && is_short) return;
     if ((adapt & RA_IN_ALT) && is_short) keys = keys_alt;
@@ -226,8 +227,10 @@ radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __r
 // three launches (histogram, row scan, scatter) instead of five.
 __global__ void __launch_bounds__(256)
 radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t* __restrict__ digit_total,
-                     uint32_t* __restrict__ sig = nullptr, int adapt = 0, const uint32_t* __restrict__ block_minmax = nullptr, uint32_t ndigits = 0)
+                     uint32_t* __restrict__ sig = nullptr, int adapt = 0, const uint32_t* __restrict__ block_minmax = nullptr, uint32_t ndigits = 0,
+                     const uint32_t* __restrict__ pred = nullptr)
 {
+    if (pred && *pred == 0u) return;
     if ((adapt & RA_SKIP) && sort_is_short(sig, adapt)) return;
     if ((adapt & RA_MINMAX) && blockIdx.x == ndigits) {      // the extra workgroup of the first pass: min / max over the blocks -> sig
         __shared__ uint32_t mm[2];
@@ -277,8 +280,9 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
                      uint32_t* __restrict__ gather_tiles, uint32_t* __restrict__ gather_width,
                      const KeyT* __restrict__ keys_in_alt = nullptr, const ValT* __restrict__ vals_in_alt = nullptr,
                      KeyT* __restrict__ keys_out_alt = nullptr, ValT* __restrict__ vals_out_alt = nullptr,
-                     const uint32_t* __restrict__ sig = nullptr, int adapt = 0)
+                     const uint32_t* __restrict__ sig = nullptr, int adapt = 0, const uint32_t* __restrict__ pred = nullptr)
 {
+    if (pred && *pred == 0u) return;
     {
         const bool is_short = sort_is_short(sig, adapt);
         if ((adapt & RA_SKIP) && is_short) return;
@@ -416,14 +420,50 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                             uint32_t nb, uint32_t* __restrict__ gcount /* [8][nb]: per-XCD bucket counts (zeroed by preprocess_fwd) */,
                             uint4* __restrict__ slab /* [nb][8][BK_CAPX]: {depth key, id, rectangle width, tile count} -- what the sort kernel
                                                         needs of a Gaussian travels with it (gathering rect / tiles by id there cost 15 us) */,
-                            float* __restrict__ zparam /* [2]: zmin, scale -- for the sort kernel */)
+                            float* __restrict__ zparam /* [2]: zmin, scale -- for the sort kernel */,
+                            // list cut (gsrast_common.h): this call's snapshot of the pose's per-tile cut depths, or null.  A Gaussian that
+                            // lies behind the cut depth of EVERY tile of its rectangle is marked LATE (bit 31 of the width word): it keeps
+                            // its place in the depth order but gets no column runs unless the forward has to fall back to the full lists
+                            const uint32_t* __restrict__ zcut_used = nullptr, uint32_t ntiles_img = 0, uint32_t gx_tiles = 0,
+                            uint32_t* __restrict__ n_late_out = nullptr,
+                            unsigned char* __restrict__ color_skip = nullptr /* [n] or null: 1 = culled or late: no list will hold this
+                                                                                  Gaussian, the colour kernel need not evaluate it */)
 {
     __shared__ uint32_t cnt[BK_MAX_BUCKETS];
     __shared__ uint32_t s_mm[2];
+    // the cut depths as maxima over cells of 2 x 2 tiles, rounded UP to the 16 leading bits of the float (exponent + 7 mantissa bits:
+    // within 0.8 % of the depth): a Gaussian is LATE when it lies behind every cell its rectangle touches -- typically four LDS reads,
+    // no memory access in the loop; a larger cut only keeps more.  (The table must stay small: with the 32 KB of bucket counters above,
+    // anything over 7 KB costs this latency-bound kernel a workgroup per compute unit.  Measured on the way: the tiles' own depths in
+    // LDS, 16 KB: 77 -> 116 us at 3 M; 8 x 8 cells in LDS and the tiles' depths walked in global memory behind them: 152 us, a
+    // dependent load per step of a divergent loop.)
+    __shared__ uint16_t s_zc[CUT_MAX_CELLS];
+    __shared__ uint32_t s_late;
     const unsigned lane = lane_id();
     const uint32_t xcd = blockIdx.x & (BK_XCD - 1);
-    if (threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; }
+    if (threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; s_late = 0u; }
     for (uint32_t k = threadIdx.x; k < nb; k += 256) cnt[k] = 0u;
+    const uint32_t gy_tiles = zcut_used ? ntiles_img / gx_tiles : 0u, cgx = (gx_tiles + 1u) / 2u, cgy = (gy_tiles + 1u) / 2u;
+    if (zcut_used) {
+        for (uint32_t c0 = threadIdx.x; c0 < cgx * cgy; c0 += 256 * 4) {
+            uint32_t v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t c = c0 + u * 256, cx = c % cgx, cy = c / cgx;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = cx * 2u + (k & 1), y = cy * 2u + (k >> 1);
+                    v[u][k] = (c < cgx * cgy && x < gx_tiles && y < gy_tiles) ? zcut_used[y * gx_tiles + x] : 0u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t c = c0 + u * 256;
+                const uint32_t m = max(max(v[u][0], v[u][1]), max(v[u][2], v[u][3]));
+                if (c < cgx * cgy) s_zc[c] = (uint16_t)(m >= 0xFFFF0000u ? 0xFFFFu : (m + 0xFFFFu) >> 16);
+            }
+        }
+    }
     __syncthreads();
     {
         // eight independent 16-byte loads per lane and round (a plain strided loop waits one memory round trip per element)
@@ -449,6 +489,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     const float zmin = __uint_as_float(s_mm[0]), zmax = __uint_as_float(s_mm[1]);
     const float scale = zmax > zmin ? (float)nb / (zmax - zmin) : 0.0f;
     if (blockIdx.x == 0 && threadIdx.x == 0) { zparam[0] = zmin; zparam[1] = scale; }
+
     uint32_t dg[BK_ITEMS], lr[BK_ITEMS];
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
@@ -477,13 +518,35 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         for (int u = 0; u < 16; u++) { if (c[u]) cnt[k0 + u * 256] = g[u]; }
     }
     __syncthreads();
+    uint32_t nlate = 0;
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
         if (key[r] != 0xFFFFFFFFu) {
+            uint32_t wword = (rc[r].y & 0xFFFFu) - (rc[r].x & 0xFFFFu);
+            if (zcut_used) {
+                const uint32_t x0 = rc[r].x & 0xFFFFu, y0 = rc[r].x >> 16, x1 = rc[r].y & 0xFFFFu, y1 = rc[r].y >> 16;
+                const uint32_t kq = key[r] >> 16;
+                bool late = wword != 0u && (x1 - x0) * (y1 - y0) <= 64u;       // (a large rectangle is not worth the walk: early)
+                if (late) {
+                    uint32_t m = 0;
+                    for (uint32_t cy = y0 >> 1; cy <= (y1 - 1u) >> 1; cy++)
+                        for (uint32_t cx = x0 >> 1; cx <= (x1 - 1u) >> 1; cx++) m = max(m, (uint32_t)s_zc[cy * cgx + cx]);
+                    late = kq > m;                                             // (kq > the rounded-up cut  =>  key > the cut)
+                }
+                if (late) { wword |= LATE_BIT; nlate++; }
+            }
+            if (color_skip) color_skip[base + r * 256 + threadIdx.x] = (wword & LATE_BIT) ? 1 : 0;
             const uint32_t pos = cnt[dg[r]] + lr[r];
             if (pos < (uint32_t)BK_CAPX)
-                slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, (rc[r].y & 0xFFFFu) - (rc[r].x & 0xFFFFu), tl[r]);
-        }
+                slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, wword, tl[r]);
+        } else if (color_skip && base + r * 256 + threadIdx.x < n) color_skip[base + r * 256 + threadIdx.x] = 1;
+    }
+    if (zcut_used) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nlate += __shfl_xor(nlate, d, 64);
+        if (lane == 0 && nlate) atomicAdd(&s_late, nlate);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_late) atomicAdd(n_late_out, s_late);
     }
 }
 
@@ -518,12 +581,16 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
                          uint32_t* __restrict__ border /* [nb][BK_CAP]: sorted Gaussian ids of each bucket */,
                          uint32_t* __restrict__ bwincl /* [nb][BK_CAP]: inclusive scan of their rectangle widths inside the bucket */,
                          uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */,
-                         uint32_t* __restrict__ bwsum /* [nb]: column runs again, compact -- every emission workgroup sums the ones in front of it */)
+                         uint32_t* __restrict__ bwsum /* [nb]: column runs again, compact -- every emission workgroup sums the ones in front of it */,
+                         // list cut: the same three over the EARLY Gaussians only (a late one counts zero runs), or null
+                         uint32_t* __restrict__ bwincl_e = nullptr, uint4* __restrict__ binfo_e = nullptr, uint32_t* __restrict__ bwsum_e = nullptr,
+                         uint32_t* __restrict__ border_e = nullptr /* [nb][BK_CAP]: the early Gaussians' ids, compact, in depth order */)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
     __shared__ uint32_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order
     __shared__ uint16_t s_wid[BK_WAVES][BK_CAP];                // widths, grouped like s_grp
     __shared__ uint32_t s_cnt[BK_WAVES][BK_SUB + 1];
+    __shared__ uint32_t s_sid[BK_WAVES][BK_CAP];                // list cut: the sorted ids (the early ones are compacted from here)
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * BK_WAVES + wave;
     if (b >= nb) return;
@@ -578,7 +645,8 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
             if (e < n) {
                 const uint32_t slot = cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)] + aux[e];
                 grp[slot] = ((unsigned long long)kv[u].x << 32) | kv[u].y;
-                wid[slot] = (uint16_t)kv[u].z;
+                // (with the list cut the image has at most CUT_MAX_TILES tiles: widths fit 15 bits, bit 15 carries "late")
+                wid[slot] = bwincl_e ? (uint16_t)((kv[u].z & 0x7FFFu) | ((kv[u].z >> 31) << 15)) : (uint16_t)kv[u].z;
             }
         }
     }
@@ -592,16 +660,43 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
         for (uint32_t q = s0; q < s1; q++) r += grp[q] < me ? 1u : 0u;
         border[(size_t)b * BK_CAP + s0 + r] = (uint32_t)me;
         aux[s0 + r] = wid[e];                                   // (possibly clipped) rectangle width = column runs
+        if (bwincl_e) s_sid[wave][s0 + r] = (uint32_t)me;
     }
     wave_sync();
     // 5. inclusive scan of the widths in sorted order: lane t owns the E consecutive elements [t*E, t*E + E)
     const uint32_t E = (n + 63) / 64;            // <= BK_CAP / 64
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
+    if (bwincl_e) {
+        // list cut: the scan over all widths, and the EARLY Gaussians compacted (ids in depth order + the scan of their widths)
+        uint32_t wsum = 0, esum = 0, ne = 0;
+        for (uint32_t e = 0; e < E; e++) {
+            const uint32_t t = lane * E + e;
+            if (t < n) { const uint32_t w = aux[t] & 0x7FFFu, late = aux[t] >> 15; wsum += w; esum += late ? 0u : w; ne += late ? 0u : 1u; }
+        }
+        uint32_t run = wave_incl_scan(wsum) - wsum, erun = wave_incl_scan(esum) - esum, epos = wave_incl_scan(ne) - ne;
+        const uint32_t wtot = __shfl(run + wsum, 63, 64), etot = __shfl(erun + esum, 63, 64), n_e = __shfl(epos + ne, 63, 64);
+        uint32_t* eid = reinterpret_cast<uint32_t*>(grp);           // (the composites are dead: their LDS holds the compacted set)
+        uint32_t* ewin = eid + BK_CAP;
+        wave_sync();
+        for (uint32_t e = 0; e < E; e++) {
+            const uint32_t t = lane * E + e;
+            if (t < n) {
+                const uint32_t w = aux[t] & 0x7FFFu, late = aux[t] >> 15;
+                run += w; aux[t] = run;
+                if (!late) { erun += w; eid[epos] = s_sid[wave][t]; ewin[epos] = erun; epos++; }
+            }
+        }
+        wave_sync();
+        for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
+        for (uint32_t t = lane; t < n_e; t += 64) { border_e[(size_t)b * BK_CAP + t] = eid[t]; bwincl_e[(size_t)b * BK_CAP + t] = ewin[t]; }
+        if (lane == 0) { binfo[b] = make_uint4(n, wtot, tsum, over); bwsum[b] = wtot; binfo_e[b] = make_uint4(n_e, etot, n - n_e, over); bwsum_e[b] = etot; }
+        return;
+    }
     uint32_t wsum = 0;
     for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) wsum += aux[t]; }
     uint32_t run = wave_incl_scan(wsum) - wsum;
     const uint32_t wtot = __shfl(run + wsum, 63, 64);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
     for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) { run += aux[t]; aux[t] = run; } }
     wave_sync();
     for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
@@ -615,11 +710,12 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
 // fence and the call's sequence number in word 15: the host spins on that word instead of on a copy + event enqueued behind the
 // kernel (a D2H copy between two kernels costs ~14 us of queue: the copy itself and the dependent-launch gaps around it).
 __device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars,
-                                                    uint32_t* host_out = nullptr, uint32_t host_seq = 0)
+                                                    uint32_t* host_out = nullptr, uint32_t host_seq = 0,
+                                                    const uint4* __restrict__ binfo_e = nullptr /* list cut: the early Gaussians' totals */)
 {
     __shared__ unsigned long long s_t[256];
-    __shared__ uint32_t s_q[256];
-    uint32_t over = 0, q = 0;
+    __shared__ uint32_t s_q[256], s_qe[256];
+    uint32_t over = 0, q = 0, qe = 0;
     unsigned long long tsum = 0;
     for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 8) {       // coalesced, eight independent loads per lane and round
         uint4 v[8];
@@ -627,16 +723,30 @@ __device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ bi
         for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * 256; v[u] = k < nb ? binfo[k] : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
         for (int u = 0; u < 8; u++) { q += v[u].y; tsum += v[u].z; over |= v[u].w; }
+        if (binfo_e) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t k = k0 + u * 256; v[u] = k < nb ? binfo_e[k] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) qe += v[u].y;
+        }
     }
-    s_t[threadIdx.x] = tsum; s_q[threadIdx.x] = q;
+    s_t[threadIdx.x] = tsum; s_q[threadIdx.x] = q; s_qe[threadIdx.x] = qe;
     over = __syncthreads_or((int)over) ? 1u : 0u;
-    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t[threadIdx.x] += s_t[threadIdx.x + st]; s_q[threadIdx.x] += s_q[threadIdx.x + st]; } __syncthreads(); }
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t[threadIdx.x] += s_t[threadIdx.x + st]; s_q[threadIdx.x] += s_q[threadIdx.x + st]; s_qe[threadIdx.x] += s_qe[threadIdx.x + st]; } __syncthreads(); }
     if (threadIdx.x == 0) {
         scalars[0] = (uint32_t)s_t[0]; scalars[1] = s_q[0]; scalars[3] = (uint32_t)(s_t[0] >> 32); scalars[11] = over;
-        if (host_out) {     // two stores to host memory: the four words the host reads on this path, then the flag
-            *reinterpret_cast<uint4*>(host_out) = make_uint4((uint32_t)s_t[0], s_q[0], over, (uint32_t)(s_t[0] >> 32));
-            __threadfence_system();
-            __hip_atomic_store(host_out + 15, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t q_early = binfo_e ? s_qe[0] : s_q[0], n_late = binfo_e ? scalars[SC_N_LATE] : 0u;
+        scalars[SC_Q_EARLY] = q_early;
+        scalars[SC_EARLY_COUNTS] = (uint32_t)s_t[0]; scalars[SC_EARLY_COUNTS + 1] = q_early; scalars[SC_EARLY_COUNTS + 2] = 0u; scalars[SC_EARLY_COUNTS + 3] = (uint32_t)(s_t[0] >> 32);
+        if (host_out) {
+            // six self-validating 64-bit words {value, sequence number}, each ONE relaxed system-scope atomic store: no fence.  (A
+            // system-scope release in front of a flag word writes the L2's dirty lines back -- with the colour kernel dirtying lines
+            // beside it this workgroup, and with it the whole kernel, lasted until that kernel was done: 35 -> 120 us at 3 M.)
+            unsigned long long* h64 = reinterpret_cast<unsigned long long*>(host_out);
+            const uint32_t vals[6] = { (uint32_t)s_t[0], s_q[0], over, (uint32_t)(s_t[0] >> 32), q_early, n_late };
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                __hip_atomic_store(h64 + k, ((unsigned long long)host_seq << 32) | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -764,8 +874,19 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                         // ranges [nb][BK_CAP] (sorted ids, inclusive width scan inside the bucket), bbase the buckets' first runs
                         const uint4* __restrict__ binfo = nullptr, const uint32_t* __restrict__ bwsum = nullptr, uint32_t nbuckets = 0,
                         uint32_t* __restrict__ scalars = nullptr /* the last workgroup leaves the totals here (depth_bucket_totals) */,
-                        uint32_t* __restrict__ host_out = nullptr, uint32_t host_seq = 0 /* ... and in pinned host memory (see depth_bucket_totals) */)
+                        uint32_t* __restrict__ host_out = nullptr, uint32_t host_seq = 0 /* ... and in pinned host memory (see depth_bucket_totals) */,
+                        // list cut: when `woffsets / binfo / bwsum` are the EARLY set, binfo_all is the set over all Gaussians (the totals
+                        // report both); pred: a launch of the predicated second binning (returns at once unless *pred != 0)
+                        const uint4* __restrict__ binfo_all = nullptr, const uint32_t* __restrict__ pred = nullptr,
+                        // ... whose workgroup `nbuckets` (one past the buckets) empties the work buckets the first pass filled and counts the event
+                        uint32_t* __restrict__ redo_bucket_cnt = nullptr, int n_redo_cnt = 0, HintTable* __restrict__ redo_hints = nullptr)
 {
+    if (pred && *pred == 0u) return;
+    if (redo_bucket_cnt && blockIdx.x == nbuckets) {
+        for (int i = threadIdx.x; i < n_redo_cnt; i += blockDim.x) redo_bucket_cnt[i] = 0u;
+        if (threadIdx.x == 0 && redo_hints) atomicAdd(&redo_hints->cut_fallbacks, 1u);
+        return;
+    }
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
     // per-Gaussian ellipse terms (fp64): det, 2tc, b, 1/c, dy_max, dx_top;  mode 0 = keep the column, 1 = clip, 2 = empty
     __shared__ double s_det[4][64], s_t2c[4][64], s_b[4][64], s_invc[4][64], s_dymax[4][64], s_dxtop[4][64];
@@ -781,7 +902,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         const uint4* w4 = reinterpret_cast<const uint4*>(bwsum);
         // workgroup 0 only sums the buckets' totals (-> scalars, and the host): it is dispatched first, so its stores to host memory
         // (slow: ~20 us) pass under the emission instead of behind it (as the last workgroup's job they made the kernel 22 us longer)
-        if (scalars && blockIdx.x == 0) { depth_bucket_totals(binfo, nbuckets, scalars, host_out, host_seq); return; }
+        if (scalars && blockIdx.x == 0) { depth_bucket_totals(binfo_all ? binfo_all : binfo, nbuckets, scalars, host_out, host_seq, binfo_all ? binfo : nullptr); return; }
         const uint32_t b = scalars ? blockIdx.x - 1u : blockIdx.x, n4 = (b + 3) / 4;
         order += (size_t)b * BK_CAP; woffsets += (size_t)b * BK_CAP;
         // the first chunk's ids and width scans are requested now (slots past the bucket's count hold stale values, never used):
@@ -899,9 +1020,11 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
 // +1 at y0, -1 at y0+h in an LDS difference array, prefix sum, one column of the digit-major table.
 __global__ void __launch_bounds__(256)
 run_hist_rows_kernel(const uint2* __restrict__ run_vals, uint32_t Q, const uint32_t* __restrict__ Q_dev,
-                     uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t nrows /* tile rows: only these table rows exist */)
+                     uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t nrows /* tile rows: only these table rows exist */,
+                     const uint32_t* __restrict__ pred = nullptr)
 {
     __shared__ int diff[257];
+    if (pred && *pred == 0u) return;
     Q = dev_count(Q, Q_dev);
     for (int k = threadIdx.x; k < 257; k += 256) diff[k] = 0;
     __syncthreads();
@@ -971,9 +1094,10 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
                              uint32_t* __restrict__ bucket_cnt /* forward launch order: [8][64] counts (zeroed), or null */,
                              uint16_t* __restrict__ bucket_list /* [8][64][Tg] */,
                              const HintTable* __restrict__ hints /* or null: what each tile of this camera pose consumed the last time (gsrast_common.h) */,
-                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */)
+                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */, const uint32_t* __restrict__ pred = nullptr)
 {
     __shared__ int diff[257];
+    if (pred && *pred == 0u) return;
     __shared__ uint32_t lcnt[XCD_GROUPS * WORK_BUCKETS], lbase[XCD_GROUPS * WORK_BUCKETS];
     const uint32_t x = blockIdx.x, y = threadIdx.x;
     bool overflow = false;
@@ -1031,8 +1155,10 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
                         uint32_t Q, const uint32_t* __restrict__ Q_dev, uint32_t capR, int ybits, uint32_t nrows, const uint32_t* __restrict__ hist_scanned,
                         const uint32_t* __restrict__ digit_total, uint32_t nblk,
                         uint32_t* __restrict__ point_list,
-                        uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */)
+                        uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */,
+                        const uint32_t* __restrict__ pred = nullptr)
 {
+    if (pred && *pred == 0u) return;
     __shared__ uint32_t s_start[RUNS_PER_BLOCK + 1]; // block-local first instance of every run (+ total at the end)
     __shared__ uint2 s_val[RUNS_PER_BLOCK];
     __shared__ uint32_t s_nruns;

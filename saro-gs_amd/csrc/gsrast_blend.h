@@ -133,9 +133,16 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       int order_from_buckets,
                       float4* __restrict__ zero4 /* or null */, uint32_t n_zero4 /* the backward's gradient records (GeomLayout::grec), zero-filled here */,
                       HintTable* __restrict__ hints /* or null: the context's launch-order hints (gsrast_common.h); this view's slot receives every tile's consumed depth */,
-                      const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */)
+                      const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */,
+                      // list cut (gsrast_common.h): zcut_used = this call's snapshot of the pose's per-tile cut depths when the lists were
+                      // built from the EARLY Gaussians only (null: full lists); a tile's list then counts as ending where its depth exceeds
+                      // the tile's cut depth -- up to there it is the full list -- and a tile with a cut whose pixels are not all
+                      // saturated at that point raises cut_scalars[SC_UNDONE].  pred: the predicated second launch over the full lists
+                      const uint32_t* __restrict__ zcut_used = nullptr, uint32_t* __restrict__ cut_scalars = nullptr,
+                      const uint32_t* __restrict__ pred = nullptr)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
+    if (pred && *pred == 0u) return;
     __shared__ float4 s0[FB];
     __shared__ float4 s1[FB];
     __shared__ float4 s2[FB];
@@ -172,6 +179,9 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t n = range.y - range.x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     if (t == 0) s_max = 0;
+    const uint32_t zc = zcut_used ? zcut_used[tile] : ZCUT_NONE;       // uniform
+    uint32_t n_safe = n;                          // entries of the list known to be ALL the tile's Gaussians up to their depth
+    bool cut_here = false;
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dm = 15.0f;
     uint32_t last = 0;
@@ -199,13 +209,19 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
         const uint32_t i = base + t;
+        bool safe = false;
         if (t < FB && i < n) {
             const uint32_t g = point_list[range.x + i];
-            s0[t] = rec0[g]; s1[t] = rec1[g]; s2[t] = rec2[g];
+            const float4 b1 = rec1[g];
+            s0[t] = rec0[g]; s1[t] = b1; s2[t] = rec2[g];
+            safe = __float_as_uint(b1.z) <= zc;             // the list is in depth order: the safe entries are a prefix
         }
-        __syncthreads();
-        const uint32_t cnt = (n - base) < FB ? (n - base) : FB;
-        if (alive == 0ull) continue;                        // whole wave saturated: only helps staging
+        uint32_t cnt = (n - base) < FB ? (n - base) : FB;
+        if (zc != ZCUT_NONE) {
+            const uint32_t ns = (uint32_t)__syncthreads_count(safe);
+            if (ns < cnt) { cnt = ns; n_safe = base + ns; cut_here = true; }      // behind this entry Gaussians may be missing: the list ends here
+        } else __syncthreads();
+        if (alive != 0ull)                                  // (a saturated wave only helps staging)
 #pragma unroll 1
         for (uint32_t r = 0; r < FB / 64u; r++) {
             const uint32_t slot = r * 64 + lane;
@@ -269,6 +285,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 }
             }
         }
+        if (cut_here) break;                                // uniform
     }
     if (inside) {
         const size_t pid = (size_t)W * py + px;
@@ -283,12 +300,30 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     uint32_t m = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
-    __syncthreads();
+    const bool all_done = __syncthreads_and(alive == 0ull) != 0;    // every pixel of the tile inside the image has saturated
     if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
     if (t == 0) {
         tile_max[tile] = s_max;
-        if (hints) hint_work(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
+        // list cut: the speculation failed for this tile if it had a cut and some pixel would have looked further
+        if (zc != ZCUT_NONE && !all_done && cut_scalars) atomicAdd(&cut_scalars[SC_UNDONE], 1u);
+        if (hints) {
+            hint_work(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
+            // the tile's next cut depth: that of the entry twice as deep (+ 32) as the deepest one consumed; none for a tile that did
+            // not saturate, or whose (full) list is shorter than that
+            uint32_t znew = ZCUT_NONE;
+            if (all_done) {
+                const uint32_t p = 2u * s_max + 32u;
+                if (p < n_safe) znew = __float_as_uint(rec1[point_list[range.x + p]].z);
+                else if (zc != ZCUT_NONE && n_safe > 0u) {
+                    // the cut list does not reach that deep: position -> depth extrapolated linearly from the list's first entry
+                    const float z0 = rec1[point_list[range.x]].z, zcf = __uint_as_float(zc);
+                    const float zn = z0 + (zcf - z0) * ((float)(p + 1u) / (float)n_safe);
+                    znew = zn < 3.0e38f ? (zn > zcf ? __float_as_uint(zn) : zc) : ZCUT_NONE;
+                } else if (zc != ZCUT_NONE) znew = zc;
+            }
+            hint_zcut(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = znew;
+        }
         // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
         if (bucket_cnt) bucket_append_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, tile, s_max);
     }

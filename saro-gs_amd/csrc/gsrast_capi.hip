@@ -45,7 +45,7 @@ std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0};  
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
 // threads driving different streams / devices with different options cannot disturb each other.
 struct DefaultOptions {
-    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0}, no_order_hint{0}, dense_backward{0};
+    std::atomic<int> exp_mode{0}, binning{0}, tile_clip{1}, cull{1}, lpt{1}, speculative{1}, fwd_ppl{0}, bwd_ppl{0}, sh_grad_factors{0}, side_stream{1}, depth_sort{0}, forward_only{0}, no_order_hint{0}, dense_backward{0}, no_list_cut{0};
 } g_def;
 gsrast_options snapshot_defaults()
 {
@@ -53,7 +53,7 @@ gsrast_options snapshot_defaults()
     o.exp_mode = g_def.exp_mode; o.binning = g_def.binning; o.tile_clip = g_def.tile_clip; o.cull = g_def.cull; o.lpt = g_def.lpt;
     o.speculative = g_def.speculative; o.fwd_pixels_per_lane = g_def.fwd_ppl; o.bwd_pixels_per_lane = g_def.bwd_ppl;
     o.sh_grad_factors = g_def.sh_grad_factors; o.side_stream = g_def.side_stream; o.depth_sort = g_def.depth_sort;
-    o.forward_only = g_def.forward_only; o.no_order_hint = g_def.no_order_hint; o.dense_backward = g_def.dense_backward;
+    o.forward_only = g_def.forward_only; o.no_order_hint = g_def.no_order_hint; o.dense_backward = g_def.dense_backward; o.no_list_cut = g_def.no_list_cut;
     return o;
 }
 bool options_valid(const gsrast_options& o)
@@ -162,7 +162,7 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
                uint32_t* hist, uint32_t* scan_tmp, hipStream_t s,
                const uint2* gather_rect = nullptr, uint32_t* gather_tiles = nullptr, uint32_t* gather_width = nullptr,
                const uint32_t* n_dev = nullptr /* n is a capacity, the real count is on the device (dev_count) */,
-               const SortAdapt<KeyT, ValT>* ad = nullptr)
+               const SortAdapt<KeyT, ValT>* ad = nullptr, const uint32_t* pred = nullptr /* predicated launch (list cut): only on the plain path below */)
 {
     if (n == 0) return GSRAST_OK;
     const uint32_t nblk = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
@@ -193,17 +193,18 @@ int radix_sort(KeyT* kA, ValT* vA, KeyT* kB, ValT* vB, uint32_t n, int bits,
     for (int p = 0; p < passes; p++) {
         const int w = (bits - shift + (passes - p) - 1) / (passes - p);   // remaining bits spread evenly (7+6 == 6+7 measured)
         const uint32_t mask = (1u << w) - 1u;
-        radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk);
+        radix_hist_kernel<KeyT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, n, n_dev, shift, mask, hist, nblk, nullptr, nullptr, 0, nullptr, pred);
         GS_LAUNCHED("radix_hist");
         const bool self_scan = nblk <= RS_SELF_SCAN_BLOCKS;      // the scatter blocks sum the few block counts themselves
         if (!self_scan) {
-            radix_rowscan_kernel<<<mask + 1, 256, 0, s>>>(hist, nblk, scan_tmp);     // one workgroup per digit value in use
+            radix_rowscan_kernel<<<mask + 1, 256, 0, s>>>(hist, nblk, scan_tmp, nullptr, 0, nullptr, 0, pred);     // one workgroup per digit value in use
             GS_LAUNCHED("radix_rowscan");
         }
         const bool last = p == passes - 1;
         radix_scatter_kernel<KeyT, ValT, ITEMS><<<nblk, RS_THREADS, 0, s>>>(kA, vA, kB, vB, n, n_dev, shift, mask, hist,
                                                                      self_scan ? nullptr : scan_tmp, nblk,
-                                                                     last ? gather_rect : nullptr, gather_tiles, gather_width);
+                                                                     last ? gather_rect : nullptr, gather_tiles, gather_width,
+                                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, pred);
         GS_LAUNCHED("radix_scatter");
         std::swap(kA, kB); std::swap(vA, vB);
         shift += w;
@@ -270,25 +271,30 @@ Readback* read_flag_prepare(uint32_t** dev_alias, uint32_t* seq)
     }
     if (!rb.dev_alias) return nullptr;
     rb.seq = rb.seq + 1u ? rb.seq + 1u : 1u;
+    for (int k = 0; k < 6; k++) reinterpret_cast<volatile unsigned long long*>(rb.pinned)[k] = 0ull;      // (no stale word may carry this number)
+    std::atomic_thread_fence(std::memory_order_seq_cst);
     *dev_alias = rb.dev_alias; *seq = rb.seq;
     return &rb;
 }
 int read_flag_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords)
 {
-    volatile uint32_t* p = rb->pinned;
+    // six 64-bit words {value, sequence number} (depth_bucket_totals): each is valid as soon as its upper half carries this call's number
+    volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(rb->pinned);
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t spins = 1; p[15] != rb->seq; spins++) {
-        if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            GS_HIP(hipStreamSynchronize(s));
-            if (p[15] == rb->seq) break;
-            GS_HIP(hipMemcpy(out, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
-            return GSRAST_OK;
+    unsigned long long w[6];
+    for (int k = 0; k < 6; k++) {
+        for (uint64_t spins = 1; (uint32_t)((w[k] = p[k]) >> 32) != rb->seq; spins++) {
+            if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                GS_HIP(hipStreamSynchronize(s));
+                if ((uint32_t)((w[k] = p[k]) >> 32) == rb->seq) break;
+                GS_HIP(hipMemcpy(out, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
+                return GSRAST_OK;
+            }
         }
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
     for (int k = 0; k < nwords; k++) out[k] = 0u;
-    out[0] = p[0]; out[1] = p[1]; out[3] = p[3];       // {R low, Q, overflow verdict, R high} (depth_bucket_totals)
-    if (nwords > 11) out[11] = p[2];
+    out[0] = (uint32_t)w[0]; out[1] = (uint32_t)w[1]; out[3] = (uint32_t)w[3];       // {R low, Q, overflow verdict, R high}
+    if (nwords > 11) { out[11] = (uint32_t)w[2]; out[SC_Q_EARLY] = (uint32_t)w[4]; out[SC_N_LATE] = (uint32_t)w[5]; }     // (list cut: early column runs, late Gaussians)
     return GSRAST_OK;
 }
 int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
@@ -306,7 +312,8 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 } // namespace
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
 struct gsrast_context {
-    std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0};
+    std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0}, last_late{0};
+    std::atomic<uint32_t> Qe_hint{0};  // list cut: column runs of the early Gaussians in recent forwards (sizes the launches over the cut lists)
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
@@ -355,7 +362,8 @@ HintTable* hints_of(gsrast_context* ctx, uint32_t T, hipStream_t s)
     if (!h.table) {
         if (hipMalloc((void**)&h.table, hint_table_bytes(T)) != hipSuccess) { h.table = nullptr; return nullptr; }
         h.T = T;
-        if (hipMemsetAsync(h.table, 0, sizeof(HintTable), s) != hipSuccess) { (void)hipFree(h.table); h.table = nullptr; return nullptr; }
+        if (hipMemsetAsync(h.table, 0, hint_zcut_offset(T), s) != hipSuccess ||
+            hipMemsetAsync(reinterpret_cast<char*>(h.table) + hint_zcut_offset(T), 0xFF, (size_t)HINT_SLOTS * T * 4, s) != hipSuccess) { (void)hipFree(h.table); h.table = nullptr; return nullptr; }
     }
     return h.table;
 }
@@ -446,6 +454,7 @@ struct BlendArgs {
     const float* dpix; float* grec;                              // backward
     float4* zero4 = nullptr; uint32_t n_zero4 = 0;               // forward (culling kernel): the gradient records to zero-fill
     HintTable* hints = nullptr; const uint32_t* hint_sel = nullptr;   // forward: the context's launch-order hints, this call's slot
+    const uint32_t* zcut_used = nullptr; uint32_t* cut_scalars = nullptr; const uint32_t* pred = nullptr;   // forward: list cut (gsrast_common.h)
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -484,7 +493,7 @@ template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
     blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
-                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel);
+                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -526,6 +535,15 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "last_runs")) return (int)c->last_Q.load();
     if (!strcmp(name, "redo_count")) return c->redo_count.load();
     if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
+    if (!strcmp(name, "last_late")) return (int)c->last_late.load();
+    if (!strcmp(name, "cut_fallbacks")) {       // a device counter in the hint table of the current device (diagnostic: waits for the device)
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32 || !c->hints[device].table) return 0;
+        uint32_t v = 0;
+        if (hipDeviceSynchronize() != hipSuccess) return GSRAST_E_DEVICE;
+        if (hipMemcpy(&v, &c->hints[device].table->cut_fallbacks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return GSRAST_E_DEVICE;
+        return (int)v;
+    }
     return GSRAST_E_ARG;
 }
 
@@ -549,6 +567,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "forward_only")) { g_def.forward_only = value ? 1 : 0; return 0; }
     if (!strcmp(name, "no_order_hint")) { g_def.no_order_hint = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dense_backward")) { g_def.dense_backward = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "no_list_cut")) { g_def.no_list_cut = value ? 1 : 0; return 0; }
     if (!strcmp(name, "lpt")) { g_def.lpt = value ? 1 : 0; return 0; }   // heaviest-tile-first launch order
     if (!strcmp(name, "hexplane_scatter")) { if (value != 0 && value != 1) return GSRAST_E_ARG; g_hex_scatter = value; return 0; }
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane") || !strcmp(name, "bwd_pixels_per_lane")) {
@@ -579,6 +598,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "forward_only")) return g_def.forward_only.load();
     if (!strcmp(name, "no_order_hint")) return g_def.no_order_hint.load();
     if (!strcmp(name, "dense_backward")) return g_def.dense_backward.load();
+    if (!strcmp(name, "no_list_cut")) return g_def.no_list_cut.load();
     if (!strcmp(name, "lpt")) return g_def.lpt.load();
     if (!strcmp(name, "hexplane_scatter")) return g_hex_scatter.load();
     return GSRAST_E_ARG;
@@ -723,6 +743,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // launch-order hints of the forward blend: per context, device and camera pose (gsrast_common.h); only with the work-bucket order
     HintTable* hints = (runbin && buckets_ok && o.cull != 0 && o.lpt != 0 && o.fwd_pixels_per_lane == 0 && !o.no_order_hint) ? hints_of(ctx, T, s) : nullptr;
     uint32_t* hint_sel = scalars + HINT_SEL;
+    // List cut (gsrast_common.h): only with the hints, the bucket depth sort, clipped lists, and a capacity hint (the cut lists are
+    // blended by the speculative launch; the verified fallback is enqueued behind it).  Whether THIS pose has cut depths is decided on the device.
+    const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && T <= CUT_MAX_TILES && (uint32_t)((cam.gx + 1) / 2) * (uint32_t)((cam.gy + 1) / 2) <= CUT_MAX_CELLS &&
+                     o.speculative != 0 && ctx->R_hint.load() != 0;
+    uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
     const bool zero_in_blend = o.cull != 0 && o.fwd_pixels_per_lane == 0 && (size_t)P * 4 <= 0xFFFFFFFFull;
@@ -735,14 +760,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         SideStream*& side; hipStream_t s; bool& launched; bool joined = false;
         ~SideJoinGuard() { if (launched && side && !joined) (void)hipStreamSynchronize(side->stream); }    // error path: cost is irrelevant
     } side_guard{ side, s, color_launched };
-    auto launch_color = [&]() -> int {
-        if (color_launched) return GSRAST_OK;
-        color_launched = true;
-        if (side) {
-            GS_HIP(hipEventRecord(side->fork, s));             // the inputs (and the buffers just handed out) are ordered on s
-            GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-            cs = side->stream;
-        }
+    // the colour kernel itself.  skip / pred (list cut): the Gaussians no list will hold are not evaluated / the predicated launch
+    // over all Gaussians in front of the second blend
+    auto color_kernels = [&](hipStream_t cs, bool early_only, const uint32_t* pred) -> int {
         {
             ProfScope ps(K_COLOR, cs);
             // d(colour)/d(view direction) for the backward (36 B / Gaussian), unless the caller said that no backward will follow
@@ -755,18 +775,37 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             float4* gz = (side || zero_in_blend) ? nullptr : at<float4>(geom, GL.grec);
             const bool staged = sh_in && M * 3 <= PP_SH_MAX && ((M * 3) & 3) == 0 && ((uintptr_t)sh_in & 15) == 0;
             const int grid = (P + PP_THREADS - 1) / PP_THREADS;
-            if (rawin) {        // (gsrast_forward_raw has checked M and the alignment of the three SH arrays)
-                if (M * 3 == PP_SH_MAX) preprocess_color_kernel<PP_SH_MAX, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
-                else preprocess_color_kernel<0, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
+            if (early_only) {       // list cut: Gaussians the bucket scatter found culled or late are skipped (gsrast_preprocess.h)
+                const unsigned char* skip = at<unsigned char>(geom, GL.color_skip);
+                const int cgrid = (P + PCC_IDS - 1) / PCC_IDS;
+                if (rawin) preprocess_color_compact_kernel<true><<<cgrid, 64 * PCC_WAVES, 0, cs>>>(P, D, M, means3D, nullptr, nullptr, raw, cam_pos, rec2, cl, sA, sB, sC, skip);
+                else preprocess_color_compact_kernel<false><<<cgrid, 64 * PCC_WAVES, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, raw, cam_pos, rec2, cl, sA, sB, sC, skip);
+            } else if (rawin) {        // (gsrast_forward_raw has checked M and the alignment of the three SH arrays)
+                if (M * 3 == PP_SH_MAX) preprocess_color_kernel<PP_SH_MAX, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
+                else preprocess_color_kernel<0, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
             } else if (staged && M * 3 == PP_SH_MAX)
-                preprocess_color_kernel<PP_SH_MAX, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
+                preprocess_color_kernel<PP_SH_MAX, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
             else if (staged)
-                preprocess_color_kernel<0, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC);
+                preprocess_color_kernel<0, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
             else
-                preprocess_color_direct_kernel<<<(P + 255) / 256, 256, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, cam_pos, rec2, cl, gz, sA, sB, sC);
+                preprocess_color_direct_kernel<false><<<(P + 255) / 256, 256, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, raw, cam_pos, rec2, cl, gz, sA, sB, sC, nullptr, pred);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
         }
+        return GSRAST_OK;
+    };
+    // List cut: a Gaussian the bucket scatter found late is in no list -- its colour is not evaluated (3 M cube: 87 % of them).
+    // Not under the diagnostic option debug_state (gsrast_debug_export shows every Gaussian's colour).
+    const bool cut_colors = cut && zero_in_blend && !g_debug_state.load();
+    auto launch_color = [&]() -> int {
+        if (color_launched) return GSRAST_OK;
+        color_launched = true;
+        if (side) {
+            GS_HIP(hipEventRecord(side->fork, s));             // the inputs (and the buffers just handed out) are ordered on s
+            GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+            cs = side->stream;
+        }
+        { int rc = color_kernels(cs, cut_colors, nullptr); if (rc != GSRAST_OK) return rc; }
         if (side) {
             GS_HIP(hipEventRecord(side->join, side->stream));
             if (!zero_in_blend) {
@@ -786,11 +825,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel);
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
+                zcut_used, T, cut ? scalars : nullptr);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel);
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
+                zcut_used, T, cut ? scalars : nullptr);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -804,9 +845,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             uint32_t* gcount = at<uint32_t>(geom, GL.bk_count);
             uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
-                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + PF_THREADS - 1) / PF_THREADS), nbk, gcount, slab, at<float>(geom, GL.bk_param));
+                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + PF_THREADS - 1) / PF_THREADS), nbk, gcount, slab, at<float>(geom, GL.bk_param),
+                                                                                                         zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
+                                                                                                         cut ? at<unsigned char>(geom, GL.color_skip) : nullptr);
                 GS_LAUNCHED("depth_bucket_scatter");
-                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
+                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base),
+                                                                                                   cut ? at<uint32_t>(geom, GL.bk_wincl_e) : nullptr, cut ? at<uint4>(geom, GL.bk_info_e) : nullptr, cut ? at<uint32_t>(geom, GL.bk_base_e) : nullptr,
+                                                                                                   cut ? at<uint32_t>(geom, GL.bk_order_e) : nullptr);
                 GS_LAUNCHED("depth_bucket_sort"); }
             totals_pending = true;      // by the run emission's last workgroup, or by launch_bucket_totals() if the host needs them first
             return GSRAST_OK;
@@ -866,7 +911,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // ---- the rest of the forward as two re-launchable pieces ----
     // run-compressed binning; nQ / capR are either exact counts (counts_dev == nullptr) or capacities with the real
     // counts read on the device (speculative launch: grids and histogram strides follow the capacities)
-    auto launch_run_binning = [&](char* binb, uint32_t capR_, uint32_t capQ_, uint32_t nQ, const uint32_t* counts_dev, const std::function<int()>& after_emit = nullptr) -> int {
+    // mode (list cut): 0 = all Gaussians (as ever); 1 = the EARLY Gaussians only (counts_dev = scalars + SC_EARLY_COUNTS); 2 = all
+    // Gaussians again behind a blend over cut lists, every kernel predicated on scalars[SC_REDO_PRED] (counts_dev = scalars)
+    auto launch_run_binning = [&](char* binb, uint32_t capR_, uint32_t capQ_, uint32_t nQ, const uint32_t* counts_dev, const std::function<int()>& after_emit = nullptr, int mode = 0) -> int {
+        const uint32_t* pred = mode == 2 ? scalars + SC_REDO_PRED : nullptr;
         const RunBinLayout RL = runbin_layout((size_t)capR_, (size_t)capQ_);
         uint16_t *rkA = at<uint16_t>(binb, RL.rkeyA), *rkB = at<uint16_t>(binb, RL.rkeyB);
         uint2 *rvA = at<uint2>(binb, RL.rvalA), *rvB = at<uint2>(binb, RL.rvalB);
@@ -877,7 +925,15 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const uint32_t* Q_dev = counts_dev ? counts_dev + 1 : nullptr;
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
-            if (bucketed)
+            if (bucketed && mode == 1)
+                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e), at<float4>(geom, GL.binrec), W, H,
+                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), nbk, scalars,
+                                                            flag_alias, flag_seq, at<uint4>(geom, GL.bk_info));
+            else if (bucketed && mode == 2)
+                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
+                                                            o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, nullptr,
+                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), (XCD_GROUPS + 1) * WORK_BUCKETS, hints);
+            else if (bucketed)
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars,
                                                             flag_alias, flag_seq);
@@ -885,26 +941,26 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
                                                                        o.tile_clip, capQ_, rkA, rvA);
             GS_LAUNCHED("emit_column_runs"); }
-        if (bucketed) totals_pending = false;
+        if (bucketed && mode != 2) totals_pending = false;
         if (after_emit) { int rc = after_emit(); if (rc != GSRAST_OK) return rc; }
         const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
         {   ProfScope ps(K_SORT_TILE, s);
-            int rc = radix_sort<uint16_t, uint2, GSRAST_RUN_SORT_ITEMS>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev);   // runs by column
+            int rc = radix_sort<uint16_t, uint2, GSRAST_RUN_SORT_ITEMS>(rkA, rvA, rkB, rvB, nQ, xbits, hist_x, rscan, s, nullptr, nullptr, nullptr, Q_dev, nullptr, pred);   // runs by column
             if (rc != GSRAST_OK) return rc;
             if (radix_passes(xbits) & 1) { std::swap(rkA, rkB); std::swap(rvA, rvB); }                   // sorted runs now in (rkA, rvA)
-            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, nQ, Q_dev, hist_y, nblk, (uint32_t)cam.gy);
+            run_hist_rows_kernel<<<nblk, 256, 0, s>>>(rvA, nQ, Q_dev, hist_y, nblk, (uint32_t)cam.gy, pred);
             GS_LAUNCHED("run_hist_rows");
-            radix_rowscan_kernel<<<cam.gy, 256, 0, s>>>(hist_y, nblk, rscan);     // one workgroup per tile row
+            radix_rowscan_kernel<<<cam.gy, 256, 0, s>>>(hist_y, nblk, rscan, nullptr, 0, nullptr, 0, pred);     // one workgroup per tile row
             GS_LAUNCHED("radix_rowscan");
-            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), (uint32_t)cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2);
+            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), (uint32_t)cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2, pred);
             GS_LAUNCHED("run_scatter_rows"); }
         {   ProfScope ps(K_RANGES, s);
             tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges,
-                                                                buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel);
+                                                                buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel, pred);
             GS_LAUNCHED("tile_ranges"); }
         return GSRAST_OK;
     };
-    auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built) -> int {
+    auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built, int mode = 0 /* list cut: as launch_run_binning */) -> int {
         { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }  // the other binning scheme / nothing to bin: not forked yet
         if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); if (zero_in_blend) side_guard.joined = true; }       // the colours (rec2) are the blend's input
         ProfScope ps(K_BLEND_FWD, s);
@@ -918,6 +974,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
         if (zero_in_blend) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
+        if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; }
+        if (mode == 2) ba.pred = scalars + SC_REDO_PRED;
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && o.lpt) {
             if (buckets_ok && fwd_lists_built) { ba.from_buckets = 1; grid = (uint32_t)(XCD_GROUPS * xcd_group_tiles_host((size_t)cam.gx, (size_t)cam.gy)); }   // the tile-range kernel already bucketed the tiles
@@ -941,6 +999,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // {instances R (low word), column runs Q, -, R (high word, run-compressed path), ..., [8] significant depth-key bits,
     //  [9] key base, [10] "three sort passes were assumed and were not enough"}
     uint32_t counts[12] = { 0 };
+    uint32_t nQ1 = 0;
     Readback* rb = nullptr;
     const bool speculative = runbin && bin != nullptr && o.speculative != 0;
     auto begin_readback = [&]() -> int { return read_u32_begin(scalars, s, 12, &rb); };
@@ -959,9 +1018,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     if (speculative) {
         const bool late = totals_pending;
         if (late) rb_flag = read_flag_prepare(&flag_alias, &flag_seq);
-        int rc = launch_run_binning(bin, cap, capQ, capQ, scalars, (late && !rb_flag) ? std::function<int()>(begin_readback) : std::function<int()>());
+        // (list cut: the sorts over the cut lists are sized for the early runs of recent forwards, not for all runs)
+        if (cut) { const uint32_t qe = ctx->Qe_hint.load(); nQ1 = qe ? std::min(capQ, grow(qe)) : capQ; }
+        int rc = launch_run_binning(bin, cap, capQ, cut ? nQ1 : capQ, cut ? scalars + SC_EARLY_COUNTS : scalars, (late && !rb_flag) ? std::function<int()>(begin_readback) : std::function<int()>(), cut ? 1 : 0);
         flag_alias = nullptr;                    // (a repeated emission below reads its counts back the ordinary way)
-        if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true);
+        if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, cut ? 1 : 0);
         if (rc != GSRAST_OK) return rc;
     }
     { int rc = rb_flag ? read_flag_finish(rb_flag, scalars, s, counts, 12) : read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
@@ -1005,8 +1066,26 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     { const uint32_t hr = ctx->R_hint.load(), hq = ctx->Q_hint.load();
       ctx->R_hint = R > hr - hr / 16 ? R : hr - hr / 16; ctx->Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
     ctx->last_R = R; ctx->last_Q = Q;
-    if (speculative && !sort_redone && R <= cap && Q <= capQ) return (int)R;          // everything is already in flight
+    ctx->last_late = cut ? counts[SC_N_LATE] : 0u;
+    if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 16 ? qe : hq - hq / 16; }
+    const bool early_fits = !cut || counts[SC_Q_EARLY] <= nQ1;
+    if (speculative && !sort_redone && R <= cap && Q <= capQ && early_fits) {          // everything is already in flight
+        if (cut && counts[SC_N_LATE] != 0u) {
+            // List cut: the lists in flight hold the early Gaussians only.  The blend verifies them; behind it, the whole binning and
+            // blend over ALL Gaussians, predicated on its verdict (gsrast_common.h).  Nothing of this runs in the steady state.
+            int rc = cut_colors ? color_kernels(s, false, scalars + SC_REDO_PRED) : GSRAST_OK;      // (the late Gaussians' colours)
+            if (rc == GSRAST_OK) rc = launch_run_binning(bin, cap, capQ, capQ, scalars, nullptr, 2);
+            if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, 2);
+            if (rc != GSRAST_OK) return rc;
+        }
+        return (int)R;
+    }
     if (speculative && !sort_redone) ctx->redo_count++;
+    if (cut_colors && color_launched) {     // everything from here on lists ALL Gaussians: the colours the list cut left out are evaluated now
+        if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));
+        int rc = color_kernels(s, false, nullptr);
+        if (rc != GSRAST_OK) return rc;
+    }
     if (speculative)    // redo: the truncated pass already appended every tile to the work buckets once
         GS_HIP(hipMemsetAsync(at<uint32_t>(img, IL.bucket_cnt), 0, (XCD_GROUPS + 1) * WORK_BUCKETS * sizeof(uint32_t), s));
     if (!bin || R > cap || Q > capQ) {   // first call, or the scene grew by more than 25 %: ask again (the callback's last answer counts)

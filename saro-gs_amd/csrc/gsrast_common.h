@@ -40,7 +40,9 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
     size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, bk_param, total;
+        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, bk_param,
+        bk_order_e, bk_wincl_e, bk_info_e, bk_base_e /* the same four over the EARLY Gaussians only, compact (list cut, below) */,
+        color_skip /* u8[P]: 1 = culled or late (list cut): the colour kernel skips it */, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
 constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is one or two self-scanned radix passes anyway
@@ -73,7 +75,7 @@ struct BinLayout {
 //   estimate (tile ranges -> forward order, forward blend's deepest consumed entry -> backward order); block b of a blend
 //   kernel finds its tile from the prefix sums of the 64 counts.  [0] = forward, [1] = backward.
 struct ImgLayout {
-    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, bucket_cnt, bucket_list, total;
+    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, bucket_cnt, bucket_list, zcut_used /* u32[T]: this call's snapshot of the pose's cut depths (list cut, below) */, total;
 };
 constexpr int WORK_BUCKETS = 64;
 constexpr size_t BUCKET_MAX_TILES = 65535;     // tile ids are stored as u16
@@ -99,15 +101,35 @@ constexpr int HINT_SLOTS = 32;
 struct HintTable {
     uint32_t key[HINT_SLOTS][2];   // 0, 0 = free
     uint32_t stamp[HINT_SLOTS];    // value of `clock` when the slot was last used
-    uint32_t clock, pad[3];
-    // followed by uint16_t work[HINT_SLOTS][T]
+    uint32_t clock, cut_fallbacks /* forwards whose cut lists turned out too short and were binned and blended again (diagnostic) */, pad[2];
+    // followed by uint16_t work[HINT_SLOTS][T], then (4-byte aligned) uint32_t zcut[HINT_SLOTS][T]
 };
 // A forward's own choice -- {slot, "the slot held estimates of this pose when the forward began"} -- lives in ITS geometry buffer
 // (scalars[HINT_SEL], [HINT_SEL + 1]), so two forwards of one context in flight on two streams do not read each other's slot.
 constexpr int HINT_SEL = 16;
 __host__ __device__ inline uint16_t* hint_work(HintTable* h, uint32_t) { return reinterpret_cast<uint16_t*>(h + 1); }
 __host__ __device__ inline const uint16_t* hint_work(const HintTable* h, uint32_t) { return reinterpret_cast<const uint16_t*>(h + 1); }
-static inline size_t hint_table_bytes(size_t T) { return sizeof(HintTable) + (size_t)HINT_SLOTS * T * 2 + 256; }
+static inline size_t hint_zcut_offset(size_t T) { return (sizeof(HintTable) + (size_t)HINT_SLOTS * T * 2 + 255) & ~(size_t)255; }
+__host__ __device__ inline uint32_t* hint_zcut(HintTable* h, uint32_t T) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h) + ((sizeof(HintTable) + (size_t)HINT_SLOTS * T * 2 + 255) & ~(size_t)255)); }
+__host__ __device__ inline const uint32_t* hint_zcut(const HintTable* h, uint32_t T) { return reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(h) + ((sizeof(HintTable) + (size_t)HINT_SLOTS * T * 2 + 255) & ~(size_t)255)); }
+static inline size_t hint_table_bytes(size_t T) { return hint_zcut_offset(T) + (size_t)HINT_SLOTS * T * 4 + 256; }
+
+// LIST CUT (round 3): the binning of an occluded scene works on instances nobody consumes (3 M cube: 23 M listed, 1.2 M consumed).  A
+// pose that has been rendered before also remembers, per tile, a CUT DEPTH -- the depth of the list entry twice as deep (+ 32) as the
+// deepest one any pixel of the tile consumed, or "none" (ZCUT_NONE) for a tile whose pixels did not all saturate.  The next forward of
+// that pose snapshots the cut depths into its own image buffer (preprocess_fwd), and the bucket scatter marks a Gaussian LATE when it
+// lies behind the cut depth of every tile of its rectangle.  Late Gaussians stay in the depth order but get no column runs: emission,
+// run sort and row expansion only see the EARLY ones.  This is a speculation, and it is verified: the forward blend treats a tile's
+// list as ending where its depth exceeds the tile's cut depth (up to there the cut list IS the full list), and a tile with a cut whose
+// pixels are not all saturated at that point raises the call's `undone` counter.  Behind the blend the forward has enqueued the whole
+// binning + blend once more over ALL Gaussians, every kernel predicated on that counter: nothing runs when the speculation held (the
+// steady state of a repeated pose), everything is redone from the full lists when it did not.  Results never depend on the table.
+constexpr uint32_t ZCUT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t CUT_MAX_TILES = 8192;      // images with more tiles -- or more than CUT_MAX_CELLS cells of 2 x 2 tiles -- render without the list cut
+constexpr uint32_t CUT_MAX_CELLS = 3072;      // (the bucket scatter keeps the cells' cut depths in LDS)
+constexpr uint32_t LATE_BIT = 0x80000000u;      // in the width word of a bucket-slab element
+// words of GeomLayout::scalars used by the list cut
+constexpr int SC_Q_EARLY = 4, SC_N_LATE = 5, SC_UNDONE = 6, SC_EARLY_COUNTS = 20 /* {R lo, Q early, -, R hi} */, SC_REDO_PRED = SC_UNDONE /* the predicate of the second binning + blend: some tile's cut list was too short */;
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
 constexpr uint32_t RS_SELF_SCAN_BLOCKS = 64;   // sorts of at most this many blocks skip the row-scan launch (radix_scatter_kernel)
@@ -160,7 +182,9 @@ static inline GeomLayout geom_layout(size_t P)
         L.bk_slab = take(nb * GSRAST_BK_CAP * 16);           // [nb][8][CAP / 8] {key, id, width, tiles}
         L.bk_order = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl = take(nb * GSRAST_BK_CAP * 4);
         L.bk_info = take(nb * 16); L.bk_base = take(nb * 4); L.bk_param = take(16);
+        L.bk_order_e = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl_e = take(nb * GSRAST_BK_CAP * 4); L.bk_info_e = take(nb * 16); L.bk_base_e = take(nb * 4);
     }
+    L.color_skip = take(Pp);
     L.total = o + 256;
     return L;
 }
@@ -220,6 +244,7 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     const size_t Tg = xcd_group_tiles_host((W + TILE_X - 1) / TILE_X, (H + TILE_Y - 1) / TILE_Y);      // list capacity of one (group, bucket)
     L.bucket_cnt = take((XCD_GROUPS + 1) * WORK_BUCKETS * 4);            // forward: per XCD group; backward: one global set
     L.bucket_list = take(T <= BUCKET_MAX_TILES ? (XCD_GROUPS * WORK_BUCKETS * (Tg ? Tg : 1) + WORK_BUCKETS * T) * 2 : 0);
+    L.zcut_used = take(T * 4);
     L.total = o + 256;
     return L;
 }

@@ -338,12 +338,13 @@ __device__ __forceinline__ void color_stage_rows(const float* __restrict__ shs, 
     const int base = blk * PP_THREADS;
     const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
     const int row = ROW ? ROW : row_rt;
+    const auto q_of = [&](int q, int n4, int) -> int { return q < n4 ? q : n4 - 1; };
     if (!RAW) {
         const int n4 = (ng * row) >> 2;
         const float4* src4 = reinterpret_cast<const float4*>(shs + (size_t)base * row);
         float4 v[PP_SH_MAX / 4];
 #pragma unroll
-        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = src4[q < n4 ? q : n4 - 1]; }
+        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = src4[q_of(q, n4, row)]; }
 #pragma unroll
         for (int u = 0; u < PP_SH_MAX / 4; u++) {
             const int q = threadIdx.x + u * PP_THREADS;
@@ -367,11 +368,11 @@ __device__ __forceinline__ void color_stage_rows(const float* __restrict__ shs, 
     const float4* ssrc4 = reinterpret_cast<const float4*>(raw.shs_res ? raw.shs_res + (size_t)base * row : raw.features_rest);
     float4 v[PP_SH_MAX / 4], vs[PP_SH_MAX / 4], vd;
 #pragma unroll
-    for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = n4r > 0 ? rsrc4[q < n4r ? q : n4r - 1] : make_float4(0.f, 0.f, 0.f, 0.f); }
-    vd = n4d > 0 ? reinterpret_cast<const float4*>(dsrc)[(int)threadIdx.x < n4d ? (int)threadIdx.x : n4d - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = n4r > 0 ? rsrc4[q_of(q, n4r, rrow)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    vd = n4d > 0 ? reinterpret_cast<const float4*>(dsrc)[q_of((int)threadIdx.x, n4d, 3)] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (raw.shs_res) {
 #pragma unroll
-        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; vs[u] = ssrc4[q < n4s ? q : n4s - 1]; }
+        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; vs[u] = ssrc4[q_of(q, n4s, row)]; }
     }
     if (rrow > 0) {
 #pragma unroll
@@ -416,9 +417,11 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
                         const float* __restrict__ campos_dev,
                         float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
                         float4* __restrict__ grec4 /* [P][4] or null: the backward's gradient records, zero-filled here when there is no side stream to do it */,
-                        float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC /* null: no backward will follow (or D = 0) */)
+                        float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC /* null: no backward will follow (or D = 0) */,
+                        const uint32_t* __restrict__ pred = nullptr /* list cut (gsrast_common.h): the predicated launch in front of the second blend */)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
+    if (pred && *pred == 0u) return;
     const int blk = blockIdx.x;
     const int i = blk * PP_THREADS + threadIdx.x;
     if (grec4) {   // this block's 128 records = 8 KB contiguous: four coalesced 16-byte stores per lane
@@ -456,14 +459,26 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
 
 // The same without LDS staging: colors_precomp, or SH rows the staged kernel does not take (more than 16 coefficients, rows
 // that are not a multiple of 16 bytes, an unaligned base).  One lane per Gaussian, rows read in place.
+// skip (list cut, gsrast_common.h; never together with grec4): [P], 1 = the bucket scatter found this Gaussian culled or LATE -- it is
+// in no list, nobody reads its colour, and its gradient record stays zero, so the backward does not read its direction derivatives
+// either: neither fetched nor evaluated (3 M cube: 87 % of them).  This kernel rather than the staged one then also for rows that one
+// would take: a masked lane costs no traffic here, and with no LDS the kernel leaves the latency-bound binning kernels beside it their
+// compute units (the staged kernel's 25 KB x 6 workgroups fill a CU's LDS: beside it the run sort's scatter took 109 us instead of 15).
+// Gaussians are taken in index order, so the rows that are fetched are fetched in address order (the early Gaussians gathered in
+// DEPTH order -- any order of a random scene -- took 140-620 us for 0.3 M rows, three forms measured: TLB reach, not bytes).
+// RAW: the row is cat(features_dc, features_rest) + shs_res, assembled in registers (one add per element, as the model's `+`).
+template <bool RAW>
 __global__ void __launch_bounds__(256)
 preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
-                               const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
+                               const float* __restrict__ colors_precomp, RawArgs raw, const float* __restrict__ campos_dev,
                                float4* __restrict__ rec2, unsigned char* __restrict__ clamped, float4* __restrict__ grec4,
-                               float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC)
+                               float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC,
+                               const unsigned char* __restrict__ skip = nullptr, const uint32_t* __restrict__ pred = nullptr)
 {
+    if (pred && *pred == 0u) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    if (skip && skip[i]) return;
     if (grec4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) grec4[4 * (size_t)i + k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -471,9 +486,24 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
     float col[3];
     unsigned cl = 0;
     if (!colors_precomp) {
-        const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+        float p[3] = { means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2] };
         const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
-        const float* my_sh = shs + (size_t)i * M * 3;
+        float asm_sh[RAW ? PP_SH_MAX : 1];
+        const float* my_sh;
+        if (RAW) {
+            raw_mean(raw, i, p);
+            const int row = M * 3;
+            const float* dc = raw.features_dc + 3 * (size_t)i;
+            const float* rest = raw.features_rest + (size_t)(row - 3) * i;
+            const float* res = raw.shs_res ? raw.shs_res + (size_t)row * i : nullptr;
+#pragma unroll
+            for (int k = 0; k < PP_SH_MAX; k++) {
+                float v = 0.0f;
+                if (k < row) { v = k < 3 ? dc[k] : rest[k - 3]; if (res) v = v + res[k]; }
+                asm_sh[k] = v;
+            }
+            my_sh = asm_sh;
+        } else my_sh = shs + (size_t)i * M * 3;
         sh_to_rgb(D, p, campos, my_sh, col);
 #pragma unroll
         for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
@@ -493,6 +523,124 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
     }
     rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
     clamped[i] = (unsigned char)cl;
+}
+
+// The colour half under the LIST CUT (gsrast_common.h): skip[i] = 1 marks a Gaussian the bucket scatter found culled or LATE -- it is
+// in no list, nobody reads its colour, and its gradient record stays zero, so the backward does not read its direction derivatives
+// either: neither fetched nor evaluated (3 M cube: 87 % of them).  A workgroup takes 1024 consecutive Gaussians, compacts the ones
+// to evaluate (ascending index order) and works through them 64 per wave: their rows are GATHERED into LDS with coalesced loads
+// (consecutive lanes read consecutive floats of a row) and evaluated from there like preprocess_color_kernel does -- the same
+// expressions on the same operands, the same bits.  Measured on the way here, 3 M cube, 0.3-0.4 M rows to evaluate: the staged kernel
+// with skipped rows' loads redirected: 138 us (it still runs every instruction, and its 25 KB x 6 workgroups fill a CU's LDS: the run
+// sort's scatter beside it 109 us instead of 15); one lane per Gaussian with masked lanes: 95 us (as many load instructions as before,
+// few lanes each); the rows gathered in DEPTH order -- any order, in a random scene -- from the depth buckets: 140-620 us in three
+// forms (TLB reach, not bytes: the gathers here walk the arrays in address order).
+// RAW: the row is cat(features_dc, features_rest) + shs_res, assembled in LDS as preprocess_color_kernel<., true> does.
+constexpr int PCC_WAVES = 2, PCC_IDS = 1024;
+__device__ __forceinline__ void pcc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+template <bool RAW>
+__global__ void __launch_bounds__(64 * PCC_WAVES)
+preprocess_color_compact_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                const float* __restrict__ colors_precomp, RawArgs raw, const float* __restrict__ campos_dev,
+                                float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
+                                float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC,
+                                const unsigned char* __restrict__ skip)
+{
+    constexpr int PER = PCC_IDS / (64 * PCC_WAVES);              // consecutive Gaussians per lane (8)
+    static_assert(PER == 8, "one 8-byte load of flags per lane");
+    __shared__ float s_rows[PCC_WAVES][64 * PP_SH_STRIDE];
+    __shared__ uint32_t s_list[PCC_IDS];
+    __shared__ uint32_t s_wtot[PCC_WAVES];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)PCC_IDS + threadIdx.x * (uint32_t)PER;
+    // 1. compact the indices to evaluate, in ascending order
+    unsigned long long fl = ~0ull;                               // eight flag bytes; past P: skipped
+    if (base + PER <= (uint32_t)P) fl = *reinterpret_cast<const unsigned long long*>(skip + base);       // (the array starts on a 256-byte boundary)
+    else for (int k = 0; k < PER; k++) if (base + k < (uint32_t)P && !skip[base + k]) fl &= ~(0xFFull << (8 * k));
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) mine += ((fl >> (8 * k)) & 0xFFull) ? 0u : 1u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (unsigned)d) incl += o; }
+    if (lane == 63u) s_wtot[wave] = incl;
+    __syncthreads();
+    uint32_t pos = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < PCC_WAVES; w++) { if ((unsigned)w < wave) pos += s_wtot[w]; total += s_wtot[w]; }
+#pragma unroll
+    for (int k = 0; k < PER; k++) if (!((fl >> (8 * k)) & 0xFFull)) s_list[pos++] = base + k;
+    __syncthreads();
+    if (total == 0) return;
+    // 2. evaluate them, 64 per wave
+    const float campos[3] = { campos_dev ? campos_dev[0] : 0.f, campos_dev ? campos_dev[1] : 0.f, campos_dev ? campos_dev[2] : 0.f };
+    const int row = M * 3;
+    float* lds = s_rows[wave];
+    for (uint32_t j0 = wave * 64u; j0 < total; j0 += 64u * PCC_WAVES) {
+        const uint32_t cnt = (total - j0) < 64u ? (total - j0) : 64u;
+        const uint32_t* ids = s_list + j0;
+        const uint32_t i = lane < cnt ? ids[lane] : 0u;
+        float col[3] = { 0.f, 0.f, 0.f };
+        unsigned cl = 0;
+        if (colors_precomp) {
+            if (lane < cnt) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
+            }
+        } else {
+            float p[3] = { 0.f, 0.f, 0.f };
+            if (lane < cnt) { p[0] = means3D[3 * (size_t)i]; p[1] = means3D[3 * (size_t)i + 1]; p[2] = means3D[3 * (size_t)i + 2]; if (RAW) raw_mean(raw, (int)i, p); }
+            // gather: element f of the cnt x len block -> row f / len, float f % len
+            const auto gather = [&](const float* __restrict__ src, int len, int off, bool add) {
+                const uint32_t tot = cnt * (uint32_t)len;
+                for (uint32_t f0 = 0; f0 < tot; f0 += 64u * 8u) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t f = f0 + u * 64u + lane;
+                        const uint32_t g = f / (uint32_t)len, e = f - g * (uint32_t)len;
+                        v[u] = f < tot ? src[(size_t)ids[g] * len + e] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t f = f0 + u * 64u + lane;
+                        const uint32_t g = f / (uint32_t)len, e = f - g * (uint32_t)len;
+                        if (f < tot) { float* d = lds + g * PP_SH_STRIDE + off + e; *d = add ? *d + v[u] : v[u]; }
+                    }
+                }
+            };
+            const float* my_sh;
+            if (row <= PP_SH_MAX) {
+                if (RAW) {
+                    gather(raw.features_dc, 3, 0, false);
+                    if (row > 3) gather(raw.features_rest, row - 3, 3, false);
+                    if (raw.shs_res) { pcc_wave_sync(); gather(raw.shs_res, row, 0, true); }
+                } else gather(shs, row, 0, false);
+                pcc_wave_sync();
+                my_sh = lds + lane * PP_SH_STRIDE;
+            } else my_sh = shs + (size_t)i * row;          // more coefficients than the staging holds (never RAW): rows in place
+            if (lane < cnt) {
+                sh_to_rgb(D, p, campos, my_sh, col);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
+                if (shdA) {
+                    const float o0 = p[0] - campos[0], o1 = p[1] - campos[1], o2 = p[2] - campos[2];
+                    const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+                    const float x = o0 / len, y = o1 / len, z = o2 / len;
+                    float dx[3], dy[3], dz[3];
+                    sh_dir_derivs(D, x, y, z, my_sh, dx, dy, dz);
+                    shdA[i] = make_float4(dx[0], dx[1], dx[2], dy[0]);
+                    shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
+                    shdC[i] = dz[2];
+                }
+            }
+            pcc_wave_sync();                               // the next round overwrites the rows
+        }
+        if (lane < cnt) {
+            rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+            clamped[i] = (unsigned char)cl;
+        }
+    }
 }
 
 // K1 forward, geometry half.  Writes radii / tiles / rect for every Gaussian, the rest only for visible ones.
@@ -517,28 +665,51 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                                                              Gaussians, for the bucket depth sort (gsrast_binning.h); {~0, 0} if it has none */,
                       uint32_t* __restrict__ zero_words, int n_zero_words /* that sort's counters: zeroed here, spread over the blocks */,
                       HintTable* __restrict__ hints /* or null: the context's launch-order hints of the forward blend (gsrast_common.h) */,
-                      uint32_t* __restrict__ hint_sel /* [2]: this call's slot and whether it held this pose already */)
+                      uint32_t* __restrict__ hint_sel /* [2]: this call's slot and whether it held this pose already */,
+                      uint32_t* __restrict__ zcut_used /* or null; [ntiles_img]: this call's snapshot of the pose's cut depths (list cut, gsrast_common.h) */,
+                      uint32_t ntiles_img, uint32_t* __restrict__ cut_scalars /* or null: GeomLayout::scalars, whose `undone` counter is zeroed here */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
-    if (hints && blockIdx.x == 0 && threadIdx.x == 0) {       // look this camera pose up; claim its slot, or the least recently used one
-        uint32_t h0 = 2166136261u, h1 = 0x9E3779B9u;
-        for (int k = 0; k < 16; k++) {
-            const uint32_t a = __float_as_uint(cam_args.view[k]), b = __float_as_uint(cam_args.proj[k]);
-            h0 = (h0 ^ a) * 16777619u; h0 = (h0 ^ b) * 16777619u;
-            h1 = (h1 + a) * 0x85EBCA6Bu; h1 ^= h1 >> 13; h1 = (h1 + b) * 0xC2B2AE35u; h1 ^= h1 >> 16;
+    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; }
+    // The camera pose's key: block 0 looks it up and claims its slot, or the least recently used one; the first blocks of the grid
+    // look it up too and copy the slot's cut depths into this call's own image buffer -- the bucket scatter and the forward blend
+    // must see the SAME values, whatever another forward of this context writes into the table meanwhile (a stale or torn snapshot
+    // is only a poorer speculation: it is verified against itself).
+    constexpr int SNAP_BLOCKS = 32;
+    const bool snap = hints && zcut_used && blockIdx.x < (unsigned)SNAP_BLOCKS;
+    if (hints && (blockIdx.x == 0 || snap)) {
+        __shared__ int s_slot;
+        if (threadIdx.x == 0) {
+            uint32_t h0 = 2166136261u, h1 = 0x9E3779B9u;
+            for (int k = 0; k < 16; k++) {
+                const uint32_t a = __float_as_uint(cam_args.view[k]), b = __float_as_uint(cam_args.proj[k]);
+                h0 = (h0 ^ a) * 16777619u; h0 = (h0 ^ b) * 16777619u;
+                h1 = (h1 + a) * 0x85EBCA6Bu; h1 ^= h1 >> 13; h1 = (h1 + b) * 0xC2B2AE35u; h1 ^= h1 >> 16;
+            }
+            h0 = (h0 ^ (uint32_t)cam_args.W) * 16777619u; h1 = (h1 + (uint32_t)cam_args.H) * 0x85EBCA6Bu;
+            h0 |= 1u;                                               // (0, 0) means "free"
+            int slot = -1, lru = 0;
+            for (int k = 0; k < HINT_SLOTS; k++) {
+                if (hints->key[k][0] == h0 && hints->key[k][1] == h1) { slot = k; break; }
+                if (hints->stamp[k] < hints->stamp[lru]) lru = k;
+            }
+            s_slot = slot;
+            if (blockIdx.x == 0) {
+                const uint32_t now = hints->clock + 1u;
+                const uint32_t found = slot >= 0 ? 1u : 0u;
+                if (slot < 0) { slot = lru; hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
+                hints->stamp[slot] = now; hints->clock = now;
+                hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
+            }
         }
-        h0 = (h0 ^ (uint32_t)cam_args.W) * 16777619u; h1 = (h1 + (uint32_t)cam_args.H) * 0x85EBCA6Bu;
-        h0 |= 1u;                                               // (0, 0) means "free"
-        const uint32_t now = hints->clock + 1u;
-        int slot = -1, lru = 0;
-        for (int k = 0; k < HINT_SLOTS; k++) {
-            if (hints->key[k][0] == h0 && hints->key[k][1] == h1) { slot = k; break; }
-            if (hints->stamp[k] < hints->stamp[lru]) lru = k;
+        if (snap) {
+            __syncthreads();
+            const int slot = s_slot;
+            const uint32_t* zc = hint_zcut(hints, ntiles_img) + (size_t)(slot < 0 ? 0 : slot) * ntiles_img;
+            const uint32_t nsb = gridDim.x < (unsigned)SNAP_BLOCKS ? gridDim.x : (unsigned)SNAP_BLOCKS;
+            for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles_img; t += nsb * blockDim.x)
+                zcut_used[t] = slot < 0 ? ZCUT_NONE : zc[t];
         }
-        const uint32_t found = slot >= 0 ? 1u : 0u;
-        if (slot < 0) { slot = lru; hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
-        hints->stamp[slot] = now; hints->clock = now;
-        hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -844,6 +1015,12 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (shs) {                                              // uniform
             clamped_in = clamped[ic];
             if (D > 0) { sdA = shdA[ic]; sdB = shdB[ic]; sdC = shdC[ic]; }
+        }
+        if (!SPARSE) {
+            // the dense form reads every Gaussian -- but under the forward's list cut (gsrast_common.h) the colour kernel has left the
+            // direction derivatives and clamp flags of a late Gaussian unwritten: its gradient record is zero, so they are taken as zero
+            const bool zero_rec = gr0.x == 0.f && gr0.y == 0.f && gr0.z == 0.f && gr0.w == 0.f && gr1.x == 0.f && gr1.y == 0.f && gr1.z == 0.f && gr1.w == 0.f && gr2.x == 0.f;
+            if (zero_rec) { sdA = make_float4(0.f, 0.f, 0.f, 0.f); sdB = sdA; sdC = 0.0f; clamped_in = 0; }
         }
     }
     const float4 dcon = make_float4(gr0.z, gr0.w, 0.0f, gr1.x);          // reference layout: .z is never written (backward.cu:549-551)

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsrast_hip.so")
 
 NUM_CHANNELS = 3  # reference config.h:15
-ABI_VERSION = 2   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
+ABI_VERSION = 3   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib: Optional[C.CDLL] = None
@@ -47,13 +47,13 @@ class OptionsStruct(C.Structure):
     _fields_ = [("exp_mode", C.c_int), ("binning", C.c_int), ("tile_clip", C.c_int), ("cull", C.c_int), ("lpt", C.c_int),
                 ("speculative", C.c_int), ("fwd_pixels_per_lane", C.c_int), ("bwd_pixels_per_lane", C.c_int),
                 ("sh_grad_factors", C.c_int), ("side_stream", C.c_int), ("grads_zeroed", C.c_int), ("backward_phase", C.c_int), ("depth_sort", C.c_int),
-                ("forward_only", C.c_int), ("no_order_hint", C.c_int), ("dense_backward", C.c_int)]
+                ("forward_only", C.c_int), ("no_order_hint", C.c_int), ("dense_backward", C.c_int), ("no_list_cut", C.c_int)]
 
 
 # Per-call options are kept PER HOST THREAD on the Python side and travel with every call (gsrast_forward_ex /
 # gsrast_backward_ex): two threads rendering on two streams with different options never see each other's settings.
-PER_CALL_OPTIONS = ("exp_mode", "binning", "tile_clip", "cull", "lpt", "speculative", "fwd_pixels_per_lane", "bwd_pixels_per_lane", "side_stream", "depth_sort", "forward_only", "no_order_hint", "dense_backward")
-_OPTION_DEFAULTS = dict(exp_mode=0, binning=0, tile_clip=1, cull=1, lpt=1, speculative=1, fwd_pixels_per_lane=0, bwd_pixels_per_lane=0, side_stream=1, depth_sort=0, forward_only=0, no_order_hint=0, dense_backward=0)
+PER_CALL_OPTIONS = ("exp_mode", "binning", "tile_clip", "cull", "lpt", "speculative", "fwd_pixels_per_lane", "bwd_pixels_per_lane", "side_stream", "depth_sort", "forward_only", "no_order_hint", "dense_backward", "no_list_cut")
+_OPTION_DEFAULTS = dict(exp_mode=0, binning=0, tile_clip=1, cull=1, lpt=1, speculative=1, fwd_pixels_per_lane=0, bwd_pixels_per_lane=0, side_stream=1, depth_sort=0, forward_only=0, no_order_hint=0, dense_backward=0, no_list_cut=0)
 _OPTION_RANGE = dict(exp_mode=(0, 1, 2), binning=(0, 1), depth_sort=(0, 1), fwd_pixels_per_lane=(0, 1, 2, 4), bwd_pixels_per_lane=(0, 1, 2, 4))
 _tls = threading.local()
 
@@ -618,6 +618,15 @@ def get_option(name: str) -> int:
     if name in _OPTION_DEFAULTS:
         return int(_thread_options()[name])
     return int(lib().gsrast_get_option(name.encode()))
+
+
+def context_query(name: str) -> int:
+    """gsrast_context_query on the calling thread's context (include/gsrast.h): "last_instances", "last_runs", "redo_count",
+    "bucket_skip", "last_late", "cut_fallbacks"."""
+    v = int(lib().gsrast_context_query(None, name.encode()))
+    if v < 0:
+        raise ValueError(f"gsrast: unknown context query: {name}")
+    return v
 
 
 def profile_read() -> dict:

@@ -926,6 +926,73 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
         _C.set_option("no_order_hint", 0)
 
 
+def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu):
+    """List cut (include/gsrast.h: options.no_list_cut): the second forward of a pose gives column runs only to the Gaussians in front
+    of the cut depth of some tile they cover.  The speculation is verified on the device: same outputs and state bit for bit, the same
+    gradients; a scene that turned transparent behind the context's back (the cut lists are too short) is redone from the full lists
+    inside the same call (cut_fallbacks counts it) and equals the oracle; the next forward has learned the new cut depths."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H = 60_000, 320, 240
+    sc = scenes.synth(P, 811, scale_mul=1.3)          # dense enough for most tiles to saturate early
+    cam = scenes.camera(2, 9, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+
+    def render(scene):
+        rs = settings_from(rast, cam, scene, gpu)
+        ten = {k: t(scene[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return (R, color.clone(), depth.clone(), radii.clone(), st["n_contrib"].clone(), st["final_T"].clone()), _C.context_query("last_late")
+
+    def same(a, b):
+        return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+    fb0 = _C.context_query("cut_fallbacks")
+    full, late0 = render(sc)                          # first render of the pose by this context: nothing to cut by
+    assert late0 == 0
+    o = orc.render(sc, cam)
+    assert full[0] == o["R"] and np.array_equal(bits(full[1].cpu().numpy()), bits(o["out_color"]))
+    cut1, late1 = render(sc)
+    cut2, late2 = render(sc)
+    assert late1 > P // 4 and late2 > P // 4, (late1, late2)         # the cube is opaque after a fraction of its depth
+    assert same(cut1, full) and same(cut2, full)
+    assert _C.context_query("cut_fallbacks") == fb0                  # the speculation held: nothing was redone
+    _C.set_option("no_list_cut", 1)
+    try:
+        off, late_off = render(sc)
+    finally:
+        _C.set_option("no_list_cut", 0)
+    assert late_off == 0 and same(off, full)
+
+    # the scene turns transparent: every tile now consumes far more than twice what it did
+    sc2 = dict(sc)
+    sc2["opacities"] = (sc["opacities"] * 0.04).astype(np.float32)
+    o2 = orc.render(sc2, cam)
+    thin, late3 = render(sc2)
+    assert late3 > 0                                                  # the cut was applied ...
+    assert _C.context_query("cut_fallbacks") == fb0 + 1               # ... found too short, and everything was redone from the full lists
+    assert thin[0] == o2["R"] and np.array_equal(bits(thin[1].cpu().numpy()), bits(o2["out_color"]))
+    assert np.array_equal(bits(thin[2].cpu().numpy()), bits(o2["out_depth"]))
+    thin2, _ = render(sc2)
+    assert same(thin2, thin)
+    assert _C.context_query("cut_fallbacks") == fb0 + 1               # the redo left cut depths that fit the new scene (or none)
+
+    # gradients through a cut forward: the autograd path, oracle bar
+    g = scenes.upstream_grad(H, W, 812) * (H * W)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)            # (re-learns the opaque scene's cut depths; may fall back once)
+    h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+    assert _C.context_query("last_late") > P // 4
+    assert np.array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+    _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
 def _poison_allocator(gpu, nbytes=256 << 20):
     """Fill the caching allocator's free blocks with NaN bit patterns, so that a torch.empty output that nobody writes is seen."""
     import torch
