@@ -140,7 +140,9 @@ class Workload:
         gy, gx = (self.H + 15) // 16, (self.W + 15) // 16
         return dict(R=ref["R"], R_eff=ref["R_eff"], P_vis=ref["P_vis"], pairs_fwd=ref["pairs"], T=gx * gy,
                     N=self.W * self.H, R_listed=cur["listed"], R_eff_listed=cur["R_eff"], pairs_listed=cur["pairs"],
-                    Q=int(_C.get_option("last_runs")))
+                    Q=int(_C.get_option("last_runs")),
+                    # list cut (include/gsrast.h: options.no_list_cut): what the last forward of this (repeated) pose left out
+                    Q_early=int(_C.context_query("last_early_runs")), late=int(_C.context_query("last_late")))
 
 
 HOST_STEPS = {}     # per-step host enqueue times of the last timed() call: a stall of the host shows up here
@@ -280,13 +282,14 @@ def stage_table(_C, wl, st, P, deg, H):
     _C.set_option("profile", 0)
     C = (deg + 1) ** 2
     Pv, R, Re, N, T = st["P_vis"], st["R"], st["R_eff"], st["N"], st["T"]
-    Rl, Q = st["R_listed"], st["Q"]
+    Rl, Q = st["R_listed"], st.get("Q_early", st["Q"])      # (under the list cut: the early Gaussians' runs and instances)
+    Pe = max(Pv - st.get("late", 0), 0)                      # Gaussians whose colour is evaluated
     passes_t = 2 if T > 256 else 1
     run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
     bucket_sort = run_binning and _C.get_option("depth_sort") == 0 and P >= 32768
     alg = {
         "preprocess_fwd": P * (44 + 20) + Pv * 64,                # geometry half: in 44 B, out radii / tiles / rect / depth key 20 B + rec0, rec1, binrec 64 B per visible Gaussian (round 3: no cov3D / depth / sort value)
-        "preprocess_color": P * (12 + 12 * C + 17 + (36 if deg > 0 else 0)),   # colour half (side stream, beside the binning): means + SH in, rec2 + clamp flags + the 9 direction derivatives out
+        "preprocess_color": (Pe if st.get("late", 0) else P) * (12 + 12 * C + 17 + (36 if deg > 0 else 0)) + (P if st.get("late", 0) else 0),   # colour half (side stream, beside the binning): means + SH in, rec2 + clamp flags + the 9 direction derivatives out (list cut: early Gaussians only, + a flag byte each)
         # bucket depth sort (default): scatter reads key + rect + tiles (16 B), writes a 16-B slab element; the sort kernel reads it
         # (twice, the second time from L2) and writes id + width scan (8 B) -- per visible Gaussian; radix passes: 20 B x 4
         "sort_depth": (P * 16 + Pv * 40) if bucket_sort else P * 20 * 4,
@@ -301,6 +304,7 @@ def stage_table(_C, wl, st, P, deg, H):
         # out: dL/dmean2D 12, dL/dopacity 4, dL/dmean3D 12, dL/dsh 12 C, dL/dscale 12, dL/drot 16  (the SH block is not read any more)
         "preprocess_bwd": P * (12 * C + 201),
         "sh_dir_derivs": Pv * (12 * C + 12 + 36) + P * 4,       # side stream, beside the blend backward: SH + mean in, 36 B out
+        "cut_redo": 0,                                          # list cut: the predicated second binning + blend (ten launches that return at once)
     }
     per_kernel = {}
     for name, nbytes in alg.items():
@@ -871,6 +875,18 @@ def main():
             no_hint = {"views_per_s": round(a.steps / d0, 3), "ms_per_step": round(d0 / a.steps * 1e3, 4), "steps": a.steps, "warmup": a.warmup}
         finally:
             _C.set_option("no_order_hint", 0)
+    # ... and with the LIST CUT switched off (options.no_list_cut; the launch-order hints stay on): a pose rendered before bins only the
+    # Gaussians in front of its tiles' cut depths -- the same best case (one pose, an unchanged scene: the speculation always holds)
+    no_cut = None
+    if world == 1:
+        _C.set_option("no_list_cut", 1)
+        try:
+            d0 = timed(wl, a.steps, a.warmup, None, 1, vp, dev)
+            no_cut = {"views_per_s": round(a.steps / d0, 3), "ms_per_step": round(d0 / a.steps * 1e3, 4), "steps": a.steps, "warmup": a.warmup}
+        finally:
+            _C.set_option("no_list_cut", 0)
+        for _ in range(3):
+            wl.step(None, 1)        # (the statistics below describe the default path again)
     st = wl.stats()
     per_kernel, pk, exp2 = (None, None, None)
     if world == 1:
@@ -904,7 +920,14 @@ def main():
             "launch_order_hint": {"headline": "on (library default): the context orders the forward blend of a camera pose it has rendered before by what "
                                               "every tile consumed then; this bench repeats one pose per rank",
                                   "switched_off": no_hint,
-                                  "note": "results never depend on it (tests/test_gpu_parity.py::test_launch_order_hints_never_change_a_result)"},
+                                  "note": "results never depend on it (tests/test_gpu_parity.py::test_launch_order_hints_never_change_a_result); "
+                                          "switched off, the list cut below is off as well (it rides on the same table)"},
+            "list_cut": {"headline": "on where it pays (library default): a pose rendered before bins only the Gaussians in front of its tiles' cut depths; "
+                                     "verified on the device, the full binning + blend enqueued behind the blend, predicated on the verdict",
+                         "late_gaussians": st.get("late"), "early_column_runs": st.get("Q_early"), "all_column_runs": st.get("Q"),
+                         "switched_off": no_cut,
+                         "cut_fallbacks_in_this_process": int(_C.context_query("cut_fallbacks")),
+                         "note": "results never depend on it (tests/test_gpu_parity.py::test_list_cut_is_verified_and_never_changes_a_result)"},
         }
 
     # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----

@@ -206,7 +206,9 @@ typedef struct gsrast_options {
                                  occluded scene a few per cent of them -- and VERIFIES the speculation on the device: a tile's list counts
                                  as ending at its cut depth, and if some pixel of a cut tile is not saturated there, the whole binning and
                                  blend run again over all Gaussians (enqueued behind the blend in any case, every kernel predicated on the
-                                 verdict).  Results never depend on it; needs tile_clip = 1, the bucket depth sort, at most 8192 tiles */
+                                 verdict).  Results never depend on it; needs tile_clip = 1, the bucket depth sort, at most 8192 tiles.  It is
+                                 applied where it pays: when the context's last forward had at least 1.5 M column runs, and not for the next 64
+                                 forwards after one in which it removed fewer than that (gsrast_set_option("list_cut_always", 1) lifts both) */
 } gsrast_options;
 void gsrast_options_init(gsrast_options* options);   /* fills in the built-in defaults listed above */
 /* A context may be used by one host thread at a time (it owns one side stream and one set of fork / join events per device, and -- per
@@ -216,7 +218,7 @@ void gsrast_options_init(gsrast_options* options);   /* fills in the built-in de
 typedef struct gsrast_context gsrast_context;
 gsrast_context* gsrast_context_create(void);
 void gsrast_context_destroy(gsrast_context* ctx);
-/* "last_late" (Gaussians the list cut left without column runs in the context's last forward call), "cut_fallbacks" (forwards on the
+/* "last_late" (Gaussians the list cut left without column runs in the context's last forward call), "last_early_runs" (column runs of the others), "cut_fallbacks" (forwards on the
  * current device whose cut lists turned out too short and were redone from the full lists; this query waits for the device),
  * "last_instances" (num_rendered), "last_runs" (column runs) of the context's last forward call, "redo_count"
  * (speculative launches / depth sorts that had to be repeated), "bucket_skip" (forwards that will still go straight to the radix

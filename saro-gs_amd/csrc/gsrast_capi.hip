@@ -39,7 +39,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0};      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0};      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -80,10 +80,12 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 // ---- per-kernel device timing (option "profile") -------------------------------------------
 enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
-                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_COUNT };
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_CUT_REDO, K_COUNT };
 const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
                                             "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
-                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color", "sh_dir_derivs" };
+                                            "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color", "sh_dir_derivs",
+                                            "cut_redo" /* list cut: the predicated second binning + blend behind the forward blend, as ONE stage */ };
+thread_local int t_prof_off = 0;      // > 0: the stages below are part of an enclosing one (cut_redo) and not recorded on their own
 struct Pending { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<Pending> g_pending;
@@ -92,7 +94,7 @@ long long g_launches[K_COUNT];
 
 struct ProfScope {
     int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(((g_profile.load() >> id_) & 1) != 0)
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(((g_profile.load() >> id_) & 1) != 0 && (t_prof_off == 0 || id_ == K_CUT_REDO))
     {
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
@@ -312,8 +314,9 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 } // namespace
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
 struct gsrast_context {
-    std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0}, last_late{0};
+    std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0}, last_late{0}, last_Qe{0};
     std::atomic<uint32_t> Qe_hint{0};  // list cut: column runs of the early Gaussians in recent forwards (sizes the launches over the cut lists)
+    std::atomic<int> cut_pause{0};     // list cut: > 0 = a recent cut forward saved too few column runs to pay for itself; that many forwards go without
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
@@ -536,6 +539,7 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "redo_count")) return c->redo_count.load();
     if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
     if (!strcmp(name, "last_late")) return (int)c->last_late.load();
+    if (!strcmp(name, "last_early_runs")) return (int)c->last_Qe.load();
     if (!strcmp(name, "cut_fallbacks")) {       // a device counter in the hint table of the current device (diagnostic: waits for the device)
         int device = 0;
         if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32 || !c->hints[device].table) return 0;
@@ -553,6 +557,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "exp_mode")) { if (value < 0 || value > 2) return GSRAST_E_ARG; g_def.exp_mode = value; return 0; }
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "list_cut_always")) { g_list_cut_always = value ? 1 : 0; return 0; }   // the list cut also where it does not pay (tests)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
@@ -584,6 +589,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "exp_mode")) return g_def.exp_mode.load();
     if (!strcmp(name, "profile")) return g_profile.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
+    if (!strcmp(name, "list_cut_always")) return g_list_cut_always.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
     if (!strcmp(name, "bwd_pixels_per_lane")) return g_def.bwd_ppl.load();
@@ -745,8 +751,15 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     uint32_t* hint_sel = scalars + HINT_SEL;
     // List cut (gsrast_common.h): only with the hints, the bucket depth sort, clipped lists, and a capacity hint (the cut lists are
     // blended by the speculative launch; the verified fallback is enqueued behind it).  Whether THIS pose has cut depths is decided on the device.
+    // It costs ~80 us per forward (the late test in the scatter, the compacting colour kernel, ten predicated launches behind the blend)
+    // and saves ~50 us per million column runs it removes: it is used when the context's last forward had at least CUT_MIN_RUNS column
+    // runs, and paused for CUT_PAUSE forwards whenever a cut forward removed fewer than that (a surface-like scene; measured
+    // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
+    constexpr uint32_t CUT_MIN_RUNS = 1500000u; constexpr int CUT_PAUSE = 64;
+    const bool cut_pays = g_list_cut_always.load() != 0 || (ctx->last_Q.load() >= CUT_MIN_RUNS && ctx->cut_pause.load() == 0);
     const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && T <= CUT_MAX_TILES && (uint32_t)((cam.gx + 1) / 2) * (uint32_t)((cam.gy + 1) / 2) <= CUT_MAX_CELLS &&
-                     o.speculative != 0 && ctx->R_hint.load() != 0;
+                     o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
+    if (!cut && !o.no_list_cut && ctx->cut_pause.load() > 0) ctx->cut_pause--;
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
@@ -1066,13 +1079,16 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     { const uint32_t hr = ctx->R_hint.load(), hq = ctx->Q_hint.load();
       ctx->R_hint = R > hr - hr / 16 ? R : hr - hr / 16; ctx->Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
     ctx->last_R = R; ctx->last_Q = Q;
-    ctx->last_late = cut ? counts[SC_N_LATE] : 0u;
+    ctx->last_late = cut ? counts[SC_N_LATE] : 0u; ctx->last_Qe = cut ? counts[SC_Q_EARLY] : counts[1];
+    if (cut && counts[SC_N_LATE] != 0u && counts[1] - counts[SC_Q_EARLY] < CUT_MIN_RUNS && !g_list_cut_always.load()) ctx->cut_pause = CUT_PAUSE;
     if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 16 ? qe : hq - hq / 16; }
     const bool early_fits = !cut || counts[SC_Q_EARLY] <= nQ1;
     if (speculative && !sort_redone && R <= cap && Q <= capQ && early_fits) {          // everything is already in flight
         if (cut && counts[SC_N_LATE] != 0u) {
             // List cut: the lists in flight hold the early Gaussians only.  The blend verifies them; behind it, the whole binning and
             // blend over ALL Gaussians, predicated on its verdict (gsrast_common.h).  Nothing of this runs in the steady state.
+            ProfScope ps(K_CUT_REDO, s);
+            struct Off { Off() { t_prof_off++; } ~Off() { t_prof_off--; } } off;
             int rc = cut_colors ? color_kernels(s, false, scalars + SC_REDO_PRED) : GSRAST_OK;      // (the late Gaussians' colours)
             if (rc == GSRAST_OK) rc = launch_run_binning(bin, cap, capQ, capQ, scalars, nullptr, 2);
             if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, 2);

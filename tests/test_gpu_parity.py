@@ -904,6 +904,7 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
     W, H = 320, 240
     cams = [scenes.camera(k, 40, W, H) for k in range(40)]          # 40 poses > 32 slots
     first = {}
+    _C.set_option("list_cut_always", 1)                              # the list cut rides on the same table: exercised here as well
     for k in (0, 1, 0, 1, 0):                                        # alternating: the third render of pose 0 runs by its own hint
         out = render(cams[k], W, H)
         if k in first:
@@ -924,6 +925,7 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
             assert same(render(cams[k], W, H), first[k])
     finally:
         _C.set_option("no_order_hint", 0)
+        _C.set_option("list_cut_always", 0)
 
 
 def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu):
@@ -952,6 +954,14 @@ def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu)
     def same(a, b):
         return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
 
+    _C.set_option("list_cut_always", 1)               # (by default the cut is only applied where it pays: scenes of millions of column runs)
+    try:
+        _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H)
+    finally:
+        _C.set_option("list_cut_always", 0)
+
+
+def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H):
     fb0 = _C.context_query("cut_fallbacks")
     full, late0 = render(sc)                          # first render of the pose by this context: nothing to cut by
     assert late0 == 0
