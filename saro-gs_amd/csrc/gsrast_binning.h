@@ -426,8 +426,8 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                             // its place in the depth order but gets no column runs unless the forward has to fall back to the full lists
                             const uint32_t* __restrict__ zcut_used = nullptr, uint32_t ntiles_img = 0, uint32_t gx_tiles = 0,
                             uint32_t* __restrict__ n_late_out = nullptr,
-                            unsigned char* __restrict__ color_skip = nullptr /* [n] or null: 1 = culled or late: no list will hold this
-                                                                                  Gaussian, the colour kernel need not evaluate it */)
+                            unsigned long long* __restrict__ color_skip = nullptr /* [ceil(n / 64)] or null: bit i = Gaussian i is culled or
+                                                                                  late: no list will hold it, the colour kernel need not evaluate it */)
 {
     __shared__ uint32_t cnt[BK_MAX_BUCKETS];
     __shared__ uint32_t s_mm[2];
@@ -521,6 +521,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     uint32_t nlate = 0;
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
+        bool skipped = true;                                                   // culled (or past the end)
         if (key[r] != 0xFFFFFFFFu) {
             uint32_t wword = (rc[r].y & 0xFFFFu) - (rc[r].x & 0xFFFFu);
             if (zcut_used) {
@@ -528,18 +529,27 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                 const uint32_t kq = key[r] >> 16;
                 bool late = wword != 0u && (x1 - x0) * (y1 - y0) <= 64u;       // (a large rectangle is not worth the walk: early)
                 if (late) {
+                    const uint32_t cx0 = x0 >> 1, cx1 = (x1 - 1u) >> 1, cy0 = y0 >> 1, cy1 = (y1 - 1u) >> 1;
                     uint32_t m = 0;
-                    for (uint32_t cy = y0 >> 1; cy <= (y1 - 1u) >> 1; cy++)
-                        for (uint32_t cx = x0 >> 1; cx <= (x1 - 1u) >> 1; cx++) m = max(m, (uint32_t)s_zc[cy * cgx + cx]);
+                    if (cx1 - cx0 <= 1u && cy1 - cy0 <= 1u)                    // the usual case: four independent reads, no loop
+                        m = max(max((uint32_t)s_zc[cy0 * cgx + cx0], (uint32_t)s_zc[cy0 * cgx + cx1]), max((uint32_t)s_zc[cy1 * cgx + cx0], (uint32_t)s_zc[cy1 * cgx + cx1]));
+                    else
+                        for (uint32_t cy = cy0; cy <= cy1; cy++)
+                            for (uint32_t cx = cx0; cx <= cx1; cx++) m = max(m, (uint32_t)s_zc[cy * cgx + cx]);
                     late = kq > m;                                             // (kq > the rounded-up cut  =>  key > the cut)
                 }
                 if (late) { wword |= LATE_BIT; nlate++; }
             }
-            if (color_skip) color_skip[base + r * 256 + threadIdx.x] = (wword & LATE_BIT) ? 1 : 0;
             const uint32_t pos = cnt[dg[r]] + lr[r];
             if (pos < (uint32_t)BK_CAPX)
                 slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, wword, tl[r]);
-        } else if (color_skip && base + r * 256 + threadIdx.x < n) color_skip[base + r * 256 + threadIdx.x] = 1;
+            skipped = (wword & LATE_BIT) != 0u;
+        }
+        if (color_skip) {       // one 64-bit word per wave and round: the wave's 64 Gaussians are consecutive
+            const unsigned long long m = __ballot(skipped);
+            const uint32_t first = base + r * 256 + (threadIdx.x & ~63u);
+            if (lane == 0 && first < n) color_skip[first >> 6] = m;
+        }
     }
     if (zcut_used) {
 #pragma unroll

@@ -801,7 +801,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             else if (staged)
                 preprocess_color_kernel<0, false><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, sh_in, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
             else
-                preprocess_color_direct_kernel<false><<<(P + 255) / 256, 256, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, raw, cam_pos, rec2, cl, gz, sA, sB, sC, nullptr, pred);
+                preprocess_color_direct_kernel<<<(P + 255) / 256, 256, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "preprocess_color", e);
         }
@@ -860,7 +860,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             {   ProfScope ps(K_SORT_DEPTH, s);
                 depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + PF_THREADS - 1) / PF_THREADS), nbk, gcount, slab, at<float>(geom, GL.bk_param),
                                                                                                          zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
-                                                                                                         cut ? at<unsigned char>(geom, GL.color_skip) : nullptr);
+                                                                                                         cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr);
                 GS_LAUNCHED("depth_bucket_scatter");
                 depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base),
                                                                                                    cut ? at<uint32_t>(geom, GL.bk_wincl_e) : nullptr, cut ? at<uint4>(geom, GL.bk_info_e) : nullptr, cut ? at<uint32_t>(geom, GL.bk_base_e) : nullptr,

@@ -42,7 +42,7 @@ struct GeomLayout {
     size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
         hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, bk_param,
         bk_order_e, bk_wincl_e, bk_info_e, bk_base_e /* the same four over the EARLY Gaussians only, compact (list cut, below) */,
-        color_skip /* u8[P]: 1 = culled or late (list cut): the colour kernel skips it */, total;
+        color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
 constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is one or two self-scanned radix passes anyway
@@ -184,7 +184,7 @@ static inline GeomLayout geom_layout(size_t P)
         L.bk_info = take(nb * 16); L.bk_base = take(nb * 4); L.bk_param = take(16);
         L.bk_order_e = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl_e = take(nb * GSRAST_BK_CAP * 4); L.bk_info_e = take(nb * 16); L.bk_base_e = take(nb * 4);
     }
-    L.color_skip = take(Pp);
+    L.color_skip = take(((Pp + 63) / 64) * 8 + 256);
     L.total = o + 256;
     return L;
 }

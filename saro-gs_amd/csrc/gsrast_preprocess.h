@@ -459,26 +459,16 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
 
 // The same without LDS staging: colors_precomp, or SH rows the staged kernel does not take (more than 16 coefficients, rows
 // that are not a multiple of 16 bytes, an unaligned base).  One lane per Gaussian, rows read in place.
-// skip (list cut, gsrast_common.h; never together with grec4): [P], 1 = the bucket scatter found this Gaussian culled or LATE -- it is
-// in no list, nobody reads its colour, and its gradient record stays zero, so the backward does not read its direction derivatives
-// either: neither fetched nor evaluated (3 M cube: 87 % of them).  This kernel rather than the staged one then also for rows that one
-// would take: a masked lane costs no traffic here, and with no LDS the kernel leaves the latency-bound binning kernels beside it their
-// compute units (the staged kernel's 25 KB x 6 workgroups fill a CU's LDS: beside it the run sort's scatter took 109 us instead of 15).
-// Gaussians are taken in index order, so the rows that are fetched are fetched in address order (the early Gaussians gathered in
-// DEPTH order -- any order of a random scene -- took 140-620 us for 0.3 M rows, three forms measured: TLB reach, not bytes).
-// RAW: the row is cat(features_dc, features_rest) + shs_res, assembled in registers (one add per element, as the model's `+`).
-template <bool RAW>
 __global__ void __launch_bounds__(256)
 preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
-                               const float* __restrict__ colors_precomp, RawArgs raw, const float* __restrict__ campos_dev,
+                               const float* __restrict__ colors_precomp, const float* __restrict__ campos_dev,
                                float4* __restrict__ rec2, unsigned char* __restrict__ clamped, float4* __restrict__ grec4,
                                float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC,
-                               const unsigned char* __restrict__ skip = nullptr, const uint32_t* __restrict__ pred = nullptr)
+                               const uint32_t* __restrict__ pred = nullptr /* list cut: the predicated launch in front of the second blend */)
 {
     if (pred && *pred == 0u) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    if (skip && skip[i]) return;
     if (grec4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) grec4[4 * (size_t)i + k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -486,24 +476,9 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
     float col[3];
     unsigned cl = 0;
     if (!colors_precomp) {
-        float p[3] = { means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2] };
+        const float p[3] = { means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2] };
         const float campos[3] = { campos_dev[0], campos_dev[1], campos_dev[2] };
-        float asm_sh[RAW ? PP_SH_MAX : 1];
-        const float* my_sh;
-        if (RAW) {
-            raw_mean(raw, i, p);
-            const int row = M * 3;
-            const float* dc = raw.features_dc + 3 * (size_t)i;
-            const float* rest = raw.features_rest + (size_t)(row - 3) * i;
-            const float* res = raw.shs_res ? raw.shs_res + (size_t)row * i : nullptr;
-#pragma unroll
-            for (int k = 0; k < PP_SH_MAX; k++) {
-                float v = 0.0f;
-                if (k < row) { v = k < 3 ? dc[k] : rest[k - 3]; if (res) v = v + res[k]; }
-                asm_sh[k] = v;
-            }
-            my_sh = asm_sh;
-        } else my_sh = shs + (size_t)i * M * 3;
+        const float* my_sh = shs + (size_t)i * M * 3;
         sh_to_rgb(D, p, campos, my_sh, col);
 #pragma unroll
         for (int c = 0; c < 3; c++) { if (col[c] < 0.0f) { cl |= 1u << c; col[c] = 0.0f; } }
@@ -525,7 +500,7 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
     clamped[i] = (unsigned char)cl;
 }
 
-// The colour half under the LIST CUT (gsrast_common.h): skip[i] = 1 marks a Gaussian the bucket scatter found culled or LATE -- it is
+// The colour half under the LIST CUT (gsrast_common.h): bit i of skip marks a Gaussian the bucket scatter found culled or LATE -- it is
 // in no list, nobody reads its colour, and its gradient record stays zero, so the backward does not read its direction derivatives
 // either: neither fetched nor evaluated (3 M cube: 87 % of them).  A workgroup takes 1024 consecutive Gaussians, compacts the ones
 // to evaluate (ascending index order) and works through them 64 per wave: their rows are GATHERED into LDS with coalesced loads
@@ -544,22 +519,22 @@ preprocess_color_compact_kernel(int P, int D, int M, const float* __restrict__ m
                                 const float* __restrict__ colors_precomp, RawArgs raw, const float* __restrict__ campos_dev,
                                 float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
                                 float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC,
-                                const unsigned char* __restrict__ skip)
+                                const unsigned char* __restrict__ skip /* bit i = skip Gaussian i; the words past P read as written by the scatter (all set) */)
 {
     constexpr int PER = PCC_IDS / (64 * PCC_WAVES);              // consecutive Gaussians per lane (8)
-    static_assert(PER == 8, "one 8-byte load of flags per lane");
+    static_assert(PER == 8, "one byte of flags per lane");
     __shared__ float s_rows[PCC_WAVES][64 * PP_SH_STRIDE];
     __shared__ uint32_t s_list[PCC_IDS];
     __shared__ uint32_t s_wtot[PCC_WAVES];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t base = blockIdx.x * (uint32_t)PCC_IDS + threadIdx.x * (uint32_t)PER;
     // 1. compact the indices to evaluate, in ascending order
-    unsigned long long fl = ~0ull;                               // eight flag bytes; past P: skipped
-    if (base + PER <= (uint32_t)P) fl = *reinterpret_cast<const unsigned long long*>(skip + base);       // (the array starts on a 256-byte boundary)
-    else for (int k = 0; k < PER; k++) if (base + k < (uint32_t)P && !skip[base + k]) fl &= ~(0xFFull << (8 * k));
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) mine += ((fl >> (8 * k)) & 0xFFull) ? 0u : 1u;
+    uint32_t fl = 0xFFu;                                         // eight flag bits; past P: skipped
+    if (base < (uint32_t)P) {
+        fl = skip[base >> 3];
+        for (int k = 0; k < PER; k++) if (base + k >= (uint32_t)P) fl |= 1u << k;
+    }
+    const uint32_t mine = (uint32_t)__builtin_popcount(~fl & 0xFFu);
     uint32_t incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (unsigned)d) incl += o; }
@@ -569,7 +544,7 @@ preprocess_color_compact_kernel(int P, int D, int M, const float* __restrict__ m
 #pragma unroll
     for (int w = 0; w < PCC_WAVES; w++) { if ((unsigned)w < wave) pos += s_wtot[w]; total += s_wtot[w]; }
 #pragma unroll
-    for (int k = 0; k < PER; k++) if (!((fl >> (8 * k)) & 0xFFull)) s_list[pos++] = base + k;
+    for (int k = 0; k < PER; k++) if (!((fl >> k) & 1u)) s_list[pos++] = base + k;
     __syncthreads();
     if (total == 0) return;
     // 2. evaluate them, 64 per wave

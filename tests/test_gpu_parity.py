@@ -1003,6 +1003,74 @@ def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H):
     _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
 
 
+def test_list_cut_under_a_changing_scene(orc, scenes, rast, gpu):
+    """A training run changes the scene between two renders of a pose.  A fixed pose, twelve random edits in a row -- opacities scaled
+    up or down, a tenth of the Gaussians pruned, the scene pushed away from / pulled towards the camera, a transparent and an opaque
+    extreme -- each rendered under the list cut (whose cut depths come from the PREVIOUS edit's render) and with the cut switched off:
+    outputs and per-pixel state bit for bit the same, whether the speculation held or the forward fell back; one edit is also taken
+    through the backward against the oracle."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H = 50_000, 256, 192
+    base = scenes.synth(P, 905, scale_mul=1.2)
+    cam = scenes.camera(5, 11, W, H)
+    rng = np.random.default_rng(906)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+    view_dir = np.asarray(cam["viewmatrix"], dtype=np.float32).reshape(4, 4)[:3, 2]     # (row-vector convention: column 2 = depth axis)
+
+    def render(scene):
+        rs = settings_from(rast, cam, scene, gpu)
+        ten = {k: t(scene[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return R, color.clone(), depth.clone(), radii.clone(), st["n_contrib"].clone(), st["final_T"].clone()
+
+    def same(a, b):
+        return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+    _C.set_option("list_cut_always", 1)
+    try:
+        render(base)                                                 # the pose's first render: leaves cut depths
+        fb0, cuts, sc = _C.context_query("cut_fallbacks"), 0, dict(base)
+        for step in range(12):
+            sc = dict(sc)
+            kind = step % 6
+            if kind == 0:
+                sc["opacities"] = np.clip(sc["opacities"] * rng.uniform(0.3, 0.8), 0.0, 1.0).astype(np.float32)
+            elif kind == 1:
+                sc["opacities"] = np.clip(sc["opacities"] * rng.uniform(1.5, 3.0), 0.0, 1.0).astype(np.float32)
+            elif kind == 2:
+                op = sc["opacities"].copy(); op[rng.random(P) < 0.1] = 0.0; sc["opacities"] = op
+            elif kind == 3:
+                sc["means3D"] = (sc["means3D"] + view_dir * rng.uniform(-0.4, 0.4)).astype(np.float32)
+            elif kind == 4:
+                sc["opacities"] = (base["opacities"] * 0.02).astype(np.float32)       # nearly transparent: every tile looks far deeper
+            else:
+                sc["opacities"] = np.full_like(base["opacities"], 0.97)              # opaque: every tile saturates at once
+            cut = render(sc)
+            cuts += _C.context_query("last_late") > 0
+            _C.set_option("no_list_cut", 1)
+            try:
+                ref = render(sc)
+            finally:
+                _C.set_option("no_list_cut", 0)
+            assert same(cut, ref), f"edit {step} (kind {kind}): the list cut changed a result"
+        assert cuts >= 8                                             # the cut really was in force most of the time ...
+        assert _C.context_query("cut_fallbacks") > fb0               # ... and at least the transparent edits made it fall back
+        g = scenes.upstream_grad(H, W, 907) * (H * W)
+        o32 = orc.render(sc, cam, g)
+        o64 = orc.render(sc, cam, g, f64=True)
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+        assert np.array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+        _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    finally:
+        _C.set_option("list_cut_always", 0)
+
+
 def _poison_allocator(gpu, nbytes=256 << 20):
     """Fill the caching allocator's free blocks with NaN bit patterns, so that a torch.empty output that nobody writes is seen."""
     import torch
