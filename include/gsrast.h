@@ -192,8 +192,8 @@ typedef struct gsrast_options {
                                  state must be given forward_only = 1 as well; it then evaluates those derivatives itself
                                  (sh_dir_derivs_kernel, re-reading the SH blocks).  0 (default) = the forward prepares them */
     int no_order_hint;        /* forward: 1 = do not use / update the context's launch-order hints.  By default a context remembers, per device and
-                                 camera pose (hash of the view and projection matrices and the image size; 32 poses, least recently used
-                                 replaced; device memory, 2 B per tile and pose), how deep every tile's list was consumed the last time
+                                 camera pose (hash of the view and projection matrices and the image size; 256 poses, least recently used
+                                 replaced; device memory, 6 B per tile and pose with the cut depths of no_list_cut below), how deep every tile's list was consumed the last time
                                  that pose was rendered, and starts the forward blend's heaviest tiles first by it -- the list length, the
                                  only estimate a first-seen pose has, is a poor one in occluded scenes.  Results never depend on it */
     int dense_backward;       /* backward: 1 = the per-Gaussian backward reads every Gaussian's inputs (round 2's form).  0 (default): a

@@ -97,7 +97,7 @@ static inline size_t xcd_group_tiles_host(size_t gx, size_t gy) { return gx * ((
 // writes the new ones.  Only the ORDER of a launch depends on it, never a result; a pose seen for the first time (or
 // options.fwd_order_hint = 0) falls back to the list lengths.  SaRO-GS renders fixed camera rigs (Neural3D: ~20 cameras x 300 frames,
 // D-NeRF: every pose again each epoch), and its evaluation of a Neural3D scene is ONE pose for 300 frames.
-constexpr int HINT_SLOTS = 32;
+constexpr int HINT_SLOTS = 256;    // camera poses per context and device (D-NeRF rigs have 100-200 training views; 6 B per tile and pose: 12.5 MB at 1080p)
 struct HintTable {
     uint32_t key[HINT_SLOTS][2];   // 0, 0 = free
     uint32_t stamp[HINT_SLOTS];    // value of `clock` when the slot was last used

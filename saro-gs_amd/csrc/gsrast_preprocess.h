@@ -654,31 +654,31 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     const bool snap = hints && zcut_used && blockIdx.x < (unsigned)SNAP_BLOCKS;
     if (hints && (blockIdx.x == 0 || snap)) {
         __shared__ int s_slot;
-        if (threadIdx.x == 0) {
-            uint32_t h0 = 2166136261u, h1 = 0x9E3779B9u;
-            for (int k = 0; k < 16; k++) {
-                const uint32_t a = __float_as_uint(cam_args.view[k]), b = __float_as_uint(cam_args.proj[k]);
-                h0 = (h0 ^ a) * 16777619u; h0 = (h0 ^ b) * 16777619u;
-                h1 = (h1 + a) * 0x85EBCA6Bu; h1 ^= h1 >> 13; h1 = (h1 + b) * 0xC2B2AE35u; h1 ^= h1 >> 16;
-            }
-            h0 = (h0 ^ (uint32_t)cam_args.W) * 16777619u; h1 = (h1 + (uint32_t)cam_args.H) * 0x85EBCA6Bu;
-            h0 |= 1u;                                               // (0, 0) means "free"
-            int slot = -1, lru = 0;
-            for (int k = 0; k < HINT_SLOTS; k++) {
-                if (hints->key[k][0] == h0 && hints->key[k][1] == h1) { slot = k; break; }
-                if (hints->stamp[k] < hints->stamp[lru]) lru = k;
-            }
-            s_slot = slot;
-            if (blockIdx.x == 0) {
-                const uint32_t now = hints->clock + 1u;
-                const uint32_t found = slot >= 0 ? 1u : 0u;
-                if (slot < 0) { slot = lru; hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
-                hints->stamp[slot] = now; hints->clock = now;
-                hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
-            }
+        __shared__ unsigned long long s_lru;
+        if (threadIdx.x == 0) { s_slot = -1; s_lru = ~0ull; }
+        __syncthreads();
+        uint32_t h0 = 2166136261u, h1 = 0x9E3779B9u;                // (uniform: every lane hashes the same 32 words)
+        for (int k = 0; k < 16; k++) {
+            const uint32_t a = __float_as_uint(cam_args.view[k]), b = __float_as_uint(cam_args.proj[k]);
+            h0 = (h0 ^ a) * 16777619u; h0 = (h0 ^ b) * 16777619u;
+            h1 = (h1 + a) * 0x85EBCA6Bu; h1 ^= h1 >> 13; h1 = (h1 + b) * 0xC2B2AE35u; h1 ^= h1 >> 16;
+        }
+        h0 = (h0 ^ (uint32_t)cam_args.W) * 16777619u; h1 = (h1 + (uint32_t)cam_args.H) * 0x85EBCA6Bu;
+        h0 |= 1u;                                                   // (0, 0) means "free"
+        for (int k = threadIdx.x; k < HINT_SLOTS; k += blockDim.x) {        // one lane per slot
+            if (hints->key[k][0] == h0 && hints->key[k][1] == h1) s_slot = k;
+            atomicMin(&s_lru, ((unsigned long long)hints->stamp[k] << 32) | (unsigned long long)k);      // least recently used, lowest index first
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            int slot = s_slot;
+            const uint32_t now = hints->clock + 1u;
+            const uint32_t found = slot >= 0 ? 1u : 0u;
+            if (slot < 0) { slot = (int)(uint32_t)(s_lru & 0xFFFFFFFFull); hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
+            hints->stamp[slot] = now; hints->clock = now;
+            hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
         }
         if (snap) {
-            __syncthreads();
             const int slot = s_slot;
             const uint32_t* zc = hint_zcut(hints, ntiles_img) + (size_t)(slot < 0 ? 0 : slot) * ntiles_img;
             const uint32_t nsb = gridDim.x < (unsigned)SNAP_BLOCKS ? gridDim.x : (unsigned)SNAP_BLOCKS;

@@ -902,7 +902,8 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
         return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
 
     W, H = 320, 240
-    cams = [scenes.camera(k, 40, W, H) for k in range(40)]          # 40 poses > 32 slots
+    NP = 264                                                         # poses > the table's 256 slots
+    cams = [scenes.camera(k, NP, W, H) for k in range(NP)]
     first = {}
     _C.set_option("list_cut_always", 1)                              # the list cut rides on the same table: exercised here as well
     for k in (0, 1, 0, 1, 0):                                        # alternating: the third render of pose 0 runs by its own hint
@@ -912,16 +913,16 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
         first[k] = out
     o = orc.render(sc, cams[0])
     assert first[0][0] == o["R"] and np.array_equal(bits(first[0][1].cpu().numpy()), bits(o["out_color"]))
-    for k in range(2, 40):                                           # overflow the table: pose 0 and 1 are evicted
+    for k in range(2, NP):                                           # overflow the table: pose 0 and 1 are evicted
         first[k] = render(cams[k], W, H)
     other = render(scenes.camera(3, 7, 200, 152), 200, 152)          # another image size: the context starts a new table
     assert same(render(scenes.camera(3, 7, 200, 152), 200, 152), other)
-    for k in (0, 1, 39, 20):
+    for k in (0, 1, NP - 1, 20):
         assert same(render(cams[k], W, H), first[k])
         assert same(render(cams[k], W, H), first[k])
     _C.set_option("no_order_hint", 1)
     try:
-        for k in (0, 39):
+        for k in (0, NP - 1):
             assert same(render(cams[k], W, H), first[k])
     finally:
         _C.set_option("no_order_hint", 0)
