@@ -930,6 +930,8 @@ sh_dir_derivs_kernel(int P, int D, int M, const float* __restrict__ means3D, con
 // RAW (gsrast_backward_raw): means3D / scales / rotations are the model's leaves as in preprocess_fwd_kernel<true>; the chain rule
 // through the activations (epilogue_small_bwd_kernel's expressions) is applied before the stores: dL_dmeans3D = d_xyz (= d_motion_res),
 // dL_dscale = d_scaling, dL_drot = d_rotation, dL_dopacity = d_opacity_logit, plus RawGrads (d_rot_res, d_trbf, the SH leaves).
+// (Measured and dropped with the list cut: not even READING the gradient record of a Gaussian the forward's scatter marked late --
+// 167 MB of the kernel's 1.0 GB at 3 M: 770 / 782 / 773 vs 783 / 773 / 768 views/s without, the kernel is bound by its 0.8 GB of stores.)
 // SPARSE (round 3, the default): a Gaussian whose gradient record is all zero -- frustum-culled, or occluded: 83 % of the 3 M bench
 // scene -- is not READ: every output is linear in the record's nine sums, so its rows are exactly zero and are written as such without
 // its mean / scale / rotation / direction derivatives (80 of the 312 bytes the kernel moves per Gaussian; -28 us of 230 at 3 M, -19 us
