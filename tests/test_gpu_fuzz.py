@@ -28,7 +28,14 @@ def _config(seed, large=False):
 def test_random_configuration_at_bucket_sort_sizes(seed, orc, scenes, rast, gpu):
     """The same sweep at Gaussian counts that take the bucket depth sort (P >= 32768) -- the context carries its capacity hints from
     one random configuration to the next, so undersized speculative launches and their repeats are part of it."""
-    _run_configuration(seed, _config(seed, large=True), orc, scenes, rast, gpu)
+    # ... and so are the list cut's depths (include/gsrast.h: options.no_list_cut), forced on here: the seven camera poses come back with
+    # another scene each time, so cut lists that hold, cut lists that are too short (the forward falls back inside the call) and stale
+    # entries of another image size all occur; every render after a pose's first one is checked exactly like the first
+    rast._C.set_option("list_cut_always", 1)
+    try:
+        _run_configuration(seed, _config(seed, large=True), orc, scenes, rast, gpu, clips=(0, 1, 1))
+    finally:
+        rast._C.set_option("list_cut_always", 0)
 
 
 @pytest.mark.parametrize("seed", range(60))
@@ -36,7 +43,7 @@ def test_random_configuration(seed, orc, scenes, rast, gpu):
     _run_configuration(seed, _config(seed), orc, scenes, rast, gpu)
 
 
-def _run_configuration(seed, c, orc, scenes, rast, gpu):
+def _run_configuration(seed, c, orc, scenes, rast, gpu, clips=(0, 1)):
     rng = c["rng"]
     P, W, H = c["P"], c["W"], c["H"]
     sc = scenes.synth(P, 2000 + seed, sh_degree=c["deg"], scale_mul=c["scale_mul"])
@@ -64,7 +71,7 @@ def _run_configuration(seed, c, orc, scenes, rast, gpu):
         names += ["dL_dscales", "dL_drotations"]
     o32 = orc.render(sc, cam, g, **kw)
     o64 = orc.render(sc, cam, g, f64=True, **kw)
-    for clip in (0, 1):
+    for clip in clips:
         h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=clip, **kw)
         if c["use_cov"]:
             # with a precomputed covariance the oracle's per-Gaussian cov3D is the input itself
