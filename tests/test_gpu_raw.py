@@ -190,3 +190,50 @@ def test_raw_rasterizer_with_no_gaussians(scenes, rast, gpu):
     assert c.shape == (3, H, W) and float(c.detach().abs().max()) == 0.0 and r.numel() == 0 and float(d.detach().abs().max()) == 0.0
     c.sum().backward()
     assert xyz.grad is not None and xyz.grad.shape == (0, 3)
+
+
+@pytest.mark.parametrize("use", [COMBOS[0], COMBOS[6], COMBOS[15]], ids=["1111", "1001", "0000"])
+def test_raw_rasterizer_under_the_list_cut(use, scenes, rast, gpu):
+    """The second and third forward of a pose through the raw entry points bin and COLOUR only the early Gaussians (include/gsrast.h:
+    options.no_list_cut; the compacting colour kernel assembles cat(dc, rest) + residual for those alone): outputs bit-identical to the
+    render without the cut, gradients of every raw leaf equal to its within fp32 accumulation order, also with every Gaussian read in the backward."""
+    P, W, H, M, deg = 50_000, 256, 192, 16, 3
+    sc, raw = _raw_scene(scenes, P, 451, M, deg)
+    raw["opacity"] = raw["opacity"] + 2.0                      # denser: most tiles saturate
+    cam = scenes.camera(2, 5, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    g = torch.from_numpy(scenes.upstream_grad(H, W, 452) * (H * W)).to(gpu)
+    names = ["xyz", "rotation", "scaling", "opacity", "f_dc", "f_rest"] + [k for k in ("motion_res", "rot_res", "trbf", "shs_res") if use[k]]
+
+    def run(dense):
+        t, kw = _tensors(raw, use, gpu)
+        m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+        rast._C.set_option("dense_backward", dense)
+        try:
+            c, r, d = rast.GaussianRasterizerRaw(rs)(t["xyz"], m2, t["rotation"], t["scaling"], t["opacity"], t["f_dc"], t["f_rest"], **kw)
+            late = rast._C.context_query("last_late")
+            c.backward(g)
+        finally:
+            rast._C.set_option("dense_backward", 0)
+        torch.cuda.synchronize()
+        return c.detach(), r, d.detach(), {k: t[k].grad.clone() for k in names}, m2.grad.clone(), late
+
+    rast._C.set_option("list_cut_always", 1)
+    try:
+        rast._C.set_option("no_list_cut", 1)                   # the reference: every Gaussian binned (leaves this pose's cut depths)
+        try:
+            first = run(0)
+        finally:
+            rast._C.set_option("no_list_cut", 0)
+        assert first[5] == 0
+        for dense in (0, 1):
+            nxt = run(dense)
+            assert nxt[5] > P // 4, nxt[5]
+            assert torch.equal(nxt[0], first[0]) and torch.equal(nxt[1], first[1]) and torch.equal(nxt[2], first[2])
+            for k in names:
+                a, b = nxt[3][k].double(), first[3][k].double()
+                assert torch.isfinite(a).all(), k
+                assert ((a - b).abs() <= 1e-5 * max(1.0, float(b.abs().max())) + 1e-4 * b.abs()).all(), k
+            assert ((nxt[4] - first[4]).abs() <= 1e-5 * max(1.0, float(first[4].abs().max())) + 1e-4 * first[4].abs()).all()
+    finally:
+        rast._C.set_option("list_cut_always", 0)
