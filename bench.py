@@ -911,7 +911,9 @@ def main():
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
                        "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],
-                       "blended_pairs_fwd": st["pairs_fwd"]},
+                       "blended_pairs_fwd": st["pairs_fwd"],
+                       # the bench repeats one camera pose: the context's pose table is in force (launch-order hints + list cut, see those keys)
+                       "repeated_pose": True, "list_cut_late_gaussians": st.get("late"), "column_runs_early": st.get("Q_early")},
             "roofline": roofline_of(st, bwd_ms, P, exp2),
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
