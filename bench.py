@@ -142,7 +142,14 @@ class Workload:
                     N=self.W * self.H, R_listed=cur["listed"], R_eff_listed=cur["R_eff"], pairs_listed=cur["pairs"],
                     Q=int(_C.get_option("last_runs")),
                     # list cut (include/gsrast.h: options.no_list_cut): what the last forward of this (repeated) pose left out
-                    Q_early=int(_C.context_query("last_early_runs")), late=int(_C.context_query("last_late")))
+                    Q_early=_query(_C, "last_early_runs"), late=_query(_C, "last_late"))
+
+
+def _query(_C, name):
+    try:
+        return int(_C.context_query(name))
+    except ValueError:          # (a library without the list cut: A/B runs of tools/ab_variants.sh)
+        return None
 
 
 HOST_STEPS = {}     # per-step host enqueue times of the last timed() call: a stall of the host shows up here
@@ -928,7 +935,7 @@ def main():
                                      "verified on the device, the full binning + blend enqueued behind the blend, predicated on the verdict",
                          "late_gaussians": st.get("late"), "early_column_runs": st.get("Q_early"), "all_column_runs": st.get("Q"),
                          "switched_off": no_cut,
-                         "cut_fallbacks_in_this_process": int(_C.context_query("cut_fallbacks")),
+                         "cut_fallbacks_in_this_process": _query(_C, "cut_fallbacks"),
                          "note": "results never depend on it (tests/test_gpu_parity.py::test_list_cut_is_verified_and_never_changes_a_result)"},
         }
 
