@@ -908,7 +908,17 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
     const unsigned lane = lane_id(), wave = t >> 6;
-    const uint32_t px = tx * TILE_X + (t & 15u), py = ty * TILE_Y + (t >> 4);
+#ifndef GSRAST_BWD_BLOCK8
+#define GSRAST_BWD_BLOCK8 1
+#endif
+    // the wave's pixels: an 8 x 8 block (lane = row * 8 + column), as in the forward -- the same 64 pixels as a 16 x 4 strip with a
+    // shorter outline, so fewer (wave, instance) pairs survive the culling test; in the transposed phase lane (k, jj) then walks
+    // column k of the block's eight rows (ONE dx per lane).  0: the 16 x 4 strip of round 2.  Alternating runs, views/s, strip ->
+    // block: 3 M 745 / 775 -> 766 / 777, 1 M 1231 -> 1244, 1 M shell 928 -> 957, 0.3 M 1609 -> 1628.  (Round 1 had rejected 8 x 8
+    // blocks for its backward, whose per-pair cross-lane reductions favoured the strip's row layout.)
+    constexpr bool B8 = GSRAST_BWD_BLOCK8 != 0;
+    const uint32_t px = B8 ? tx * TILE_X + (wave & 1u) * 8u + (lane & 7u) : tx * TILE_X + (t & 15u);
+    const uint32_t py = B8 ? ty * TILE_Y + (wave >> 1) * 8u + (lane >> 3) : ty * TILE_Y + (t >> 4);
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -916,8 +926,9 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     const uint32_t tm = tile_max[tile];
     const uint32_t n = tm < n_all ? tm : n_all;       // instances at list position >= n touch no pixel
     const size_t plane = (size_t)W * H;
-    const float sx0 = (float)(tx * TILE_X), sx1 = sx0 + 15.0f;
-    const float sy0 = (float)(ty * TILE_Y + wave * 4u);
+    const float sx0 = B8 ? (float)(tx * TILE_X + (wave & 1u) * 8u) : (float)(tx * TILE_X), sx1 = sx0 + (B8 ? 7.0f : 15.0f);
+    const float sy0 = B8 ? (float)(ty * TILE_Y + (wave >> 1) * 8u) : (float)(ty * TILE_Y + wave * 4u);
+    const float sy1 = sy0 + (B8 ? 7.0f : 3.0f);
 
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const size_t pid = (size_t)W * py + px;
@@ -972,7 +983,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
             const float4 a = valid ? s0[lane] : make_float4(0.f, 0.f, 1.f, 0.f);
             const float czv = valid ? s1[lane].x : 1.f;
             const float thr = valid ? s1[lane].w : 1.f;
-            mk = __ballot(valid && spos < strip_last && strip_may_touch(a, czv, thr, sx0, sx1, sy0, sy0 + 3.0f));
+            mk = __ballot(valid && spos < strip_last && strip_may_touch(a, czv, thr, sx0, sx1, sy0, sy1));
         }
 #pragma unroll 1
         for (uint32_t g = 0; g < (uint32_t)(BATCH / GB); g++) {
@@ -1040,8 +1051,8 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 const float uu = ud.x, dd = ud.y;
                 float4 dp = prow[i * 8];
                 asm volatile("" : "+v"(dp.w));                       // all four components "used": one ds_read_b128 (4 LDS cycles), not a ds_read_b96 (8)
-                const float dx = (i & 1) ? dxb : dxa;
-                const float dy = a.y - (sy0 + (float)(i >> 1));
+                const float dx = B8 ? dxa : ((i & 1) ? dxb : dxa);      // (8 x 8 block: pixel k + 8 i = column k of row i)
+                const float dy = a.y - (sy0 + (float)(B8 ? i : (i >> 1)));
                 const float gxv = uu * dx, gyv = uu * dy;            // the opacity factor of dL/dG = opacity * dL/dalpha is applied once, below
                 Sx += gxv; Sy += gyv;
                 Sxx = __builtin_fmaf(gxv, dx, Sxx); Sxy = __builtin_fmaf(gxv, dy, Sxy); Syy = __builtin_fmaf(gyv, dy, Syy);
