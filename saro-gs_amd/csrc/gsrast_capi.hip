@@ -773,8 +773,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         SideStream*& side; hipStream_t s; bool& launched; bool joined = false;
         ~SideJoinGuard() { if (launched && side && !joined) (void)hipStreamSynchronize(side->stream); }    // error path: cost is irrelevant
     } side_guard{ side, s, color_launched };
-    // the colour kernel itself.  skip / pred (list cut): the Gaussians no list will hold are not evaluated / the predicated launch
-    // over all Gaussians in front of the second blend
+    // the colour kernel itself.  List cut: early_only = only the Gaussians the bucket scatter did not mark culled or late (the compacting
+    // kernel); pred = the predicated launch over ALL Gaussians in front of the second blend
     auto color_kernels = [&](hipStream_t cs, bool early_only, const uint32_t* pred) -> int {
         {
             ProfScope ps(K_COLOR, cs);
