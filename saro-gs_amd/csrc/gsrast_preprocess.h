@@ -511,7 +511,10 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
 // few lanes each); the rows gathered in DEPTH order -- any order, in a random scene -- from the depth buckets: 140-620 us in three
 // forms (TLB reach, not bytes: the gathers here walk the arrays in address order).
 // RAW: the row is cat(features_dc, features_rest) + shs_res, assembled in LDS as preprocess_color_kernel<., true> does.
-constexpr int PCC_WAVES = 2, PCC_IDS = 1024;
+#ifndef GSRAST_PCC_WAVES
+#define GSRAST_PCC_WAVES 2        // waves per workgroup (512 Gaussians each): 1 / 2 / 4 measured 747 / 761-767 / 765-769 views/s at 3 M, 1219 / 1220 / 1209 at 1 M
+#endif
+constexpr int PCC_WAVES = GSRAST_PCC_WAVES, PCC_IDS = 512 * PCC_WAVES;
 __device__ __forceinline__ void pcc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 template <bool RAW>
 __global__ void __launch_bounds__(64 * PCC_WAVES)
