@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -92,9 +93,31 @@ std::vector<Pending> g_pending;
 double g_total_ms[K_COUNT];
 long long g_launches[K_COUNT];
 
+// roctx ranges (the stages as named ranges in a rocprofv3 --marker-trace): only with GSRAST_ROCTX set in the environment, the
+// marker library looked up at run time (no link-time dependency).  A range brackets the host's ENQUEUE of a stage, as ranges do.
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (!getenv("GSRAST_ROCTX")) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+    ~RoctxRange() { if (on) (void)roctx().pop(); }
+};
+
 struct ProfScope {
-    int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(((g_profile.load() >> id_) & 1) != 0 && (t_prof_off == 0 || id_ == K_CUT_REDO))
+    int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on; RoctxRange range;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(((g_profile.load() >> id_) & 1) != 0 && (t_prof_off == 0 || id_ == K_CUT_REDO)), range(kKernelNames[id_])
     {
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
@@ -684,6 +707,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                       const gsrast_raw_inputs* rawin)
 {
     (void)prefiltered;
+    RoctxRange range_fwd(rawin ? "gsrast_forward_raw" : "gsrast_forward");
     RawArgs raw{};
     if (rawin) {
         raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
@@ -1541,6 +1565,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
                        const gsrast_raw_inputs* rawin, const gsrast_raw_grads* rawout)
 {
+    RoctxRange range_bwd(rawin ? "gsrast_backward_raw" : "gsrast_backward");
     RawArgs raw{}; RawGrads rawg{};
     if (rawin) {
         raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
