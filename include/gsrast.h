@@ -206,7 +206,7 @@ typedef struct gsrast_options {
                                  occluded scene a few per cent of them -- and VERIFIES the speculation on the device: a tile's list counts
                                  as ending at its cut depth, and if some pixel of a cut tile is not saturated there, the whole binning and
                                  blend run again over all Gaussians (enqueued behind the blend in any case, every kernel predicated on the
-                                 verdict).  Results never depend on it; needs tile_clip = 1, the bucket depth sort, at most 8192 tiles.  It is
+                                 verdict).  Results never depend on it; needs tile_clip = 1 and the bucket depth sort.  It is
                                  applied where it pays: when the context's last forward had at least 1.5 M column runs, and not for the next 64
                                  forwards after one in which it removed fewer than that (gsrast_set_option("list_cut_always", 1) lifts both) */
 } gsrast_options;

@@ -427,11 +427,13 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                             const uint32_t* __restrict__ zcut_used = nullptr, uint32_t ntiles_img = 0, uint32_t gx_tiles = 0,
                             uint32_t* __restrict__ n_late_out = nullptr,
                             unsigned long long* __restrict__ color_skip = nullptr /* [ceil(n / 64)] or null: bit i = Gaussian i is culled or
-                                                                                  late: no list will hold it, the colour kernel need not evaluate it */)
+                                                                                  late: no list will hold it, the colour kernel need not evaluate it */,
+                            uint32_t cshift = 1 /* the cells of the cut-depth table are (1 << cshift)^2 tiles: 2 x 2 up to 1080p-class images,
+                                                   4 x 4 / 8 x 8 for larger ones (at most CUT_MAX_CELLS cells) */)
 {
     __shared__ uint32_t cnt[BK_MAX_BUCKETS];
     __shared__ uint32_t s_mm[2];
-    // the cut depths as maxima over cells of 2 x 2 tiles, rounded UP to the 16 leading bits of the float (exponent + 7 mantissa bits:
+    // the cut depths as maxima over cells of 2 x 2 tiles (4 x 4 / 8 x 8 for images of more than CUT_MAX_CELLS such cells), rounded UP to the 16 leading bits of the float (exponent + 7 mantissa bits:
     // within 0.8 % of the depth): a Gaussian is LATE when it lies behind every cell its rectangle touches -- typically four LDS reads,
     // no memory access in the loop; a larger cut only keeps more.  (The table must stay small: with the 32 KB of bucket counters above,
     // anything over 7 KB costs this latency-bound kernel a workgroup per compute unit.  Measured on the way: the tiles' own depths in
@@ -443,8 +445,17 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     const uint32_t xcd = blockIdx.x & (BK_XCD - 1);
     if (threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; s_late = 0u; }
     for (uint32_t k = threadIdx.x; k < nb; k += 256) cnt[k] = 0u;
-    const uint32_t gy_tiles = zcut_used ? ntiles_img / gx_tiles : 0u, cgx = (gx_tiles + 1u) / 2u, cgy = (gy_tiles + 1u) / 2u;
-    if (zcut_used) {
+    const uint32_t csz = 1u << cshift;
+    const uint32_t gy_tiles = zcut_used ? ntiles_img / gx_tiles : 0u, cgx = (gx_tiles + csz - 1u) >> cshift, cgy = (gy_tiles + csz - 1u) >> cshift;
+    if (zcut_used && cshift != 1u) {        // larger cells (images beyond the 1080p class): plain loops
+        for (uint32_t c = threadIdx.x; c < cgx * cgy; c += 256) {
+            const uint32_t cx = c % cgx, cy = c / cgx;
+            uint32_t m = 0;
+            for (uint32_t y = cy << cshift; y < min((cy + 1u) << cshift, gy_tiles); y++)
+                for (uint32_t x = cx << cshift; x < min((cx + 1u) << cshift, gx_tiles); x++) m = max(m, zcut_used[y * gx_tiles + x]);
+            s_zc[c] = (uint16_t)(m >= 0xFFFF0000u ? 0xFFFFu : (m + 0xFFFFu) >> 16);
+        }
+    } else if (zcut_used) {
         for (uint32_t c0 = threadIdx.x; c0 < cgx * cgy; c0 += 256 * 4) {
             uint32_t v[4][4];
 #pragma unroll
@@ -529,7 +540,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                 const uint32_t kq = key[r] >> 16;
                 bool late = wword != 0u && (x1 - x0) * (y1 - y0) <= 64u;       // (a large rectangle is not worth the walk: early)
                 if (late) {
-                    const uint32_t cx0 = x0 >> 1, cx1 = (x1 - 1u) >> 1, cy0 = y0 >> 1, cy1 = (y1 - 1u) >> 1;
+                    const uint32_t cx0 = x0 >> cshift, cx1 = (x1 - 1u) >> cshift, cy0 = y0 >> cshift, cy1 = (y1 - 1u) >> cshift;
                     uint32_t m = 0;
                     if (cx1 - cx0 <= 1u && cy1 - cy0 <= 1u)                    // the usual case: four independent reads, no loop
                         m = max(max((uint32_t)s_zc[cy0 * cgx + cx0], (uint32_t)s_zc[cy0 * cgx + cx1]), max((uint32_t)s_zc[cy1 * cgx + cx0], (uint32_t)s_zc[cy1 * cgx + cx1]));
@@ -655,7 +666,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
             if (e < n) {
                 const uint32_t slot = cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)] + aux[e];
                 grp[slot] = ((unsigned long long)kv[u].x << 32) | kv[u].y;
-                // (with the list cut the image has at most CUT_MAX_TILES tiles: widths fit 15 bits, bit 15 carries "late")
+                // (with the list cut the image has fewer than 32768 tile columns -- cut_cell_shift: widths fit 15 bits, bit 15 carries "late")
                 wid[slot] = bwincl_e ? (uint16_t)((kv[u].z & 0x7FFFu) | ((kv[u].z >> 31) << 15)) : (uint16_t)kv[u].z;
             }
         }

@@ -781,8 +781,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
     constexpr uint32_t CUT_MIN_RUNS = 1500000u; constexpr int CUT_PAUSE = 64;
     const bool cut_pays = g_list_cut_always.load() != 0 || (ctx->last_Q.load() >= CUT_MIN_RUNS && ctx->cut_pause.load() == 0);
-    const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && T <= CUT_MAX_TILES && (uint32_t)((cam.gx + 1) / 2) * (uint32_t)((cam.gy + 1) / 2) <= CUT_MAX_CELLS &&
-                     o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
+    const int cut_cs = cut_cell_shift((size_t)cam.gx, (size_t)cam.gy);
+    const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
     if (!cut && !o.no_list_cut && ctx->cut_pause.load() > 0) ctx->cut_pause--;
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
@@ -884,7 +884,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             {   ProfScope ps(K_SORT_DEPTH, s);
                 depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + PF_THREADS - 1) / PF_THREADS), nbk, gcount, slab, at<float>(geom, GL.bk_param),
                                                                                                          zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
-                                                                                                         cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr);
+                                                                                                         cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs);
                 GS_LAUNCHED("depth_bucket_scatter");
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)

@@ -125,8 +125,14 @@ static inline size_t hint_table_bytes(size_t T) { return hint_zcut_offset(T) + (
 // binning + blend once more over ALL Gaussians, every kernel predicated on that counter: nothing runs when the speculation held (the
 // steady state of a repeated pose), everything is redone from the full lists when it did not.  Results never depend on the table.
 constexpr uint32_t ZCUT_NONE = 0xFFFFFFFFu;
-constexpr uint32_t CUT_MAX_TILES = 8192;      // images with more tiles -- or more than CUT_MAX_CELLS cells of 2 x 2 tiles -- render without the list cut
-constexpr uint32_t CUT_MAX_CELLS = 3072;      // (the bucket scatter keeps the cells' cut depths in LDS)
+constexpr uint32_t CUT_MAX_CELLS = 3072;      // the bucket scatter keeps the cut depths in LDS as maxima over cells of 2 x 2 tiles -- 4 x 4 or 8 x 8 for images
+                                              // with more than this many cells (4K: 4 x 4); images beyond 8 x 8 cells render without the list cut
+static inline int cut_cell_shift(size_t gx, size_t gy)      // 1, 2, 3, or 0 = no list cut (also: the bucket sort packs widths into 15 bits)
+{
+    if (gx >= 32768) return 0;
+    for (int cs = 1; cs <= 3; cs++) { const size_t c = (size_t)1 << cs; if (((gx + c - 1) >> cs) * ((gy + c - 1) >> cs) <= CUT_MAX_CELLS) return cs; }
+    return 0;
+}
 constexpr uint32_t LATE_BIT = 0x80000000u;      // in the width word of a bucket-slab element
 // words of GeomLayout::scalars used by the list cut
 constexpr int SC_Q_EARLY = 4, SC_N_LATE = 5, SC_UNDONE = 6, SC_EARLY_COUNTS = 20 /* {R lo, Q early, -, R hi} */, SC_REDO_PRED = SC_UNDONE /* the predicate of the second binning + blend: some tile's cut list was too short */;

@@ -1004,6 +1004,56 @@ def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H):
     _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
 
 
+def test_list_cut_on_a_large_image(scenes, rast, gpu):
+    """An image of more than 3072 cells of 2 x 2 tiles (here 2048 x 1600: 128 x 100 tiles) keeps its cut depths in 4 x 4-tile cells
+    (gsrast_common.h: cut_cell_shift): same results with and without the cut, also after the scene turned transparent."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H = 80_000, 2048, 1600
+    sc = scenes.synth(P, 921, scale_mul=1.5)
+    cam = scenes.camera(1, 5, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+
+    def render(scene):
+        rs = settings_from(rast, cam, scene, gpu)
+        ten = {k: t(scene[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return (R, color.clone(), depth.clone(), radii.clone(), st["n_contrib"].clone(), st["final_T"].clone()), _C.context_query("last_late")
+
+    def same(a, b):
+        return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+    _C.set_option("list_cut_always", 1)
+    try:
+        _C.set_option("no_list_cut", 1)
+        try:
+            ref, _ = render(sc)
+        finally:
+            _C.set_option("no_list_cut", 0)
+        a, late_a = render(sc)
+        b, late_b = render(sc)
+        assert late_a > 1000 and late_b > 1000, (late_a, late_b)        # (a sparse scene at this size: few tiles saturate, few Gaussians are late)
+        assert same(a, ref) and same(b, ref)
+        fb0 = _C.context_query("cut_fallbacks")
+        sc2 = dict(sc)
+        sc2["opacities"] = (sc["opacities"] * 0.03).astype(np.float32)
+        thin, late_c = render(sc2)
+        assert late_c > 0 and _C.context_query("cut_fallbacks") == fb0 + 1
+        _C.set_option("no_list_cut", 1)
+        try:
+            ref2, _ = render(sc2)
+        finally:
+            _C.set_option("no_list_cut", 0)
+        assert same(thin, ref2)
+    finally:
+        _C.set_option("list_cut_always", 0)
+
+
 def test_list_cut_under_a_changing_scene(orc, scenes, rast, gpu):
     """A training run changes the scene between two renders of a pose.  A fixed pose, twelve random edits in a row -- opacities scaled
     up or down, a tenth of the Gaussians pruned, the scene pushed away from / pulled towards the camera, a transparent and an opaque
