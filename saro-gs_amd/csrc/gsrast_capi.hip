@@ -863,12 +863,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, cut ? scalars : nullptr);
+                zcut_used, T, scalars);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, cut ? scalars : nullptr);
+                zcut_used, T, scalars);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -1123,6 +1123,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         return (int)R;
     }
     if (speculative && !sort_redone) ctx->redo_count++;
+    if (cut) GS_HIP(hipMemsetAsync(scalars + SC_N_LATE, 0, sizeof(uint32_t), s));      // (the backward must not take a late Gaussian's rows for zero: below it is listed)
     if (cut_colors && color_launched) {     // everything from here on lists ALL Gaussians: the colours the list cut left out are evaluated now
         if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));
         int rc = color_kernels(s, false, nullptr);
@@ -1634,6 +1635,30 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         }
         if (side) GS_HIP(hipEventRecord(side->join, side->stream));
     }
+    // List cut (gsrast_common.h): the zero rows of the Gaussians the forward left out are written on the side stream, beside the blend
+    // backward; preprocess_bwd then neither reads nor writes them.  Both kernels check on the device that the forward's cut was in force
+    // and held.  Only where it pays for the two events (large scenes), with the sparse per-Gaussian backward, in a one-phase call.
+    bool late_fill = false;
+    if (do_blend && do_geom && R > 0 && !o.dense_backward && o.side_stream && (P >= 1500000 || g_list_cut_always.load() != 0)) {
+        if (!side) {
+            side = side_stream_of(thread_context());
+            if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); }
+        }
+        if (side) {
+            LateRowsArgs la{}; int n = 0;
+            auto add = [&](float* p, int rl) { if (p && rl > 0) { la.ptr[n] = p; la.rowlen[n] = rl; n++; } };
+            add(dL_dmean2D, 3); add(dL_dopacity, 1); add(dL_dmean3D, 3); add(dL_dconic, 4); add(dL_dcolor, 3); add(dL_dcov3D, 6);
+            if (rawin || use_sr) { add(dL_dscale, 3); add(dL_drot, 4); }
+            if (rawin) { add(rawg.d_rot_res, 7); add(rawg.d_trbf, 1); add(rawg.d_shs_res, M * 3); add(rawg.d_dc, 3); add(rawg.d_rest, M * 3 - 3); }
+            else if (use_sh && !o.sh_grad_factors) add(dL_dsh, M * 3);
+            la.n = n;
+            late_rows_zero_kernel<<<1024, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
+            GS_HIP(hipEventRecord(side->join, side->stream));
+            late_fill = true;
+        }
+    }
     if (do_blend && R > 0) {
         ProfScope ps(K_BLEND_BWD, s);
         const uint32_t grid = ((T + 7) / 8) * 8;
@@ -1682,8 +1707,12 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         const int factors = (!rawin && use_sh && o.sh_grad_factors) ? 1 : 0;
 #define GS_PB_ARGS P, D, M, means3D, radii, raw, rawg, sh_in, at<unsigned char>(geom, GL.clamped), at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), \
                    at<float>(geom, GL.shdC), sc_in, ro_in, cov, cam, reinterpret_cast<const float4*>(grec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,  \
-                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors
+                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars)
         const bool skip = !o.dense_backward;        // Gaussians with an all-zero gradient record are not read
+        if (late_fill) {       // (late_fill implies skip) grouped: 1024 Gaussians per workgroup, the ones late_rows_zero_kernel does not write compacted
+            const int gg = (P + PB_GROUP - 1) / PB_GROUP;
+            if (rawin) preprocess_bwd_kernel<true, true, true><<<gg, PP_THREADS, 0, s>>>(GS_PB_ARGS); else preprocess_bwd_kernel<false, true, true><<<gg, PP_THREADS, 0, s>>>(GS_PB_ARGS);
+        } else
         if (rawin) { if (skip) preprocess_bwd_kernel<true, true><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); else preprocess_bwd_kernel<true, false><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); }
         else { if (skip) preprocess_bwd_kernel<false, true><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); else preprocess_bwd_kernel<false, false><<<pb_grid, PP_THREADS, 0, s>>>(GS_PB_ARGS); }
 #undef GS_PB_ARGS

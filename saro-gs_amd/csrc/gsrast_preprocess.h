@@ -265,6 +265,27 @@ constexpr int PP_SH_MAX = 48;                   // (3+1)^2 coefficients x 3 chan
 constexpr int PP_SH_STRIDE = PP_SH_MAX + 1;     // +1: conflict-free per-lane reads.  25 KB of LDS per workgroup = 6 workgroups per CU;
                                                 // both kernels are latency-bound at that occupancy (4 per CU: +17 %, 3: +40 %)
 
+#ifndef GSRAST_PB_GROUP
+#define GSRAST_PB_GROUP 1024
+#endif
+constexpr int PB_GROUP = GSRAST_PB_GROUP;      // Gaussians per workgroup of the GROUPED per-Gaussian backward (preprocess_bwd_kernel): 1024, 2048 or 4096
+// rows [off, off + len) of the LDS rows 0 .. cnt-1 to dst[ids[r]][0 .. len): the compacted Gaussians' rows, one by one (coalesced within a row)
+__device__ __forceinline__ void scatter_sh_rows(float* __restrict__ dst, int rowlen, int off, int len, const uint32_t* ids, int cnt, const float* lds)
+{
+    if ((rowlen & 3) == 0 && (off & 3) == 0 && (len & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        const int r4 = len >> 2;
+        for (int q = threadIdx.x; q < cnt * r4; q += PP_THREADS) {
+            const int r = q / r4, c = (q - r * r4) * 4;
+            const float* sp = lds + r * PP_SH_STRIDE + off + c;
+            reinterpret_cast<float4*>(dst + (size_t)ids[r] * rowlen)[c >> 2] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    } else {
+        for (int f = threadIdx.x; f < cnt * len; f += PP_THREADS) {
+            const int r = f / len, c = f - r * len;
+            dst[(size_t)ids[r] * rowlen + c] = lds[r * PP_SH_STRIDE + off + c];
+        }
+    }
+}
 __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_all, int P, int M, int base, const float* lds)
 {
     const int ng = (P - base) < PP_THREADS ? (P - base) : PP_THREADS;
@@ -648,7 +669,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       uint32_t ntiles_img, uint32_t* __restrict__ cut_scalars /* or null: GeomLayout::scalars, whose `undone` counter is zeroed here */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
-    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; }
+    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; }      // (always: the backward reads them)
     // The camera pose's key: block 0 looks it up and claims its slot, or the least recently used one; the first blocks of the grid
     // look it up too and copy the slot's cut depths into this call's own image buffer -- the bucket scatter and the forward blend
     // must see the SAME values, whatever another forward of this context writes into the table meanwhile (a stale or torn snapshot
@@ -941,7 +962,7 @@ sh_dir_derivs_kernel(int P, int D, int M, const float* __restrict__ means3D, con
 // at 1 M).  Measured and dropped: not writing those rows either, the arrays zero-filled by a kernel on the side stream under the blend
 // backward -- preprocess_bwd 229 -> 130 us at 3 M, but the fill's 700 MB slowed the VALU-bound blend backward by 45 us and the extra
 // launches cost the small scenes 10-50 us: no better than this at 3 M, worse everywhere else.
-template <bool RAW, bool SPARSE>
+template <bool RAW, bool SPARSE, bool GROUPED = false>
 __global__ void __launch_bounds__(PP_THREADS)
 preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii, RawArgs raw, RawGrads rawg,
                       const float* __restrict__ shs /* only its presence matters: the coefficients are not read */,
@@ -955,13 +976,60 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                       float* __restrict__ dL_drot,
-                      int sh_factors /* the caller exchanges dL/dsh by its factor (sh_factor_kernel has written it): dL_dsh rows are not written */)
+                      int sh_factors /* the caller exchanges dL/dsh by its factor (sh_factor_kernel has written it): dL_dsh rows are not written */,
+                      // GROUPED (with the forward's list cut, gsrast_common.h): a workgroup takes PB_GROUP consecutive Gaussians, 128 per round.
+                      // Bit i of late_bits = Gaussian i was culled or LATE -- it is in no list, its gradient record is still the zero the
+                      // forward left, all its output rows are zero: late_rows_zero_kernel writes them on the side stream WHILE the blend
+                      // backward runs, and this kernel neither reads nor writes such a Gaussian: it COMPACTS the others (ascending index
+                      // order) and works through them densely (3 M cube: 0.4 M of 3 M), their dL/dsh rows leaving one by one.  Both
+                      // kernels trust the bits only if the forward's scalars say that the cut was in force (SC_N_LATE != 0) and held
+                      // (SC_UNDONE == 0: no second binning over all Gaussians); otherwise the rounds are the group's eight blocks of 128
+                      const unsigned long long* __restrict__ late_bits = nullptr, const uint32_t* __restrict__ cut_scalars = nullptr)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
-    const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+    __shared__ uint32_t s_list[GROUPED ? PB_GROUP : 1];
+    __shared__ uint32_t s_wtot[PP_THREADS / 64];
     const int ncoef = (D + 1) * (D + 1);
     const bool staged = shs && M * 3 <= PP_SH_MAX;
     float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
+    const bool late_rows = GROUPED && late_bits && cut_scalars[SC_N_LATE] != 0u && cut_scalars[SC_UNDONE] == 0u;      // (uniform)
+    const int gbase = blockIdx.x * (GROUPED ? PB_GROUP : PP_THREADS);
+    int nround = 1;
+    uint32_t total = 0;
+    if (GROUPED) {
+        constexpr int PER = PB_GROUP / PP_THREADS;               // consecutive Gaussians per lane: one, two or four bytes of bits
+        static_assert(PER == 8 || PER == 16 || PER == 32, "whole bytes of flags per lane, at most a word");
+        if (late_rows) {
+            const uint32_t b0 = (uint32_t)gbase + threadIdx.x * (uint32_t)PER;
+            uint32_t fl = 0xFFFFFFFFu;
+            if (b0 < (uint32_t)P) {
+                const unsigned char* bytes = reinterpret_cast<const unsigned char*>(late_bits) + (b0 >> 3);
+                fl = PER == 8 ? (uint32_t)bytes[0] : PER == 16 ? (uint32_t)*reinterpret_cast<const unsigned short*>(bytes) : *reinterpret_cast<const uint32_t*>(bytes);
+                for (int k = 0; k < PER; k++) if (b0 + k >= (uint32_t)P) fl |= 1u << k;      // (the array is padded: the word may reach past P)
+            }
+            if (PER < 32) fl |= ~0u << (PER & 31);
+            const uint32_t mine = (uint32_t)__builtin_popcount(~fl);
+            uint32_t incl = mine;
+            const unsigned ln = threadIdx.x & 63u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (ln >= (unsigned)d) incl += o; }
+            if (ln == 63u) s_wtot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t pos = incl - mine;
+#pragma unroll
+            for (int w = 0; w < PP_THREADS / 64; w++) { if ((unsigned)w < (threadIdx.x >> 6)) pos += s_wtot[w]; total += s_wtot[w]; }
+#pragma unroll
+            for (int k = 0; k < PER; k++) if (!((fl >> k) & 1u)) s_list[pos++] = b0 + k;
+            __syncthreads();
+            nround = (int)((total + PP_THREADS - 1) / PP_THREADS);
+        } else {
+            const int left = P - gbase;
+            nround = left <= 0 ? 0 : (left >= PB_GROUP ? PB_GROUP / PP_THREADS : (left + PP_THREADS - 1) / PP_THREADS);
+        }
+    }
+    for (int round = 0; round < nround; round++) {
+    int i = gbase + round * PP_THREADS + threadIdx.x;
+    if (GROUPED && late_rows) { const uint32_t j = (uint32_t)round * PP_THREADS + threadIdx.x; i = j < total ? (int)s_list[j] : P; }
     // every per-Gaussian input is requested up front, before the SH rows are staged (see preprocess_fwd_kernel): the loads used
     // to sit behind the staging barrier, the radius test and each other -- five memory round trips in a latency-bound kernel.
     // (SPARSE: the record and the radius first, the rest only for the Gaussians that need it.)
@@ -1179,10 +1247,49 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     } // live
     if (staged && !sh_factors) {
         __syncthreads();
-        if (RAW) {      // the rows leave as the gradient of shs_res (whole) and / or of the two SH leaves (split): whatever the caller gave
-            if (rawg.d_shs_res) stage_sh_out(rawg.d_shs_res, P, M, blockIdx.x * PP_THREADS, sh_lds);
-            if (rawg.d_dc) stage_sh_out_split(rawg.d_dc, rawg.d_rest, P, M * 3, blockIdx.x * PP_THREADS, sh_lds);
-        } else stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
+        const int rbase = gbase + round * PP_THREADS;
+        if (GROUPED && late_rows) {      // the compacted Gaussians' rows leave one by one
+            const uint32_t* ids = s_list + round * PP_THREADS;
+            const int cnt = (int)min((uint32_t)PP_THREADS, total - (uint32_t)round * PP_THREADS);
+            if (RAW) {
+                if (rawg.d_shs_res) scatter_sh_rows(rawg.d_shs_res, M * 3, 0, M * 3, ids, cnt, sh_lds);
+                if (rawg.d_dc) { scatter_sh_rows(rawg.d_dc, 3, 0, 3, ids, cnt, sh_lds); if (M > 1) scatter_sh_rows(rawg.d_rest, M * 3 - 3, 3, M * 3 - 3, ids, cnt, sh_lds); }
+            } else scatter_sh_rows(dL_dsh, M * 3, 0, M * 3, ids, cnt, sh_lds);
+        } else if (RAW) {      // the rows leave as the gradient of shs_res (whole) and / or of the two SH leaves (split): whatever the caller gave
+            if (rawg.d_shs_res) stage_sh_out(rawg.d_shs_res, P, M, rbase, sh_lds);
+            if (rawg.d_dc) stage_sh_out_split(rawg.d_dc, rawg.d_rest, P, M * 3, rbase, sh_lds);
+        } else stage_sh_out(dL_dsh, P, M, rbase, sh_lds);
+        if (GROUPED) __syncthreads();           // the next round overwrites the rows
+    }
+    } // round
+}
+
+// The zero rows of the Gaussians the forward's list cut left out (gsrast_common.h; preprocess_bwd_kernel's late_bits): 87 % of the 0.8 GB
+// the per-Gaussian backward writes at 3 M.  They depend on nothing the blend backward produces, so they are written on the side stream
+// WHILE that VALU-bound kernel runs.  One wave per 64 consecutive Gaussians (one word of bits), every output array in turn, coalesced.
+struct LateRowsArgs { float* ptr[12]; int rowlen[12]; int n; };
+__global__ void __launch_bounds__(256)
+late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, const uint32_t* __restrict__ cut_scalars, LateRowsArgs a)
+{
+    if (cut_scalars[SC_N_LATE] == 0u || cut_scalars[SC_UNDONE] != 0u) return;       // the same verdict as preprocess_bwd_kernel's
+    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t nw = ((uint32_t)P + 63u) / 64u;
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4u) {
+        unsigned long long m = late_bits[w];
+        const uint32_t base = w * 64u, left = (uint32_t)P - base;
+        if (left < 64u) m &= (1ull << left) - 1ull;              // (rows past P do not exist)
+        if (m == 0ull) continue;
+        for (int k = 0; k < a.n; k++) {
+            const uint32_t rl = (uint32_t)a.rowlen[k];
+            float* dst = a.ptr[k] + (size_t)base * rl;
+            if ((rl & 3u) == 0u && ((uintptr_t)dst & 15) == 0) {
+                const uint32_t r4 = rl >> 2;
+                float4* dst4 = reinterpret_cast<float4*>(dst);
+                for (uint32_t q = lane; q < 64u * r4; q += 64u) if ((m >> (q / r4)) & 1ull) dst4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (uint32_t f = lane; f < 64u * rl; f += 64u) if ((m >> (f / rl)) & 1ull) dst[f] = 0.0f;
+            }
+        }
     }
 }
 
