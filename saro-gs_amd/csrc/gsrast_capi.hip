@@ -30,6 +30,9 @@
 #include <cmath>
 #include <cstring>
 #include <dlfcn.h>
+#ifndef GSRAST_LATE_FILL_WGS
+#define GSRAST_LATE_FILL_WGS 256      // workgroups of late_rows_zero_kernel beside the blend backward: as few as finish under it -- 3 M views/s with 64 / 128 / 256 / 512 / 1024 / 4096: 676 (too slow: the per-Gaussian backward waits) / 803-806 / 790-813 / 806-808 / 801-804 / 797; 2 M: 883 / 935 / 953
+#endif
 #include <functional>
 #include <mutex>
 #include <string>
@@ -1652,7 +1655,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
             if (rawin) { add(rawg.d_rot_res, 7); add(rawg.d_trbf, 1); add(rawg.d_shs_res, M * 3); add(rawg.d_dc, 3); add(rawg.d_rest, M * 3 - 3); }
             else if (use_sh && !o.sh_grad_factors) add(dL_dsh, M * 3);
             la.n = n;
-            late_rows_zero_kernel<<<1024, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la);
+            late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
             GS_HIP(hipEventRecord(side->join, side->stream));
