@@ -268,7 +268,7 @@ constexpr int PP_SH_STRIDE = PP_SH_MAX + 1;     // +1: conflict-free per-lane re
 #ifndef GSRAST_PB_GROUP
 #define GSRAST_PB_GROUP 1024
 #endif
-constexpr int PB_GROUP = GSRAST_PB_GROUP;      // Gaussians per workgroup of the GROUPED per-Gaussian backward (preprocess_bwd_kernel): 1024, 2048 or 4096
+constexpr int PB_GROUP = GSRAST_PB_GROUP;      // Gaussians per workgroup of the GROUPED per-Gaussian backward (preprocess_bwd_kernel): 512 ... 4096
 // rows [off, off + len) of the LDS rows 0 .. cnt-1 to dst[ids[r]][0 .. len): the compacted Gaussians' rows, one by one (coalesced within a row)
 __device__ __forceinline__ void scatter_sh_rows(float* __restrict__ dst, int rowlen, int off, int len, const uint32_t* ids, int cnt, const float* lds)
 {
@@ -998,13 +998,13 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     uint32_t total = 0;
     if (GROUPED) {
         constexpr int PER = PB_GROUP / PP_THREADS;               // consecutive Gaussians per lane: one, two or four bytes of bits
-        static_assert(PER == 8 || PER == 16 || PER == 32, "whole bytes of flags per lane, at most a word");
+        static_assert(PER == 4 || PER == 8 || PER == 16 || PER == 32, "a nibble, or whole bytes up to a word, of flags per lane");
         if (late_rows) {
             const uint32_t b0 = (uint32_t)gbase + threadIdx.x * (uint32_t)PER;
             uint32_t fl = 0xFFFFFFFFu;
             if (b0 < (uint32_t)P) {
                 const unsigned char* bytes = reinterpret_cast<const unsigned char*>(late_bits) + (b0 >> 3);
-                fl = PER == 8 ? (uint32_t)bytes[0] : PER == 16 ? (uint32_t)*reinterpret_cast<const unsigned short*>(bytes) : *reinterpret_cast<const uint32_t*>(bytes);
+                fl = PER == 4 ? ((uint32_t)bytes[0] >> (b0 & 4u)) & 0xFu : PER == 8 ? (uint32_t)bytes[0] : PER == 16 ? (uint32_t)*reinterpret_cast<const unsigned short*>(bytes) : *reinterpret_cast<const uint32_t*>(bytes);
                 for (int k = 0; k < PER; k++) if (b0 + k >= (uint32_t)P) fl |= 1u << k;      // (the array is padded: the word may reach past P)
             }
             if (PER < 32) fl |= ~0u << (PER & 31);
