@@ -1107,20 +1107,19 @@ __device__ __forceinline__ uint32_t row_instances_before_run(const uint2* __rest
     const uint32_t incl = block_excl_scan(mine, &tot) + mine;
     return (threadIdx.x < nrows ? hist_scanned[(size_t)threadIdx.x * nblk + b0] : 0u) + incl;
 }
-__global__ void __launch_bounds__(256)
-tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q,
+__device__ __forceinline__ void
+tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q,
                              const uint32_t* __restrict__ counts_dev /* optional {R lo, Q, -, R hi}: speculative launch */,
                              uint32_t capR, int gx, int gy, const uint32_t* __restrict__ hist_scanned,
                              const uint32_t* __restrict__ digit_total, uint32_t nblk, uint2* __restrict__ ranges,
                              uint32_t* __restrict__ bucket_cnt /* forward launch order: [8][64] counts (zeroed), or null */,
                              uint16_t* __restrict__ bucket_list /* [8][64][Tg] */,
                              const HintTable* __restrict__ hints /* or null: what each tile of this camera pose consumed the last time (gsrast_common.h) */,
-                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */, const uint32_t* __restrict__ pred = nullptr)
+                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */)
 {
     __shared__ int diff[257];
-    if (pred && *pred == 0u) return;
     __shared__ uint32_t lcnt[XCD_GROUPS * WORK_BUCKETS], lbase[XCD_GROUPS * WORK_BUCKETS];
-    const uint32_t x = blockIdx.x, y = threadIdx.x;
+    const uint32_t x = column, y = threadIdx.x;
     bool overflow = false;
     if (counts_dev) {
         // The launch was sized for capacities (Q = capQ).  If the real counts do not fit, the lists are truncated:
@@ -1171,15 +1170,13 @@ tile_ranges_from_runs_kernel(const uint16_t* __restrict__ run_keys, const uint2*
 // The run an instance belongs to is found without searching: every run sets ONE bit (at its first
 // instance) in a per-sub-batch LDS bitmap, and "number of run starts at or before slot i" is a word
 // prefix count plus a popcount of the slot's word.
-__global__ void __launch_bounds__(RS_THREADS)
-run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column */,
+__device__ __forceinline__ void
+run_scatter_rows_body(uint32_t block /* = blockIdx.x of a launch of its own */, const uint2* __restrict__ run_vals /* sorted by column */,
                         uint32_t Q, const uint32_t* __restrict__ Q_dev, uint32_t capR, int ybits, uint32_t nrows, const uint32_t* __restrict__ hist_scanned,
                         const uint32_t* __restrict__ digit_total, uint32_t nblk,
                         uint32_t* __restrict__ point_list,
-                        uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */,
-                        const uint32_t* __restrict__ pred = nullptr)
+                        uint32_t* __restrict__ total_out /* number of instances written (<= R with row clipping) */)
 {
-    if (pred && *pred == 0u) return;
     __shared__ uint32_t s_start[RUNS_PER_BLOCK + 1]; // block-local first instance of every run (+ total at the end)
     __shared__ uint2 s_val[RUNS_PER_BLOCK];
     __shared__ uint32_t s_nruns;
@@ -1191,9 +1188,9 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
     __shared__ uint32_t xv[RUN_CHUNK];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t t = threadIdx.x;
-    const uint32_t r0 = blockIdx.x * RUNS_PER_BLOCK;
+    const uint32_t r0 = block * RUNS_PER_BLOCK;
     Q = dev_count(Q, Q_dev);
-    if (r0 >= Q && blockIdx.x != 0) return;                    // block past the end of a capacity-sized launch (uniform)
+    if (r0 >= Q && block != 0) return;                    // block past the end of a capacity-sized launch (uniform)
     const uint32_t nslots = r0 >= Q ? 0u : ((Q - r0) < (uint32_t)RUNS_PER_BLOCK ? (Q - r0) : (uint32_t)RUNS_PER_BLOCK);
     uint32_t nruns;                                   // non-empty runs of this block (row clipping leaves h = 0 slots)
     {   // stage the non-empty runs, compacted; exclusive prefix of their heights = first instance of each run
@@ -1219,8 +1216,8 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
         if (t == 0) { s_start[RUNS_PER_BLOCK] = tot & 0xFFFFFu; s_nruns = tot >> 20; }
         uint32_t gtot;
         const uint32_t dbase = block_excl_scan(t < nrows ? digit_total[t] : 0u, &gtot);   // instances in lower tile rows, globally
-        if (blockIdx.x == 0 && t == 0) *total_out = gtot;
-        running[t] = dbase + (t < nrows ? hist_scanned[(size_t)t * nblk + blockIdx.x] : 0u);
+        if (block == 0 && t == 0) *total_out = gtot;
+        running[t] = dbase + (t < nrows ? hist_scanned[(size_t)t * nblk + block] : 0u);
     }
     __syncthreads();
     const uint32_t ninst = s_start[RUNS_PER_BLOCK];
@@ -1304,6 +1301,22 @@ run_scatter_rows_kernel(const uint2* __restrict__ run_vals /* sorted by column *
         }
         __syncthreads();
     }
+}
+
+// The row pass and the tile ranges in ONE launch: both only read the scanned row histogram and the column-sorted runs, neither reads what
+// the other writes.  Workgroups [0, nblk) expand and rank the instances of their runs, workgroups [nblk, nblk + gx) compute the ranges
+// of their tile column (one launch fewer per forward, and one fewer among the predicated launches of the list cut).
+__global__ void __launch_bounds__(RS_THREADS)
+rows_and_ranges_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q, const uint32_t* __restrict__ counts_dev,
+                       uint32_t capR, int ybits, int gx, int gy, const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ digit_total,
+                       uint32_t nblk, uint32_t* __restrict__ point_list, uint32_t* __restrict__ total_out, uint2* __restrict__ ranges,
+                       uint32_t* __restrict__ bucket_cnt, uint16_t* __restrict__ bucket_list, const HintTable* __restrict__ hints,
+                       const uint32_t* __restrict__ hint_sel, const uint32_t* __restrict__ pred /* or null: predicated launch */)
+{
+    static_assert(RS_THREADS == 256, "one lane per tile row in the ranges part");
+    if (pred && *pred == 0u) return;
+    if (blockIdx.x < nblk) run_scatter_rows_body(blockIdx.x, run_vals, Q, counts_dev ? counts_dev + 1 : nullptr, capR, ybits, (uint32_t)gy, hist_scanned, digit_total, nblk, point_list, total_out);
+    else tile_ranges_from_runs_body(blockIdx.x - nblk, run_keys, run_vals, Q, counts_dev, capR, gx, gy, hist_scanned, digit_total, nblk, ranges, bucket_cnt, bucket_list, hints, hint_sel);
 }
 
 // Launch order of the blend kernels: tiles sorted by descending work (bucketed counting sort,

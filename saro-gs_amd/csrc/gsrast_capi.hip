@@ -994,12 +994,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             GS_LAUNCHED("run_hist_rows");
             radix_rowscan_kernel<<<cam.gy, 256, 0, s>>>(hist_y, nblk, rscan, nullptr, 0, nullptr, 0, pred);     // one workgroup per tile row
             GS_LAUNCHED("radix_rowscan");
-            run_scatter_rows_kernel<<<nblk, RS_THREADS, 0, s>>>(rvA, nQ, Q_dev, capR_, tile_bits((size_t)cam.gy), (uint32_t)cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2, pred);
-            GS_LAUNCHED("run_scatter_rows"); }
-        {   ProfScope ps(K_RANGES, s);
-            tile_ranges_from_runs_kernel<<<cam.gx, 256, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, cam.gx, cam.gy, hist_y, rscan, nblk, ranges,
-                                                                buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel, pred);
-            GS_LAUNCHED("tile_ranges"); }
+            // the row pass and the tile ranges in one launch (gsrast_binning.h)
+            rows_and_ranges_kernel<<<nblk + (uint32_t)cam.gx, RS_THREADS, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, tile_bits((size_t)cam.gy), cam.gx, cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2, ranges,
+                                                                                 buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel, pred);
+            GS_LAUNCHED("rows_and_ranges"); }
         return GSRAST_OK;
     };
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built, int mode = 0 /* list cut: as launch_run_binning */) -> int {
