@@ -531,6 +531,8 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
 // sort's scatter beside it 109 us instead of 15); one lane per Gaussian with masked lanes: 95 us (as many load instructions as before,
 // few lanes each); the rows gathered in DEPTH order -- any order, in a random scene -- from the depth buckets: 140-620 us in three
 // forms (TLB reach, not bytes: the gathers here walk the arrays in address order).
+// (Measured and dropped: each compacted lane reading its own row into registers with 16-byte loads, no LDS -- the colour kernel 108 ->
+// 122 us, the step -4 % at 3 M and 1 M: the rows of a wave are ~8 rows apart, every 64-byte sector is fetched four times.)
 // RAW: the row is cat(features_dc, features_rest) + shs_res, assembled in LDS as preprocess_color_kernel<., true> does.
 #ifndef GSRAST_PCC_WAVES
 #define GSRAST_PCC_WAVES 2        // waves per workgroup (512 Gaussians each): 1 / 2 / 4 measured 747 / 761-767 / 765-769 views/s at 3 M, 1219 / 1220 / 1209 at 1 M
