@@ -200,7 +200,7 @@ typedef struct gsrast_options {
                                  Gaussian whose gradient record is all zero (frustum-culled, or occluded: its gradient IS zero) gets its
                                  zero rows written without its inputs being read */
     int no_list_cut;          /* forward: 1 = always bin every Gaussian.  0 (default): LIST CUT -- with the launch-order hints a context also
-                                 remembers, per pose and tile, a cut depth (that of the list entry twice as deep as the deepest one any pixel
+                                 remembers, per pose and tile, a cut depth (that of the list entry 1.5 x as deep as the deepest one any pixel
                                  of the tile consumed the last time; none for a tile whose pixels did not all saturate).  The next forward of
                                  that pose gives column runs only to the Gaussians in front of the cut depth of some tile they cover -- in an
                                  occluded scene a few per cent of them -- and VERIFIES the speculation on the device: a tile's list counts

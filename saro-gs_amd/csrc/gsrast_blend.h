@@ -20,6 +20,11 @@
 #pragma once
 #include "gsrast_common.h"
 
+#ifndef GSRAST_CUT_MARGIN_X4
+#define GSRAST_CUT_MARGIN_X4 6u      // the next cut depth of a tile = that of the list entry (this / 4) x as deep as the deepest one consumed, + 32: 1.5 x.
+                                     // Alternating runs, views/s with 1.25 x / 1.5 x / 2 x: 3 M 825-832 / 795-824 / 771-809, 1 M 1215-1279 / 1267-1280 / 1229-1242 -- the cut is in
+                                     // DEPTH (cloned or split Gaussians in front of it shift list positions, not the depth at which a tile saturates), 1.5 x leaves room for pruning
+#endif
 namespace gsrast {
 
 #ifdef GSRAST_DEBUG_COUNTERS
@@ -309,11 +314,11 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         if (zc != ZCUT_NONE && !all_done && cut_scalars) atomicAdd(&cut_scalars[SC_UNDONE], 1u);
         if (hints) {
             hint_work(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
-            // the tile's next cut depth: that of the entry twice as deep (+ 32) as the deepest one consumed; none for a tile that did
+            // the tile's next cut depth: that of the entry 1.5 x as deep (+ 32) as the deepest one consumed; none for a tile that did
             // not saturate, or whose (full) list is shorter than that
             uint32_t znew = ZCUT_NONE;
             if (all_done) {
-                const uint32_t p = 2u * s_max + 32u;
+                const uint32_t p = GSRAST_CUT_MARGIN_X4 * s_max / 4u + 32u;
                 if (p < n_safe) znew = __float_as_uint(rec1[point_list[range.x + p]].z);
                 else if (zc != ZCUT_NONE && n_safe > 0u) {
                     // the cut list does not reach that deep: position -> depth extrapolated linearly from the list's first entry

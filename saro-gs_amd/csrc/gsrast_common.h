@@ -115,7 +115,7 @@ __host__ __device__ inline const uint32_t* hint_zcut(const HintTable* h, uint32_
 static inline size_t hint_table_bytes(size_t T) { return hint_zcut_offset(T) + (size_t)HINT_SLOTS * T * 4 + 256; }
 
 // LIST CUT (round 3): the binning of an occluded scene works on instances nobody consumes (3 M cube: 23 M listed, 1.2 M consumed).  A
-// pose that has been rendered before also remembers, per tile, a CUT DEPTH -- the depth of the list entry twice as deep (+ 32) as the
+// pose that has been rendered before also remembers, per tile, a CUT DEPTH -- the depth of the list entry 1.5 x as deep (+ 32) as the
 // deepest one any pixel of the tile consumed, or "none" (ZCUT_NONE) for a tile whose pixels did not all saturate.  The next forward of
 // that pose snapshots the cut depths into its own image buffer (preprocess_fwd), and the bucket scatter marks a Gaussian LATE when it
 // lies behind the cut depth of every tile of its rectangle.  Late Gaussians stay in the depth order but get no column runs: emission,

@@ -980,7 +980,7 @@ def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H):
         _C.set_option("no_list_cut", 0)
     assert late_off == 0 and same(off, full)
 
-    # the scene turns transparent: every tile now consumes far more than twice what it did
+    # the scene turns transparent: every tile now consumes far more than 1.5 x what it did
     sc2 = dict(sc)
     sc2["opacities"] = (sc["opacities"] * 0.04).astype(np.float32)
     o2 = orc.render(sc2, cam)
