@@ -603,18 +603,22 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
                          uint32_t* __restrict__ bwincl /* [nb][BK_CAP]: inclusive scan of their rectangle widths inside the bucket */,
                          uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */,
                          uint32_t* __restrict__ bwsum /* [nb]: column runs again, compact -- every emission workgroup sums the ones in front of it */,
-                         // list cut: the same three over the EARLY Gaussians only (a late one counts zero runs), or null
-                         uint32_t* __restrict__ bwincl_e = nullptr, uint4* __restrict__ binfo_e = nullptr, uint32_t* __restrict__ bwsum_e = nullptr,
-                         uint32_t* __restrict__ border_e = nullptr /* [nb][BK_CAP]: the early Gaussians' ids, compact, in depth order */)
+                         // list cut (gsrast_common.h), EARLY-ONLY mode (binfo_all != null): the four arrays above receive the bucket's EARLY
+                         // Gaussians only -- the late ones (bit 31 of the width word) are not sorted at all, they only count into
+                         // binfo_all = {all elements, all column runs, all tiles, overflow}: what the host's counts and num_rendered are made
+                         // of.  Should the cut lists turn out too short, this kernel runs again over everything (pred, plain mode)
+                         uint4* __restrict__ binfo_all = nullptr,
+                         const uint32_t* __restrict__ pred = nullptr /* the predicated launch among the ones behind the forward blend */)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
     __shared__ uint32_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order
     __shared__ uint16_t s_wid[BK_WAVES][BK_CAP];                // widths, grouped like s_grp
     __shared__ uint32_t s_cnt[BK_WAVES][BK_SUB + 1];
-    __shared__ uint32_t s_sid[BK_WAVES][BK_CAP];                // list cut: the sorted ids (the early ones are compacted from here)
+    if (pred && *pred == 0u) return;
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * BK_WAVES + wave;
     if (b >= nb) return;
+    const bool early_only = binfo_all != nullptr;
     unsigned long long* grp = s_grp[wave];
     uint32_t* aux = s_aux[wave];
     uint16_t* wid = s_wid[wave];
@@ -631,20 +635,26 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     start[0] = 0u;
 #pragma unroll
     for (int x = 0; x < BK_XCD; x++) start[x + 1] = __builtin_amdgcn_readlane(inc, x);
-    const uint32_t n = start[BK_XCD];
+    const uint32_t n_all = start[BK_XCD];
     for (uint32_t k = lane; k <= (uint32_t)BK_SUB; k += 64) cnt[k] = 0u;
     wave_sync();
-    // 1. arrival rank inside the sub-interval; the tile counts are only summed
-    uint32_t tsum = 0;
-    for (uint32_t e0 = lane; e0 < n; e0 += 64 * 4) {
+    // 1. arrival rank inside the sub-interval; the tile counts (and, early-only, the late Gaussians' widths) are only summed
+    uint32_t tsum = 0, wall = 0;
+    for (uint32_t e0 = lane; e0 < n_all; e0 += 64 * 4) {
         uint4 kv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; kv[u] = e < n ? bucket_element(slab, b, start, e) : make_uint4(0u, 0u, 0u, 0u); }
+        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; kv[u] = e < n_all ? bucket_element(slab, b, start, e) : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; if (e < n) { aux[e] = atomicAdd(&cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)], 1u); tsum += kv[u].w; } }
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = e0 + u * 64;
+            if (e < n_all) {
+                tsum += kv[u].w; wall += kv[u].z & ~LATE_BIT;
+                if (!(early_only && (kv[u].z & LATE_BIT))) aux[e] = atomicAdd(&cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)], 1u);
+            }
+        }
     }
     wave_sync();
-    // 2. exclusive scan of the BK_SUB counters in place (lane owns four consecutive ones); cnt[BK_SUB] = n
+    // 2. exclusive scan of the BK_SUB counters in place (lane owns four consecutive ones); cnt[BK_SUB] = elements to sort
     {
         uint32_t v[BK_SUB / 64], sum = 0;
 #pragma unroll
@@ -655,19 +665,19 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
         if (lane == 63) cnt[BK_SUB] = run;
     }
     wave_sync();
+    const uint32_t n = cnt[BK_SUB];             // (= n_all unless early-only)
     // 3. group by sub-interval (the slab is read again: L2)
-    for (uint32_t e0 = lane; e0 < n; e0 += 64 * 4) {
+    for (uint32_t e0 = lane; e0 < n_all; e0 += 64 * 4) {
         uint4 kv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; kv[u] = e < n ? bucket_element(slab, b, start, e) : make_uint4(0u, 0u, 0u, 0u); }
+        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + u * 64; kv[u] = e < n_all ? bucket_element(slab, b, start, e) : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t e = e0 + u * 64;
-            if (e < n) {
+            if (e < n_all && !(early_only && (kv[u].z & LATE_BIT))) {
                 const uint32_t slot = cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)] + aux[e];
                 grp[slot] = ((unsigned long long)kv[u].x << 32) | kv[u].y;
-                // (with the list cut the image has fewer than 32768 tile columns -- cut_cell_shift: widths fit 15 bits, bit 15 carries "late")
-                wid[slot] = bwincl_e ? (uint16_t)((kv[u].z & 0x7FFFu) | ((kv[u].z >> 31) << 15)) : (uint16_t)kv[u].z;
+                wid[slot] = (uint16_t)(kv[u].z & ~LATE_BIT);
             }
         }
     }
@@ -681,47 +691,24 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
         for (uint32_t q = s0; q < s1; q++) r += grp[q] < me ? 1u : 0u;
         border[(size_t)b * BK_CAP + s0 + r] = (uint32_t)me;
         aux[s0 + r] = wid[e];                                   // (possibly clipped) rectangle width = column runs
-        if (bwincl_e) s_sid[wave][s0 + r] = (uint32_t)me;
     }
     wave_sync();
     // 5. inclusive scan of the widths in sorted order: lane t owns the E consecutive elements [t*E, t*E + E)
     const uint32_t E = (n + 63) / 64;            // <= BK_CAP / 64
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
-    if (bwincl_e) {
-        // list cut: the scan over all widths, and the EARLY Gaussians compacted (ids in depth order + the scan of their widths)
-        uint32_t wsum = 0, esum = 0, ne = 0;
-        for (uint32_t e = 0; e < E; e++) {
-            const uint32_t t = lane * E + e;
-            if (t < n) { const uint32_t w = aux[t] & 0x7FFFu, late = aux[t] >> 15; wsum += w; esum += late ? 0u : w; ne += late ? 0u : 1u; }
-        }
-        uint32_t run = wave_incl_scan(wsum) - wsum, erun = wave_incl_scan(esum) - esum, epos = wave_incl_scan(ne) - ne;
-        const uint32_t wtot = __shfl(run + wsum, 63, 64), etot = __shfl(erun + esum, 63, 64), n_e = __shfl(epos + ne, 63, 64);
-        uint32_t* eid = reinterpret_cast<uint32_t*>(grp);           // (the composites are dead: their LDS holds the compacted set)
-        uint32_t* ewin = eid + BK_CAP;
-        wave_sync();
-        for (uint32_t e = 0; e < E; e++) {
-            const uint32_t t = lane * E + e;
-            if (t < n) {
-                const uint32_t w = aux[t] & 0x7FFFu, late = aux[t] >> 15;
-                run += w; aux[t] = run;
-                if (!late) { erun += w; eid[epos] = s_sid[wave][t]; ewin[epos] = erun; epos++; }
-            }
-        }
-        wave_sync();
-        for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
-        for (uint32_t t = lane; t < n_e; t += 64) { border_e[(size_t)b * BK_CAP + t] = eid[t]; bwincl_e[(size_t)b * BK_CAP + t] = ewin[t]; }
-        if (lane == 0) { binfo[b] = make_uint4(n, wtot, tsum, over); bwsum[b] = wtot; binfo_e[b] = make_uint4(n_e, etot, n - n_e, over); bwsum_e[b] = etot; }
-        return;
-    }
     uint32_t wsum = 0;
     for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) wsum += aux[t]; }
     uint32_t run = wave_incl_scan(wsum) - wsum;
     const uint32_t wtot = __shfl(run + wsum, 63, 64);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { tsum += __shfl_xor(tsum, d, 64); wall += __shfl_xor(wall, d, 64); }
     for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) { run += aux[t]; aux[t] = run; } }
     wave_sync();
     for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
-    if (lane == 0) { binfo[b] = make_uint4(n, wtot, tsum, over); bwsum[b] = wtot; }
+    if (lane == 0) {
+        if (early_only) { binfo[b] = make_uint4(n, wtot, n_all - n, over); binfo_all[b] = make_uint4(n_all, wall, tsum, over); }
+        else binfo[b] = make_uint4(n, wtot, tsum, over);
+        bwsum[b] = wtot;
+    }
 }
 
 // Totals of the buckets: {num_rendered lo, Q, -, num_rendered hi} and the overflow verdict into `scalars` -- by the last workgroup of

@@ -891,9 +891,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 GS_LAUNCHED("depth_bucket_scatter");
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)
-                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base),
-                                                                                                   cut ? at<uint32_t>(geom, GL.bk_wincl_e) : nullptr, cut ? at<uint4>(geom, GL.bk_info_e) : nullptr, cut ? at<uint32_t>(geom, GL.bk_base_e) : nullptr,
-                                                                                                   cut ? at<uint32_t>(geom, GL.bk_order_e) : nullptr);
+                // list cut: only the bucket's EARLY Gaussians are sorted (into the early set); the late ones count into bk_info's totals
+                if (cut) depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e),
+                                                                                                            at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), at<uint4>(geom, GL.bk_info));
+                else depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl),
+                                                                                                        at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
                 GS_LAUNCHED("depth_bucket_sort"); }
             totals_pending = true;      // by the run emission's last workgroup, or by launch_bucket_totals() if the host needs them first
             return GSRAST_OK;
@@ -971,15 +973,23 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), nbk, scalars,
                                                             flag_alias, flag_seq, at<uint4>(geom, GL.bk_info));
-            else if (bucketed && mode == 2)
+            else if (bucketed && mode == 2) {
+                // (the first pass sorted the early Gaussians only: the buckets are sorted again, whole)
+                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order),
+                                                                                                   at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nullptr, pred);
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, nullptr,
-                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), (XCD_GROUPS + 1) * WORK_BUCKETS, hints);
-            else if (bucketed)
+                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), (XCD_GROUPS + 1) * WORK_BUCKETS, hints); }
+            else if (bucketed) {
+                if (cut) {      // (a list-cut forward sorted the early Gaussians only, and now everything is listed after all: the buckets are sorted again, whole)
+                    depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order),
+                                                                                                       at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
+                    GS_LAUNCHED("depth_bucket_sort");
+                }
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars,
                                                             flag_alias, flag_seq);
-            else
+            } else
                 emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
                                                                        o.tile_clip, capQ_, rkA, rvA);
             GS_LAUNCHED("emit_column_runs"); }
