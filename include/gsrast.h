@@ -401,13 +401,6 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
                              const float* levels, const float* d_features, float* d_pts, float* d_levels, int mips_built,
                              char* scratch, void* stream);
 
-/* ---- beyond SURVEY 8f: weight / bias gradient of an fp32 Linear layer over M ~ 1e6 rows (split-K on the fp32 matrix cores) ----
- * dW[N1][N2] (+)= sum_r G[r][n1] * X[r][n2];  db[N1] (+)= sum_r G[r][n1]  (db may be NULL).  G [M][N1], X [M][N2] row-major fp32,
- * widths <= 128.  This is torch.nn.Linear's weight / bias gradient for the deformation heads of scene/saro_gaussian.py:104-110
- * (G = grad_output, X = input), the measured bottleneck of the dynamic-stage iteration.  accumulate = 0 zeroes
- * the outputs first. */
-int gsrast_linear_wgrad(int M, int N1, int N2, const float* G, const float* X, float* dW, float* db, int accumulate, void* stream);
-
 const char* gsrast_last_error(void);
 int gsrast_abi_version(void);
 

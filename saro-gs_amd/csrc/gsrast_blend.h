@@ -184,7 +184,9 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t n = range.y - range.x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     if (t == 0) s_max = 0;
-    const uint32_t zc = zcut_used ? zcut_used[tile] : ZCUT_NONE;       // uniform
+    // (a call in which the scatter marked NO Gaussian late has full lists whatever the snapshot says: nothing may be cut short, and
+    // the host enqueues no second pass for it -- cut_scalars[SC_N_LATE] is final, the scatter ran before the binning)
+    const uint32_t zc = (zcut_used && cut_scalars[SC_N_LATE] != 0u) ? zcut_used[tile] : ZCUT_NONE;       // uniform
     uint32_t n_safe = n;                          // entries of the list known to be ALL the tile's Gaussians up to their depth
     bool cut_here = false;
 

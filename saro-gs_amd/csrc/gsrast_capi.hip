@@ -20,7 +20,6 @@
 #include "gsrast_adam.h"
 #include "gsrast_knn.h"
 #include "gsrast_hexplane.h"
-#include "gsrast_mlp.h"
 
 #include <algorithm>
 #include <atomic>
@@ -352,6 +351,8 @@ struct gsrast_context {
     std::mutex mu;
 };
 namespace {
+// counters of "that many forwards go without ..." shared by the lanes of a view-parallel caller: never below zero
+inline void dec_to_zero(std::atomic<int>& a) { int v = a.load(); while (v > 0 && !a.compare_exchange_weak(v, v - 1)) { } }
 // The context's side stream on the current device (created on first use, lowest priority: its bandwidth-heavy kernels should fill
 // the gaps the critical path leaves, not compete with it for compute units).  nullptr if it cannot be had.
 SideStream* side_stream_of(gsrast_context* ctx)
@@ -786,7 +787,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool cut_pays = g_list_cut_always.load() != 0 || (ctx->last_Q.load() >= CUT_MIN_RUNS && ctx->cut_pause.load() == 0);
     const int cut_cs = cut_cell_shift((size_t)cam.gx, (size_t)cam.gy);
     const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
-    if (!cut && !o.no_list_cut && ctx->cut_pause.load() > 0) ctx->cut_pause--;
+    if (!cut && !o.no_list_cut) dec_to_zero(ctx->cut_pause);
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
@@ -1077,7 +1078,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     }
     { int rc = rb_flag ? read_flag_finish(rb_flag, scalars, s, counts, 12) : read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
     bool sort_redone = false;
-    if (!bucket_sort && o.depth_sort == 0 && ctx->bucket_skip.load() > 0) ctx->bucket_skip--;
+    if (!bucket_sort && o.depth_sort == 0) dec_to_zero(ctx->bucket_skip);
     if (bucket_sort) {
         if (counts[11] == 0 && ctx->bucket_backoff.load() > 0 && ++ctx->bucket_clean >= 64) { ctx->bucket_backoff = 0; ctx->bucket_clean = 0; }   // the scene changed: forget
         if (counts[11] != 0) {
@@ -1516,29 +1517,6 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
         hex_grad_uv_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(a, pts, levels, d_features, d_pts, d_levels);
         GS_LAUNCHED("hex_grad_uv");
     }
-    return GSRAST_OK;
-}
-
-int gsrast_linear_wgrad(int M, int N1, int N2, const float* G, const float* X, float* dW, float* db, int accumulate, void* stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    if (M < 0 || N1 < 1 || N2 < 1 || N1 > MLP_MAX_N || N2 > MLP_MAX_N) return fail(GSRAST_E_ARG, "linear_wgrad: widths must be in [1, 128]");
-    if (!dW || (M > 0 && (!G || !X))) return fail(GSRAST_E_ARG, "linear_wgrad: NULL pointer");
-    if (!accumulate) {
-        GS_HIP(hipMemsetAsync(dW, 0, (size_t)N1 * N2 * 4, s));
-        if (db) GS_HIP(hipMemsetAsync(db, 0, (size_t)N1 * 4, s));
-    }
-    if (M == 0) return GSRAST_OK;
-    const int nb1 = (N1 + 31) / 32, nb2 = (N2 + 31) / 32;
-    const int jstep = 4 / (nb1 <= 1 ? 1 : (nb1 == 2 ? 2 : 4));
-    const int nj = (nb2 + jstep - 1) / jstep;         // 32-column blocks of dW per wave
-    int rows = (M + 1023) / 1024;                     // ~1000 workgroups share the rows (each ends with N1 x N2 atomics)
-    rows = std::max(128, (rows + 31) / 32 * 32);
-    const int chunks = (M + rows - 1) / rows;
-    if (nj <= 1) mlp_wgrad_kernel<1, 16><<<chunks, 256, 0, s>>>(G, X, M, N1, N2, rows, dW, db);
-    else if (nj == 2) mlp_wgrad_kernel<2, 8><<<chunks, 256, 0, s>>>(G, X, M, N1, N2, rows, dW, db);
-    else mlp_wgrad_kernel<4, 4><<<chunks, 256, 0, s>>>(G, X, M, N1, N2, rows, dW, db);
-    GS_LAUNCHED("mlp_wgrad");
     return GSRAST_OK;
 }
 

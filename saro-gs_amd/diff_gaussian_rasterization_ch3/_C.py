@@ -36,7 +36,7 @@ EXPORTS = (
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
     "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
-    "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward", "gsrast_linear_wgrad",
+    "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query",
     "gsrast_forward_ex", "gsrast_backward_ex", "gsrast_forward_raw", "gsrast_backward_raw",
 )
@@ -187,8 +187,6 @@ def lib() -> C.CDLL:
     L.gsrast_hexplane_forward.argtypes = [ci, ci, ci, ci, ci, C.POINTER(PlaneStruct), vp, vp, vp, vp, vp]
     L.gsrast_hexplane_backward.restype = ci
     L.gsrast_hexplane_backward.argtypes = [ci, ci, ci, ci, ci, C.POINTER(PlaneStruct), vp, vp, vp, vp, vp, ci, vp, vp]
-    L.gsrast_linear_wgrad.restype = ci
-    L.gsrast_linear_wgrad.argtypes = [ci, ci, ci, vp, vp, vp, vp, ci, vp]
     L.gsrast_last_error.restype = C.c_char_p
     L.gsrast_abi_version.restype = ci
     if L.gsrast_abi_version() != ABI_VERSION:

@@ -100,9 +100,6 @@ def test_widened_rows_reject_bad_arguments_without_a_device(rast, L):
     assert L.gsrast_hexplane_forward(10, 4, 32, 32, 1, far, None, None, None, None, None) == -1
     off = (PS * 1)(PS(None, None, 64, 64, 0, 1, 7, 16))        # feature block [16, 48) outside a 32-float row
     assert L.gsrast_hexplane_backward(10, 4, 32, 32, 1, off, None, None, None, None, None, 0, None, None) == -1
-    assert L.gsrast_linear_wgrad(10, 129, 8, None, None, None, None, 0, None) == -1
-    assert L.gsrast_linear_wgrad(10, 8, 0, None, None, None, None, 0, None) == -1
-    assert L.gsrast_linear_wgrad(10, 8, 8, None, None, None, None, 0, None) == -1      # NULL dW
 
 
 def test_raw_entry_points_reject_bad_arguments_before_any_device_work(L, rast):

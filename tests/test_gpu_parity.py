@@ -1054,6 +1054,56 @@ def test_list_cut_on_a_large_image(scenes, rast, gpu):
         _C.set_option("list_cut_always", 0)
 
 
+def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
+    """a pose may hold cut depths while the scatter marks NO Gaussian late (rectangles of more than 64 tiles are
+    never late; a Gaussian over a tile without a cut stays early).  The host then enqueues no second pass, so the blend must not
+    cut any list short either: a scene of screen-filling Gaussians is rendered opaque (tiles saturate, cut depths are learned),
+    then nearly transparent at the same pose -- every pixel looks far behind the remembered cut depth -- and must equal the oracle."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, NBIG, W, H = 33_000, 400, 320, 240             # (P >= the bucket depth sort's minimum: the cut rides on it)
+    sc = scenes.synth(P, 931)
+    rng = np.random.default_rng(932)
+    sc["means3D"][NBIG:, :] = 50.0                     # everything but the big ones: far outside the frustum, culled
+    sc["means3D"][:NBIG] = rng.uniform(-1.0, 1.0, size=(NBIG, 3)).astype(np.float32)
+    sc["scales"][:NBIG] = rng.uniform(0.4, 0.6, size=(NBIG, 3)).astype(np.float32)
+    sc["opacities"][:NBIG] = 0.97
+    cam = scenes.camera(1, 7, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+
+    def render(scene):
+        rs = settings_from(rast, cam, scene, gpu)
+        ten = {k: t(scene[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return (R, color.clone(), depth.clone(), st["n_contrib"].clone(), st["final_T"].clone()), _C.context_query("last_late")
+
+    _C.set_option("list_cut_always", 1)
+    try:
+        a, _ = render(sc)
+        b, late_b = render(sc)                         # this one snapshots the cut depths the first left
+        o = orc.render(sc, cam)
+        assert (o["final_T"] < 1e-4).mean() > 0.5      # most pixels saturate: most tiles have a cut depth
+        assert late_b == 0                             # ... and still nobody is late
+        assert np.array_equal(bits(b[1].cpu().numpy()), bits(o["out_color"]))
+        fb0 = _C.context_query("cut_fallbacks")
+        sc2 = dict(sc)
+        sc2["opacities"] = (sc["opacities"] * 0.02).astype(np.float32)
+        thin, late_c = render(sc2)
+        o2 = orc.render(sc2, cam)
+        assert late_c == 0 and _C.context_query("cut_fallbacks") == fb0
+        assert thin[0] == o2["R"]
+        assert np.array_equal(bits(thin[1].cpu().numpy()), bits(o2["out_color"]))
+        assert np.array_equal(bits(thin[2].cpu().numpy()), bits(o2["out_depth"]))
+        assert np.array_equal(thin[3].cpu().numpy().reshape(-1), np.asarray(o2["n_contrib"]).reshape(-1))
+    finally:
+        _C.set_option("list_cut_always", 0)
+
+
 def test_list_cut_under_a_changing_scene(orc, scenes, rast, gpu):
     """A training run changes the scene between two renders of a pose.  A fixed pose, twelve random edits in a row -- opacities scaled
     up or down, a tenth of the Gaussians pruned, the scene pushed away from / pulled towards the camera, a transparent and an opaque
