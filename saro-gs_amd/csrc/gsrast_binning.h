@@ -387,8 +387,10 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
 // fallback and serves the instance-level binning).
 // An LSD radix pass costs three dependent launches, the scan that follows three more, and at 1e6 Gaussians all of them are launch /
 // latency bound (sort 85-110 us + scan 23 us for 16 MB of keys).  Three launches do the same job:
-//   depth_bucket_scatter_kernel  every visible Gaussian goes to bucket floor((z - zmin) * NB / (zmax - zmin)) -- monotone in z;
-//       NB ~ P / 256 buckets keep a few hundred elements each.  No histogram, no scan: a bucket owns a fixed slab of (key, index)
+//   depth_bucket_scatter_kernel  every visible Gaussian goes to bucket floor(NB * CDF(z)) -- monotone in z -- where CDF is the running
+//       sum of the sampled depth histogram preprocess_fwd left (round 4, gsrast_common.h: buckets of equal POPULATION, whatever the
+//       depth distribution; rounds 2-3 cut [zmin, zmax] into equal intervals, which overflowed on any peak);
+//       NB ~ P / 256 buckets keep a few hundred elements each.  No scan: a bucket owns a fixed slab of (key, index)
 //       slots, a workgroup ranks its 2048 elements per bucket with LDS atomics and reserves slab space with ONE returning global
 //       atomic per non-empty bucket.  Counters and slabs are kept PER XCD (workgroup b runs on XCD b mod 8; each XCD has its own
 //       L2): with one counter set all eight L2s fight over the same 128 cache lines and the atomics alone cost 15 us.
@@ -399,28 +401,24 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
 //   depth_bucket_scan_kernel     one workgroup: exclusive scan of the buckets' width totals (-> first column run of each bucket, Q),
 //       sum of their tile counts (-> num_rendered), the overflow verdict.
 // emit_column_runs_kernel then runs one workgroup per bucket.  Culled Gaussians (key ~0) are never touched.
-// zmin / zmax come from preprocess_fwd_kernel (per-block minima / maxima, reduced by every scatter workgroup).  A scene whose depths
-// pile up (more Gaussians in one bucket than its slab holds) raises a flag the host reads back with the instance counts; the
+// A scene whose depths pile up beyond the histogram's resolution (more Gaussians in one bucket than its slab holds: thousands at
+// one depth) raises a flag the host reads back with the instance counts; the
 // forward then repeats the sort with the radix passes and the context uses those for its next calls (gsrast_forward).
 constexpr int BK_CAP = GSRAST_BK_CAP;    // slots per bucket = the largest bucket the LDS sort takes
 constexpr int BK_XCD = 8;                // counter / slab sets
 constexpr int BK_CAPX = BK_CAP / BK_XCD; // slots per (bucket, XCD) sub-slab
 constexpr int BK_MAX_BUCKETS = 8192;
 constexpr int BK_ITEMS = 8;              // elements per lane of the scatter kernel
-__device__ __forceinline__ uint32_t depth_bucket_of(uint32_t key, float zmin, float scale, uint32_t nb)
-{
-    const float t = (__uint_as_float(key) - zmin) * scale;        // monotone in the key: subtraction, product and truncation all are
-    const uint32_t d = (uint32_t)t;                               // (t >= 0; a NaN or huge product saturates / clamps below)
-    return d < nb ? d : nb - 1u;
-}
-
 __global__ void __launch_bounds__(256)
 depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                            uint32_t n, const uint32_t* __restrict__ block_zrange, uint32_t nzblk,
+                            uint32_t n, const uint32_t* __restrict__ zhist /* [ZH_COPIES][ZH_BINS]: sampled histogram of the visible depth keys (preprocess_fwd) */,
+                            uint32_t zh_klo, int zh_shift /* its bins: 2^shift key steps each, from klo (gsrast_common.h) */,
                             uint32_t nb, uint32_t* __restrict__ gcount /* [8][nb]: per-XCD bucket counts (zeroed by preprocess_fwd) */,
                             uint4* __restrict__ slab /* [nb][8][BK_CAPX]: {depth key, id, rectangle width, tile count} -- what the sort kernel
                                                         needs of a Gaussian travels with it (gathering rect / tiles by id there cost 15 us) */,
-                            float* __restrict__ zparam /* [2]: zmin, scale -- for the sort kernel */,
+                            uint32_t* __restrict__ bkey_out /* [nb + 1]: first key the bucket map sends to bucket b (approximately: the map's
+                                                               inverse) -- the sort kernel spreads a bucket's elements over its sub-intervals by it */,
+                            uint32_t* __restrict__ zbins_out /* scalars[SC_ZBINS]: first | last << 16 occupied bin (the host's next range hint) */,
                             // list cut (gsrast_common.h): this call's snapshot of the pose's per-tile cut depths, or null.  A Gaussian that
                             // lies behind the cut depth of EVERY tile of its rectangle is marked LATE (bit 31 of the width word): it keeps
                             // its place in the depth order but gets no column runs unless the forward has to fall back to the full lists
@@ -431,20 +429,48 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                             uint32_t cshift = 1 /* the cells of the cut-depth table are (1 << cshift)^2 tiles: 2 x 2 up to 1080p-class images,
                                                    4 x 4 / 8 x 8 for larger ones (at most CUT_MAX_CELLS cells) */)
 {
-    __shared__ uint32_t cnt[BK_MAX_BUCKETS];
-    __shared__ uint32_t s_mm[2];
+    // per-bucket counters of this workgroup, two 16-bit counters per word (a workgroup has 2048 elements): 16 KB instead of 32 -- with
+    // the 4 KB of the bucket map and the 6 KB of cut depths this latency-bound kernel keeps five workgroups per compute unit
+    __shared__ uint32_t cnt[BK_MAX_BUCKETS / 2];
+    __shared__ uint32_t s_C[ZH_BINS + 1];          // running sum of (histogram + 1): strictly increasing
+    __shared__ uint32_t s_fl[2];
     // the cut depths as maxima over cells of 2 x 2 tiles (4 x 4 / 8 x 8 for images of more than CUT_MAX_CELLS such cells), rounded UP to the 16 leading bits of the float (exponent + 7 mantissa bits:
     // within 0.8 % of the depth): a Gaussian is LATE when it lies behind every cell its rectangle touches -- typically four LDS reads,
-    // no memory access in the loop; a larger cut only keeps more.  (The table must stay small: with the 32 KB of bucket counters above,
-    // anything over 7 KB costs this latency-bound kernel a workgroup per compute unit.  Measured on the way: the tiles' own depths in
+    // no memory access in the loop; a larger cut only keeps more.  (The table must stay small: measured on the way: the tiles' own depths in
     // LDS, 16 KB: 77 -> 116 us at 3 M; 8 x 8 cells in LDS and the tiles' depths walked in global memory behind them: 152 us, a
     // dependent load per step of a divergent loop.)
     __shared__ uint16_t s_zc[CUT_MAX_CELLS];
     __shared__ uint32_t s_late;
     const unsigned lane = lane_id();
     const uint32_t xcd = blockIdx.x & (BK_XCD - 1);
-    if (threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; s_late = 0u; }
-    for (uint32_t k = threadIdx.x; k < nb; k += 256) cnt[k] = 0u;
+    if (threadIdx.x == 0) { s_late = 0u; s_fl[0] = 0xFFFFu; s_fl[1] = 0u; }
+    for (uint32_t k = threadIdx.x; k < nb / 2u; k += 256) cnt[k] = 0u;
+    // (the keys are requested first: their round trip passes under the construction of the bucket map)
+    const uint32_t base = blockIdx.x * (256 * BK_ITEMS);
+    uint32_t key[BK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BK_ITEMS; r++) { const uint32_t i = base + r * 256 + threadIdx.x; key[r] = i < n ? keys[i] : 0xFFFFFFFFu; }
+    static_assert(ZH_BINS == 4 * 256, "one uint4 of the histogram per lane");
+    {   // the bucket map: running sum of the sampled histogram, one pseudo-count per bin (an unsampled bin keeps a positive width)
+        uint4 hv = reinterpret_cast<const uint4*>(zhist)[threadIdx.x];
+#pragma unroll
+        for (int x = 1; x < ZH_COPIES; x++) {      // (one copy per XCD)
+            const uint4 v = reinterpret_cast<const uint4*>(zhist)[x * (ZH_BINS / 4) + threadIdx.x];
+            hv.x += v.x; hv.y += v.y; hv.z += v.z; hv.w += v.w;
+        }
+        const uint32_t h0 = hv.x + 1u, h1 = hv.y + 1u, h2 = hv.z + 1u, h3 = hv.w + 1u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(h0 + h1 + h2 + h3, &tot);
+        s_C[4 * threadIdx.x] = ex; s_C[4 * threadIdx.x + 1] = ex + h0; s_C[4 * threadIdx.x + 2] = ex + h0 + h1; s_C[4 * threadIdx.x + 3] = ex + h0 + h1 + h2;
+        if (threadIdx.x == 255) s_C[ZH_BINS] = tot;
+        if (blockIdx.x == 0) {          // (uniform) what the host derives its next range hint from
+            const uint32_t any = hv.x | hv.y | hv.z | hv.w;
+            if (any) {
+                const uint32_t f = 4u * threadIdx.x + (hv.x ? 0u : hv.y ? 1u : hv.z ? 2u : 3u), l = 4u * threadIdx.x + (hv.w ? 3u : hv.z ? 2u : hv.y ? 1u : 0u);
+                atomicMin(&s_fl[0], f); atomicMax(&s_fl[1], l);
+            }
+        }
+    }
     const uint32_t csz = 1u << cshift;
     const uint32_t gy_tiles = zcut_used ? ntiles_img / gx_tiles : 0u, cgx = (gx_tiles + csz - 1u) >> cshift, cgy = (gy_tiles + csz - 1u) >> cshift;
     if (zcut_used && cshift != 1u) {        // larger cells (images beyond the 1080p class): plain loops
@@ -476,36 +502,28 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         }
     }
     __syncthreads();
-    {
-        // eight independent 16-byte loads per lane and round (a plain strided loop waits one memory round trip per element)
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        const uint4* zr = reinterpret_cast<const uint4*>(block_zrange);     // two blocks per load; the array is padded to an even count
-        const uint32_t n4 = (nzblk + 1) / 2;
-        for (uint32_t q0 = threadIdx.x; q0 < n4; q0 += 256 * 8) {
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t q = q0 + u * 256; v[u] = q < n4 ? zr[q] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u); }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { lo = min(lo, min(v[u].x, v[u].z)); hi = max(hi, max(v[u].y, v[u].w)); }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
-        if (lane == 0) { atomicMin(&s_mm[0], lo); atomicMax(&s_mm[1], hi); }
-    }
-    const uint32_t base = blockIdx.x * (256 * BK_ITEMS);
-    uint32_t key[BK_ITEMS];
-#pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) { const uint32_t i = base + r * 256 + threadIdx.x; key[r] = i < n ? keys[i] : 0xFFFFFFFFu; }
-    __syncthreads();
-    const float zmin = __uint_as_float(s_mm[0]), zmax = __uint_as_float(s_mm[1]);
-    const float scale = zmax > zmin ? (float)nb / (zmax - zmin) : 0.0f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { zparam[0] = zmin; zparam[1] = scale; }
+    const float scale = (float)nb / (float)s_C[ZH_BINS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zbins_out = s_fl[0] == 0xFFFFu ? 0xFFFFFFFFu : (s_fl[0] | (s_fl[1] << 16));
 
     uint32_t dg[BK_ITEMS], lr[BK_ITEMS];
 #pragma unroll
     for (int r = 0; r < BK_ITEMS; r++) {
         dg[r] = 0u; lr[r] = 0u;
-        if (key[r] != 0xFFFFFFFFu) { dg[r] = depth_bucket_of(key[r], zmin, scale, nb); lr[r] = atomicAdd(&cnt[dg[r]], 1u); }
+        if (key[r] != 0xFFFFFFFFu) {
+            // bucket = floor(nb * CDF(key)), the CDF linear inside a bin.  Monotone in the key: (bin, position) is, the conversion of the
+            // position, its scaling by a power of two, fma, product with a positive constant and truncation are, and a bin's largest
+            // value cannot exceed the next bin's start (c1 is representable: the rounded fma stays <= c1)
+            uint32_t bin, pos; int wlog;
+            zh_locate(key[r], zh_klo, zh_shift, bin, pos, wlog);
+            const float fscale = __uint_as_float((uint32_t)(127 - wlog) << 23);      // 2^-wlog
+            const uint32_t fr = pos;
+            const uint32_t c0 = s_C[bin], c1 = s_C[bin + 1u];
+            const float u = __builtin_fmaf((float)(c1 - c0), fminf((float)fr * fscale, 0.99999994f), (float)c0);
+            const uint32_t d = (uint32_t)(u * scale);
+            dg[r] = d < nb ? d : nb - 1u;
+            const uint32_t sh = (dg[r] & 1u) * 16u;
+            lr[r] = (atomicAdd(&cnt[dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        }
     }
     // what travels with the element: coalesced, requested here so that the loads pass under the atomics' round trip below
     uint2 rc[BK_ITEMS]; uint32_t tl[BK_ITEMS];
@@ -519,14 +537,24 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     // one returning global atomic per non-empty bucket of this workgroup, sixteen in flight per lane (issued back to back: a loop
     // that stores each result before it asks for the next waits a full memory round trip per bucket)
     uint32_t* gc = gcount + (size_t)xcd * nb;
-    for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 16) {
-        uint32_t c[16], g[16];
+    for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 16) {      // (a lane owns counter k: a wave's atomics go to 64 consecutive words)
+        uint32_t g[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const uint32_t k = k0 + u * 256; c[u] = k < nb ? cnt[k] : 0u; }
+        for (int u = 0; u < 16; u++) {
+            const uint32_t k = k0 + u * 256;
+            const uint32_t c = k < nb ? (cnt[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu : 0u;
+            g[u] = 0xFFFFFFFFu;                                     // "no element of this workgroup in the bucket"
+            if (c) g[u] = atomicAdd(&gc[k], c);
+        }
 #pragma unroll
-        for (int u = 0; u < 16; u++) { g[u] = 0u; if (c[u]) g[u] = atomicAdd(&gc[k0 + u * 256], c[u]); }
-#pragma unroll
-        for (int u = 0; u < 16; u++) { if (c[u]) cnt[k0 + u * 256] = g[u]; }
+        for (int u = 0; u < 16; u++) {
+            // the sub-slab's first free slot, saturated (a position past the sub-slab's end is never stored); the even lane writes the
+            // word for itself and its odd neighbour
+            const uint32_t mine = g[u] < 0xFFFFu ? g[u] : 0xFFFFu;
+            const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+            const uint32_t k = k0 + u * 256;
+            if (!(threadIdx.x & 1u) && k < nb) cnt[k >> 1] = mine | (other << 16);
+        }
     }
     __syncthreads();
     uint32_t nlate = 0;
@@ -551,7 +579,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                 }
                 if (late) { wword |= LATE_BIT; nlate++; }
             }
-            const uint32_t pos = cnt[dg[r]] + lr[r];
+            const uint32_t pos = ((cnt[dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + lr[r];
             if (pos < (uint32_t)BK_CAPX)
                 slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, wword, tl[r]);
             skipped = (wword & LATE_BIT) != 0u;
@@ -568,6 +596,21 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         if (lane == 0 && nlate) atomicAdd(&s_late, nlate);
         __syncthreads();
         if (threadIdx.x == 0 && s_late) atomicAdd(n_late_out, s_late);
+    }
+    {   // the map's inverse at the bucket boundaries, a few per workgroup: the key where the running sum reaches b * total / nb
+        const uint32_t per = (nb + gridDim.x) / gridDim.x;      // ceil((nb + 1) / gridDim.x)
+        const uint32_t b = blockIdx.x * per + threadIdx.x;
+        if (threadIdx.x < per && b <= nb) {
+            const float u = (float)b * ((float)s_C[ZH_BINS] / (float)nb);
+            uint32_t i = 0;
+#pragma unroll
+            for (uint32_t st = ZH_BINS / 2; st; st >>= 1) if ((float)s_C[i + st] <= u) i += st;       // largest bin whose start is <= u
+            const long long k0 = zh_bin_start(i, zh_klo, zh_shift), k1 = zh_bin_start(i + 1u, zh_klo, zh_shift);
+            const float c0 = (float)s_C[i], c1 = (float)s_C[i + 1u];
+            const float f = fminf(fmaxf((u - c0) / (c1 - c0), 0.0f), 1.0f);
+            const long long k = k0 + (long long)(f * (float)(k1 - k0));
+            bkey_out[b] = k < 0 ? 0u : (k < (long long)ZH_KEY_TOP ? (uint32_t)k : ZH_KEY_TOP);
+        }
     }
 }
 
@@ -590,15 +633,9 @@ __device__ __forceinline__ uint4 bucket_element(const uint4* __restrict__ slab, 
     for (int q = 1; q < BK_XCD; q++) { const bool ge = e >= start[q]; x += ge ? 1u : 0u; s0 = ge ? start[q] : s0; }
     return slab[((size_t)b * BK_XCD + x) * BK_CAPX + (e - s0)];
 }
-__device__ __forceinline__ uint32_t depth_sub_bucket(uint32_t key, float zmin, float scale, uint32_t b)
-{
-    const float t = (__uint_as_float(key) - zmin) * scale - (float)b;      // in [0, 1) except in the clamped last bucket
-    const uint32_t d = (uint32_t)(t * (float)BK_SUB);
-    return d < (uint32_t)BK_SUB ? d : (uint32_t)BK_SUB - 1u;
-}
-
 __global__ void __launch_bounds__(64 * BK_WAVES)
-depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb, const float* __restrict__ zparam,
+depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb,
+                         const uint32_t* __restrict__ bkey /* [nb + 1]: the buckets' key intervals (the scatter's bucket map, inverted) */,
                          uint32_t* __restrict__ border /* [nb][BK_CAP]: sorted Gaussian ids of each bucket */,
                          uint32_t* __restrict__ bwincl /* [nb][BK_CAP]: inclusive scan of their rectangle widths inside the bucket */,
                          uint4* __restrict__ binfo /* [nb]: {elements, column runs, tiles, overflow} */,
@@ -623,7 +660,15 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     uint32_t* aux = s_aux[wave];
     uint16_t* wid = s_wid[wave];
     uint32_t* cnt = s_cnt[wave];
-    const float zmin = zparam[0], scale = zparam[1];
+    // this bucket's key interval, cut into BK_SUB equal sub-intervals (an approximate interval is as good as the exact one: every
+    // position is clamped into the bucket, only monotonicity matters)
+    const uint32_t sub_lo = bkey[b], sub_hi = bkey[b + 1u];
+    const float sub_scale = (float)BK_SUB / (float)(sub_hi > sub_lo ? sub_hi - sub_lo : 1u);
+    auto sub_of = [&](uint32_t key) -> uint32_t {       // monotone in the key, clamped into [0, BK_SUB)
+        if (key <= sub_lo) return 0u;
+        const uint32_t d = (uint32_t)((float)(key - sub_lo) * sub_scale);
+        return d < (uint32_t)BK_SUB ? d : (uint32_t)BK_SUB - 1u;
+    };
     // the eight sub-slab counts: lanes 0-7 load, an 8-lane inclusive scan gives the sub-slabs' first positions in the bucket
     uint32_t c = lane < (unsigned)BK_XCD ? gcount[(size_t)lane * nb + b] : 0u;
     const uint32_t over = __ballot(c > (uint32_t)BK_CAPX) != 0ull ? 1u : 0u;
@@ -649,7 +694,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
             const uint32_t e = e0 + u * 64;
             if (e < n_all) {
                 tsum += kv[u].w; wall += kv[u].z & ~LATE_BIT;
-                if (!(early_only && (kv[u].z & LATE_BIT))) aux[e] = atomicAdd(&cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)], 1u);
+                if (!(early_only && (kv[u].z & LATE_BIT))) aux[e] = atomicAdd(&cnt[sub_of(kv[u].x)], 1u);
             }
         }
     }
@@ -675,7 +720,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
         for (int u = 0; u < 4; u++) {
             const uint32_t e = e0 + u * 64;
             if (e < n_all && !(early_only && (kv[u].z & LATE_BIT))) {
-                const uint32_t slot = cnt[depth_sub_bucket(kv[u].x, zmin, scale, b)] + aux[e];
+                const uint32_t slot = cnt[sub_of(kv[u].x)] + aux[e];
                 grp[slot] = ((unsigned long long)kv[u].x << 32) | kv[u].y;
                 wid[slot] = (uint16_t)(kv[u].z & ~LATE_BIT);
             }
@@ -685,7 +730,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     // 4. final position = start of the group + smaller composites inside it; the id goes out, the width into LDS at that position
     for (uint32_t e = lane; e < n; e += 64) {
         const unsigned long long me = grp[e];
-        const uint32_t d2 = depth_sub_bucket((uint32_t)(me >> 32), zmin, scale, b);
+        const uint32_t d2 = sub_of((uint32_t)(me >> 32));
         const uint32_t s0 = cnt[d2], s1 = cnt[d2 + 1];
         uint32_t r = 0;
         for (uint32_t q = s0; q < s1; q++) r += grp[q] < me ? 1u : 0u;
@@ -747,13 +792,13 @@ __device__ __forceinline__ void depth_bucket_totals(const uint4* __restrict__ bi
         scalars[SC_Q_EARLY] = q_early;
         scalars[SC_EARLY_COUNTS] = (uint32_t)s_t[0]; scalars[SC_EARLY_COUNTS + 1] = q_early; scalars[SC_EARLY_COUNTS + 2] = 0u; scalars[SC_EARLY_COUNTS + 3] = (uint32_t)(s_t[0] >> 32);
         if (host_out) {
-            // six self-validating 64-bit words {value, sequence number}, each ONE relaxed system-scope atomic store: no fence.  (A
+            // seven self-validating 64-bit words {value, sequence number}, each ONE relaxed system-scope atomic store: no fence.  (A
             // system-scope release in front of a flag word writes the L2's dirty lines back -- with the colour kernel dirtying lines
             // beside it this workgroup, and with it the whole kernel, lasted until that kernel was done: 35 -> 120 us at 3 M.)
             unsigned long long* h64 = reinterpret_cast<unsigned long long*>(host_out);
-            const uint32_t vals[6] = { (uint32_t)s_t[0], s_q[0], over, (uint32_t)(s_t[0] >> 32), q_early, n_late };
+            const uint32_t vals[7] = { (uint32_t)s_t[0], s_q[0], over, (uint32_t)(s_t[0] >> 32), q_early, n_late, scalars[SC_ZBINS] };
 #pragma unroll
-            for (int k = 0; k < 6; k++)
+            for (int k = 0; k < 7; k++)
                 __hip_atomic_store(h64 + k, ((unsigned long long)host_seq << 32) | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -887,12 +932,15 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                         // report both); pred: a launch of the predicated second binning (returns at once unless *pred != 0)
                         const uint4* __restrict__ binfo_all = nullptr, const uint32_t* __restrict__ pred = nullptr,
                         // ... whose workgroup `nbuckets` (one past the buckets) empties the work buckets the first pass filled and counts the event
-                        uint32_t* __restrict__ redo_bucket_cnt = nullptr, int n_redo_cnt = 0, HintTable* __restrict__ redo_hints = nullptr)
+                        uint32_t* __restrict__ redo_bucket_cnt = nullptr, int n_redo_cnt = 0, HintTable* __restrict__ redo_hints = nullptr,
+                        unsigned long long* __restrict__ host_fallback = nullptr, uint32_t host_fb_seq = 0 /* ... and tells the host (pinned word: the
+                                                              sequence number of the call that fell back): a context whose cuts keep failing pauses them */)
 {
     if (pred && *pred == 0u) return;
     if (redo_bucket_cnt && blockIdx.x == nbuckets) {
         for (int i = threadIdx.x; i < n_redo_cnt; i += blockDim.x) redo_bucket_cnt[i] = 0u;
         if (threadIdx.x == 0 && redo_hints) atomicAdd(&redo_hints->cut_fallbacks, 1u);
+        if (threadIdx.x == 0 && host_fallback) __hip_atomic_store(host_fallback, ((unsigned long long)host_fb_seq << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];

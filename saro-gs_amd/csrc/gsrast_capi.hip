@@ -83,11 +83,12 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 // ---- per-kernel device timing (option "profile") -------------------------------------------
 enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
-                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_CUT_REDO, K_COUNT };
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_CUT_REDO, K_LATE_ZERO, K_COUNT };
 const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
                                             "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
                                             "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color", "sh_dir_derivs",
-                                            "cut_redo" /* list cut: the predicated second binning + blend behind the forward blend, as ONE stage */ };
+                                            "cut_redo" /* list cut: the predicated second binning + blend behind the forward blend, as ONE stage */,
+                                            "late_rows_zero" /* list cut: the late Gaussians' zero rows, on the side stream beside the blend backward */ };
 thread_local int t_prof_off = 0;      // > 0: the stages below are part of an enclosing one (cut_redo) and not recorded on their own
 struct Pending { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -245,7 +246,13 @@ struct Readback {     // 64 pinned bytes + one event per (host thread, device); 
     uint32_t* pinned = nullptr; hipEvent_t ev = nullptr;   // thread_local would call into the HIP runtime at thread / process exit,
     uint32_t* dev_alias = nullptr;                         // possibly after the runtime itself has been torn down
     uint32_t seq = 0;       // dev_alias: the same 64 bytes as the device sees them (a kernel stores the counts there itself: read_flag_*)
+    uint32_t fb_seen = 0;   // list cut: sequence number of the last fallback this thread has taken note of (word RB_FALLBACK)
+    bool prepared = false;  // read_flag_prepare has run for the forward in progress (the pose-found word is waited for before the counts)
 };
+// 64-bit words of the pinned buffer (128 bytes): 0-6 the counts of depth_bucket_totals, then
+constexpr int RB_FOUND = 7;        // {1 = the pose had a slot in the context's table, sequence number}: preprocess_fwd, at its very start
+constexpr int RB_FALLBACK = 8;     // {1, sequence number of the call}: the predicated second binning of a list-cut forward has run
+constexpr size_t RB_BYTES = 128;
 constexpr int kMaxDevices = 32;
 thread_local Readback t_readback[kMaxDevices];     // one per (host thread, device): events belong to a device
 // begin: enqueue the copy + event; finish: spin until it landed.  Work enqueued between the two runs on the GPU while
@@ -258,10 +265,10 @@ int read_u32_begin(const uint32_t* dev, hipStream_t s, int nwords, Readback** ha
     if (device < 0 || device >= kMaxDevices) return GSRAST_OK;      // exotic topology: finish() does a blocking copy
     Readback& rb = t_readback[device];
     if (!rb.pinned) {
-        GS_HIP(hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable | hipHostMallocMapped));
+        GS_HIP(hipHostMalloc((void**)&rb.pinned, RB_BYTES, hipHostMallocPortable | hipHostMallocMapped));
         GS_HIP(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
         if (hipHostGetDevicePointer((void**)&rb.dev_alias, rb.pinned, 0) != hipSuccess) rb.dev_alias = nullptr;
-        rb.pinned[15] = 0u;
+        memset(rb.pinned, 0, RB_BYTES);
     }
     GS_HIP(hipMemcpyAsync(rb.pinned, dev, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost, s));
     GS_HIP(hipEventRecord(rb.ev, s));
@@ -291,25 +298,25 @@ Readback* read_flag_prepare(uint32_t** dev_alias, uint32_t* seq)
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return nullptr;
     Readback& rb = t_readback[device];
     if (!rb.pinned) {
-        if (hipHostMalloc((void**)&rb.pinned, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { rb.pinned = nullptr; return nullptr; }
+        if (hipHostMalloc((void**)&rb.pinned, RB_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { rb.pinned = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipHostGetDevicePointer((void**)&rb.dev_alias, rb.pinned, 0) != hipSuccess) rb.dev_alias = nullptr;
-        rb.pinned[15] = 0u;
+        memset(rb.pinned, 0, RB_BYTES);
     }
     if (!rb.dev_alias) return nullptr;
     rb.seq = rb.seq + 1u ? rb.seq + 1u : 1u;
-    for (int k = 0; k < 6; k++) reinterpret_cast<volatile unsigned long long*>(rb.pinned)[k] = 0ull;      // (no stale word may carry this number)
+    for (int k = 0; k <= RB_FOUND; k++) reinterpret_cast<volatile unsigned long long*>(rb.pinned)[k] = 0ull;      // (no stale word may carry this number)
     std::atomic_thread_fence(std::memory_order_seq_cst);
     *dev_alias = rb.dev_alias; *seq = rb.seq;
     return &rb;
 }
 int read_flag_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords)
 {
-    // six 64-bit words {value, sequence number} (depth_bucket_totals): each is valid as soon as its upper half carries this call's number
+    // seven 64-bit words {value, sequence number} (depth_bucket_totals): each is valid as soon as its upper half carries this call's number
     volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(rb->pinned);
     const auto t0 = std::chrono::steady_clock::now();
-    unsigned long long w[6];
-    for (int k = 0; k < 6; k++) {
+    unsigned long long w[7];
+    for (int k = 0; k < 7; k++) {
         for (uint64_t spins = 1; (uint32_t)((w[k] = p[k]) >> 32) != rb->seq; spins++) {
             if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
                 GS_HIP(hipStreamSynchronize(s));
@@ -321,8 +328,30 @@ int read_flag_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t*
     }
     for (int k = 0; k < nwords; k++) out[k] = 0u;
     out[0] = (uint32_t)w[0]; out[1] = (uint32_t)w[1]; out[3] = (uint32_t)w[3];       // {R low, Q, overflow verdict, R high}
-    if (nwords > 11) { out[11] = (uint32_t)w[2]; out[SC_Q_EARLY] = (uint32_t)w[4]; out[SC_N_LATE] = (uint32_t)w[5]; }     // (list cut: early column runs, late Gaussians)
+    if (nwords > 11) { out[11] = (uint32_t)w[2]; out[SC_Q_EARLY] = (uint32_t)w[4]; out[SC_N_LATE] = (uint32_t)w[5]; out[SC_ZBINS] = (uint32_t)w[6]; }     // (list cut: early column runs, late Gaussians; the depth histogram's occupied bins)
     return GSRAST_OK;
+}
+// the pose-found word of preprocess_fwd (RB_FOUND): 1 / 0, or 1 ("size the launches as for a known pose") if it does not arrive
+bool read_found(Readback* rb)
+{
+    volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(rb->pinned) + RB_FOUND;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long w;
+    for (uint64_t spins = 1; (uint32_t)((w = *p) >> 32) != rb->seq; spins++)
+        if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return true;
+    return (uint32_t)w != 0u;
+}
+// has the device reported a list-cut fallback this thread has not taken note of yet (RB_FALLBACK)?
+bool take_fallback_event()
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return false;
+    Readback& rb = t_readback[device];
+    if (!rb.pinned) return false;
+    const uint32_t sq = (uint32_t)(reinterpret_cast<volatile unsigned long long*>(rb.pinned)[RB_FALLBACK] >> 32);
+    if (sq == 0u || sq == rb.fb_seen) return false;
+    rb.fb_seen = sq;
+    return true;
 }
 int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 {
@@ -342,6 +371,13 @@ struct gsrast_context {
     std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0}, last_late{0}, last_Qe{0};
     std::atomic<uint32_t> Qe_hint{0};  // list cut: column runs of the early Gaussians in recent forwards (sizes the launches over the cut lists)
     std::atomic<int> cut_pause{0};     // list cut: > 0 = a recent cut forward saved too few column runs to pay for itself; that many forwards go without
+    std::atomic<uint32_t> cut_pause_P{0};   // ... in a scene of this many Gaussians (another scene: the pause is void)
+    // ... or its cut lists keep turning out too short (a scene that changes between two visits of a pose: SaRO-GS's time-varying
+    // opacity): every fallback costs a whole second forward and is reported by the device (RB_FALLBACK); two in close succession pause
+    // the cut, for twice as long each time (32 ... 1024 forwards), 64 cut forwards without one forget
+    std::atomic<int> cut_fb_score{0}, cut_fb_pause{0}, cut_ok_streak{0};
+    // equalised depth buckets (gsrast_common.h): the key range the depth histogram's bins cover, learned from the previous forwards
+    std::atomic<uint32_t> zh_klo{ZH_KLO_DEFAULT}; std::atomic<int> zh_shift{ZH_SHIFT_DEFAULT};
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
@@ -567,6 +603,7 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
     if (!strcmp(name, "last_late")) return (int)c->last_late.load();
     if (!strcmp(name, "last_early_runs")) return (int)c->last_Qe.load();
+    if (!strcmp(name, "cut_pause")) return c->cut_pause.load();      // forwards the list cut still sits out (too little saved, or its lists kept failing)
     if (!strcmp(name, "cut_fallbacks")) {       // a device counter in the hint table of the current device (diagnostic: waits for the device)
         int device = 0;
         if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32 || !c->hints[device].table) return 0;
@@ -764,6 +801,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // says radix sort
     const bool bucket_sort = runbin && o.depth_sort == 0 && (size_t)P >= BUCKET_SORT_MIN_P && ctx->bucket_skip.load() == 0;
     const uint32_t nbk = depth_buckets_host((size_t)P);
+    // equalised depth buckets: the histogram's bins (range hint of this context) and which waves of preprocess_fwd are sampled (512-1024 of them)
+    const uint32_t zh_klo = ctx->zh_klo.load(); const int zh_shift = ctx->zh_shift.load();
+    uint32_t zh_wave_mask = 0u;
+    while ((((size_t)P + 63) / 64) / ((size_t)zh_wave_mask + 1) > 1024) zh_wave_mask = 2u * zh_wave_mask + 1u;
     // Colour half of the per-Gaussian forward (SH -> RGB: most of its bytes) on the context's side stream, forked off the
     // caller's stream here and joined in front of the blend: it overlaps the geometry kernel, the depth sort and the binning.
     SideStream* side = nullptr;
@@ -784,6 +825,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // runs, and paused for CUT_PAUSE forwards whenever a cut forward removed fewer than that (a surface-like scene; measured
     // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
     constexpr uint32_t CUT_MIN_RUNS = 1500000u; constexpr int CUT_PAUSE = 64;
+    {   // (a pause belongs to the scene that earned it: a context that moves on to a scene of another size starts afresh)
+        const uint32_t pp = ctx->cut_pause_P.load();
+        if (ctx->cut_pause.load() > 0 && (pp > (uint32_t)P ? pp - (uint32_t)P : (uint32_t)P - pp) > pp / 8) ctx->cut_pause = 0;
+    }
     const bool cut_pays = g_list_cut_always.load() != 0 || (ctx->last_Q.load() >= CUT_MIN_RUNS && ctx->cut_pause.load() == 0);
     const int cut_cs = cut_cell_shift((size_t)cam.gx, (size_t)cam.gy);
     const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
@@ -856,23 +901,31 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         }
         return GSRAST_OK;
     };
+    // list cut: the device says at once whether the pose has a slot in the table (RB_FOUND); the launches over the cut lists of a pose
+    // that has none -- everything is early -- are sized for all column runs, not for the early runs of recent forwards (a launch
+    // that turned out too small cost a first-seen pose a whole second forward: 1.35 instead of 1.05 ms forward-only at 3 M)
+    Readback* rb_pre = nullptr; uint32_t* pre_alias = nullptr; uint32_t pre_seq = 0;
+    if (cut) rb_pre = read_flag_prepare(&pre_alias, &pre_seq);
+    unsigned long long* host_found = rb_pre ? reinterpret_cast<unsigned long long*>(pre_alias) + RB_FOUND : nullptr;
     {
         ProfScope ps(K_PREPROCESS_FWD, s);
         const int pf_grid = (P + PF_THREADS - 1) / PF_THREADS;
         float* cov_dbg = g_debug_state.load() ? at<float>(geom, GL.cov3D) : nullptr;     // 24 B / Gaussian nobody but gsrast_debug_export reads
         const int clip = (runbin && o.tile_clip) ? 1 : 0;
-        uint32_t* zr = bucket_sort ? at<uint32_t>(geom, GL.zrange) : nullptr;
+        // equalised depth buckets (gsrast_common.h): the sampled depth histogram, zeroed in front of the kernel that fills it
+        uint32_t* zr = bucket_sort ? at<uint32_t>(geom, GL.zhist) : nullptr;
+        if (zr) GS_HIP(hipMemsetAsync(zr, 0, ZH_COPIES * ZH_BINS * sizeof(uint32_t), s));
         const int nzero = bucket_sort ? (int)nbk * BK_XCD : 0;
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars);
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
+                zcut_used, T, scalars, host_found, pre_seq);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars);
+                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
+                zcut_used, T, scalars, host_found, pre_seq);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -886,16 +939,16 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             uint32_t* gcount = at<uint32_t>(geom, GL.bk_count);
             uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
-                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zrange), (uint32_t)((P + PF_THREADS - 1) / PF_THREADS), nbk, gcount, slab, at<float>(geom, GL.bk_param),
+                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zhist), zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
                                                                                                          zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
                                                                                                          cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs);
                 GS_LAUNCHED("depth_bucket_scatter");
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)
                 // list cut: only the bucket's EARLY Gaussians are sorted (into the early set); the late ones count into bk_info's totals
-                if (cut) depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e),
+                if (cut) depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e),
                                                                                                             at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), at<uint4>(geom, GL.bk_info));
-                else depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl),
+                else depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl),
                                                                                                         at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
                 GS_LAUNCHED("depth_bucket_sort"); }
             totals_pending = true;      // by the run emission's last workgroup, or by launch_bucket_totals() if the host needs them first
@@ -976,14 +1029,15 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                                                             flag_alias, flag_seq, at<uint4>(geom, GL.bk_info));
             else if (bucketed && mode == 2) {
                 // (the first pass sorted the early Gaussians only: the buckets are sorted again, whole)
-                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order),
+                depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order),
                                                                                                    at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nullptr, pred);
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, nullptr,
-                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), (XCD_GROUPS + 1) * WORK_BUCKETS, hints); }
+                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), (XCD_GROUPS + 1) * WORK_BUCKETS, hints,
+                                                            rb_pre ? reinterpret_cast<unsigned long long*>(pre_alias) + RB_FALLBACK : nullptr, pre_seq); }
             else if (bucketed) {
                 if (cut) {      // (a list-cut forward sorted the early Gaussians only, and now everything is listed after all: the buckets are sorted again, whole)
-                    depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<float>(geom, GL.bk_param), at<uint32_t>(geom, GL.bk_order),
+                    depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order),
                                                                                                        at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
                     GS_LAUNCHED("depth_bucket_sort");
                 }
@@ -1068,15 +1122,43 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // out not to fit, the device published empty ranges and the two pieces are simply launched again with exact sizes.
     if (speculative) {
         const bool late = totals_pending;
-        if (late) rb_flag = read_flag_prepare(&flag_alias, &flag_seq);
+        if (late) { if (rb_pre) { rb_flag = rb_pre; flag_alias = pre_alias; flag_seq = pre_seq; } else rb_flag = read_flag_prepare(&flag_alias, &flag_seq); }
+        const bool pose_known = !(cut && rb_pre) || read_found(rb_pre);
         // (list cut: the sorts over the cut lists are sized for the early runs of recent forwards, not for all runs)
-        if (cut) { const uint32_t qe = ctx->Qe_hint.load(); nQ1 = qe ? std::min(capQ, grow(qe)) : capQ; }
+        // (the early set differs from pose to pose -- 0.98 M / 1.29 M column runs at two neighbouring poses of the 3 M cube --, a launch
+        // sized too small costs a whole second forward, one sized too large a few empty workgroups: half again as much as the largest of
+        // the recent forwards)
+        if (cut) { const uint32_t qe = ctx->Qe_hint.load(); nQ1 = (qe && pose_known) ? std::min<uint64_t>(capQ, (uint64_t)qe + qe / 2 + 4096) : capQ; }
         int rc = launch_run_binning(bin, cap, capQ, cut ? nQ1 : capQ, cut ? scalars + SC_EARLY_COUNTS : scalars, (late && !rb_flag) ? std::function<int()>(begin_readback) : std::function<int()>(), cut ? 1 : 0);
         flag_alias = nullptr;                    // (a repeated emission below reads its counts back the ordinary way)
         if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, cut ? 1 : 0);
         if (rc != GSRAST_OK) return rc;
     }
     { int rc = rb_flag ? read_flag_finish(rb_flag, scalars, s, counts, 12) : read_u32_finish(rb, scalars, s, counts, 12); if (rc != GSRAST_OK) return rc; }
+    // equalised depth buckets: the MIDDLE of the next forward's histogram (448-895 bins) covers this one's occupied key range, padded by
+    // an eighth on either side (the tails beyond take a view a whole range away); it widens at once and narrows slowly (consecutive
+    // forwards render different views).  Returns whether this call's table was a learned one that held every key.
+    auto learn_depth_range = [&](uint32_t zb) -> bool {
+        if (zb == 0xFFFFFFFFu) return true;
+        const uint32_t first = zb & 0xFFFFu, last = zb >> 16;
+        const long long top = ZH_KEY_TOP, bot = ZH_KLO_DEFAULT;
+        long long kmin = std::max(zh_bin_start(first, zh_klo, zh_shift), bot), kmax = std::min(zh_bin_start(last + 1u, zh_klo, zh_shift), top);
+        if (kmax <= kmin) kmax = kmin + 1;
+        const long long span = kmax - kmin;
+        const bool coarse = zh_shift == ZH_SHIFT_DEFAULT && zh_klo == ZH_KLO_DEFAULT;
+        const bool clipped = first == 0u || last >= (uint32_t)ZH_BINS - 1u;          // keys may lie beyond the table's tails
+        const long long pad_lo = first == 0u ? 4 * span : span / 8 + 1, pad_hi = last >= (uint32_t)ZH_BINS - 1u ? 4 * span : span / 8 + 1;
+        long long lo = std::max(kmin - pad_lo, bot), hi = std::min(kmax + pad_hi, top);
+        if (!coarse) {      // (the middle of the previous table)
+            const long long plo = zh_klo, phi = (long long)zh_klo + ((long long)ZH_MID << zh_shift);
+            lo = lo < plo ? lo : plo + (lo - plo) / 8;
+            hi = hi > phi ? hi : phi - (phi - hi) / 8;
+        }
+        int sh = 0;
+        while (((hi - lo) >> sh) >= (long long)ZH_MID) sh++;
+        ctx->zh_klo = (uint32_t)lo; ctx->zh_shift = sh;
+        return !coarse && !clipped;
+    };
     bool sort_redone = false;
     if (!bucket_sort && o.depth_sort == 0) dec_to_zero(ctx->bucket_skip);
     if (bucket_sort) {
@@ -1086,6 +1168,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             ctx->redo_count++;      // start with those for a while (everything enqueued so far used a wrong order, as below)
             // exponential back-off: 16 radix forwards after the first overflow, twice as many after each further one (a scene whose
             // depths pile up for good pays the discarded speculative launch ever more rarely), capped at 4096
+            // ... unless the histogram behind the bucket map was not up to this view (a context's first forward: four bins per octave;
+            // a depth range that has moved out of the table): the range is learned from this call, the next forward tries again at once
+            if (learn_depth_range(counts[SC_ZBINS]))
             { const int prev = ctx->bucket_backoff.load(); const int next = prev <= 0 ? 16 : (prev >= 2048 ? 4096 : prev * 2);
               ctx->bucket_backoff = next; ctx->bucket_skip = next; }
             ctx->depth_short = 0;   // the radix path's pass-count hint is stale (not refreshed on the bucket path): assume four passes
@@ -1107,19 +1192,32 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     }
     if (runbin && counts[3] != 0) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     auto t2 = std::chrono::steady_clock::now();
-    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u%s\n",
+    if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u%s | cut %d (pays %d: last_Q %u pause %d) late %u Q_early %u nQ1 %u capQ %u bucket_sort %d (over %u) hints %d zh %08x >> %d bins %u-%u\n",
                        std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, counts[0], counts[1],
-                       speculative ? " (speculative)" : "");
+                       speculative ? " (speculative)" : "", (int)cut, (int)cut_pays, ctx->last_Q.load(), ctx->cut_pause.load(), counts[SC_N_LATE], counts[SC_Q_EARLY], nQ1, capQ,
+                       (int)bucket_sort, counts[11], hints ? 1 : 0, zh_klo, zh_shift, counts[SC_ZBINS] & 0xFFFFu, counts[SC_ZBINS] >> 16);
     if (counts[0] > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     const uint32_t R = counts[0], Q = counts[1];
+    if (bucket_sort && !sort_redone) (void)learn_depth_range(counts[SC_ZBINS]);
     // capacity hints decay slowly: consecutive calls render different views, a buffer sized for the largest recent one
     // keeps the speculative launch valid
     { const uint32_t hr = ctx->R_hint.load(), hq = ctx->Q_hint.load();
       ctx->R_hint = R > hr - hr / 16 ? R : hr - hr / 16; ctx->Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
     ctx->last_R = R; ctx->last_Q = Q;
     ctx->last_late = cut ? counts[SC_N_LATE] : 0u; ctx->last_Qe = cut ? counts[SC_Q_EARLY] : counts[1];
-    if (cut && counts[SC_N_LATE] != 0u && counts[1] - counts[SC_Q_EARLY] < CUT_MIN_RUNS && !g_list_cut_always.load()) ctx->cut_pause = CUT_PAUSE;
-    if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 16 ? qe : hq - hq / 16; }
+    if (cut && counts[SC_N_LATE] != 0u && counts[1] - counts[SC_Q_EARLY] < CUT_MIN_RUNS && !g_list_cut_always.load()) { ctx->cut_pause = CUT_PAUSE; ctx->cut_pause_P = (uint32_t)P; }
+    if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 32 ? qe : hq - hq / 32; }
+    // fallbacks of this thread's earlier cut forwards, as the device reported them (everything enqueued before this forward's counts has run)
+    if (take_fallback_event()) {
+        ctx->cut_ok_streak = 0;
+        if ((ctx->cut_fb_score += 8) >= 16 && !g_list_cut_always.load()) {
+            const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 32 : (prev >= 512 ? 1024 : prev * 2);
+            ctx->cut_fb_pause = len; ctx->cut_pause = len; ctx->cut_pause_P = (uint32_t)P; ctx->cut_fb_score = 0;
+        }
+    } else if (cut && counts[SC_N_LATE] != 0u) {
+        if (ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
+        if (++ctx->cut_ok_streak >= 64) ctx->cut_fb_pause = 0;
+    }
     const bool early_fits = !cut || counts[SC_Q_EARLY] <= nQ1;
     if (speculative && !sort_redone && R <= cap && Q <= capQ && early_fits) {          // everything is already in flight
         if (cut && counts[SC_N_LATE] != 0u) {
@@ -1641,7 +1739,8 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
             if (rawin) { add(rawg.d_rot_res, 7); add(rawg.d_trbf, 1); add(rawg.d_shs_res, M * 3); add(rawg.d_dc, 3); add(rawg.d_rest, M * 3 - 3); }
             else if (use_sh && !o.sh_grad_factors) add(dL_dsh, M * 3);
             la.n = n;
-            late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la);
+            {   ProfScope ps(K_LATE_ZERO, side->stream);
+                late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la); }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
             GS_HIP(hipEventRecord(side->join, side->stream));

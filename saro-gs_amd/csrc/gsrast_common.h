@@ -32,15 +32,16 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   shdA/B   float4[P] x2, shdC f32[P]   d(colour)/d(view direction) {dx[3], dy[3], dz[3]}, 36 B: written by the forward's colour kernel
 //                        while the SH block is in LDS (round 3; sh_dir_derivs_kernel in the backward for a forward_only state), so that the
 //                        per-Gaussian backward reads 36 B instead of 12*M
-//   zrange   u32[2 ceil(P/256)]  per-block minimum / maximum depth key (preprocess_fwd); the bucket depth sort (gsrast_binning.h, NB ~ P/256
-//                        buckets of CAP slots): bk_count u32[8][NB], bk_slab uint4[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
+//   zhist    u32[8][ZH_BINS]  sampled histogram (one copy per XCD) of the visible depth keys (preprocess_fwd; zeroed by a memset in front of it):
+//                        the bucket depth sort (gsrast_binning.h, NB ~ P/256 buckets of CAP slots) cuts the depth axis into
+//                        buckets of EQUAL POPULATION by it; bk_count u32[8][NB], bk_slab uint4[NB][8][CAP/8] (arrival order), bk_order / bk_wincl
 //                        u32[NB][CAP] (sorted ids, inclusive width scan inside the bucket), bk_info uint4[NB], bk_base u32[NB] (compact column-run totals)
 //   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
 struct GeomLayout {
     size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zrange, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base, bk_param,
+        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zhist, bk_key, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base,
         bk_order_e, bk_wincl_e, bk_info_e, bk_base_e /* the same four over the EARLY Gaussians only, compact (list cut, below) */,
         color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */, total;
 };
@@ -52,6 +53,52 @@ constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is 
 #ifndef GSRAST_BK_CAP
 #define GSRAST_BK_CAP 1024        // slots per bucket
 #endif
+// Equalised depth buckets (round 4).  Buckets of equal DEPTH width overflow as soon as the depth distribution has a peak (the bench cube
+// seen along a diagonal at 3 M: a triangular density, 2 x the mean in the middle -- 366 Gaussians per bucket on average, 128 slots per
+// (bucket, XCD) sub-slab; a trained scene's walls and floors are worse): the forward then fell back to the radix passes, with an
+// exponential back-off, and lost the list cut with them.  preprocess_fwd therefore also leaves a SAMPLED HISTOGRAM of the visible depth
+// keys (ZH_BINS bins over a key range the context expects from its previous forwards, below -- positive floats order
+// like their bits, so a bin is an interval of log-depth; ~130 k sampled Gaussians, one fire-and-forget atomic each), and the scatter
+// maps a key through the histogram's running sum, linearly inside a bin: bucket = floor(nb * CDF(key)) -- monotone in the key whatever
+// the histogram holds (a stale range or a torn count is only a poorer balance; an overflow still takes the radix path), equal
+// population per bucket when it is right.
+constexpr int ZH_BINS = 1024, ZH_COPIES = 8 /* one histogram per XCD (workgroup b runs on XCD b mod 8): same-address atomics from eight L2s serialise at the memory side -- 187 k of them on ~300 bins of ONE table cost the geometry kernel 65 us */;
+// The table's bins: ZH_MID bins of 2^shift key steps from kmid -- the range the context expects --, and ZH_TAIL bins of sixteen times
+// that width on either side, so that a view whose depth range lies a whole range away from the expected one still spreads over
+// bins (a key beyond the tails is clamped into the end bin: many of those pile up in one bucket).
+constexpr int ZH_TAIL = 64, ZH_MID = ZH_BINS - 2 * ZH_TAIL, ZH_TAIL_LOG = 4;
+constexpr uint32_t ZH_KLO_DEFAULT = 0x3E400000u;   // just below the bits of 0.2f (a visible Gaussian has z > 0.2, auxiliary.h:154)
+constexpr int ZH_SHIFT_DEFAULT = 21;              // 896 bins of 2^21 key steps (4 per octave) reach past every finite float: the first forward of a context
+constexpr uint32_t ZH_KEY_TOP = 0x7F800000u;      // no finite positive float lies above
+// bin of a key, its position inside the bin and log2 of the bin's width -- monotone in the key: (bin, pos) increases lexicographically
+// (32-bit arithmetic throughout: keys and kmid are below 2^31, shift <= ZH_SHIFT_DEFAULT, so ZH_MID << shift < 2^31 and the tails'
+// bin width 2^(shift + 4) <= 2^25)
+__host__ __device__ inline void zh_locate(uint32_t key, uint32_t kmid, int shift, uint32_t& bin, uint32_t& pos, int& wlog)
+{
+    const int d = (int)key - (int)kmid;
+    const int wt = shift + ZH_TAIL_LOG;
+    if (d < 0) {
+        wlog = wt;
+        const uint32_t m = (uint32_t)(-d - 1), t = m >> wt, w1 = (1u << wt) - 1u;
+        if (t >= (uint32_t)ZH_TAIL) { bin = 0u; pos = 0u; }
+        else { bin = (uint32_t)(ZH_TAIL - 1) - t; pos = w1 - (m & w1); }
+    } else if (((uint32_t)d >> shift) < (uint32_t)ZH_MID) {
+        wlog = shift;
+        bin = (uint32_t)ZH_TAIL + ((uint32_t)d >> shift); pos = (uint32_t)d & ((1u << shift) - 1u);
+    } else {
+        wlog = wt;
+        const uint32_t e = (uint32_t)d - ((uint32_t)ZH_MID << shift), t = e >> wt, w1 = (1u << wt) - 1u;
+        if (t >= (uint32_t)ZH_TAIL) { bin = (uint32_t)ZH_BINS - 1u; pos = w1; }
+        else { bin = (uint32_t)(ZH_TAIL + ZH_MID) + t; pos = e & w1; }
+    }
+}
+// first key of a bin (bin == ZH_BINS: one past the table), as a signed 64-bit number: the low tail may reach below zero
+__host__ __device__ inline long long zh_bin_start(uint32_t bin, uint32_t kmid, int shift)
+{
+    if (bin < (uint32_t)ZH_TAIL) return (long long)kmid - ((long long)((uint32_t)ZH_TAIL - bin) << (shift + ZH_TAIL_LOG));
+    if (bin < (uint32_t)(ZH_TAIL + ZH_MID)) return (long long)kmid + ((long long)(bin - (uint32_t)ZH_TAIL) << shift);
+    return (long long)kmid + ((long long)ZH_MID << shift) + ((long long)(bin - (uint32_t)(ZH_TAIL + ZH_MID)) << (shift + ZH_TAIL_LOG));
+}
 static inline uint32_t depth_buckets_host(size_t P)     // buckets of the depth sort: ~P / 256, a power of two in [256, 8192] (gsrast_binning.h)
 {
     uint32_t nb = 256;
@@ -135,6 +182,7 @@ static inline int cut_cell_shift(size_t gx, size_t gy)      // 1, 2, 3, or 0 = n
 }
 constexpr uint32_t LATE_BIT = 0x80000000u;      // in the width word of a bucket-slab element
 // words of GeomLayout::scalars used by the list cut
+constexpr int SC_ZBINS = 7 /* first | last << 16 occupied bin of the sampled depth histogram (0xFFFFFFFF: no sample) */;
 constexpr int SC_Q_EARLY = 4, SC_N_LATE = 5, SC_UNDONE = 6, SC_EARLY_COUNTS = 20 /* {R lo, Q early, -, R hi} */, SC_REDO_PRED = SC_UNDONE /* the predicate of the second binning + blend: some tile's cut list was too short */;
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
@@ -180,14 +228,14 @@ static inline GeomLayout geom_layout(size_t P)
     L.keyC = take(Pp * 4); L.valC = take(Pp * 4);                               // third buffer pair of the adaptive depth sort
     L.sort_minmax = take(2 * rs_blocks_n(Pp, GSRAST_DEPTH_ITEMS) * 4);
     L.shdA = take(Pp * 16); L.shdB = take(Pp * 16); L.shdC = take(Pp * 4);
-    // bucket depth sort (gsrast_binning.h): per-block depth ranges of preprocess_fwd (256 Gaussians per block), bucket counters, slabs
-    L.zrange = take(((Pp + 255) / 256 + 1) * 8);
+    // bucket depth sort (gsrast_binning.h): sampled depth histogram of preprocess_fwd and its running sum, bucket counters, slabs
+    L.zhist = take(ZH_COPIES * ZH_BINS * 4);
     {
         const size_t nb = Pp >= BUCKET_SORT_MIN_P ? depth_buckets_host(Pp) : 0;
         L.bk_count = take(nb * 8 * 4);                       // [8 XCDs][nb]
         L.bk_slab = take(nb * GSRAST_BK_CAP * 16);           // [nb][8][CAP / 8] {key, id, width, tiles}
         L.bk_order = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl = take(nb * GSRAST_BK_CAP * 4);
-        L.bk_info = take(nb * 16); L.bk_base = take(nb * 4); L.bk_param = take(16);
+        L.bk_info = take(nb * 16); L.bk_base = take(nb * 4); L.bk_key = take((nb + 1) * 4);
         L.bk_order_e = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl_e = take(nb * GSRAST_BK_CAP * 4); L.bk_info_e = take(nb * 16); L.bk_base_e = take(nb * 4);
     }
     L.color_skip = take(((Pp + 63) / 64) * 8 + 256);

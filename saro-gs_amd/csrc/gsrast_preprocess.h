@@ -662,13 +662,16 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       uint32_t* __restrict__ sort_key, uint32_t* __restrict__ sort_val /* or null */,
                       int clip_rect /* run-compressed binning with tile_clip: rect / binrec get the clipped rectangle */,
                       uint32_t* __restrict__ bucket_cnt /* [8 + 1][64] work-bucket counters of this call: zeroed here */,
-                      uint32_t* __restrict__ block_zrange /* [gridDim.x][2] or null: minimum / maximum depth key of this block's visible
-                                                             Gaussians, for the bucket depth sort (gsrast_binning.h); {~0, 0} if it has none */,
+                      uint32_t* __restrict__ zhist /* [ZH_COPIES][ZH_BINS] or null: sampled histogram of the visible depth keys, for the bucket depth sort
+                                                      (gsrast_common.h: equalised buckets; zeroed by a memset in front of this kernel) */,
+                      uint32_t zh_klo /* kmid */, int zh_shift, uint32_t zh_wave_mask /* wave w of the grid is sampled iff (hash(w) & mask) == 0 */,
                       uint32_t* __restrict__ zero_words, int n_zero_words /* that sort's counters: zeroed here, spread over the blocks */,
                       HintTable* __restrict__ hints /* or null: the context's launch-order hints of the forward blend (gsrast_common.h) */,
                       uint32_t* __restrict__ hint_sel /* [2]: this call's slot and whether it held this pose already */,
                       uint32_t* __restrict__ zcut_used /* or null; [ntiles_img]: this call's snapshot of the pose's cut depths (list cut, gsrast_common.h) */,
-                      uint32_t ntiles_img, uint32_t* __restrict__ cut_scalars /* or null: GeomLayout::scalars, whose `undone` counter is zeroed here */)
+                      uint32_t ntiles_img, uint32_t* __restrict__ cut_scalars /* or null: GeomLayout::scalars, whose `undone` counter is zeroed here */,
+                      unsigned long long* __restrict__ host_found = nullptr, uint32_t host_seq = 0 /* pinned host word: {this pose was in the table, the
+                                                             call's sequence number} -- the host sizes the launches over the cut lists by it */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
     if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; }      // (always: the backward reads them)
@@ -703,6 +706,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
             if (slot < 0) { slot = (int)(uint32_t)(s_lru & 0xFFFFFFFFull); hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
             hints->stamp[slot] = now; hints->clock = now;
             hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
+            if (host_found) __hip_atomic_store(host_found, ((unsigned long long)host_seq << 32) | (unsigned long long)found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (snap) {
             const int slot = s_slot;
@@ -820,21 +824,12 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     sort_key[i] = key;
     if (sort_val) sort_val[i] = (uint32_t)i;        // the radix depth sort's values; the bucket sort carries the index in its slab element
     } // i < P
-    if (block_zrange) {     // depth range of the block's visible Gaussians (positive floats order like their bits; culled: key = ~0)
-        __shared__ uint32_t s_lo[PF_THREADS / 64], s_hi[PF_THREADS / 64];
-        uint32_t lo = key, hi = key == 0xFFFFFFFFu ? 0u : key;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
-        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t blo = s_lo[0], bhi = s_hi[0];
-#pragma unroll
-            for (int w = 1; w < PF_THREADS / 64; w++) { blo = min(blo, s_lo[w]); bhi = max(bhi, s_hi[w]); }
-            block_zrange[2 * blockIdx.x] = blo;
-            block_zrange[2 * blockIdx.x + 1] = bhi;
-            if (blockIdx.x == gridDim.x - 1 && (gridDim.x & 1u)) { block_zrange[2 * gridDim.x] = 0xFFFFFFFFu; block_zrange[2 * gridDim.x + 1] = 0u; }   // read in pairs
-        }
+    // equalised depth buckets: every sampled wave's visible Gaussians count into the depth histogram (one fire-and-forget atomic each,
+    // ~65 k per launch, into the workgroup's XCD's own copy; the scatter turns the histogram into its bucket map -- any histogram gives a correct order)
+    if (zhist && key != 0xFFFFFFFFu && ((((uint32_t)i >> 6) * 0x9E3779B1u >> 12) & zh_wave_mask) == 0u) {       // (a pseudo-random subset of the waves: every XCD's copy gets its share)
+        uint32_t bin, pos; int wlog;
+        zh_locate(key, zh_klo, zh_shift, bin, pos, wlog);
+        atomicAdd(&zhist[(blockIdx.x & (unsigned)(ZH_COPIES - 1)) * (unsigned)ZH_BINS + bin], 1u);
     }
 }
 

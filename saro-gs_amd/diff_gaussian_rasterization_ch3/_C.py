@@ -620,7 +620,7 @@ def get_option(name: str) -> int:
 
 def context_query(name: str) -> int:
     """gsrast_context_query on the calling thread's context (include/gsrast.h): "last_instances", "last_runs", "redo_count",
-    "bucket_skip", "last_late", "cut_fallbacks"."""
+    "bucket_skip", "last_late", "last_early_runs", "cut_pause", "cut_fallbacks"."""
     v = int(lib().gsrast_context_query(None, name.encode()))
     if v < 0:
         raise ValueError(f"gsrast: unknown context query: {name}")

@@ -304,7 +304,8 @@ def test_depth_sort_pass_hint_follows_the_scene(orc, scenes, rast, gpu):
 
 
 def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu):
-    """The default depth sort puts the Gaussians into ~P/256 depth buckets of fixed capacity.  A scene whose depths pile up -- here
+    """The default depth sort puts the Gaussians into ~P/256 depth buckets of fixed capacity (of equal population by a sampled depth
+    histogram, round 4).  A scene whose depths pile up beyond any histogram's resolution -- here
     three thin sheets facing the camera, 20 000 Gaussians at (nearly) one depth each -- overflows a bucket: the device reports it
     with the instance counts, the forward repeats the sort with the radix passes (one redo) and the context goes straight to
     those for its next calls.  Every forward equals the oracle entry by entry; equal depths fall in index order."""
@@ -334,9 +335,13 @@ def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu):
             np.testing.assert_array_equal(h["ranges"], o32["ranges"])
             np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
             if step == 0:
-                assert _C.get_option("redo_count") - redo0 == 1, "the first forward must have re-sorted"
+                # (round 4: the context's first overflow under a depth histogram that was not made for this view -- a fresh context's
+                # coarse one, or another scene's range -- only re-learns the range; the second forward's fine histogram cannot pull
+                # 20 000 equal keys apart either, and THAT starts the pause)
+                redos = _C.get_option("redo_count") - redo0
+                assert redos in (1, 2), "the first forward must have re-sorted"
                 assert _C.get_option("bucket_skip") > 0
-        assert _C.get_option("redo_count") - redo0 == 1, "later forwards start with the radix sort"
+        assert _C.get_option("redo_count") - redo0 == redos, "later forwards start with the radix sort"
     finally:
         # let the context forget: an ordinary scene, until the bucket sort is tried (and kept) again
         sc2 = scenes.synth(P, 10)
@@ -413,3 +418,130 @@ def test_bucket_depth_sort_with_an_undersized_speculative_launch(orc, scenes, ra
                 np.testing.assert_array_equal(h["ranges"], o32["ranges"])
             np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
     assert _C.get_option("redo_count") - redo0 >= 1 and _C.get_option("bucket_skip") == 0
+
+
+def test_bucket_depth_sort_equalises_a_peaked_depth_distribution(orc, scenes, rast, gpu):
+    """Round 4: the depth buckets are cut by a sampled depth histogram (equal population), not into equal depth intervals.  A scene
+    with 70 % of its Gaussians in a layer 0.06 deep (a wall facing the camera, normal depth profile, sigma 0.03 of a depth range of
+    3.3) put ten times a bucket's capacity into a few equal-width buckets (10 000 in one of 512); now the first forward of the
+    context may still fall back (its histogram has four bins per octave), the following ones -- also from other poses, and after
+    the wall has moved -- keep the bucket sort (no redo, no pause) and equal the oracle entry by entry.  (What the histogram cannot
+    resolve is a DISCONTINUITY of the density inside one of its bins -- a hard-edged slab: the radix path takes that)"""
+    from gpu_harness import run_hip
+    P, W, H = 120_000, 480, 360
+    sc = scenes.synth(P, 41)
+    cam0 = scenes.camera(0, 6, W, H)
+    V = np.asarray(cam0["viewmatrix"], dtype=np.float64).reshape(4, 4)
+    axis = V[:3, 2] / np.linalg.norm(V[:3, 2])
+    rng = np.random.default_rng(42)
+    m = sc["means3D"].astype(np.float64)
+    wall = rng.random(P) < 0.7
+    depth_off = rng.normal(0.3, 0.03, size=P)
+    m[wall] = m[wall] - np.outer(m[wall] @ axis, axis) + np.outer(depth_off[wall], axis)
+    sc = dict(sc); sc["means3D"] = m.astype(np.float32)
+    sc["opacities"] = (sc["opacities"] * 0.05).astype(np.float32)          # (translucent: the lists are consumed deep into the wall)
+    _C = rast._C
+    run_hip(rast, sc, cam0, gpu, tile_clip=0)                               # lets the context learn the range (may fall back once)
+    for _ in range(40):                                                    # (a pause left by another test)
+        if _C.get_option("bucket_skip") == 0:
+            break
+        run_hip(rast, sc, cam0, gpu, tile_clip=0)
+    assert _C.get_option("bucket_skip") == 0
+    run_hip(rast, sc, cam0, gpu, tile_clip=0)
+    redo0 = _C.get_option("redo_count")
+    for k, shift in ((0, 0.0), (1, 0.0), (0, 0.35), (2, -0.2)):
+        scn = dict(sc); scn["means3D"] = (m + np.outer(np.where(wall, shift, 0.0), axis)).astype(np.float32)
+        cam = scenes.camera(k, 6, W, H)
+        o32 = orc.render(scn, cam)
+        h = run_hip(rast, scn, cam, gpu, tile_clip=0)
+        assert h["R"] == o32["R"]
+        np.testing.assert_array_equal(h["point_list"], o32["point_list"], err_msg=f"pose {k} shift {shift}")
+        np.testing.assert_array_equal(h["ranges"], o32["ranges"])
+        np.testing.assert_array_equal(h["out_color"].view(np.uint32), o32["out_color"].view(np.uint32))
+    assert _C.get_option("redo_count") == redo0 and _C.get_option("bucket_skip") == 0
+
+
+def test_list_cut_engages_under_pose_alternation(scenes, rast, gpu):
+    """the pose table must work in the reference's call pattern -- different cameras one after the other
+    (train.py:198-226) -- not only on one repeated pose.  Four poses of a ring dealt round-robin over the 3 M-Gaussian cube (the
+    diagonal views' depth histogram has a peak: rounds 2-3's equal-width depth buckets overflowed there, the forward fell back
+    to the radix sort with a growing pause and the cut never engaged again): from every pose's second visit on the list cut is in
+    force (more than a quarter of the Gaussians late), no forward is redone, no pause is set -- by the library's own defaults,
+    no `list_cut_always`.  Outputs of a cut visit equal the first visit's bit for bit."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H, V = 3_000_000, 1920, 1080, 4
+    sc = scenes.synth(P, 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    e = torch.empty(0)
+    cams = [scenes.camera(k, 8, W, H) for k in range(V)]
+    rss = [settings_from(rast, c, sc, gpu) for c in cams]
+
+    def render(k):
+        rs = rss[k]
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        return R, color, depth, _C.context_query("last_late")
+
+    for k in range(V):                    # lets the context size its launches and learn the depth range (first forwards may be redone)
+        render(k)
+    first = {}
+    for k in range(V):
+        first[k] = render(k)
+    redo0 = _C.get_option("redo_count")
+    for visit in range(3):
+        for k in range(V):
+            R, color, depth, late = render(k)
+            assert late > P // 4, f"visit {visit} of pose {k}: the list cut is not in force (late = {late})"
+            assert R == first[k][0] and torch.equal(color, first[k][1]) and torch.equal(depth, first[k][2])
+    assert _C.get_option("redo_count") == redo0 and _C.get_option("bucket_skip") == 0
+
+
+def test_list_cut_pauses_itself_when_its_lists_keep_failing(scenes, rast, gpu):
+    """SaRO-GS renders one camera at many timestamps, and opacity = sigmoid(.) * trbf(t) makes two visits of a pose different scenes
+    (scene/saro_gaussian.py:788-831).  A failed speculation is correct but costs a whole second forward; the device reports it
+    to the host (a pinned word written by the predicated second binning), and a context whose cut lists keep failing stops
+    cutting: here one pose, the scene alternating between opaque and nearly transparent on every call -- by the library's own
+    defaults (no list_cut_always) at most three forwards fall back before the cut pauses itself; every output equals the
+    cut-less render bit for bit."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H = 1_000_000, 1920, 1080
+    sc = scenes.synth(P, 0)
+    cam = scenes.camera(0, 8, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    thin = ten["opacities"] * 0.03
+    e = torch.empty(0)
+    rs = settings_from(rast, cam, sc, gpu)
+
+    def render(op):
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, op, ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        return R, color, depth
+
+    _C.set_option("no_list_cut", 1)
+    try:
+        want = {0: render(ten["opacities"]), 1: render(thin)}
+    finally:
+        _C.set_option("no_list_cut", 0)
+    for _ in range(3):
+        render(ten["opacities"])                        # the context learns the opaque scene's cut depths
+    assert _C.context_query("last_late") > P // 4 and _C.context_query("cut_pause") == 0
+    fb0 = _C.context_query("cut_fallbacks")
+    for i in range(24):
+        k = (i + 1) % 2                                 # transparent, opaque, transparent, ...
+        R, color, depth = render(thin if k else ten["opacities"])
+        assert R == want[k][0] and torch.equal(color, want[k][1]) and torch.equal(depth, want[k][2]), f"call {i}"
+    fallbacks = _C.context_query("cut_fallbacks") - fb0
+    assert 1 <= fallbacks <= 3, fallbacks
+    assert _C.context_query("cut_pause") > 0
+    for _ in range(40):                                 # (leave the context as the next test expects it: the pause served)
+        if _C.context_query("cut_pause") == 0:
+            break
+        render(ten["opacities"])

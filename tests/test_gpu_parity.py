@@ -1067,7 +1067,7 @@ def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
     rng = np.random.default_rng(932)
     sc["means3D"][NBIG:, :] = 50.0                     # everything but the big ones: far outside the frustum, culled
     sc["means3D"][:NBIG] = rng.uniform(-1.0, 1.0, size=(NBIG, 3)).astype(np.float32)
-    sc["scales"][:NBIG] = rng.uniform(0.4, 0.6, size=(NBIG, 3)).astype(np.float32)
+    sc["scales"][:NBIG] = rng.uniform(1.0, 1.5, size=(NBIG, 3)).astype(np.float32)     # sigma ~ 100 px: every rectangle is the whole image
     sc["opacities"][:NBIG] = 0.97
     cam = scenes.camera(1, 7, W, H)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
@@ -1087,7 +1087,7 @@ def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
         a, _ = render(sc)
         b, late_b = render(sc)                         # this one snapshots the cut depths the first left
         o = orc.render(sc, cam)
-        assert (o["final_T"] < 1e-4).mean() > 0.5      # most pixels saturate: most tiles have a cut depth
+        assert (np.asarray(o["n_contrib"]) < 100).mean() > 0.9      # pixels stop a few dozen entries into their 400-entry lists: the tiles saturate and get cut depths
         assert late_b == 0                             # ... and still nobody is late
         assert np.array_equal(bits(b[1].cpu().numpy()), bits(o["out_color"]))
         fb0 = _C.context_query("cut_fallbacks")
@@ -1099,7 +1099,7 @@ def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
         assert thin[0] == o2["R"]
         assert np.array_equal(bits(thin[1].cpu().numpy()), bits(o2["out_color"]))
         assert np.array_equal(bits(thin[2].cpu().numpy()), bits(o2["out_depth"]))
-        assert np.array_equal(thin[3].cpu().numpy().reshape(-1), np.asarray(o2["n_contrib"]).reshape(-1))
+        assert np.array_equal(bits(thin[4].cpu().numpy()), bits(np.asarray(o2["final_T"], dtype=np.float32)))     # (n_contrib counts positions of the CLIPPED lists: not comparable)
     finally:
         _C.set_option("list_cut_always", 0)
 

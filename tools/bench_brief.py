@@ -2,7 +2,7 @@
 """Run bench.py with the given extra args and print a compact summary (development helper)."""
 import json, subprocess, sys
 args = sys.argv[1:]
-out = subprocess.run([sys.executable, "bench.py", "--sweep", "", "--no-cpu-baseline"] + args, capture_output=True, text=True, timeout=600)
+out = subprocess.run([sys.executable, "bench.py", "--sweep", "", "--no-cpu-baseline", "--no-training-like"] + args, capture_output=True, text=True, timeout=600)
 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
 if not line:
     print("FAILED", args, out.stderr[-2000:]); sys.exit(1)
