@@ -44,9 +44,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--exchange", choices=("factors", "allreduce"), default="factors",
-                    help="multi-GPU gradient exchange: 'factors' = all-reduce 11 + all-gather 3 floats/Gaussian (default), "
-                         "'allreduce' = all-reduce all 59 floats/Gaussian")
+    ap.add_argument("--exchange", choices=("sparse", "factors", "allreduce"), default="sparse",
+                    help="multi-GPU gradient exchange: 'factors' = all-reduce 11 + all-gather 3 floats/Gaussian, 'sparse' (default) = the "
+                         "same for the rows some rank touched only, 'allreduce' = all-reduce all 59 floats/Gaussian")
     ap.add_argument("--exp-mode", type=int, default=None, help="0 fixed-sequence (default), 1 ocml, 2 v_exp_f32")
     ap.add_argument("--sweep", type=str, default="100000,300000,1000000,3000000",
                     help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
@@ -117,9 +117,11 @@ class Workload:
         if bucket is not None and world > 1:
             # the backward wrote the leaf gradients straight into the bucket (zero-copy GradArena)
             if getattr(bucket, "sh_factors", False):
-                self.vp.exchange_gradients(bucket, L["means3D"].detach(), world)     # all-reduce 11 + all-gather 3 floats/Gaussian
+                # all-reduce 11 + all-gather 3 floats/Gaussian -- sparse: of the rows some rank touched only
+                self.exchanged = self.vp.exchange_gradients(bucket, L["means3D"].detach(), world, sparse=getattr(self, "sparse", False))
             else:
                 self.vp.allreduce_mean_inplace(bucket.flat, world)                    # all-reduce 59 floats/Gaussian
+                self.exchanged = {"allreduce": bucket.flat.numel() * 4, "allgather": 0, "rows": self.P}
         return radii
 
     def _forward_state(self, rs=None):
@@ -1015,8 +1017,9 @@ def main():
         # into it directly.  Default exchange: all-reduce of the 11 dense floats + all-gather of the 3-float factor of
         # dL/dsh, recombined locally (view_parallel.exchange_gradients); --exchange allreduce: ONE in-place all-reduce
         # of all 59 floats.  Both give the batch-mean gradient of set_batch_gradient (saro_gaussian.py:266-276).
-        bucket = _C.GradArena(P, 16, dev, sh_factors=(a.exchange == "factors"), world=world)
+        bucket = _C.GradArena(P, 16, dev, sh_factors=(a.exchange != "allreduce"), world=world)
         _C.set_grad_arena(bucket)
+        wl.sparse = a.exchange == "sparse"
         if a.exchange == "factors":
             import view_parallel
             view_parallel.overlap_factor_exchange(True)     # the all-gather starts between the two phases of the backward
@@ -1101,7 +1104,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4] stress-1080p: {scene_fn}(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
                                    + ((" + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
-                                       if a.exchange == "factors" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if world > 1 else ""),
+                                       + (" -- of the rows some rank touched only" if a.exchange == "sparse" else "")
+                                       if a.exchange != "allreduce" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if world > 1 else ""),
+                       "exchange": a.exchange if world > 1 else None,
+                       "exchange_bytes_per_rank_and_step": getattr(wl, "exchanged", None) if world > 1 else None,
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
                        "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],

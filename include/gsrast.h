@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSRAST_ABI_VERSION 3   /* 3: gsrast_options.no_list_cut (the struct grew).  2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
+#define GSRAST_ABI_VERSION 4   /* 4: gsrast_raw_grads.d_sh_factor (the struct grew), gsrast_sh_grad_combine_rows.  3: gsrast_options.no_list_cut (the struct grew).  2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
                                     reference); options.forward_only; gsrast_forward_raw / gsrast_backward_raw */
 #define GSRAST_TILE_X 16 /* reference config.h:16 */
 #define GSRAST_TILE_Y 16 /* reference config.h:17 */
@@ -132,6 +132,14 @@ size_t gsrast_image_bytes(int width, int height);
  * chunks = N records of chunk_stride floats: [3P floats g_r | 3 floats campos_r | padding].  All device pointers. */
 int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
                            float scale, float* dL_dsh /*[P][M][3]*/, void* stream);
+/* The same recombination for an exchange that moves only the rows some rank touched, and for the raw leaves (round 4):
+ *   chunks = N records of chunk_stride floats: [3 * rows floats g_r | 3 floats campos_r | padding], rows <= P;
+ *   row_of [P] or NULL: Gaussian i's factor is row row_of[i] of every record, -1 = no rank sent it (its dL/dsh is zero);
+ *   NULL: rows == P, row i (then this is gsrast_sh_grad_combine);
+ *   the result goes to dL_dsh [P][M][3] (rows [dc | rest]) and / or, split, to d_features_dc [P][1][3] + d_features_rest [P][M-1][3]
+ *   (the gradients of SaRO-GS's two SH leaves, scene/saro_gaussian.py:836-845); every row of every array given is written. */
+int gsrast_sh_grad_combine_rows(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride, int rows,
+                                const int* row_of, float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
 
 /* Parity-test helper: copies internal state out in the reference's array layout
  * (GeometryState / BinningState / ImageState members, rasterizer_impl.h:30-65).  Any output
@@ -335,6 +343,10 @@ typedef struct gsrast_raw_grads {   /* every array is fully overwritten */
     float* d_features_dc;         /* [P][1][3]    } may both be NULL when d_shs_res is given (its rows are [dc | rest]); given together with it, */
     float* d_features_rest;       /* [P][M-1][3]  } the rows are written twice -- cheaper than slicing them out afterwards */
     float* d_shs_res;             /* [P][M][3] or NULL; requires shs_res */
+    float* d_sh_factor;           /* [P][3] or NULL (round 4, multi-GPU): the FACTOR of the SH leaves' gradient (gsrast_sh_grad_combine) instead of
+                                     its 48 products per Gaussian -- d_features_dc / d_features_rest may then be NULL and are not written (the caller
+                                     completes them with gsrast_sh_grad_combine_rows after the exchange); not together with shs_res / d_shs_res, whose
+                                     gradient every rank needs whole for its own view */
 } gsrast_raw_grads;
 int gsrast_forward_raw(gsrast_context* ctx, const gsrast_options* options,
                        gsrast_alloc_fn geometry_alloc, void* geometry_ctx,

@@ -1625,8 +1625,26 @@ int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, con
     if (P < 0 || N < 1 || M < 1 || D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail(GSRAST_E_ARG, "sh_grad_combine: bad sizes");
     if (P == 0) return GSRAST_OK;
     if (!means3D || !chunks || !dL_dsh || chunk_stride < (size_t)3 * P + 3) return fail(GSRAST_E_ARG, "sh_grad_combine: NULL or short buffer");
-    sh_grad_combine_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(P, D, M, N, means3D, chunks, chunk_stride, scale, dL_dsh);
+    sh_grad_combine_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(P, D, M, N, means3D, chunks, chunk_stride, scale, dL_dsh, P, nullptr, nullptr, nullptr);
     GS_LAUNCHED("sh_grad_combine");
+    return GSRAST_OK;
+}
+
+int gsrast_sh_grad_combine_rows(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride, int rows,
+                                const int* row_of, float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || N < 1 || M < 1 || D < 0 || D > 3 || (D + 1) * (D + 1) > M || rows < 0 || rows > P || (!row_of && rows != P))
+        return fail(GSRAST_E_ARG, "sh_grad_combine_rows: bad sizes");
+    if (P == 0) return GSRAST_OK;
+    if (!means3D || !chunks || chunk_stride < (size_t)3 * rows + 3) return fail(GSRAST_E_ARG, "sh_grad_combine_rows: NULL or short buffer");
+    if (!dL_dsh && !d_features_dc) return fail(GSRAST_E_ARG, "sh_grad_combine_rows: no output array");
+    if (d_features_dc && M > 1 && !d_features_rest) return fail(GSRAST_E_ARG, "sh_grad_combine_rows: d_features_dc without d_features_rest");
+    if (d_features_dc && (M * 3 > PP_SH_MAX || ((M * 3) & 3) || (((uintptr_t)d_features_dc | (uintptr_t)d_features_rest) & 15)))
+        return fail(GSRAST_E_ARG, "sh_grad_combine_rows: the split outputs need M = 4 or 16 and 16-byte aligned arrays");
+    sh_grad_combine_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(P, D, M, N, means3D, chunks, chunk_stride, scale, dL_dsh, rows, row_of,
+                                                                                   d_features_dc, d_features_rest);
+    GS_LAUNCHED("sh_grad_combine_rows");
     return GSRAST_OK;
 }
 
@@ -1792,7 +1810,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         const float* sh_in = rawin ? shs : (use_sh ? shs : nullptr);
         const float* sc_in = rawin ? scales : (use_sr ? scales : nullptr);
         const float* ro_in = rawin ? rotations : (use_sr ? rotations : nullptr);
-        const int factors = (!rawin && use_sh && o.sh_grad_factors) ? 1 : 0;
+        const int factors = (use_sh && o.sh_grad_factors) ? 1 : 0;
 #define GS_PB_ARGS P, D, M, means3D, radii, raw, rawg, sh_in, at<unsigned char>(geom, GL.clamped), at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), \
                    at<float>(geom, GL.shdC), sc_in, ro_in, cov, cam, reinterpret_cast<const float4*>(grec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,  \
                    dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars)
@@ -1833,13 +1851,18 @@ int gsrast_backward_raw(const gsrast_options* options, int P, int D, int M, int 
     if (!out->dL_dmean2D || !out->d_xyz || !out->d_rotation || !out->d_scaling || !out->d_opacity_logit) return fail(GSRAST_E_ARG, "backward_raw: NULL required gradient output");
     if ((in->rot_res != nullptr) != (out->d_rot_res != nullptr) && in->rot_res == nullptr) return fail(GSRAST_E_ARG, "backward_raw: d_rot_res without rot_res");
     if (out->d_shs_res && !in->shs_res) return fail(GSRAST_E_ARG, "backward_raw: d_shs_res without shs_res");
-    if ((out->d_features_dc != nullptr) != (M > 1 ? out->d_features_rest != nullptr : out->d_features_dc != nullptr) || (!out->d_shs_res && !out->d_features_dc))
+    const bool fac = out->d_sh_factor != nullptr;       // the SH leaves' gradient leaves as its [P][3] factor (multi-GPU exchange)
+    if (fac && (in->shs_res || out->d_shs_res)) return fail(GSRAST_E_ARG, "backward_raw: d_sh_factor cannot be combined with shs_res / d_shs_res");
+    if ((out->d_features_dc != nullptr) != (M > 1 ? out->d_features_rest != nullptr : out->d_features_dc != nullptr) || (!fac && !out->d_shs_res && !out->d_features_dc))
         return fail(GSRAST_E_ARG, "backward_raw: give d_features_dc + d_features_rest and / or (with shs_res) d_shs_res, whose rows hold both");
     if (((uintptr_t)out->d_rotation | (uintptr_t)out->d_features_dc | (uintptr_t)out->d_features_rest | (uintptr_t)out->d_shs_res) & 15)
         return fail(GSRAST_E_ARG, "backward_raw: d_rotation / d_features_dc / d_features_rest / d_shs_res must be 16-byte aligned");
     gsrast_options o = options ? *options : snapshot_defaults();
-    o.sh_grad_factors = 0;      // the factor exchange needs the rasterizer's own dL/dsh layout
-    float* sh_marker = out->d_shs_res ? out->d_shs_res : out->d_features_dc;
+    o.sh_grad_factors = fac ? 1 : 0;
+    gsrast_raw_grads og = *out;
+    if (fac) { og.d_features_dc = nullptr; og.d_features_rest = nullptr; }     // (not written: the caller completes them after the exchange)
+    out = &og;
+    float* sh_marker = fac ? out->d_sh_factor : (out->d_shs_res ? out->d_shs_res : out->d_features_dc);
     return backward_impl(&o, P, D, M, R, background, width, height, in->xyz, in->features_dc, nullptr, in->scaling, scale_modifier, in->rotation, nullptr,
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, out->dL_dmean2D,
                          nullptr, out->d_opacity_logit, nullptr, out->d_xyz, nullptr, sh_marker, out->d_scaling, out->d_rotation, stream, in, out);

@@ -1294,9 +1294,12 @@ late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, c
 //   dL_dsh[i][k][c] = scale * sum_r w_k(dir(means3D[i] - campos_r)) * g_r[i][c],   r in rank order.
 // chunks: N records of `stride` floats: [3P floats g | 3 floats campos | padding].  With N = 1, scale = 1 the result is
 // bit-identical to what preprocess_bwd_kernel writes itself (0 + w*g).
+// rows / row_of (gsrast_sh_grad_combine_rows): the records hold `rows` factors, Gaussian i's is row row_of[i] (-1: nobody sent it, its
+// gradient is zero); d_dc / d_rest: the result split into SaRO-GS's two SH leaves (and / or whole into dL_dsh).
 __global__ void __launch_bounds__(PP_THREADS)
 sh_grad_combine_kernel(int P, int D, int M, int N, const float* __restrict__ means3D, const float* __restrict__ chunks,
-                       size_t stride, float scale, float* __restrict__ dL_dsh)
+                       size_t stride, float scale, float* __restrict__ dL_dsh, int rows, const int* __restrict__ row_of,
+                       float* __restrict__ d_dc, float* __restrict__ d_rest)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     const int i = blockIdx.x * PP_THREADS + threadIdx.x;
@@ -1304,14 +1307,15 @@ sh_grad_combine_kernel(int P, int D, int M, int N, const float* __restrict__ mea
     float acc[PP_SH_MAX];
 #pragma unroll
     for (int k = 0; k < PP_SH_MAX; k++) acc[k] = 0.0f;
-    if (i < P) {
+    const int row = i < P ? (row_of ? row_of[i] : i) : -1;
+    if (row >= 0) {
         const float pos[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
         for (int r = 0; r < N; r++) {
             const float* ch = chunks + (size_t)r * stride;
-            const float o0 = pos[0] - ch[3 * (size_t)P], o1 = pos[1] - ch[3 * (size_t)P + 1], o2 = pos[2] - ch[3 * (size_t)P + 2];
+            const float o0 = pos[0] - ch[3 * (size_t)rows], o1 = pos[1] - ch[3 * (size_t)rows + 1], o2 = pos[2] - ch[3 * (size_t)rows + 2];
             const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
             const float x = o0 / len, y = o1 / len, z = o2 / len;
-            const float g[3] = { ch[3 * (size_t)i], ch[3 * (size_t)i + 1], ch[3 * (size_t)i + 2] };
+            const float g[3] = { ch[3 * (size_t)row], ch[3 * (size_t)row + 1], ch[3 * (size_t)row + 2] };
 #define ACC(k, w) { const float w_ = (w); acc[(k) * 3 + 0] += w_ * g[0]; acc[(k) * 3 + 1] += w_ * g[1]; acc[(k) * 3 + 2] += w_ * g[2]; }
             ACC(0, kSH0);
             if (D > 0) {
@@ -1339,9 +1343,14 @@ sh_grad_combine_kernel(int P, int D, int M, int N, const float* __restrict__ mea
             for (int k = 0; k < PP_SH_MAX; k++) if (k < M * 3) my_lds[k] = N == 1 && scale == 1.0f ? acc[k] : acc[k] * scale;
         }
         __syncthreads();
-        stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
+        if (dL_dsh) stage_sh_out(dL_dsh, P, M, blockIdx.x * PP_THREADS, sh_lds);
+        if (d_dc) stage_sh_out_split(d_dc, d_rest, P, M * 3, blockIdx.x * PP_THREADS, sh_lds);
     } else if (i < P) {
-        for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = k < PP_SH_MAX ? acc[k] * scale : 0.0f;
+        for (int k = 0; k < M * 3; k++) {
+            const float v = k < PP_SH_MAX ? acc[k] * scale : 0.0f;
+            if (dL_dsh) dL_dsh[(size_t)i * M * 3 + k] = v;
+            if (d_dc) { if (k < 3) d_dc[(size_t)i * 3 + k] = v; else d_rest[(size_t)i * (M * 3 - 3) + (k - 3)] = v; }
+        }
     }
 }
 

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsrast_hip.so")
 
 NUM_CHANNELS = 3  # reference config.h:15
-ABI_VERSION = 3   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib: Optional[C.CDLL] = None
@@ -34,7 +34,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
+    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query",
@@ -92,7 +92,7 @@ class RawInputsStruct(C.Structure):
 class RawGradsStruct(C.Structure):
     """gsrast_raw_grads (include/gsrast.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("dL_dmean2D", "d_xyz", "d_rotation", "d_scaling", "d_rot_res", "d_opacity_logit", "d_trbf",
-                                          "d_features_dc", "d_features_rest", "d_shs_res")]
+                                          "d_features_dc", "d_features_rest", "d_shs_res", "d_sh_factor")]
 
 
 class AdamGroupStruct(C.Structure):
@@ -171,6 +171,8 @@ def lib() -> C.CDLL:
     L.gsrast_loss_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
     L.gsrast_sh_grad_combine.restype = ci
     L.gsrast_sh_grad_combine.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, cf, vp, vp]
+    L.gsrast_sh_grad_combine_rows.restype = ci
+    L.gsrast_sh_grad_combine_rows.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_activate_forward.restype = ci
     L.gsrast_activate_forward.argtypes = [ci, ci] + [vp] * 16
     L.gsrast_activate_backward.restype = ci
@@ -247,19 +249,24 @@ class GradArena:
     # backward writes the per-view FACTOR g[P,3] of dL/dsh (include/gsrast.h, gsrast_sh_grad_combine) into `factor`,
     # ranks all-gather the factors (+ their camera positions) and every rank recombines dL/dsh locally.
     ORDER_FACTORS = (("means3D", 3), ("opacity", 1), ("scales", 3), ("rotations", 4), ("sh", None))
+    # raw=True (round 4): the bucket of GaussianRasterizerRaw's six LEAVES -- SaRO-GS's own call pattern, where the rasterizer's
+    # `shs` is cat(features_dc, features_rest) [+ residual], never a leaf (scene/saro_gaussian.py:836-845): dense part first, the
+    # two SH leaves last (with sh_factors they are completed by gsrast_sh_grad_combine_rows after the exchange)
+    ORDER_RAW = (("xyz", 3), ("opacity_logit", 1), ("scaling", 3), ("rotation", 4), ("features_dc", 3), ("features_rest", -1))
 
-    def __init__(self, P: int, M: int, device: torch.device, sh_factors: bool = False, world: int = 1):
-        self.P, self.M, self.sh_factors, self.world = P, M, bool(sh_factors), int(world)
-        order = self.ORDER_FACTORS if sh_factors else self.ORDER
-        self.widths = {name: (M * 3 if w is None else w) for name, w in order}
+    def __init__(self, P: int, M: int, device: torch.device, sh_factors: bool = False, world: int = 1, raw: bool = False):
+        self.P, self.M, self.sh_factors, self.world, self.raw = P, M, bool(sh_factors), int(world), bool(raw)
+        order = self.ORDER_RAW if raw else (self.ORDER_FACTORS if sh_factors else self.ORDER)
+        self.widths = {name: (M * 3 if w is None else ((M - 1) * 3 if w == -1 else w)) for name, w in order}
         self.offsets, o = {}, 0
         for name, _ in order:
             self.offsets[name] = o
             o += ((P * self.widths[name] + 3) // 4) * 4        # every segment starts on a 16-byte boundary (float4 stores of dL/drot)
         self.flat = torch.zeros(o, dtype=torch.float32, device=device)
         self.dirty = False                                     # a backward has written this step's gradients
+        self.dense_names = tuple(n for n, _ in order if n not in ("sh", "features_dc", "features_rest"))
         if sh_factors:
-            self.dense = self.flat[: self.offsets["sh"]]                      # 11 floats / Gaussian: the all-reduced part
+            self.dense = self.flat[: self.offsets["features_dc" if raw else "sh"]]   # 11 floats / Gaussian: the all-reduced part
             self.chunk = ((3 * P + 3 + 3) // 4) * 4                            # [3P g | 3 campos | pad], 16-byte multiple
             self.factor = torch.zeros(self.chunk, dtype=torch.float32, device=device)
             self.gathered = torch.zeros(self.world * self.chunk, dtype=torch.float32, device=device)
@@ -269,6 +276,10 @@ class GradArena:
         """Start of a step: the next backward writes into the arena again.  (Does not touch memory: the backward overwrites
         every element; set the leaves' .grad to None first, or autograd would add the arena to itself.)"""
         self.dirty = False
+
+    def dense_segments(self):
+        """The dense (non-SH) gradient arrays as [P, w] views of the bucket, in bucket order."""
+        return [self.flat[self.offsets[n]: self.offsets[n] + self.P * self.widths[n]].view(self.P, self.widths[n]) for n in self.dense_names]
 
     def take(self, name: str, shape, zero: bool) -> torch.Tensor:
         n = self.P * self.widths[name]
@@ -528,8 +539,26 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
     background, viewmatrix, projmatrix, campos = f(background, "bg"), f(viewmatrix, "viewmatrix"), f(projmatrix, "projmatrix"), f(campos, "campos")
     dL_dout_color = f(dL_dout_color, "dL_dout_color")
     o = dict(dtype=torch.float32, device=dev)
-    g = dict(dL_dmeans2D=torch.empty((P, 3), **o), xyz=torch.empty((P, 3), **o), rotation=torch.empty((P, 4), **o), scaling=torch.empty((P, 3), **o),
-             opacity_logit=torch.empty((P, 1), **o))
+    ar = _grad_arena
+    if ar is not None and not (getattr(ar, "raw", False) and ar.P == P and ar.M == M and ar.flat.device == dev):
+        ar = None                       # (the bucket of another call shape)
+    if ar is not None and ar.dirty:     # a second backward of the same step (GradArena docstring)
+        if ar.sh_factors:
+            raise RuntimeError("GradArena(sh_factors=True): a second backward before zero_grad() would overwrite the first view's "
+                               "factor; use one view per rank and exchange, or the plain arena (which accumulates)")
+        ar = None
+    factors = ar is not None and ar.sh_factors
+    if factors and keep["shs_res"] is not None:
+        raise RuntimeError("GradArena(raw=True, sh_factors=True) cannot serve a call with shs_residual: every rank needs the whole "
+                           "gradient of its own residual; use GradArena(raw=True) + view_parallel.allreduce_mean_inplace")
+    if ar is not None:
+        ar.dirty = True
+
+    def out(name, shape):
+        return ar.take(name, shape, False) if ar is not None else torch.empty(shape, **o)
+
+    g = dict(dL_dmeans2D=torch.empty((P, 3), **o), xyz=out("xyz", (P, 3)), rotation=out("rotation", (P, 4)), scaling=out("scaling", (P, 3)),
+             opacity_logit=out("opacity_logit", (P, 1)))
     if keep["rot_res"] is not None:
         g["rot_res"] = torch.empty((P, 7), **o)
     if keep["trbf"] is not None:
@@ -538,19 +567,36 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
         g["shs_res"] = torch.empty((P, M, 3), **o)
     # the two SH leaves get their own contiguous gradients also when the residual's gradient holds the same rows: autograd would copy
     # strided slices of it into the leaves' .grad (two elementwise kernels, 96 us at 1 M), the kernel writes them for a third of that
-    g["features_dc"], g["features_rest"] = torch.empty((P, 1, 3), **o), torch.empty((P, M - 1, 3), **o)
+    g["features_dc"], g["features_rest"] = out("features_dc", (P, 1, 3)), out("features_rest", (P, M - 1, 3))
     p_dc, p_rest = g["features_dc"].data_ptr(), _ptr(g["features_rest"])
+    p_fac = None
+    if factors:
+        # the two SH leaves' gradients (views of the bucket) are returned to autograd as usual but only become valid after
+        # sh_grad_combine(); the kernel writes this view's factor g[P,3], the camera position goes behind it
+        ar.factor[3 * P: 3 * P + 3].copy_(campos.reshape(-1)[:3])
+        ar.last_degree = int(degree)
+        p_dc, p_rest, p_fac = None, None, ar.factor.data_ptr()
     gs = RawGradsStruct(dL_dmean2D=g["dL_dmeans2D"].data_ptr(), d_xyz=g["xyz"].data_ptr(), d_rotation=g["rotation"].data_ptr(),
                         d_scaling=g["scaling"].data_ptr(), d_rot_res=_ptr(g.get("rot_res")), d_opacity_logit=g["opacity_logit"].data_ptr(),
-                        d_trbf=_ptr(g.get("trbf")), d_features_dc=p_dc, d_features_rest=p_rest, d_shs_res=_ptr(g.get("shs_res")))
+                        d_trbf=_ptr(g.get("trbf")), d_features_dc=p_dc, d_features_rest=p_rest, d_shs_res=_ptr(g.get("shs_res")),
+                        d_sh_factor=p_fac)
     if P != 0:
         radii_c = radii.contiguous()
         with torch.cuda.device(dev):
-            rc = L.gsrast_backward_raw(
-                C.byref(_options_struct(options=options, grads_zeroed=first_backward)), P, int(degree), M, int(R), _ptr(background), W, H,
-                C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                _ptr(radii_c), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL_dout_color), C.byref(gs),
-                torch.cuda.current_stream(dev).cuda_stream)
+            def call(phase):
+                return L.gsrast_backward_raw(
+                    C.byref(_options_struct(options=options, grads_zeroed=first_backward, backward_phase=phase)), P, int(degree), M, int(R),
+                    _ptr(background), W, H, C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                    float(tan_fovx), float(tan_fovy), _ptr(radii_c), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                    _ptr(dL_dout_color), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream)
+
+            if factors and _factor_ready_hook is not None:
+                rc = call(1)                     # blend backward + the factors
+                if rc == 0:
+                    _factor_ready_hook(ar)       # e.g. the asynchronous all-gather of the factors
+                    rc = call(2)                 # the per-Gaussian backward, beside it
+            else:
+                rc = call(0)
         if rc != 0:
             raise _err(rc, "gsrast_backward_raw")
     if keep["motion_res"] is not None:
@@ -558,21 +604,28 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
     return g
 
 
-def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Tensor, n_views: int, scale: float) -> torch.Tensor:
-    """dL/dsh of `n_views` views from their factors (include/gsrast.h: gsrast_sh_grad_combine), written into the
-    arena's dL/dsh region (the tensor autograd already handed out as shs.grad)."""
+def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Tensor, n_views: int, scale: float,
+                    rows: Optional[int] = None, row_of: Optional[torch.Tensor] = None, chunk_stride: Optional[int] = None):
+    """dL/dsh of `n_views` views from their factors (include/gsrast.h: gsrast_sh_grad_combine / _rows), written into the arena's
+    SH region(s) -- the tensor(s) autograd already handed out as shs.grad, or as features_dc.grad / features_rest.grad for a raw
+    arena.  rows / row_of: the records hold only `rows` factors, Gaussian i's is row row_of[i] (int32 [P], -1 = not sent)."""
     L = lib()
     P, M = arena.P, arena.M
-    out = arena.take("sh", (P, M, 3), False)
+    if getattr(arena, "raw", False):
+        whole, dc, rest = None, arena.take("features_dc", (P, 1, 3), False), arena.take("features_rest", (P, M - 1, 3), False)
+    else:
+        whole, dc, rest = arena.take("sh", (P, M, 3), False), None, None
     if P == 0:
-        return out
+        return whole if whole is not None else (dc, rest)
     dev = means3D.device
     with torch.cuda.device(dev):
-        rc = L.gsrast_sh_grad_combine(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
-                                      arena.chunk, float(scale), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        rc = L.gsrast_sh_grad_combine_rows(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
+                                           int(chunk_stride if chunk_stride is not None else arena.chunk), int(P if rows is None else rows),
+                                           None if row_of is None else row_of.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
+                                           torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
-        raise _err(rc, "gsrast_sh_grad_combine")
-    return out
+        raise _err(rc, "gsrast_sh_grad_combine_rows")
+    return whole if whole is not None else (dc, rest)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

@@ -109,18 +109,27 @@ def allreduce_mean_inplace(flat: torch.Tensor, batch: int) -> None:
     flat.mul_(1.0 / batch)
 
 
-def exchange_gradients(arena, means3D: torch.Tensor, batch: int) -> None:
+def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = False) -> Dict[str, int]:
     """Cross-rank mean of one view-per-rank backward whose leaf gradients live in a GradArena built with
-    sh_factors=True (diff_gaussian_rasterization_ch3/_C.py).  Same result as all-reducing all 59 floats per Gaussian
-    (up to fp32 summation order), with 2.6x fewer bytes on the links:
+    sh_factors=True (diff_gaussian_rasterization_ch3/_C.py; raw=True for GaussianRasterizerRaw's six leaves -- SaRO-GS's own call
+    pattern, where `shs` is never a leaf).  Same result as all-reducing all 59 floats per Gaussian (up to fp32 summation order),
+    with 2.6x fewer bytes on the links:
 
       * the dense part (means3D, opacity, scales, rotations: 11 floats / Gaussian) is all-reduced in place;
       * dL/dsh (48 floats / Gaussian) is NOT exchanged.  Each view's dL/dsh row k is w_k(view direction) * g with g the
         view's clamp-masked colour gradient (3 floats): ranks all-gather g (+ their camera position, 3 floats) and every
-        rank evaluates  (1/batch) * sum_r w(dir_r) (x) g_r  itself (gsrast_sh_grad_combine, one HIP kernel).
+        rank evaluates  (1/batch) * sum_r w(dir_r) (x) g_r  itself (gsrast_sh_grad_combine_rows, one HIP kernel).
 
     xGMI is point-to-point, 7 links per GPU: an all-gather of 12 B/Gaussian/rank plus an all-reduce of 44 B/Gaussian
-    moves ~160 B per Gaussian and rank at 8 GPUs, the plain all-reduce of 236 B/Gaussian moves ~410 B."""
+    moves ~160 B per Gaussian and rank at 8 GPUs, the plain all-reduce of 236 B/Gaussian moves ~410 B.
+
+    sparse=True (round 4): only the rows SOME rank touched travel.  A view's gradient rows are exactly zero for every Gaussian it
+    did not blend -- culled, left out by the list cut, or occluded: ~90 % of the 3 M bench scene per view -- so ranks first take the
+    MAX of a one-byte "my rows are non-zero" flag per Gaussian (P bytes all-reduced), then exchange the union's rows only: a
+    compacted [n, 11] all-reduce and a compacted [n, 3] all-gather; rows outside the union are zero on every rank and stay so.
+    One host synchronisation per step (the union's size), beside the one every forward already has.
+
+    Returns the bytes this rank handed to the collectives: {"allreduce", "allgather", "rows"}."""
     from diff_gaussian_rasterization_ch3 import _C
     if not getattr(arena, "sh_factors", False):
         raise ValueError("exchange_gradients needs GradArena(..., sh_factors=True)")
@@ -128,9 +137,36 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int) -> None:
     n_views = dist.get_world_size() if multi else 1
     if n_views != arena.world:
         raise ValueError(f"arena was built for {arena.world} ranks, the process group has {n_views}")
+    P = arena.P
+    pending = getattr(arena, "_gather_work", None)
+    if sparse and multi and pending is None and P > 0:
+        segs = arena.dense_segments()
+        fac = arena.factor[: 3 * P].view(P, 3)
+        touched = (fac != 0).any(dim=1)
+        for sg in segs:
+            touched |= (sg != 0).any(dim=1)
+        touched = touched.to(torch.uint8)
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX)
+        idx = torch.nonzero(touched, as_tuple=False).squeeze(1)          # (host synchronisation: every rank learns the same n)
+        n = int(idx.numel())
+        comp = torch.cat([sg.index_select(0, idx) for sg in segs], dim=1).contiguous()       # [n, 11]
+        allreduce_mean_inplace(comp.view(-1), batch)
+        o = 0
+        for sg in segs:
+            sg.index_copy_(0, idx, comp[:, o: o + sg.shape[1]])
+            o += sg.shape[1]
+        stride = ((3 * n + 3 + 3) // 4) * 4
+        mine = torch.zeros(stride, dtype=torch.float32, device=fac.device)
+        mine[: 3 * n] = fac.index_select(0, idx).reshape(-1)
+        mine[3 * n: 3 * n + 3] = arena.factor[3 * P: 3 * P + 3]
+        gathered = torch.empty(n_views * stride, dtype=torch.float32, device=fac.device)
+        dist.all_gather_into_tensor(gathered, mine)
+        row_of = torch.full((P,), -1, dtype=torch.int32, device=fac.device)
+        row_of[idx] = torch.arange(n, dtype=torch.int32, device=fac.device)
+        _C.sh_grad_combine(arena, means3D, gathered, n_views, 1.0 / batch, rows=n, row_of=row_of, chunk_stride=stride)
+        return {"allreduce": comp.numel() * 4 + P, "allgather": stride * 4, "rows": n}
     allreduce_mean_inplace(arena.dense, batch)
     if multi:
-        pending = getattr(arena, "_gather_work", None)
         if pending is not None:                    # started inside the backward (overlap_factor_exchange)
             pending.wait()
             arena._gather_work = None
@@ -140,6 +176,7 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int) -> None:
     else:
         chunks = arena.factor
     _C.sh_grad_combine(arena, means3D, chunks, n_views, 1.0 / batch)
+    return {"allreduce": arena.dense.numel() * 4 if multi else 0, "allgather": arena.chunk * 4 if multi else 0, "rows": P}
 
 
 def overlap_factor_exchange(enable: bool = True) -> None:

@@ -1,6 +1,7 @@
 """Helper of tests/test_gpu_multirank.py (run under torch.distributed.run, 2 ranks, gloo, both ranks on cuda:0):
 one view per rank; the batch-mean leaf gradients from the factor exchange (all-reduce 11 + all-gather 3 floats per
-Gaussian, recombined locally) must equal those from the plain all-reduce of all 59 floats."""
+Gaussian, recombined locally) must equal those from the plain all-reduce of all 59 floats -- also with only the touched rows
+travelling (sparse), and for the RAW leaves of GaussianRasterizerRaw (raw GradArena)."""
 import os
 import sys
 
@@ -37,15 +38,58 @@ def main():
         _C.set_grad_arena(None)
         vp.overlap_factor_exchange(False)
     assert started == [True] and getattr(arena, "_gather_work", None) is None, started
+    # only the rows some rank touched travel (exchange_gradients(sparse=True)): same mean
+    arena = _C.GradArena(P, 16, dev, sh_factors=True, world=world)
+    _C.set_grad_arena(arena)
+    wl.sparse = True
+    wl.step(arena, world)
+    torch.cuda.synchronize()
+    res["factors_sparse"] = {k: v.grad.detach().clone() for k, v in wl.leaves.items()}
+    sent = dict(wl.exchanged)
+    _C.set_grad_arena(None)
+    wl.sparse = False
+    assert 0 < sent["rows"] < P and sent["allreduce"] < P * 44, sent          # (fewer rows than Gaussians: most are never blended)
+
+    # the RAW leaves (GaussianRasterizerRaw: SaRO-GS's call pattern, `shs` is cat(features_dc, features_rest), never a leaf)
+    L = wl.leaves
+    raw = dict(xyz=L["means3D"].detach().clone(), rotation=L["rotations"].detach().clone(), scaling=torch.log(L["scales"].detach()),
+               opacity=torch.logit(L["opacities"].detach().clamp(1e-4, 1 - 1e-4)), f_dc=L["shs"].detach()[:, :1].contiguous(),
+               f_rest=L["shs"].detach()[:, 1:].contiguous())
+    raw = {k: v.requires_grad_(True) for k, v in raw.items()}
+    raster_raw = rast.GaussianRasterizerRaw(wl.rs)
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    res_raw = {}
+    for mode in ("allreduce", "factors", "factors_sparse"):
+        arena = _C.GradArena(P, 16, dev, sh_factors=(mode != "allreduce"), world=world, raw=True)
+        _C.set_grad_arena(arena)
+        for v in list(raw.values()) + [m2]:
+            v.grad = None
+        arena.zero_grad()
+        color, _, _ = raster_raw(raw["xyz"], m2, raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"])
+        color.backward(wl.g)
+        if mode == "allreduce":
+            vp.allreduce_mean_inplace(arena.flat, world)
+        else:
+            vp.exchange_gradients(arena, raw["xyz"].detach(), world, sparse=(mode == "factors_sparse"))
+        torch.cuda.synchronize()
+        assert all(v.grad.data_ptr() >= arena.flat.data_ptr() and v.grad.data_ptr() < arena.flat.data_ptr() + arena.flat.numel() * 4 for v in raw.values()), "the raw leaves' gradients must be views of the bucket"
+        res_raw[mode] = {k: v.grad.detach().clone() for k, v in raw.items()}
+        _C.set_grad_arena(None)
     worst = 0.0
+    for k in res_raw["allreduce"]:
+        for other_mode in ("factors", "factors_sparse"):
+            a, b = res_raw["allreduce"][k], res_raw[other_mode][k]
+            worst = max(worst, ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item())
+        assert res_raw["allreduce"][k].abs().max().item() > 0, k
     for k in res["allreduce"]:
-        for other_mode in ("factors", "factors_overlapped"):
+        for other_mode in ("factors", "factors_overlapped", "factors_sparse"):
             a, b = res["allreduce"][k], res[other_mode][k]
             err = ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item()     # <= 1: within 1e-6 abs + 1e-4 rel
             worst = max(worst, err)
         assert a.abs().max().item() > 0, k
     # every rank must hold the same averaged gradient
-    flat = torch.cat([v.reshape(-1) for v in list(res["factors"].values()) + list(res["factors_overlapped"].values())])
+    flat = torch.cat([v.reshape(-1) for v in list(res["factors"].values()) + list(res["factors_overlapped"].values()) + list(res["factors_sparse"].values())
+                      + list(res_raw["factors"].values()) + list(res_raw["factors_sparse"].values())])
     other = flat.clone()
     torch.distributed.broadcast(other, src=0)
     same = bool(((flat - other).abs() <= 1e-7 + 1e-5 * other.abs()).all())

@@ -321,3 +321,107 @@ def test_bucket_rebuilt_after_densification_changes_P(tmp_path):
         np.testing.assert_allclose(got["grads"][n].numpy(), want_g[n].numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
     np.testing.assert_array_equal(got["stats"]["radii"].numpy(), want_s["radii"].numpy().astype(np.float32))
     np.testing.assert_allclose(got["stats"]["viewspace_point_grad"].numpy(), want_s["viewspace_point_grad"].numpy(), rtol=2e-5, atol=1e-9)
+
+
+# ---- sparse factor exchange (round 4): only the rows some rank touched travel ----------------------------------------------------
+def _sh_weights(dirs, deg):
+    """w_k(direction) of forward.cu:20-71 / backward.cu:78-141 (what gsrast_sh_grad_combine_rows evaluates): [n, 16]."""
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+    C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+          -0.5900435899266435)
+    w = torch.zeros((dirs.shape[0], 16), dtype=dirs.dtype)
+    w[:, 0] = C0
+    if deg > 0:
+        w[:, 1], w[:, 2], w[:, 3] = -C1 * y, C1 * z, -C1 * x
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        w[:, 4], w[:, 5], w[:, 6], w[:, 7], w[:, 8] = C2[0] * xy, C2[1] * yz, C2[2] * (2 * zz - xx - yy), C2[3] * xz, C2[4] * (xx - yy)
+    if deg > 2:
+        w[:, 9], w[:, 10] = C3[0] * y * (3 * xx - yy), C3[1] * xy * z
+        w[:, 11], w[:, 12] = C3[2] * y * (4 * zz - xx - yy), C3[3] * z * (2 * zz - 3 * xx - 3 * yy)
+        w[:, 13], w[:, 14], w[:, 15] = C3[4] * x * (4 * zz - xx - yy), C3[5] * z * (xx - yy), C3[6] * x * (xx - 3 * yy)
+    return w
+
+
+def _sparse_worker(rank, world, port, out_dir, raw):
+    for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import scenes
+    import view_parallel as vp
+    from diff_gaussian_rasterization_ch3 import _C
+    from oracle import oracle as orc
+    vp.init_from_env("gloo")
+    P, W, H, deg, M = 600, 64, 48, 3, 16
+    sc = scenes.synth(P, 13)
+    cam = scenes.camera(rank, world, W, H)
+    g = scenes.upstream_grad(H, W, 5) * (H * W)
+    o = orc.render(sc, cam, g)                        # the oracle stands in for the GPU backward of this rank's view
+    arena = _C.GradArena(P, M, torch.device("cpu"), sh_factors=True, world=world, raw=raw)
+    names = ("xyz", "opacity_logit", "scaling", "rotation") if raw else ("means3D", "opacity", "scales", "rotations")
+    for n, k in zip(names, ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")):
+        arena.take(n, (P, arena.widths[n]), False).copy_(torch.from_numpy(o[k].astype(np.float32)).reshape(P, -1))
+    fac = torch.from_numpy((o["dL_dcolors"] * (1 - o["clamped"].astype(np.float32)) * (o["radii"] > 0)[:, None]).astype(np.float32))
+    arena.factor[: 3 * P] = fac.reshape(-1)
+    arena.factor[3 * P: 3 * P + 3] = torch.from_numpy(np.asarray(cam["campos"], np.float32))
+    arena.last_degree = deg
+    means = torch.from_numpy(sc["means3D"])
+    calls = {}
+
+    def combine(ar, means3D, chunks, n_views, scale, rows=None, row_of=None, chunk_stride=None):      # the HIP kernel's arithmetic, in torch
+        rows = ar.P if rows is None else rows
+        stride = ar.chunk if chunk_stride is None else chunk_stride
+        row_of = torch.arange(ar.P) if row_of is None else row_of.long()
+        acc = torch.zeros((ar.P, 16, 3))
+        have = row_of >= 0
+        for r in range(n_views):
+            ch = chunks[r * stride: (r + 1) * stride]
+            gr = ch[: 3 * rows].view(rows, 3)[row_of[have]]
+            d = means3D[have] - ch[3 * rows: 3 * rows + 3]
+            d = d / d.norm(dim=1, keepdim=True)
+            acc[have] += _sh_weights(d, ar.last_degree)[:, :, None] * gr[:, None, :]
+        acc *= scale
+        calls.update(rows=rows, n_have=int(have.sum()))
+        if getattr(ar, "raw", False):
+            ar.take("features_dc", (ar.P, 1, 3), False).copy_(acc[:, :1])
+            ar.take("features_rest", (ar.P, 15, 3), False).copy_(acc[:, 1:])
+        else:
+            ar.take("sh", (ar.P, 16, 3), False).copy_(acc)
+
+    _C.sh_grad_combine = combine
+    sent = vp.exchange_gradients(arena, means, world, sparse=True)
+    # the literal mean of scene/saro_gaussian.py:266-276 over the batch: every rank's full gradients, summed / batch
+    full = torch.cat([torch.from_numpy(o[k].astype(np.float32)).reshape(-1) for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
+    dist.all_reduce(full)
+    full /= world
+    if raw:
+        sh = torch.cat([arena.take("features_dc", (P, 1, 3), False), arena.take("features_rest", (P, 15, 3), False)], dim=1)
+    else:
+        sh = arena.take("sh", (P, 16, 3), False)
+    got = torch.cat([arena.take(n, (P, arena.widths[n]), False).reshape(-1) for n in names] + [sh.reshape(-1)])
+    err = float(((got - full).abs() / (1e-6 + 1e-4 * full.abs())).max())
+    visible_somewhere = torch.from_numpy((o["radii"] > 0).astype(np.float32))
+    dist.all_reduce(visible_somewhere, op=dist.ReduceOp.MAX)
+    ok = err <= 1.0 and 0 < sent["rows"] <= int(visible_somewhere.sum()) and calls["rows"] == sent["rows"] == calls["n_have"] \
+        and sent["allreduce"] == sent["rows"] * 44 + P and sent["allgather"] >= sent["rows"] * 12
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(f"{ok} err {err:.3f} rows {sent['rows']} of {P}")
+    vp.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("raw", [False, True], ids=["rasterizer_leaves", "raw_leaves"])
+@pytest.mark.parametrize("world", [2, 8], ids=["two_ranks", "cfg4_eight_ranks"])
+def test_sparse_factor_exchange_equals_the_literal_batch_mean(tmp_path, world, raw):
+    """exchange_gradients(sparse=True) on CPU over gloo, the oracle as each rank's backward and the combine kernel's arithmetic
+    restated in torch: the union of touched rows is agreed on with a MAX all-reduce of one byte per Gaussian, only those rows are
+    all-reduced (11 floats) / all-gathered (3 floats), and every leaf gradient -- the rasterizer's own five, or the six RAW leaves
+    of GaussianRasterizerRaw with dL/dsh split into features_dc / features_rest -- equals the reference's batch mean
+    (scene/saro_gaussian.py:266-276); the bytes handed to the collectives follow the row count."""
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path), raw), nprocs=world, join=True)
+    reports = [open(tmp_path / f"ok{r}").read() for r in range(world)]
+    assert all(r.startswith("True") for r in reports), reports
