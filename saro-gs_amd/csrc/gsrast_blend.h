@@ -27,8 +27,10 @@
 #endif
 namespace gsrast {
 
-#ifdef GSRAST_DEBUG_COUNTERS
+#if defined(GSRAST_DEBUG_COUNTERS) || defined(GSRAST_DEBUG_TIMING)
 __device__ unsigned long long g_dbg[16];
+#endif
+#if defined(GSRAST_DEBUG_COUNTERS) && !defined(GSRAST_DEBUG_TIMING)
 #define GS_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane_id() == 0) atomicAdd(&g_dbg[i], v_); } while (0)
 #else
 #define GS_COUNT(i, v) do { } while (0)
@@ -282,7 +284,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     Dm = __builtin_amdgcn_inverse_ballot_w64(m_cross) ? b.z : Dm;
                     m_above &= ~(m_here & __builtin_amdgcn_ballot_w64(!(test_T > 0.5f)));      // T == 0.5 exactly: never crosses (T > 0.5 fails from then on)
                 }
-#ifdef GSRAST_DEBUG_COUNTERS
+#if defined(GSRAST_DEBUG_COUNTERS) && !defined(GSRAST_DEBUG_TIMING)
                 if (lane == 0) { atomicAdd(&g_dbg[1], 1ull); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(m_upd)); if (m_upd) atomicAdd(&g_dbg[3], 1ull); }
 #endif
                 if (m_term) {                                              // rare: some pixel is done
@@ -882,6 +884,12 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 // (Also measured and dropped: v_exp_f32 for the backward's exp with the exact sequence only when some lane's alpha is within 1e-7 of
 // 1/255 -- the decision stays the forward's, ~20 issue cycles per pair fewer on paper: 332 -> 332 us.  The kernel is not short of
 // issue slots for that chain; the exp hides under the LDS round trips of the pair's records.)
+// (Round 4, measured and dropped -- the kernel is bound by VALU throughput, not by waiting: DOUBLE-BUFFERED staging, the records of batch
+// b + 1 written and the sums of batch b - 1 committed while batch b is processed, ONE workgroup barrier per batch instead of three: 0.46 ->
+// 0.46 ms at 3 M, 0.326 -> 0.358 (batches of 64, 35 KB of LDS) / 0.338 (batches of 32) at 1 M, shell 0.513 -> 0.564 / 0.530; SIX workgroups
+// per compute unit (27.1 KB of LDS, 76 VGPRs): 0.457 -> 0.478 at 3 M, 0.327 -> 0.340 at 1 M; s_setprio 3 for tiles of more than 256 / 768
+// consumed entries: nothing; and the launch is NOT the heavy tiles' serial chain: consuming at most 256 entries per tile (16 % of the
+// entries gone, wrong gradients) takes 0.455 -> 0.403 ms, in proportion.)
 template <int EXPMODE>
 __global__ void __launch_bounds__(256)
 blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -907,13 +915,15 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     __shared__ __attribute__((aligned(16))) float acc[BATCH][AS];       // the batch's sums, shared by the four waves (LDS float adds to distinct addresses)
     // {u, dch} of the current group, [instance][pixel of the wave's strip]
     __shared__ float2 pbuf[NW][GB][PS];
-    __shared__ float4 dpt[NW][64];        // dL/dpixel of the strip's pixels, for the transposed phase
     __shared__ uint32_t s_tile;
     if (blockIdx.x >= ntiles) return;
     const uint32_t tile = bucket_cnt ? tile_from_buckets_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, blockIdx.x, &s_tile)
                                      : (order ? order[blockIdx.x] : blockIdx.x);
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
     const uint32_t t = threadIdx.x;
+#ifdef GSRAST_DEBUG_TIMING
+    const long long dbg_t0 = wall_clock64();
+#endif
     const unsigned lane = lane_id(), wave = t >> 6;
 #ifndef GSRAST_BWD_BLOCK8
 #define GSRAST_BWD_BLOCK8 1
@@ -952,7 +962,20 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
         for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
         strip_last = __builtin_amdgcn_readfirstlane(m);
     }
-    dpt[wave][lane] = make_float4(dp0, dp1, dp2, 0.0f);
+    // dL/dpixel of the eight pixels lane (k, jj) walks in the transposed phase (column k of the block's rows): the same 24 numbers for
+    // every group of the launch -- kept in registers (exchanged once through the strip buffer) instead of eight 16-byte LDS reads per phase
+    // (round 4: two thirds of the phase's LDS traffic and 4 KB of LDS gone; 96 VGPRs = still five waves per SIMD; blend_bwd 0.452 -> 0.442 ms at
+    // 3 M, 0.325 -> 0.322 at 1 M, shell 0.513 -> 0.502)
+    float dpr[8][3];
+    {
+        float4* ex = reinterpret_cast<float4*>(&pbuf[wave][0][0]);
+        ex[lane] = make_float4(dp0, dp1, dp2, 0.0f);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned kk = lane & 7u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float4 v = ex[kk + 8 * i]; dpr[i][0] = v.x; dpr[i][1] = v.y; dpr[i][2] = v.z; }
+        __builtin_amdgcn_wave_barrier();
+    }
     // transposed phase: this lane's role
     const unsigned k = lane & 7u, jj = lane >> 3;
     const float commit_scale = k == 0 ? -0.5f * (float)W : k == 1 ? -0.5f * (float)H : (k >= 2 && k <= 4) ? -0.5f : 1.0f;
@@ -1042,6 +1065,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 pbuf[wave][jb][lane] = make_float2(u, dch);
             }
             if (!alive) continue;
+            GS_COUNT(8, 1); GS_COUNT(9, __popc(alive));
             __builtin_amdgcn_wave_barrier();            // same wave: the LDS executes its accesses in order, no s_barrier needed
             // ---- transposed phase: lane (k, jj) sums pixels k, k + 8, ..., k + 56 of instance jj ----
             const uint32_t j = g * GB + jj;
@@ -1050,14 +1074,12 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
             const float dxa = a.x - pxk0, dxb = a.x - pxk1;
             float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
             const float2* urow = &pbuf[wave][jj][k];
-            const float4* prow = &dpt[wave][k];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const float2 ud = urow[i * 8];
                 asm volatile("" ::: "memory");                       // keeps the 8-byte reads apart: merged into ds_read2_b64 they cost 8 LDS cycles per pair, apart 2 each
                 const float uu = ud.x, dd = ud.y;
-                float4 dp = prow[i * 8];
-                asm volatile("" : "+v"(dp.w));                       // all four components "used": one ds_read_b128 (4 LDS cycles), not a ds_read_b96 (8)
+                const float4 dp = make_float4(dpr[i][0], dpr[i][1], dpr[i][2], 0.f);
                 const float dx = B8 ? dxa : ((i & 1) ? dxb : dxa);      // (8 x 8 block: pixel k + 8 i = column k of row i)
                 const float dy = a.y - (sy0 + (float)(B8 ? i : (i >> 1)));
                 const float gxv = uu * dx, gyv = uu * dy;            // the opacity factor of dL/dG = opacity * dL/dalpha is applied once, below
@@ -1085,6 +1107,15 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
             }
         }
     }
+#ifdef GSRAST_DEBUG_TIMING
+    if (t == 0) {       // the longest workgroup (10 ns ticks), its list length, the launch's first start and last end
+        const long long t1 = wall_clock64();
+        atomicMax(&g_dbg[10], (unsigned long long)(t1 - dbg_t0));
+        atomicMin(&g_dbg[11], (unsigned long long)dbg_t0);
+        atomicMax(&g_dbg[12], (unsigned long long)t1);
+        if ((unsigned long long)(t1 - dbg_t0) >= g_dbg[10]) g_dbg[13] = n;
+    }
+#endif
 }
 
 } // namespace gsrast

@@ -652,6 +652,7 @@ int gsrast_get_option(const char* name)
     if (!name) return GSRAST_E_ARG;
     if (!strcmp(name, "exp_mode")) return g_def.exp_mode.load();
     if (!strcmp(name, "profile")) return g_profile.load();
+    if (!strcmp(name, "bwd_transposed")) return g_bwd_transposed.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
     if (!strcmp(name, "list_cut_always")) return g_list_cut_always.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
@@ -1955,11 +1956,11 @@ int gsrast_loss_backward(int C, int H, int W, const float* img, const float* gt,
 
 } // extern "C"
 
-#ifdef GSRAST_DEBUG_COUNTERS
+#if defined(GSRAST_DEBUG_COUNTERS) || defined(GSRAST_DEBUG_TIMING)
 extern "C" int gsrast_debug_counters(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gsrast::g_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gsrast::g_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[16] = {0}; z[11] = ~0ull /* (a minimum) */; if (hipMemcpyToSymbol(HIP_SYMBOL(gsrast::g_dbg), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

@@ -321,12 +321,13 @@ def test_backward_blend_per_pair_reduction_variant(orc, scenes, rast, gpu):
     o32 = orc.render(sc, cam, g)
     o64 = orc.render(sc, cam, g, f64=True)
     names = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"]
+    default = rast._C.get_option("bwd_transposed")
     for v in (0, 1):
         rast._C.set_option("bwd_transposed", v)
         try:
             h = run_hip(rast, sc, cam, gpu, dL_dcolor=g)
         finally:
-            rast._C.set_option("bwd_transposed", 1)
+            rast._C.set_option("bwd_transposed", default)
         _check_forward_exact(o32, h)
         _check_grads(o64, o32, h, names, strict=True)
 

@@ -13,13 +13,21 @@ try:
     wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, 1, torch.device("cuda:0"))
     L = _C.lib()
     out = (ctypes.c_ulonglong * 16)()
-    wl.step(None, 1); torch.cuda.synchronize()
+    for _ in range(int(os.environ.get('WARM', '1'))):
+        wl.step(None, 1)
+    torch.cuda.synchronize()
     L.gsrast_debug_counters(out, 1)
+    import ctypes as C_
+    init = (ctypes.c_ulonglong * 16)(); init[11] = 2**63
     wl.step(None, 1); torch.cuda.synchronize()
     L.gsrast_debug_counters(out, 1)
     v = list(out)
     print("RAW", v)
     print("fwd: survivor iterations %d, with a lane in range %d, with a contribution %d, contributing lanes %d (%.1f / iteration)" % (v[0], v[1], v[3], v[2], v[2] / max(v[1], 1)))
     print("bwd: survivor iterations %d, with a contribution %d, contributing lanes %d (%.1f / contributing iteration), lanes still in reach (pos < last) %.1f / iteration" % (v[4], v[5], v[6], v[6] / max(v[5], 1), v[7] / max(v[4], 1)))
+    if v[10]:
+        print("bwd blend: longest workgroup %.1f us (list prefix walked: %d entries), launch first start -> last end %.1f us" % (v[10] / 100.0, v[13], (v[12] - v[11]) / 100.0))
+    if v[8]:
+        print("bwd transposed phases %d, live instances in them %d (%.2f of 8)" % (v[8], v[9], v[9] / v[8]))
 finally:
     shutil.copy("/tmp/orig.so", lib)
