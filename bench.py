@@ -526,19 +526,20 @@ def in_flight_row(rast, scenes, P, W, H, deg, dev, steps, warmup, lanes=2):
             "note": "throughput of a batch loop with two views in flight (distributed_step(views_in_flight=2)); `value` above is one view at a time"}
 
 
-def measure_point(rast, scenes, vp, P, W, H, deg, dev, steps, warmup, full=False, kind="cube"):
-    """One more workload with the headline's protocol (same steps / warm-up).  full: also the roofline object and the stage table."""
+def measure_point(rast, scenes, vp, P, W, H, deg, dev, steps, warmup, full=False, kind="cube", poses=1):
+    """One more workload with the headline's protocol (same steps / warm-up, the same number of poses dealt round-robin, every pose
+    seen before).  full: also the roofline object and the stage table."""
     _C = rast._C
-    wl = Workload(rast, scenes, P, W, H, deg, 0, 1, dev, kind=kind)
+    wl = Workload(rast, scenes, P, W, H, deg, 0, max(poses, 1), dev, kind=kind, poses=poses)
     kid = {_C.lib().gsrast_profile_kernel_name(k).decode(): k for k in range(_C.lib().gsrast_profile_kernel_count())}
-    for _ in range(warmup):
+    for _ in range(max(warmup, 3 * poses)):
         wl.step(None, 1)
     torch.cuda.synchronize(dev)
     _C.profile_reset()
     if full:
         _C.set_option("profile", 1 << kid["blend_bwd"])
     d = timed(wl, steps, 0, None, 1, vp, dev)
-    out = {"views_per_s": round(steps / d, 3), "ms_per_step": round(d / steps * 1e3, 4), "steps": steps, "warmup": warmup}
+    out = {"views_per_s": round(steps / d, 3), "ms_per_step": round(d / steps * 1e3, 4), "steps": steps, "warmup": warmup, "poses": poses}
     if full:
         prof = _C.profile_read()
         _C.set_option("profile", 0)
@@ -1149,7 +1150,7 @@ def main():
                 sweep[str(p)] = {"views_per_s": result["value"], "ms_per_step": result["ms_per_step"], "steps": a.steps, "warmup": a.warmup}
                 continue
             full = p == 1_000_000           # the 1 M point (rounds 1-2's headline) keeps its own roofline object and stage table
-            m = measure_point(rast, scenes, vp, p, W, H, deg, dev, a.steps, a.warmup, full=full)
+            m = measure_point(rast, scenes, vp, p, W, H, deg, dev, a.steps, a.warmup, full=full, poses=n_poses)
             if full:
                 result["sweep_1M_1080p"] = m
             sweep[str(p)] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup")}
@@ -1157,11 +1158,11 @@ def main():
         # the other single-GPU shapes BASELINE.json names (synthetic stand-ins): informational, same protocol
         other = {}
         for tag, p, w, h in (("cfg2_100k_800x800", 100_000, 800, 800), ("cfg3_1M_1352x1014", 1_000_000, 1352, 1014)):
-            other[tag] = measure_point(rast, scenes, vp, p, w, h, deg, dev, a.steps, a.warmup)
+            other[tag] = measure_point(rast, scenes, vp, p, w, h, deg, dev, a.steps, a.warmup, poses=n_poses)
         result["baseline_configs"] = other
         # a second occlusion regime (scenes.synth_shell: a surface, R_eff ~ R) at the headline's size: the binning / culling / launch
         # order choices are not tuned to the cube's early termination alone
-        m = measure_point(rast, scenes, vp, 1_000_000, W, H, deg, dev, a.steps, a.warmup, full=True, kind="shell")
+        m = measure_point(rast, scenes, vp, 1_000_000, W, H, deg, dev, a.steps, a.warmup, full=True, kind="shell", poses=n_poses)
         result["shell_scene_1080p"] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup", "config", "per_stage")}
         result["shell_scene_1080p"]["blend_bwd_ms"] = m["roofline"]["avg_launch_ms"]
         # NOT the headline protocol: two views of a batch in flight on two streams of the one GPU (what

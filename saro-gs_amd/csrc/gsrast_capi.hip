@@ -883,7 +883,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     };
     // List cut: a Gaussian the bucket scatter found late is in no list -- its colour is not evaluated (3 M cube: 87 % of them).
     // Not under the diagnostic option debug_state (gsrast_debug_export shows every Gaussian's colour).
-    const bool cut_colors = cut && zero_in_blend && !g_debug_state.load();
+    bool cut_colors = cut && zero_in_blend && !g_debug_state.load();       // (switched off below for a pose the table does not know: everything is early)
     auto launch_color = [&]() -> int {
         if (color_launched) return GSRAST_OK;
         color_launched = true;
@@ -984,6 +984,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // run beside it stretch less.  Two alternating runs each, views/s, entry -> here: 3 M 609 -> 619, 2 M 745 -> 753, 1 M 1059 -> 1082,
     // 0.3 M 1504 -> 1551, 0.1 M 1878 -> 1894, shell 1 M 884 -> 917, cfg2 2692 -> 2787.  Behind the geometry kernel only: 3 M -3.8 %
     // (the scatter beside the colours); behind the run emission: 3 M -4 % (the colours end after the binning, the blend waits).
+    // (a pose without a slot in the table has no cut depths: every visible Gaussian is early and the plain colour kernel, not the
+    // compacting one, evaluates them -- the device said so at the very start of preprocess_fwd, long before this point)
+    const bool pose_known = !(cut && rb_pre) || read_found(rb_pre);
+    if (!pose_known) cut_colors = false;
     { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
@@ -1124,7 +1128,6 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     if (speculative) {
         const bool late = totals_pending;
         if (late) { if (rb_pre) { rb_flag = rb_pre; flag_alias = pre_alias; flag_seq = pre_seq; } else rb_flag = read_flag_prepare(&flag_alias, &flag_seq); }
-        const bool pose_known = !(cut && rb_pre) || read_found(rb_pre);
         // (list cut: the sorts over the cut lists are sized for the early runs of recent forwards, not for all runs)
         // (the early set differs from pose to pose -- 0.98 M / 1.29 M column runs at two neighbouring poses of the 3 M cube --, a launch
         // sized too small costs a whole second forward, one sized too large a few empty workgroups: half again as much as the largest of
