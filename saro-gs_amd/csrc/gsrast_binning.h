@@ -645,7 +645,10 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
                          // binfo_all = {all elements, all column runs, all tiles, overflow}: what the host's counts and num_rendered are made
                          // of.  Should the cut lists turn out too short, this kernel runs again over everything (pred, plain mode)
                          uint4* __restrict__ binfo_all = nullptr,
-                         const uint32_t* __restrict__ pred = nullptr /* the predicated launch among the ones behind the forward blend */)
+                         const uint32_t* __restrict__ pred = nullptr /* the predicated launch among the ones behind the forward blend */,
+                         // completion pass of the list cut: only the Gaussians whose bit is set are sorted (the CANDIDATES: their rectangle
+                         // touches a tile whose cut list was too short); binfo = their {elements, column runs, tiles, overflow}
+                         const unsigned long long* __restrict__ keep_bits = nullptr)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
     __shared__ uint32_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order
@@ -693,8 +696,10 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
         for (int u = 0; u < 4; u++) {
             const uint32_t e = e0 + u * 64;
             if (e < n_all) {
-                tsum += kv[u].w; wall += kv[u].z & ~LATE_BIT;
-                if (!(early_only && (kv[u].z & LATE_BIT))) aux[e] = atomicAdd(&cnt[sub_of(kv[u].x)], 1u);
+                const bool kept = !(early_only && (kv[u].z & LATE_BIT)) && (!keep_bits || ((keep_bits[kv[u].y >> 6] >> (kv[u].y & 63u)) & 1ull));
+                if (!keep_bits || kept) tsum += kv[u].w;
+                wall += kv[u].z & ~LATE_BIT;
+                if (kept) aux[e] = atomicAdd(&cnt[sub_of(kv[u].x)], 1u);
             }
         }
     }
@@ -719,7 +724,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t e = e0 + u * 64;
-            if (e < n_all && !(early_only && (kv[u].z & LATE_BIT))) {
+            if (e < n_all && !(early_only && (kv[u].z & LATE_BIT)) && (!keep_bits || ((keep_bits[kv[u].y >> 6] >> (kv[u].y & 63u)) & 1ull))) {
                 const uint32_t slot = cnt[sub_of(kv[u].x)] + aux[e];
                 grp[slot] = ((unsigned long long)kv[u].x << 32) | kv[u].y;
                 wid[slot] = (uint16_t)(kv[u].z & ~LATE_BIT);
@@ -807,6 +812,46 @@ __global__ void __launch_bounds__(256)
 depth_bucket_scan_kernel(const uint4* __restrict__ binfo, uint32_t nb, uint32_t* __restrict__ scalars /* [0] R lo, [1] Q, [3] R hi, [11] overflow */)
 {
     depth_bucket_totals(binfo, nb, scalars);
+}
+
+// Completion pass of the list cut (round 4; gsrast_common.h): which Gaussians touch a tile whose cut list was too short?  One lane per
+// Gaussian in INDEX order (coalesced 8-byte reads of the tile rectangles), the flags of the tiles listed again in LDS as a bitmap.
+// cand: bit i = Gaussian i is visible and its rectangle holds such a tile -- the completion pass sorts, lists and blends those only;
+// skip: the forward's "culled or late" bits lose the candidates (a late candidate is listed after all: the backward must not take its
+// rows for zero); skip2: bit i = the pass need NOT evaluate Gaussian i's colour (only the late candidates' colours are missing).
+__global__ void __launch_bounds__(256)
+cut_candidates_kernel(uint32_t P, const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect, const unsigned char* __restrict__ need2,
+                      uint32_t ntiles, uint32_t gx, unsigned long long* __restrict__ skip, unsigned long long* __restrict__ cand,
+                      unsigned long long* __restrict__ skip2, const uint32_t* __restrict__ pred)
+{
+    __shared__ uint32_t s_need[(BUCKET_MAX_TILES + 32) / 32];
+    if (pred && *pred == 0u) return;
+    const uint32_t nw = (ntiles + 31u) / 32u;
+    for (uint32_t w = threadIdx.x; w < nw; w += 256) {
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < 32u; k++) { const uint32_t t = w * 32u + k; if (t < ntiles && need2[t]) m |= 1u << k; }
+        s_need[w] = m;
+    }
+    __syncthreads();
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < ((P + 63u) & ~63u); i0 += gridDim.x * 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool c = false;
+        if (i < P && tiles[i] != 0u) {
+            const uint2 rc = rect[i];
+            const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+            if ((x1 - x0) * (y1 - y0) > 1024u) c = true;      // (a huge rectangle is not worth the walk)
+            else
+                for (uint32_t y = y0; y < y1 && !c; y++)
+                    for (uint32_t x = x0; x < x1; x++) { const uint32_t t = y * gx + x; if ((s_need[t >> 5] >> (t & 31u)) & 1u) { c = true; break; } }
+        }
+        const unsigned long long m = __ballot(c);
+        if ((threadIdx.x & 63u) == 0u && i < ((P + 63u) & ~63u)) {
+            const unsigned long long old = skip[i >> 6];
+            cand[i >> 6] = m;
+            skip2[i >> 6] = ~(old & m);
+            skip[i >> 6] = old & ~m;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -934,13 +979,26 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                         // ... whose workgroup `nbuckets` (one past the buckets) empties the work buckets the first pass filled and counts the event
                         uint32_t* __restrict__ redo_bucket_cnt = nullptr, int n_redo_cnt = 0, HintTable* __restrict__ redo_hints = nullptr,
                         unsigned long long* __restrict__ host_fallback = nullptr, uint32_t host_fb_seq = 0 /* ... and tells the host (pinned word: the
-                                                              sequence number of the call that fell back): a context whose cuts keep failing pauses them */)
+                                                              sequence number of the call and how many tiles were listed again): a context whose cuts keep failing pauses them */,
+                        // COMPLETION pass (round 4): the buckets hold the CANDIDATES only; a column run is kept only if it crosses a tile that
+                        // is listed again (need2[tile] != 0), and the bookkeeping workgroup also leaves the pass's totals in pass2_counts
+                        const unsigned char* __restrict__ need2 = nullptr, int gx_tiles = 0, uint32_t* __restrict__ pass2_counts = nullptr)
 {
     if (pred && *pred == 0u) return;
     if (redo_bucket_cnt && blockIdx.x == nbuckets) {
         for (int i = threadIdx.x; i < n_redo_cnt; i += blockDim.x) redo_bucket_cnt[i] = 0u;
         if (threadIdx.x == 0 && redo_hints) atomicAdd(&redo_hints->cut_fallbacks, 1u);
-        if (threadIdx.x == 0 && host_fallback) __hip_atomic_store(host_fallback, ((unsigned long long)host_fb_seq << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0 && host_fallback) __hip_atomic_store(host_fallback, ((unsigned long long)host_fb_seq << 32) | (unsigned long long)(*pred ? *pred : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (pass2_counts) {       // {tile counts lo, column runs, -, hi} of the candidates: what the sorts behind this emission are sized by
+            __shared__ unsigned long long s_t2[256];
+            __shared__ uint32_t s_q2[256];
+            unsigned long long ts = 0; uint32_t q = 0;
+            for (uint32_t k = threadIdx.x; k < nbuckets; k += 256) { const uint4 v = binfo[k]; q += v.y; ts += v.z; }
+            s_t2[threadIdx.x] = ts; s_q2[threadIdx.x] = q;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t2[threadIdx.x] += s_t2[threadIdx.x + st]; s_q2[threadIdx.x] += s_q2[threadIdx.x + st]; } __syncthreads(); }
+            if (threadIdx.x == 0) { pass2_counts[0] = (uint32_t)s_t2[0]; pass2_counts[1] = s_q2[0]; pass2_counts[2] = 0u; pass2_counts[3] = (uint32_t)(s_t2[0] >> 32); }
+        }
         return;
     }
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
@@ -1066,6 +1124,12 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
             else { y0 = (uint32_t)tlo; h = (uint32_t)(thi - tlo + 1); }
             yhv = y0 | (h << 16);
         }
+        if (need2 && (yhv >> 16) != 0u) {        // completion pass: a run that crosses no tile listed again lists nothing
+            const uint32_t y0 = yhv & 0xFFFFu, h = yhv >> 16;
+            bool any = false;
+            for (uint32_t yy = y0; yy < y0 + h; yy++) any |= need2[yy * (uint32_t)gx_tiles + x] != 0;
+            if (!any) yhv = y0;
+        }
         run_keys[wstart + o] = (uint16_t)x;
         run_vals[wstart + o] = make_uint2(s_g[wave][sidx], yhv);
     }
@@ -1150,7 +1214,10 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
                              uint32_t* __restrict__ bucket_cnt /* forward launch order: [8][64] counts (zeroed), or null */,
                              uint16_t* __restrict__ bucket_list /* [8][64][Tg] */,
                              const HintTable* __restrict__ hints /* or null: what each tile of this camera pose consumed the last time (gsrast_common.h) */,
-                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */)
+                             const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */,
+                             // completion pass of the list cut: only the tiles listed again (need2 != 0) get a range -- into the point list's
+                             // second half (list_offset) -- and a place in the launch order; the others keep the first pass's
+                             const unsigned char* __restrict__ need2 = nullptr, uint32_t list_offset = 0)
 {
     __shared__ int diff[257];
     __shared__ uint32_t lcnt[XCD_GROUPS * WORK_BUCKETS], lbase[XCD_GROUPS * WORK_BUCKETS];
@@ -1164,8 +1231,9 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
         if (!overflow) Q = counts_dev[1];
     }
     uint32_t work = 0;
+    const bool mine = y < (uint32_t)gy && (!need2 || need2[y * (uint32_t)gx + x] != 0);
     if (overflow) {
-        if (y < (uint32_t)gy) ranges[y * (uint32_t)gx + x] = make_uint2(0u, 0u);
+        if (mine) ranges[y * (uint32_t)gx + x] = make_uint2(0u, 0u);
     } else {
     const uint32_t nrows = (uint32_t)gy;
     const uint32_t row_total = y < nrows ? digit_total[y] : 0u;
@@ -1175,8 +1243,8 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
     const uint32_t F1 = first_run_of_column(run_keys, Q, x + 1u);
     const uint32_t before0 = row_instances_before_run(run_vals, Q, F0, hist_scanned, nblk, nrows, row_total, diff);
     const uint32_t before1 = row_instances_before_run(run_vals, Q, F1, hist_scanned, nblk, nrows, row_total, diff);
-    if (y < (uint32_t)gy)
-        ranges[y * (uint32_t)gx + x] = before1 > before0 ? make_uint2(row_base + before0, row_base + before1) : make_uint2(0u, 0u);
+    if (mine)
+        ranges[y * (uint32_t)gx + x] = before1 > before0 ? make_uint2(list_offset + row_base + before0, list_offset + row_base + before1) : make_uint2(0u, 0u);
     work = before1 > before0 ? before1 - before0 : 0u;
     // forward launch order: the prefix this tile consumed the last time this pose was rendered, if the context knows (never more than the list)
     if (hints && hint_sel[1] && work && y < (uint32_t)gy) {
@@ -1191,12 +1259,12 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
         __syncthreads();
         const uint32_t idx = (y % (uint32_t)XCD_GROUPS) * WORK_BUCKETS + work_bucket(work);
         uint32_t slot = 0;
-        if (y < (uint32_t)gy) slot = atomicAdd(&lcnt[idx], 1u);
+        if (mine) slot = atomicAdd(&lcnt[idx], 1u);
         __syncthreads();
         for (uint32_t i = y; i < (uint32_t)(XCD_GROUPS * WORK_BUCKETS); i += blockDim.x) lbase[i] = lcnt[i] ? atomicAdd(&bucket_cnt[i], lcnt[i]) : 0u;
         __syncthreads();
         const size_t Tg = (size_t)gx * (size_t)((gy + XCD_GROUPS - 1) / XCD_GROUPS);
-        if (y < (uint32_t)gy) bucket_list[(size_t)idx * Tg + lbase[idx] + slot] = (uint16_t)(y * (uint32_t)gx + x);
+        if (mine) bucket_list[(size_t)idx * Tg + lbase[idx] + slot] = (uint16_t)(y * (uint32_t)gx + x);
     }
 }
 
@@ -1346,12 +1414,13 @@ rows_and_ranges_kernel(const uint16_t* __restrict__ run_keys, const uint2* __res
                        uint32_t capR, int ybits, int gx, int gy, const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ digit_total,
                        uint32_t nblk, uint32_t* __restrict__ point_list, uint32_t* __restrict__ total_out, uint2* __restrict__ ranges,
                        uint32_t* __restrict__ bucket_cnt, uint16_t* __restrict__ bucket_list, const HintTable* __restrict__ hints,
-                       const uint32_t* __restrict__ hint_sel, const uint32_t* __restrict__ pred /* or null: predicated launch */)
+                       const uint32_t* __restrict__ hint_sel, const uint32_t* __restrict__ pred /* or null: predicated launch */,
+                       const unsigned char* __restrict__ need2 = nullptr, uint32_t list_offset = 0 /* completion pass: see tile_ranges_from_runs_body (point_list is then the second half) */)
 {
     static_assert(RS_THREADS == 256, "one lane per tile row in the ranges part");
     if (pred && *pred == 0u) return;
     if (blockIdx.x < nblk) run_scatter_rows_body(blockIdx.x, run_vals, Q, counts_dev ? counts_dev + 1 : nullptr, capR, ybits, (uint32_t)gy, hist_scanned, digit_total, nblk, point_list, total_out);
-    else tile_ranges_from_runs_body(blockIdx.x - nblk, run_keys, run_vals, Q, counts_dev, capR, gx, gy, hist_scanned, digit_total, nblk, ranges, bucket_cnt, bucket_list, hints, hint_sel);
+    else tile_ranges_from_runs_body(blockIdx.x - nblk, run_keys, run_vals, Q, counts_dev, capR, gx, gy, hist_scanned, digit_total, nblk, ranges, bucket_cnt, bucket_list, hints, hint_sel, need2, list_offset);
 }
 
 // Launch order of the blend kernels: tiles sorted by descending work (bucketed counting sort,

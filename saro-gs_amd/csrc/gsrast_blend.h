@@ -146,7 +146,11 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       // the tile's cut depth -- up to there it is the full list -- and a tile with a cut whose pixels are not all
                       // saturated at that point raises cut_scalars[SC_UNDONE].  pred: the predicated second launch over the full lists
                       const uint32_t* __restrict__ zcut_used = nullptr, uint32_t* __restrict__ cut_scalars = nullptr,
-                      const uint32_t* __restrict__ pred = nullptr)
+                      const uint32_t* __restrict__ pred = nullptr,
+                      // round 4: a tile whose cut list was too short is flagged (tile_flags[tile] = 1) for the COMPLETION pass, which
+                      // lists the Gaussians that touch such tiles -- all of them, late or not -- and blends those tiles again from
+                      // their full lists (the launch with `pred`); every other tile is final after this launch
+                      unsigned char* __restrict__ tile_flags = nullptr)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
     if (pred && *pred == 0u) return;
@@ -315,7 +319,9 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     if (t == 0) {
         tile_max[tile] = s_max;
         // list cut: the speculation failed for this tile if it had a cut and some pixel would have looked further
-        if (zc != ZCUT_NONE && !all_done && cut_scalars) atomicAdd(&cut_scalars[SC_UNDONE], 1u);
+        const bool again = zc != ZCUT_NONE && !all_done;
+        if (tile_flags) tile_flags[tile] = again ? 1 : 0;
+        if (again && cut_scalars) atomicAdd(&cut_scalars[SC_UNDONE], 1u);
         if (hints) {
             hint_work(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
             // the tile's next cut depth: that of the entry 1.5 x as deep (+ 32) as the deepest one consumed; none for a tile that did
@@ -333,8 +339,9 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
             }
             hint_zcut(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = znew;
         }
-        // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed
-        if (bucket_cnt) bucket_append_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, tile, s_max);
+        // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed (a tile that is blended
+        // again enters the order then)
+        if (bucket_cnt && !(again && tile_flags)) bucket_append_global(bucket_cnt + XCD_GROUPS * WORK_BUCKETS, bucket_list + (size_t)XCD_GROUPS * WORK_BUCKETS * xcd_group_tiles((uint32_t)gx, ntiles), ntiles, tile, s_max);
     }
 }
 

@@ -138,7 +138,9 @@ int post_launch(const char* what, hipStream_t s)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSRAST_E_DEVICE, what, e);
-    if (g_debug_sync.load()) {
+    static const bool env_sync = getenv("GSRAST_DEBUG_SYNC") != nullptr;      // (diagnostics: localise a faulting launch)
+    if (g_debug_sync.load() || env_sync) {
+        if (env_sync) fprintf(stderr, "[gsrast] %s\n", what);
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(GSRAST_E_DEVICE, what, e);
     }
@@ -341,17 +343,19 @@ bool read_found(Readback* rb)
         if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return true;
     return (uint32_t)w != 0u;
 }
-// has the device reported a list-cut fallback this thread has not taken note of yet (RB_FALLBACK)?
-bool take_fallback_event()
+// has the device reported a completion pass of the list cut this thread has not taken note of yet (RB_FALLBACK)?  Returns the number
+// of tiles that pass listed again (0: nothing new).
+uint32_t take_fallback_event()
 {
     int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return false;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return 0u;
     Readback& rb = t_readback[device];
-    if (!rb.pinned) return false;
-    const uint32_t sq = (uint32_t)(reinterpret_cast<volatile unsigned long long*>(rb.pinned)[RB_FALLBACK] >> 32);
-    if (sq == 0u || sq == rb.fb_seen) return false;
+    if (!rb.pinned) return 0u;
+    const unsigned long long w = reinterpret_cast<volatile unsigned long long*>(rb.pinned)[RB_FALLBACK];
+    const uint32_t sq = (uint32_t)(w >> 32);
+    if (sq == 0u || sq == rb.fb_seen) return 0u;
     rb.fb_seen = sq;
-    return true;
+    return (uint32_t)w ? (uint32_t)w : 1u;
 }
 int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 {
@@ -490,10 +494,12 @@ __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ v, uin
 // one workgroup per tile: the 64-bit keys of the reference, rebuilt from the tile's range
 __global__ void __launch_bounds__(256)
 export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals_sorted,
-                   const float4* __restrict__ rec1 /* .z = depth */, uint64_t* keys, uint32_t* point_list)
+                   const float4* __restrict__ rec1 /* .z = depth */, uint64_t* keys, uint32_t* point_list, uint32_t R /* entries of the two output arrays */)
 {
     const uint2 r = ranges[blockIdx.x];
-    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += 256) {
+    // (a tile the list cut's completion pass listed again has its range in the point list's second half, past R: not exported -- the
+    // entry-by-entry comparisons run with tile_clip = 0, i.e. without the cut)
+    for (uint32_t i = r.x + threadIdx.x; i < r.y && i < R; i += 256) {
         const uint32_t g = vals_sorted[i];
         if (keys) keys[i] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__float_as_uint(rec1[g].z);
         if (point_list) point_list[i] = g;
@@ -521,6 +527,7 @@ struct BlendArgs {
     float4* zero4 = nullptr; uint32_t n_zero4 = 0;               // forward (culling kernel): the gradient records to zero-fill
     HintTable* hints = nullptr; const uint32_t* hint_sel = nullptr;   // forward: the context's launch-order hints, this call's slot
     const uint32_t* zcut_used = nullptr; uint32_t* cut_scalars = nullptr; const uint32_t* pred = nullptr;   // forward: list cut (gsrast_common.h)
+    unsigned char* tile_flags = nullptr;                         // forward: tiles the completion pass lists and blends again
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -559,7 +566,7 @@ template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
     blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
-                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred);
+                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred, a.tile_flags);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -863,10 +870,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             const bool staged = sh_in && M * 3 <= PP_SH_MAX && ((M * 3) & 3) == 0 && ((uintptr_t)sh_in & 15) == 0;
             const int grid = (P + PP_THREADS - 1) / PP_THREADS;
             if (early_only) {       // list cut: Gaussians the bucket scatter found culled or late are skipped (gsrast_preprocess.h)
-                const unsigned char* skip = at<unsigned char>(geom, GL.color_skip);
+                // (with `pred`: the completion pass -- the colours of the late Gaussians that are listed after all, GeomLayout::skip2)
+                const unsigned char* skip = at<unsigned char>(geom, pred ? GL.skip2 : GL.color_skip);
                 const int cgrid = (P + PCC_IDS - 1) / PCC_IDS;
-                if (rawin) preprocess_color_compact_kernel<true><<<cgrid, 64 * PCC_WAVES, 0, cs>>>(P, D, M, means3D, nullptr, nullptr, raw, cam_pos, rec2, cl, sA, sB, sC, skip);
-                else preprocess_color_compact_kernel<false><<<cgrid, 64 * PCC_WAVES, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, raw, cam_pos, rec2, cl, sA, sB, sC, skip);
+                if (rawin) preprocess_color_compact_kernel<true><<<cgrid, 64 * PCC_WAVES, 0, cs>>>(P, D, M, means3D, nullptr, nullptr, raw, cam_pos, rec2, cl, sA, sB, sC, skip, pred);
+                else preprocess_color_compact_kernel<false><<<cgrid, 64 * PCC_WAVES, 0, cs>>>(P, D, M, means3D, sh_in, colors_precomp, raw, cam_pos, rec2, cl, sA, sB, sC, skip, pred);
             } else if (rawin) {        // (gsrast_forward_raw has checked M and the alignment of the three SH arrays)
                 if (M * 3 == PP_SH_MAX) preprocess_color_kernel<PP_SH_MAX, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
                 else preprocess_color_kernel<0, true><<<grid, PP_THREADS, 0, cs>>>(P, D, M, means3D, nullptr, raw, cam_pos, rec2, cl, gz, sA, sB, sC, pred);
@@ -1033,13 +1041,16 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), nbk, scalars,
                                                             flag_alias, flag_seq, at<uint4>(geom, GL.bk_info));
             else if (bucketed && mode == 2) {
-                // (the first pass sorted the early Gaussians only: the buckets are sorted again, whole)
+                // COMPLETION pass: only the CANDIDATES -- the Gaussians, early or late, whose rectangle touches a tile flagged by the
+                // blend -- are sorted (the buckets' non-early arrays are free) and listed, and only into flagged tiles
                 depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order),
-                                                                                                   at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nullptr, pred);
+                                                                                                   at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nullptr, pred,
+                                                                                                   at<unsigned long long>(geom, GL.cand_bits));
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, nullptr,
-                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), (XCD_GROUPS + 1) * WORK_BUCKETS, hints,
-                                                            rb_pre ? reinterpret_cast<unsigned long long*>(pre_alias) + RB_FALLBACK : nullptr, pre_seq); }
+                                                            nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), XCD_GROUPS * WORK_BUCKETS /* (the forward's order only: the backward's keeps the tiles that are final) */, hints,
+                                                            rb_pre ? reinterpret_cast<unsigned long long*>(pre_alias) + RB_FALLBACK : nullptr, pre_seq,
+                                                            at<unsigned char>(img, IL.tile_flags), cam.gx, scalars + SC_PASS2); }
             else if (bucketed) {
                 if (cut) {      // (a list-cut forward sorted the early Gaussians only, and now everything is listed after all: the buckets are sorted again, whole)
                     depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order),
@@ -1065,8 +1076,10 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             radix_rowscan_kernel<<<cam.gy, 256, 0, s>>>(hist_y, nblk, rscan, nullptr, 0, nullptr, 0, pred);     // one workgroup per tile row
             GS_LAUNCHED("radix_rowscan");
             // the row pass and the tile ranges in one launch (gsrast_binning.h)
-            rows_and_ranges_kernel<<<nblk + (uint32_t)cam.gx, RS_THREADS, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, tile_bits((size_t)cam.gy), cam.gx, cam.gy, hist_y, rscan, nblk, plist_w, scalars + 2, ranges,
-                                                                                 buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel, pred);
+            rows_and_ranges_kernel<<<nblk + (uint32_t)cam.gx, RS_THREADS, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, tile_bits((size_t)cam.gy), cam.gx, cam.gy, hist_y, rscan, nblk,
+                                                                                 mode == 2 ? plist_w + capR_ : plist_w, mode == 2 ? scalars + SC_PASS2 + 2 : scalars + 2, ranges,
+                                                                                 buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel, pred,
+                                                                                 mode == 2 ? at<unsigned char>(img, IL.tile_flags) : nullptr, mode == 2 ? capR_ : 0u);
             GS_LAUNCHED("rows_and_ranges"); }
         return GSRAST_OK;
     };
@@ -1082,9 +1095,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
         const int ppl = pick_ppl(T, false, o);
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
-        if (zero_in_blend) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
+        if (zero_in_blend && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
-        if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; }
+        if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; ba.tile_flags = at<unsigned char>(img, IL.tile_flags); }
         if (mode == 2) ba.pred = scalars + SC_REDO_PRED;
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && o.lpt) {
@@ -1212,7 +1225,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     if (cut && counts[SC_N_LATE] != 0u && counts[1] - counts[SC_Q_EARLY] < CUT_MIN_RUNS && !g_list_cut_always.load()) { ctx->cut_pause = CUT_PAUSE; ctx->cut_pause_P = (uint32_t)P; }
     if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 32 ? qe : hq - hq / 32; }
     // fallbacks of this thread's earlier cut forwards, as the device reported them (everything enqueued before this forward's counts has run)
-    if (take_fallback_event()) {
+    // (a completion pass over a few tiles is cheap and expected; one over a quarter of the image is a cut that did not pay)
+    if (take_fallback_event() > T / 4u) {
         ctx->cut_ok_streak = 0;
         if ((ctx->cut_fb_score += 8) >= 16 && !g_list_cut_always.load()) {
             const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 32 : (prev >= 512 ? 1024 : prev * 2);
@@ -1229,8 +1243,14 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             // blend over ALL Gaussians, predicated on its verdict (gsrast_common.h).  Nothing of this runs in the steady state.
             ProfScope ps(K_CUT_REDO, s);
             struct Off { Off() { t_prof_off++; } ~Off() { t_prof_off--; } } off;
-            int rc = cut_colors ? color_kernels(s, false, scalars + SC_REDO_PRED) : GSRAST_OK;      // (the late Gaussians' colours)
-            if (rc == GSRAST_OK) rc = launch_run_binning(bin, cap, capQ, capQ, scalars, nullptr, 2);
+            // (round 4: a COMPLETION pass, not a second forward: the Gaussians that touch a flagged tile -- the candidates --, their
+            // missing colours, their column runs through flagged tiles, and the flagged tiles' blend from their full lists)
+            cut_candidates_kernel<<<std::min((P + 255) / 256, 2048), 256, 0, s>>>((uint32_t)P, tiles, rect, at<unsigned char>(img, IL.tile_flags), T, (uint32_t)cam.gx,
+                                                                                at<unsigned long long>(geom, GL.color_skip), at<unsigned long long>(geom, GL.cand_bits),
+                                                                                at<unsigned long long>(geom, GL.skip2), scalars + SC_REDO_PRED);
+            GS_LAUNCHED("cut_candidates");
+            int rc = cut_colors ? color_kernels(s, true, scalars + SC_REDO_PRED) : GSRAST_OK;      // (the late candidates' colours)
+            if (rc == GSRAST_OK) rc = launch_run_binning(bin, cap, capQ, capQ, scalars + SC_PASS2, nullptr, 2);
             if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, 2);
             if (rc != GSRAST_OK) return rc;
         }
@@ -1890,7 +1910,7 @@ int gsrast_debug_export(int P, int R, int width, int height, const char* geom_bu
     GS_LAUNCHED("export_geom");
     if (R > 0 && binning_buffer && image_buffer && (keys_sorted || point_list)) {
         export_keys_kernel<<<T, 256, 0, s>>>(at<uint2>(image_buffer, IL.ranges), at<uint32_t>(binning_buffer, 0),
-                                             at<float4>(geom_buffer, GL.rec1), keys_sorted, point_list);
+                                             at<float4>(geom_buffer, GL.rec1), keys_sorted, point_list, (uint32_t)R);
         GS_LAUNCHED("export_keys");
     }
     if (image_buffer) {

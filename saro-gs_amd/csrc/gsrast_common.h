@@ -43,7 +43,9 @@ struct GeomLayout {
     size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
         hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zhist, bk_key, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base,
         bk_order_e, bk_wincl_e, bk_info_e, bk_base_e /* the same four over the EARLY Gaussians only, compact (list cut, below) */,
-        color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */, total;
+        color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */,
+        cand_bits /* u64[ceil(P / 64)]: bit i = Gaussian i touches a tile the completion pass lists again */,
+        skip2 /* u64[ceil(P / 64)]: bit i = the completion pass need NOT evaluate Gaussian i's colour (it is not a late candidate) */, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
 constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is one or two self-scanned radix passes anyway
@@ -122,7 +124,8 @@ struct BinLayout {
 //   estimate (tile ranges -> forward order, forward blend's deepest consumed entry -> backward order); block b of a blend
 //   kernel finds its tile from the prefix sums of the 64 counts.  [0] = forward, [1] = backward.
 struct ImgLayout {
-    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, bucket_cnt, bucket_list, zcut_used /* u32[T]: this call's snapshot of the pose's cut depths (list cut, below) */, total;
+    size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, bucket_cnt, bucket_list, zcut_used /* u32[T]: this call's snapshot of the pose's cut depths (list cut, below) */,
+        tile_flags /* u8[T]: 1 = the tile's cut list was too short: the completion pass lists and blends it again (list cut, below) */, total;
 };
 constexpr int WORK_BUCKETS = 64;
 constexpr size_t BUCKET_MAX_TILES = 65535;     // tile ids are stored as u16
@@ -183,6 +186,7 @@ static inline int cut_cell_shift(size_t gx, size_t gy)      // 1, 2, 3, or 0 = n
 constexpr uint32_t LATE_BIT = 0x80000000u;      // in the width word of a bucket-slab element
 // words of GeomLayout::scalars used by the list cut
 constexpr int SC_ZBINS = 7 /* first | last << 16 occupied bin of the sampled depth histogram (0xFFFFFFFF: no sample) */;
+constexpr int SC_PASS2 = 24 /* {instances (tile counts) lo, column runs, -, hi} of the completion pass's candidates */;
 constexpr int SC_Q_EARLY = 4, SC_N_LATE = 5, SC_UNDONE = 6, SC_EARLY_COUNTS = 20 /* {R lo, Q early, -, R hi} */, SC_REDO_PRED = SC_UNDONE /* the predicate of the second binning + blend: some tile's cut list was too short */;
 
 constexpr int RS_THREADS = 256;     // radix sort: 4 waves
@@ -239,6 +243,8 @@ static inline GeomLayout geom_layout(size_t P)
         L.bk_order_e = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl_e = take(nb * GSRAST_BK_CAP * 4); L.bk_info_e = take(nb * 16); L.bk_base_e = take(nb * 4);
     }
     L.color_skip = take(((Pp + 63) / 64) * 8 + 256);
+    L.cand_bits = take(((Pp + 63) / 64) * 8 + 256);
+    L.skip2 = take(((Pp + 63) / 64) * 8 + 256);
     L.total = o + 256;
     return L;
 }
@@ -277,7 +283,7 @@ static inline RunBinLayout runbin_layout(size_t capR, size_t capQ)
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     if (!capR) capR = 1;
     if (!capQ) capQ = 1;
-    L.point_list = take(capR * 4);
+    L.point_list = take(2 * capR * 4);      // (second half: the lists of the tiles the completion pass of the list cut lists again, below)
     L.rkeyA = take(capQ * 2); L.rkeyB = take(capQ * 2); L.rvalA = take(capQ * 8); L.rvalB = take(capQ * 8);
     L.hist_x = take(256 * rs_blocks_n(capQ, GSRAST_RUN_SORT_ITEMS) * 4);
     L.hist_y = take(256 * ((capQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK) * 4);
@@ -299,6 +305,7 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     L.bucket_cnt = take((XCD_GROUPS + 1) * WORK_BUCKETS * 4);            // forward: per XCD group; backward: one global set
     L.bucket_list = take(T <= BUCKET_MAX_TILES ? (XCD_GROUPS * WORK_BUCKETS * (Tg ? Tg : 1) + WORK_BUCKETS * T) * 2 : 0);
     L.zcut_used = take(T * 4);
+    L.tile_flags = take(T);
     L.total = o + 256;
     return L;
 }

@@ -545,8 +545,10 @@ preprocess_color_compact_kernel(int P, int D, int M, const float* __restrict__ m
                                 const float* __restrict__ colors_precomp, RawArgs raw, const float* __restrict__ campos_dev,
                                 float4* __restrict__ rec2, unsigned char* __restrict__ clamped,
                                 float4* __restrict__ shdA, float4* __restrict__ shdB, float* __restrict__ shdC,
-                                const unsigned char* __restrict__ skip /* bit i = skip Gaussian i; the words past P read as written by the scatter (all set) */)
+                                const unsigned char* __restrict__ skip /* bit i = skip Gaussian i; the words past P read as written by the scatter (all set) */,
+                                const uint32_t* __restrict__ pred = nullptr /* or: a launch of the list cut's completion pass (returns unless *pred != 0) */)
 {
+    if (pred && *pred == 0u) return;
     constexpr int PER = PCC_IDS / (64 * PCC_WAVES);              // consecutive Gaussians per lane (8)
     static_assert(PER == 8, "one byte of flags per lane");
     __shared__ float s_rows[PCC_WAVES][64 * PP_SH_STRIDE];
@@ -989,7 +991,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int ncoef = (D + 1) * (D + 1);
     const bool staged = shs && M * 3 <= PP_SH_MAX;
     float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
-    const bool late_rows = GROUPED && late_bits && cut_scalars[SC_N_LATE] != 0u && cut_scalars[SC_UNDONE] == 0u;      // (uniform)
+    const bool late_rows = GROUPED && late_bits && cut_scalars[SC_N_LATE] != 0u;      // (uniform; the completion pass has taken the Gaussians it listed after all out of the bits)
     const int gbase = blockIdx.x * (GROUPED ? PB_GROUP : PP_THREADS);
     int nround = 1;
     uint32_t total = 0;
@@ -1268,7 +1270,7 @@ struct LateRowsArgs { float* ptr[12]; int rowlen[12]; int n; };
 __global__ void __launch_bounds__(256)
 late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, const uint32_t* __restrict__ cut_scalars, LateRowsArgs a)
 {
-    if (cut_scalars[SC_N_LATE] == 0u || cut_scalars[SC_UNDONE] != 0u) return;       // the same verdict as preprocess_bwd_kernel's
+    if (cut_scalars[SC_N_LATE] == 0u) return;       // the same verdict as preprocess_bwd_kernel's
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t nw = ((uint32_t)P + 63u) / 64u;
     for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4u) {
