@@ -427,7 +427,14 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                             unsigned long long* __restrict__ color_skip = nullptr /* [ceil(n / 64)] or null: bit i = Gaussian i is culled or
                                                                                   late: no list will hold it, the colour kernel need not evaluate it */,
                             uint32_t cshift = 1 /* the cells of the cut-depth table are (1 << cshift)^2 tiles: 2 x 2 up to 1080p-class images,
-                                                   4 x 4 / 8 x 8 for larger ones (at most CUT_MAX_CELLS cells) */)
+                                                   4 x 4 / 8 x 8 for larger ones (at most CUT_MAX_CELLS cells) */,
+                            // LAYER mode (round 4): without remembered cut depths -- a pose the table does not know (layer_mode 1 and
+                            // hint_sel[1] == 0), or no table at all (layer_mode 2) -- every tile's cut depth is ONE depth: the key below
+                            // which the nearest `layer_frac` of the visible Gaussians lie (the bucket map's inverse).  The first pass
+                            // then lists that layer only; the completion pass behind the blend lists the rest into the tiles that did
+                            // not saturate inside it.  zcut_used (uninitialised or all "none") is filled with that key here
+                            int layer_mode = 0, const uint32_t* __restrict__ hint_sel = nullptr, float layer_frac = 0.125f,
+                            uint32_t* __restrict__ zcut_fill = nullptr)
 {
     // per-bucket counters of this workgroup, two 16-bit counters per word (a workgroup has 2048 elements): 16 KB instead of 32 -- with
     // the 4 KB of the bucket map and the 6 KB of cut depths this latency-bound kernel keeps five workgroups per compute unit
@@ -458,7 +465,30 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             const uint4 v = reinterpret_cast<const uint4*>(zhist)[x * (ZH_BINS / 4) + threadIdx.x];
             hv.x += v.x; hv.y += v.y; hv.z += v.z; hv.w += v.w;
         }
-        const uint32_t h0 = hv.x + 1u, h1 = hv.y + 1u, h2 = hv.z + 1u, h3 = hv.w + 1u;
+        // The histogram is a SAMPLE (a few tens of thousands of keys): a bin at the foot of the depth profile expects a handful of
+        // samples and may hold a third of that, which sends three buckets' worth of Gaussians to one bucket (measured on the cube:
+        // pose 29 of a 32-pose ring overflowed a sub-slab on every visit).  The middle bins are smoothed with the binomial weights
+        // 1 4 6 4 1 (two passes of 1 2 1): the noise of a bin falls to a half, a straight ramp is unchanged; the wide tail bins keep
+        // their own count.  Everything is in sixteenths of a sample from here on, plus a quarter sample per bin (an unsampled bin
+        // keeps a positive width); the total stays far below 2^24, exact in the floats below.
+        s_C[4 * threadIdx.x] = hv.x; s_C[4 * threadIdx.x + 1] = hv.y; s_C[4 * threadIdx.x + 2] = hv.z; s_C[4 * threadIdx.x + 3] = hv.w;
+        __syncthreads();
+        uint32_t h0 = 16u * hv.x, h1 = 16u * hv.y, h2 = 16u * hv.z, h3 = 16u * hv.w;
+        if (4u * threadIdx.x >= (uint32_t)ZH_TAIL && 4u * threadIdx.x < (uint32_t)(ZH_TAIL + ZH_MID)) {
+            static_assert(ZH_TAIL % 4 == 0 && ZH_MID % 4 == 0, "a lane's four bins lie on one side of the tails' boundaries");
+            uint32_t w[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = (int)(4u * threadIdx.x) - 2 + q;
+                w[q] = s_C[i < ZH_TAIL ? ZH_TAIL : (i >= ZH_TAIL + ZH_MID ? ZH_TAIL + ZH_MID - 1 : i)];
+            }
+            h0 = w[0] + 4u * w[1] + 6u * w[2] + 4u * w[3] + w[4];
+            h1 = w[1] + 4u * w[2] + 6u * w[3] + 4u * w[4] + w[5];
+            h2 = w[2] + 4u * w[3] + 6u * w[4] + 4u * w[5] + w[6];
+            h3 = w[3] + 4u * w[4] + 6u * w[5] + 4u * w[6] + w[7];
+        }
+        h0 += 4u; h1 += 4u; h2 += 4u; h3 += 4u;
+        __syncthreads();                         // (every lane has read its neighbours' raw counts: the running sum may replace them)
         uint32_t tot;
         const uint32_t ex = block_excl_scan(h0 + h1 + h2 + h3, &tot);
         s_C[4 * threadIdx.x] = ex; s_C[4 * threadIdx.x + 1] = ex + h0; s_C[4 * threadIdx.x + 2] = ex + h0 + h1; s_C[4 * threadIdx.x + 3] = ex + h0 + h1 + h2;
@@ -471,9 +501,11 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             }
         }
     }
+    const bool layer = zcut_used && (layer_mode == 2 || (layer_mode == 1 && hint_sel[1] == 0u));      // (uniform)
     const uint32_t csz = 1u << cshift;
     const uint32_t gy_tiles = zcut_used ? ntiles_img / gx_tiles : 0u, cgx = (gx_tiles + csz - 1u) >> cshift, cgy = (gy_tiles + csz - 1u) >> cshift;
-    if (zcut_used && cshift != 1u) {        // larger cells (images beyond the 1080p class): plain loops
+    if (layer) { }
+    else if (zcut_used && cshift != 1u) {        // larger cells (images beyond the 1080p class): plain loops
         for (uint32_t c = threadIdx.x; c < cgx * cgy; c += 256) {
             const uint32_t cx = c % cgx, cy = c / cgx;
             uint32_t m = 0;
@@ -504,6 +536,18 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     __syncthreads();
     const float scale = (float)nb / (float)s_C[ZH_BINS];
     if (blockIdx.x == 0 && threadIdx.x == 0) *zbins_out = s_fl[0] == 0xFFFFu ? 0xFFFFFFFFu : (s_fl[0] | (s_fl[1] << 16));
+    uint32_t kB = ZCUT_NONE;
+    if (layer) {      // the layer's far end: the key where the running sum reaches layer_frac of the samples (every lane computes the same)
+        const float u = layer_frac * (float)s_C[ZH_BINS];
+        uint32_t i = 0;
+#pragma unroll
+        for (uint32_t st = ZH_BINS / 2; st; st >>= 1) if ((float)s_C[i + st] <= u) i += st;
+        const long long k0 = zh_bin_start(i, zh_klo, zh_shift), k1 = zh_bin_start(i + 1u, zh_klo, zh_shift);
+        const float c0 = (float)s_C[i], c1 = (float)s_C[i + 1u];
+        const long long k = k0 + (long long)(fminf(fmaxf((u - c0) / (c1 - c0), 0.0f), 1.0f) * (float)(k1 - k0));
+        kB = k < 1 ? 1u : (k < (long long)ZH_KEY_TOP ? (uint32_t)k : ZH_KEY_TOP);
+        for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < ntiles_img; t += gridDim.x * 256u) zcut_fill[t] = kB;
+    }
 
     uint32_t dg[BK_ITEMS], lr[BK_ITEMS];
 #pragma unroll
@@ -567,7 +611,8 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                 const uint32_t x0 = rc[r].x & 0xFFFFu, y0 = rc[r].x >> 16, x1 = rc[r].y & 0xFFFFu, y1 = rc[r].y >> 16;
                 const uint32_t kq = key[r] >> 16;
                 bool late = wword != 0u && (x1 - x0) * (y1 - y0) <= 64u;       // (a large rectangle is not worth the walk: early)
-                if (late) {
+                if (layer) late = late && key[r] > kB;
+                else if (late) {
                     const uint32_t cx0 = x0 >> cshift, cx1 = (x1 - 1u) >> cshift, cy0 = y0 >> cshift, cy1 = (y1 - 1u) >> cshift;
                     uint32_t m = 0;
                     if (cx1 - cx0 <= 1u && cy1 - cy0 <= 1u)                    // the usual case: four independent reads, no loop
@@ -988,7 +1033,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
     if (redo_bucket_cnt && blockIdx.x == nbuckets) {
         for (int i = threadIdx.x; i < n_redo_cnt; i += blockDim.x) redo_bucket_cnt[i] = 0u;
         if (threadIdx.x == 0 && redo_hints) atomicAdd(&redo_hints->cut_fallbacks, 1u);
-        if (threadIdx.x == 0 && host_fallback) __hip_atomic_store(host_fallback, ((unsigned long long)host_fb_seq << 32) | (unsigned long long)(*pred ? *pred : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t q2 = 1u;
         if (pass2_counts) {       // {tile counts lo, column runs, -, hi} of the candidates: what the sorts behind this emission are sized by
             __shared__ unsigned long long s_t2[256];
             __shared__ uint32_t s_q2[256];
@@ -997,8 +1042,10 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
             s_t2[threadIdx.x] = ts; s_q2[threadIdx.x] = q;
             __syncthreads();
             for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) { s_t2[threadIdx.x] += s_t2[threadIdx.x + st]; s_q2[threadIdx.x] += s_q2[threadIdx.x + st]; } __syncthreads(); }
-            if (threadIdx.x == 0) { pass2_counts[0] = (uint32_t)s_t2[0]; pass2_counts[1] = s_q2[0]; pass2_counts[2] = 0u; pass2_counts[3] = (uint32_t)(s_t2[0] >> 32); }
+            if (threadIdx.x == 0) { pass2_counts[0] = (uint32_t)s_t2[0]; pass2_counts[1] = s_q2[0]; pass2_counts[2] = 0u; pass2_counts[3] = (uint32_t)(s_t2[0] >> 32); q2 = s_q2[0] ? s_q2[0] : 1u; }
         }
+        // (the host is told what the pass cost: the candidates' column runs -- a context whose passes keep costing too much pauses the cut)
+        if (threadIdx.x == 0 && host_fallback) __hip_atomic_store(host_fallback, ((unsigned long long)host_fb_seq << 32) | (unsigned long long)q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];

@@ -42,7 +42,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0};      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -344,7 +344,7 @@ bool read_found(Readback* rb)
     return (uint32_t)w != 0u;
 }
 // has the device reported a completion pass of the list cut this thread has not taken note of yet (RB_FALLBACK)?  Returns the number
-// of tiles that pass listed again (0: nothing new).
+// of column runs of that pass's candidates (0: nothing new).
 uint32_t take_fallback_event()
 {
     int device = 0;
@@ -629,6 +629,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "list_cut_always")) { g_list_cut_always = value ? 1 : 0; return 0; }   // the list cut also where it does not pay (tests)
+    if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
     if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
@@ -662,6 +663,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "bwd_transposed")) return g_bwd_transposed.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
     if (!strcmp(name, "list_cut_always")) return g_list_cut_always.load();
+    if (!strcmp(name, "layer_cut")) return g_layer_cut.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
     if (!strcmp(name, "bwd_pixels_per_lane")) return g_def.bwd_ppl.load();
@@ -839,7 +841,14 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     }
     const bool cut_pays = g_list_cut_always.load() != 0 || (ctx->last_Q.load() >= CUT_MIN_RUNS && ctx->cut_pause.load() == 0);
     const int cut_cs = cut_cell_shift((size_t)cam.gx, (size_t)cam.gy);
-    const bool cut = hints && bucket_sort && o.tile_clip != 0 && !o.no_list_cut && cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
+    // Round 4: the cut no longer needs the pose table.  With remembered cut depths (a pose the table knows) the first pass lists what lies
+    // in front of them; WITHOUT -- a first-seen pose, the table switched off -- it lists the nearest eighth of the Gaussians (one cut
+    // depth for every tile: LAYER mode, depth_bucket_scatter_kernel), and the completion pass behind the blend lists the rest into the
+    // tiles that did not saturate inside that layer.  Either way the result is exact, and a pause (the passes did not pay) stops both.
+    const bool cut_base = runbin && buckets_ok && o.cull != 0 && o.lpt != 0 && o.fwd_pixels_per_lane == 0 && bucket_sort && o.tile_clip != 0 && !o.no_list_cut &&
+                          cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
+    const bool cut = cut_base && (hints != nullptr || g_layer_cut.load() != 0);
+    const int layer_mode = !cut || g_layer_cut.load() == 0 ? 0 : (hints ? 1 : 2);
     if (!cut && !o.no_list_cut) dec_to_zero(ctx->cut_pause);
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
@@ -950,7 +959,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             {   ProfScope ps(K_SORT_DEPTH, s);
                 depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zhist), zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
                                                                                                          zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
-                                                                                                         cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs);
+                                                                                                         cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs,
+                                                                                                         layer_mode, hint_sel, 0.125f, zcut_used);
                 GS_LAUNCHED("depth_bucket_scatter");
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)
@@ -994,8 +1004,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // (the scatter beside the colours); behind the run emission: 3 M -4 % (the colours end after the binning, the blend waits).
     // (a pose without a slot in the table has no cut depths: every visible Gaussian is early and the plain colour kernel, not the
     // compacting one, evaluates them -- the device said so at the very start of preprocess_fwd, long before this point)
-    const bool pose_known = !(cut && rb_pre) || read_found(rb_pre);
-    if (!pose_known) cut_colors = false;
+    const bool pose_known = !(cut && rb_pre && hints) || read_found(rb_pre);
+    if (!pose_known && layer_mode == 0) cut_colors = false;
     { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
@@ -1145,7 +1155,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         // (the early set differs from pose to pose -- 0.98 M / 1.29 M column runs at two neighbouring poses of the 3 M cube --, a launch
         // sized too small costs a whole second forward, one sized too large a few empty workgroups: half again as much as the largest of
         // the recent forwards)
-        if (cut) { const uint32_t qe = ctx->Qe_hint.load(); nQ1 = (qe && pose_known) ? std::min<uint64_t>(capQ, (uint64_t)qe + qe / 2 + 4096) : capQ; }
+        // (LAYER mode -- an unknown pose, or no table: the nearest eighth of the Gaussians owns about a fifth of the column runs)
+        if (cut) {
+            const uint32_t qe = ctx->Qe_hint.load();
+            const bool layer_call = layer_mode == 2 || (layer_mode == 1 && !pose_known);
+            const uint64_t want = layer_call ? std::max<uint64_t>((uint64_t)qe + qe / 2, (uint64_t)ctx->Q_hint.load() / 3) + 4096 : (uint64_t)qe + qe / 2 + 4096;
+            nQ1 = (qe && (pose_known || layer_mode != 0)) ? std::min<uint64_t>(capQ, want) : capQ;
+        }
         int rc = launch_run_binning(bin, cap, capQ, cut ? nQ1 : capQ, cut ? scalars + SC_EARLY_COUNTS : scalars, (late && !rb_flag) ? std::function<int()>(begin_readback) : std::function<int()>(), cut ? 1 : 0);
         flag_alias = nullptr;                    // (a repeated emission below reads its counts back the ordinary way)
         if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, cut ? 1 : 0);
@@ -1179,15 +1195,18 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     bool sort_redone = false;
     if (!bucket_sort && o.depth_sort == 0) dec_to_zero(ctx->bucket_skip);
     if (bucket_sort) {
-        if (counts[11] == 0 && ctx->bucket_backoff.load() > 0 && ++ctx->bucket_clean >= 64) { ctx->bucket_backoff = 0; ctx->bucket_clean = 0; }   // the scene changed: forget
+        if (counts[11] == 0 && ctx->bucket_clean.load() < 1024 && ++ctx->bucket_clean >= 64) ctx->bucket_backoff = 0;      // the scene changed: forget
         if (counts[11] != 0) {
-            ctx->bucket_clean = 0;      // more Gaussians at (nearly) one depth than a bucket holds: sort again with the radix passes, and
-            ctx->redo_count++;      // start with those for a while (everything enqueued so far used a wrong order, as below)
-            // exponential back-off: 16 radix forwards after the first overflow, twice as many after each further one (a scene whose
-            // depths pile up for good pays the discarded speculative launch ever more rarely), capped at 4096
+            const int clean_before = ctx->bucket_clean.exchange(0);      // more Gaussians at (nearly) one depth than a bucket holds: sort
+            ctx->redo_count++;      // again with the radix passes (everything enqueued so far used a wrong order, as below)
+            // An ISOLATED overflow (32 clean forwards before it: one pose of a cycle whose depth profile has a hard edge inside a
+            // histogram bin, which doubles a few buckets' share and now and then tips one over) costs this one repeat and nothing
+            // else.  Overflows in quick succession start with the radix passes for a while -- exponential back-off: 16 radix forwards,
+            // twice as many after each further one (a scene whose depths pile up for good pays the discarded speculative launch ever
+            // more rarely), capped at 4096 --
             // ... unless the histogram behind the bucket map was not up to this view (a context's first forward: four bins per octave;
             // a depth range that has moved out of the table): the range is learned from this call, the next forward tries again at once
-            if (learn_depth_range(counts[SC_ZBINS]))
+            if (learn_depth_range(counts[SC_ZBINS]) && (clean_before < 32 || ctx->bucket_backoff.load() > 0))
             { const int prev = ctx->bucket_backoff.load(); const int next = prev <= 0 ? 16 : (prev >= 2048 ? 4096 : prev * 2);
               ctx->bucket_backoff = next; ctx->bucket_skip = next; }
             ctx->depth_short = 0;   // the radix path's pass-count hint is stale (not refreshed on the bucket path): assume four passes
@@ -1225,10 +1244,17 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     if (cut && counts[SC_N_LATE] != 0u && counts[1] - counts[SC_Q_EARLY] < CUT_MIN_RUNS && !g_list_cut_always.load()) { ctx->cut_pause = CUT_PAUSE; ctx->cut_pause_P = (uint32_t)P; }
     if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 32 ? qe : hq - hq / 32; }
     // fallbacks of this thread's earlier cut forwards, as the device reported them (everything enqueued before this forward's counts has run)
-    // (a completion pass over a few tiles is cheap and expected; one over a quarter of the image is a cut that did not pay)
-    if (take_fallback_event() > T / 4u) {
-        ctx->cut_ok_streak = 0;
-        if ((ctx->cut_fb_score += 8) >= 16 && !g_list_cut_always.load()) {
+    // (a completion pass over a few tiles is cheap and expected; its cost grows with the tiles it lists again: one over an eighth of
+    // the image counts like rounds 3's whole second forward, smaller ones in proportion)
+    if (const uint32_t q2 = take_fallback_event()) {       // (the column runs of the pass's candidates)
+        // up to an eighth of all column runs is what a pass is expected to cost (LAYER mode lists a few per cent again on every
+        // call); a quarter and more counts like round 3's whole second forward, in between in proportion
+        const uint32_t qall = std::max(ctx->last_Q.load(), 8u), lo = qall / 8u;
+        const int pts = q2 <= lo ? 0 : (int)std::min<uint64_t>(8u, ((uint64_t)(q2 - lo) * 8u + lo - 1u) / lo);
+        if (trace) fprintf(stderr, "[gsrast] completion pass reported: %u column runs of %u, %d points on a score of %d\n", q2, qall, pts, ctx->cut_fb_score.load());
+        if (pts == 0 && ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
+        if (pts >= 4) ctx->cut_ok_streak = 0;
+        if ((ctx->cut_fb_score += pts) >= 16 && !g_list_cut_always.load()) {
             const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 32 : (prev >= 512 ? 1024 : prev * 2);
             ctx->cut_fb_pause = len; ctx->cut_pause = len; ctx->cut_pause_P = (uint32_t)P; ctx->cut_fb_score = 0;
         }

@@ -959,14 +959,34 @@ def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu)
     _C.set_option("list_cut_always", 1)               # (by default the cut is only applied where it pays: scenes of millions of column runs)
     try:
         _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H)
+        # option "layer_cut" (off by default, DESIGN.md: measured slower): a pose WITHOUT remembered cut depths lists the nearest
+        # eighth of the Gaussians first and completes the tiles that did not saturate inside it -- same results, another pose
+        cam2 = scenes.camera(5, 9, W, H)
+
+        def render2(scene):
+            nonlocal cam
+            keep, cam = cam, cam2
+            try:
+                return render(scene)
+            finally:
+                cam = keep
+        _C.set_option("layer_cut", 1)
+        try:
+            _list_cut_body(orc, scenes, rast, gpu, _C, render2, same, sc, cam2, P, W, H, layer=True)
+        finally:
+            _C.set_option("layer_cut", 0)
     finally:
         _C.set_option("list_cut_always", 0)
 
 
-def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H):
+def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H, layer=False):
     fb0 = _C.context_query("cut_fallbacks")
-    full, late0 = render(sc)                          # first render of the pose by this context: nothing to cut by
-    assert late0 == 0
+    full, late0 = render(sc)                          # first render of the pose by this context: no remembered cut depths
+    if layer:                                         # option "layer_cut": a depth LAYER is listed first and completed behind the blend
+        assert late0 > 0
+        fb0 = _C.context_query("cut_fallbacks")       # (completion passes so far)
+    else:
+        assert late0 == 0                             # nothing to cut by
     o = orc.render(sc, cam)
     assert full[0] == o["R"] and np.array_equal(bits(full[1].cpu().numpy()), bits(o["out_color"]))
     cut1, late1 = render(sc)
