@@ -378,7 +378,7 @@ struct gsrast_context {
     std::atomic<uint32_t> cut_pause_P{0};   // ... in a scene of this many Gaussians (another scene: the pause is void)
     // ... or its cut lists keep turning out too short (a scene that changes between two visits of a pose: SaRO-GS's time-varying
     // opacity): every fallback costs a whole second forward and is reported by the device (RB_FALLBACK); two in close succession pause
-    // the cut, for twice as long each time (32 ... 1024 forwards), 64 cut forwards without one forget
+    // the cut, for twice as long each time (64 ... 1024 forwards; back on probation: one more such pass pauses again), 64 cut forwards without one forget
     std::atomic<int> cut_fb_score{0}, cut_fb_pause{0}, cut_ok_streak{0};
     // equalised depth buckets (gsrast_common.h): the key range the depth histogram's bins cover, learned from the previous forwards
     std::atomic<uint32_t> zh_klo{ZH_KLO_DEFAULT}; std::atomic<int> zh_shift{ZH_SHIFT_DEFAULT};
@@ -1255,8 +1255,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (pts == 0 && ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
         if (pts >= 4) ctx->cut_ok_streak = 0;
         if ((ctx->cut_fb_score += pts) >= 16 && !g_list_cut_always.load()) {
-            const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 32 : (prev >= 512 ? 1024 : prev * 2);
-            ctx->cut_fb_pause = len; ctx->cut_pause = len; ctx->cut_pause_P = (uint32_t)P; ctx->cut_fb_score = 0;
+            // (on probation after the pause: the score restarts at half the bar, ONE more pass of that size pauses again, twice as long)
+            const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 64 : (prev >= 512 ? 1024 : prev * 2);
+            ctx->cut_fb_pause = len; ctx->cut_pause = len; ctx->cut_pause_P = (uint32_t)P; ctx->cut_fb_score = 8;
         }
     } else if (cut && counts[SC_N_LATE] != 0u) {
         if (ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
