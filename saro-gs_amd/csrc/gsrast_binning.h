@@ -408,7 +408,17 @@ constexpr int BK_CAP = GSRAST_BK_CAP;    // slots per bucket = the largest bucke
 constexpr int BK_XCD = 8;                // counter / slab sets
 constexpr int BK_CAPX = BK_CAP / BK_XCD; // slots per (bucket, XCD) sub-slab
 constexpr int BK_MAX_BUCKETS = 8192;
-constexpr int BK_ITEMS = 8;              // elements per lane of the scatter kernel
+// Elements per lane of the scatter kernel.  The kernel is a chain of latencies (histogram -> LDS ranks -> returning global atomics ->
+// slab stores), its workgroups all take about the same time, and a launch costs as many workgroup latencies as it has ROUNDS of
+// resident workgroups: with 8 elements per lane (102 VGPRs, five workgroups per CU, 1280 resident) 3 M Gaussians are 1465
+// workgroups -- two rounds, the second 14 % full: 117 us.  16 per lane (165 VGPRs, three per CU, 768 resident) makes them 733
+// workgroups in ONE round: 92 us (measured at 3 M under pose cycling: sort_depth 0.150 -> 0.125 ms; 14 or 20 per lane, two rounds
+// again: 0.158).  A round holds ~3.1 M elements whatever the choice (registers grow with the elements per lane), so the host
+// picks 16 where that turns two rounds into one (depth_scatter_items) and 8 otherwise.
+constexpr int BK_ITEMS = 8, BK_ITEMS_WIDE = 16;
+constexpr uint32_t BK_ROUND = 1280u * 256u * BK_ITEMS, BK_ROUND_WIDE = 768u * 256u * BK_ITEMS_WIDE;      // elements of one round (256 CUs)
+__host__ __device__ inline int depth_scatter_items(size_t n) { return n > BK_ROUND && n <= BK_ROUND_WIDE ? BK_ITEMS_WIDE : BK_ITEMS; }
+template <int BK_ITEMS_T>
 __global__ void __launch_bounds__(256)
 depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                             uint32_t n, const uint32_t* __restrict__ zhist /* [ZH_COPIES][ZH_BINS]: sampled histogram of the visible depth keys (preprocess_fwd) */,
@@ -453,10 +463,10 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     if (threadIdx.x == 0) { s_late = 0u; s_fl[0] = 0xFFFFu; s_fl[1] = 0u; }
     for (uint32_t k = threadIdx.x; k < nb / 2u; k += 256) cnt[k] = 0u;
     // (the keys are requested first: their round trip passes under the construction of the bucket map)
-    const uint32_t base = blockIdx.x * (256 * BK_ITEMS);
-    uint32_t key[BK_ITEMS];
+    const uint32_t base = blockIdx.x * (256 * BK_ITEMS_T);
+    uint32_t key[BK_ITEMS_T];
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) { const uint32_t i = base + r * 256 + threadIdx.x; key[r] = i < n ? keys[i] : 0xFFFFFFFFu; }
+    for (int r = 0; r < BK_ITEMS_T; r++) { const uint32_t i = base + r * 256 + threadIdx.x; key[r] = i < n ? keys[i] : 0xFFFFFFFFu; }
     static_assert(ZH_BINS == 4 * 256, "one uint4 of the histogram per lane");
     {   // the bucket map: running sum of the sampled histogram, one pseudo-count per bin (an unsampled bin keeps a positive width)
         uint4 hv = reinterpret_cast<const uint4*>(zhist)[threadIdx.x];
@@ -549,9 +559,9 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < ntiles_img; t += gridDim.x * 256u) zcut_fill[t] = kB;
     }
 
-    uint32_t dg[BK_ITEMS], lr[BK_ITEMS];
+    uint32_t dg[BK_ITEMS_T], lr[BK_ITEMS_T];
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {
+    for (int r = 0; r < BK_ITEMS_T; r++) {
         dg[r] = 0u; lr[r] = 0u;
         if (key[r] != 0xFFFFFFFFu) {
             // bucket = floor(nb * CDF(key)), the CDF linear inside a bin.  Monotone in the key: (bin, position) is, the conversion of the
@@ -570,9 +580,9 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         }
     }
     // what travels with the element: coalesced, requested here so that the loads pass under the atomics' round trip below
-    uint2 rc[BK_ITEMS]; uint32_t tl[BK_ITEMS];
+    uint2 rc[BK_ITEMS_T]; uint32_t tl[BK_ITEMS_T];
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {      // (culled Gaussians have rect = tiles = 0)
+    for (int r = 0; r < BK_ITEMS_T; r++) {      // (culled Gaussians have rect = tiles = 0)
         const uint32_t i = base + r * 256 + threadIdx.x;
         rc[r] = make_uint2(0u, 0u); tl[r] = 0u;
         if (i < n) { rc[r] = rect[i]; tl[r] = tiles[i]; }
@@ -603,7 +613,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     __syncthreads();
     uint32_t nlate = 0;
 #pragma unroll
-    for (int r = 0; r < BK_ITEMS; r++) {
+    for (int r = 0; r < BK_ITEMS_T; r++) {
         bool skipped = true;                                                   // culled (or past the end)
         if (key[r] != 0xFFFFFFFFu) {
             uint32_t wword = (rc[r].y & 0xFFFFu) - (rc[r].x & 0xFFFFu);

@@ -957,10 +957,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             uint32_t* gcount = at<uint32_t>(geom, GL.bk_count);
             uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
-                depth_bucket_scatter_kernel<<<(P + 256 * BK_ITEMS - 1) / (256 * BK_ITEMS), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zhist), zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
-                                                                                                         zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
-                                                                                                         cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs,
-                                                                                                         layer_mode, hint_sel, 0.125f, zcut_used);
+                const int items = depth_scatter_items((size_t)P);       // (elements per lane: whatever makes the launch ONE round of workgroups)
+                auto scatter = items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE> : depth_bucket_scatter_kernel<BK_ITEMS>;
+                scatter<<<(P + 256 * items - 1) / (256 * items), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zhist), zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
+                                                                               zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
+                                                                               cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs,
+                                                                               layer_mode, hint_sel, 0.125f, zcut_used);
                 GS_LAUNCHED("depth_bucket_scatter");
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)

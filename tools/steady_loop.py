@@ -1,0 +1,18 @@
+#!/usr/bin/env python
+"""The headline loop and nothing else (development helper for rocprofv3 --kernel-trace + tools/timeline.py):
+   python tools/steady_loop.py [P=3e6] [poses=8] [steps=160] [option=value ...]"""
+import sys
+sys.path[:0] = ["/root/repo", "/root/repo/saro-gs_amd"]
+import torch, bench, scenes
+import diff_gaussian_rasterization_ch3 as rast
+P = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 160
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    rast._C.set_option(k, int(v))
+dev = torch.device("cuda:0")
+wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, V, dev)
+for i in range(N):
+    wl.step(None, 1)
+torch.cuda.synchronize()
