@@ -25,4 +25,17 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU 
 f=$(ls $out/pmc_sq/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_SQ.txt
 rm -rf $out/pmc_sq
+# L2 hit rate, fabric request sizes, LDS conflicts: one pass per group (a group a box does not know is skipped: its file stays empty)
+rocprofv3 --list-avail > $out/${tag}_counters_avail.txt 2>&1
+i=0
+for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1))
+  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_x$i -o pmc -- python bench.py $extra --steps 5 --warmup 2 --sweep "" --no-cpu-baseline --no-training-like > /dev/null 2> $out/pmc_x$i.err
+  f=$(ls $out/pmc_x$i/*counter_collection.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_X$i.txt
+  rm -rf $out/pmc_x$i
+done
+grep -c . $out/${tag}_counters_avail.txt > /dev/null && grep -o "TCC_[A-Z0-9_]*\|SQ_LDS_[A-Z_]*" $out/${tag}_counters_avail.txt | sort -u | tr '\n' ' ' > $out/${tag}_counters_tcc_lds_names.txt; rm -f $out/${tag}_counters_avail.txt
+# stream timeline of one steady-state step of the headline loop (8 poses round-robin)
+bash tools/timeline_run.sh ${tag}_3M 3e6 8 120 && cp gpurun_out/timeline_${tag}_3M.txt $out/${tag}_timeline_3M.txt
 ls -la $out
