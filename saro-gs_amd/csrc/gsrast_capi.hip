@@ -387,7 +387,8 @@ struct gsrast_context {
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
     std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
-    struct Hints { HintTable* table = nullptr; uint32_t T = 0; } hints[32];   // per device: launch-order hints of the forward blend (gsrast_common.h), device memory
+    struct Hints { HintTable* table = nullptr; uint32_t T = 0; uint64_t used = 0; } hints[32][4];   // (one table per image size in use, up to four: train / eval resolutions alternate)
+    uint64_t hints_clock = 0;   // per device: launch-order hints of the forward blend (gsrast_common.h), device memory
     std::mutex mu;
 };
 namespace {
@@ -425,10 +426,20 @@ HintTable* hints_of(gsrast_context* ctx, uint32_t T, hipStream_t s)
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto& h = ctx->hints[device];
-    if (h.table && h.T != T) {       // another image size: the estimates mean nothing (rare: drain, then start over)
-        (void)hipStreamSynchronize(s); (void)hipFree(h.table); h.table = nullptr;
+    // one table per tile count, up to four per device (train and eval resolutions, mixed camera sizes: each keeps its poses); a fifth
+    // size takes over the least recently used table's place (rare: drain, then start over)
+    gsrast_context::Hints* hp = nullptr;
+    for (auto& c : ctx->hints[device]) if (c.table && c.T == T) hp = &c;
+    if (!hp) {
+        for (auto& c : ctx->hints[device]) if (!c.table) { hp = &c; break; }
+        if (!hp) {
+            hp = &ctx->hints[device][0];
+            for (auto& c : ctx->hints[device]) if (c.used < hp->used) hp = &c;
+            (void)hipStreamSynchronize(s); (void)hipFree(hp->table); hp->table = nullptr;
+        }
     }
+    auto& h = *hp;
+    h.used = ++ctx->hints_clock;
     if (!h.table) {
         if (hipMalloc((void**)&h.table, hint_table_bytes(T)) != hipSuccess) { h.table = nullptr; return nullptr; }
         h.T = T;
@@ -438,7 +449,8 @@ HintTable* hints_of(gsrast_context* ctx, uint32_t T, hipStream_t s)
     return h.table;
 }
 gsrast_context* thread_context()
-{   // deliberately leaked at thread exit (a few words): see Readback above for why nothing here has a destructor
+{   // deliberately leaked at thread exit -- the host words AND the device pose tables it has grown (12.5 MB per image size at 1080p, include/gsrast.h):
+    // see Readback above for why nothing here has a destructor; a host thread that renders and exits should use gsrast_context_create / _destroy
     thread_local gsrast_context* c = new gsrast_context();
     return c;
 }
@@ -591,7 +603,7 @@ gsrast_context* gsrast_context_create(void) { return new (std::nothrow) gsrast_c
 void gsrast_context_destroy(gsrast_context* c)
 {
     if (!c) return;
-    for (auto& h : c->hints) if (h.table) (void)hipFree(h.table);
+    for (auto& d : c->hints) for (auto& h : d) if (h.table) (void)hipFree(h.table);
     for (SideStream& x : c->side) {
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
@@ -613,11 +625,15 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "cut_pause")) return c->cut_pause.load();      // forwards the list cut still sits out (too little saved, or its lists kept failing)
     if (!strcmp(name, "cut_fallbacks")) {       // a device counter in the hint table of the current device (diagnostic: waits for the device)
         int device = 0;
-        if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32 || !c->hints[device].table) return 0;
-        uint32_t v = 0;
+        if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return 0;
         if (hipDeviceSynchronize() != hipSuccess) return GSRAST_E_DEVICE;
-        if (hipMemcpy(&v, &c->hints[device].table->cut_fallbacks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return GSRAST_E_DEVICE;
-        return (int)v;
+        uint32_t sum = 0;                       // (over the device's tables: one per image size)
+        for (const auto& h : c->hints[device]) {
+            uint32_t v = 0;
+            if (h.table && hipMemcpy(&v, &h.table->cut_fallbacks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return GSRAST_E_DEVICE;
+            sum += v;
+        }
+        return (int)sum;
     }
     return GSRAST_E_ARG;
 }

@@ -1075,6 +1075,44 @@ def test_list_cut_on_a_large_image(scenes, rast, gpu):
         _C.set_option("list_cut_always", 0)
 
 
+def test_list_cut_survives_alternating_image_sizes(scenes, rast, gpu):
+    """a context keeps one pose table per image size (up to four): train and eval resolutions that alternate call by
+    call each keep their poses' cut depths -- the cut is in force on every visit after a size's first, with the same results as without."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P = 60_000
+    sc = scenes.synth(P, 811, scale_mul=1.3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+
+    def render(W, H):
+        cam = scenes.camera(2, 9, W, H)
+        rs = settings_from(rast, cam, sc, gpu)
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        return (R, color.clone(), depth.clone(), radii.clone()), _C.context_query("last_late")
+
+    sizes = ((320, 240), (400, 304), (256, 192))
+    _C.set_option("no_list_cut", 1)
+    try:
+        ref = {wh: render(*wh)[0] for wh in sizes}
+    finally:
+        _C.set_option("no_list_cut", 0)
+    _C.set_option("list_cut_always", 1)
+    try:
+        for visit in range(3):
+            for wh in sizes:
+                out, late = render(*wh)
+                assert out[0] == ref[wh][0] and all(torch.equal(a, b) for a, b in zip(out[1:], ref[wh][1:])), (visit, wh)
+                if visit >= 1:
+                    assert late > P // 8, (visit, wh, late)      # the size's table was kept while the other sizes were rendered
+    finally:
+        _C.set_option("list_cut_always", 0)
+
+
 def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
     """a pose may hold cut depths while the scatter marks NO Gaussian late (rectangles of more than 64 tiles are
     never late; a Gaussian over a tile without a cut stays early).  The host then enqueues no second pass, so the blend must not
