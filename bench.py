@@ -239,7 +239,7 @@ def roofline_of(st, bwd_ms, P, exp2=None):
         if pj and pj.get("gaussians", 3_000_000 if "3M" in name else 1_000_000) == P:
             traffic, src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
             vi = pj.get("valu_wave_insts_per_launch")
-            mix = _profile_json("r03_valu_mix.json") or _profile_json("r02_valu_mix.json")
+            mix = _profile_json("r04_valu_mix.json") or _profile_json("r03_valu_mix.json") or _profile_json("r02_valu_mix.json")
             cal = _profile_json("r02_valu_calib.json")
             if vi and bwd_ms > 0 and mix and cal:
                 cyc = mix["kernels"]["blend_bwd_cull_t_kernel"]["avg_cycles_per_valu_inst"]

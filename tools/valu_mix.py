@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Static VALU instruction mix of the blend kernels' per-(wave, instance) loop, priced with the MEASURED issue cost of each
-instruction class (profiles/r02_valu_calib.json, tools/valu_calib.hip) -> profiles/r02_valu_mix.json.
+instruction class (profiles/r02_valu_calib.json, tools/valu_calib.hip) -> profiles/<tag>_valu_mix.json (tag = argv[1], default r04).
 
     python tools/valu_mix.py            # compiles csrc/gsrast_capi.hip with -save-temps into a temp dir, no GPU needed
 
@@ -89,7 +89,8 @@ def main():
             "avg_cycles_per_valu_inst": round(cyc / n, 3),
             "loop_other": {"salu": sum(1 for l in loop if l.split()[0].startswith("s_")), "lds": sum(1 for l in loop if l.split()[0].startswith("ds_"))},
             "whole_kernel_mix": km}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_valu_mix.json"), "w"), indent=1)
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_valu_mix.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
