@@ -201,7 +201,7 @@ static inline size_t rs_blocks(size_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK;
 #define GSRAST_DEPTH_ITEMS 8      // elements per lane in the depth sort (P elements): measured 16 -> 112 us, 8 -> 95, 4 -> 99, 2 -> 122
 #endif
 #ifndef GSRAST_RUN_SORT_ITEMS
-#define GSRAST_RUN_SORT_ITEMS 16  // ... in the sort of the column runs (Q elements): 4 / 8 / 16 measured equal
+#define GSRAST_RUN_SORT_ITEMS 8   // ... in the sort of the column runs (Q elements): 4 / 8 / 16 measured equal on full lists (8.7 M runs); under the list cut (1.1 M runs, one round of workgroups either way) 8 makes the pass 5 us shorter than 16
 #endif
 static inline size_t rs_blocks_n(size_t n, int items) { return (n + (size_t)RS_THREADS * items - 1) / ((size_t)RS_THREADS * items); }
 static inline size_t scan_tmp_elems(size_t n)
