@@ -8,6 +8,6 @@ import sys, re
 t = sys.stdin.read()
 m = re.search(r'views/s ([0-9.]+) ms/step ([0-9.]+)', t)
 g = lambda k: (re.search(r\"'%s': ([0-9.]+)\" % k, t) or [None, '?'])[1]
-print('views/s', m.group(1) if m else t[:200], 'ms', m.group(2) if m else '', 'fwd', g('blend_fwd'), 'bwd', g('blend_bwd'), 'sort_depth', g('sort_depth'), 'cut_redo', g('cut_redo'), 'pbwd', g('preprocess_bwd'), 'emit', g('emit_instances'), 'sort_tile', g('sort_tile'))
+print('views/s', m.group(1) if m else t[:200], 'ms', m.group(2) if m else '', 'fwd', g('blend_fwd'), 'bwd', g('blend_bwd'), 'sort_depth', g('sort_depth'), 'cut_redo', g('cut_redo'), 'pbwd', g('preprocess_bwd'), 'emit', g('emit_instances'), 'sort_tile', g('sort_tile'), 'pfwd', g('preprocess_fwd'), 'lrz', g('late_rows_zero'))
 "; done
 cp /tmp/orig.so $L
