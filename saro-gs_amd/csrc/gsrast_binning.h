@@ -1037,7 +1037,10 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                                                               sequence number of the call and how many tiles were listed again): a context whose cuts keep failing pauses them */,
                         // COMPLETION pass (round 4): the buckets hold the CANDIDATES only; a column run is kept only if it crosses a tile that
                         // is listed again (need2[tile] != 0), and the bookkeeping workgroup also leaves the pass's totals in pass2_counts
-                        const unsigned char* __restrict__ need2 = nullptr, int gx_tiles = 0, uint32_t* __restrict__ pass2_counts = nullptr)
+                        const unsigned char* __restrict__ need2 = nullptr, int gx_tiles = 0, uint32_t* __restrict__ pass2_counts = nullptr,
+                        // binrec == null (list cut: preprocess_fwd did not write the 32-byte binning records): the same numbers from the blend's
+                        // records and the rectangles -- three gathers instead of two, for the few Gaussians that are listed
+                        const float4* __restrict__ rec0 = nullptr, const float4* __restrict__ rec1 = nullptr, const uint2* __restrict__ rect = nullptr)
 {
     if (pred && *pred == 0u) return;
     if (redo_bucket_cnt && blockIdx.x == nbuckets) {
@@ -1111,8 +1114,13 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         uint2 rc = make_uint2(0u, 0u);
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
         if (w != 0u) {
-            r0 = binrec[2 * (size_t)g]; r1 = binrec[2 * (size_t)g + 1];
-            rc = make_uint2(__float_as_uint(r1.z), __float_as_uint(r1.w));
+            if (binrec) {
+                r0 = binrec[2 * (size_t)g]; r1 = binrec[2 * (size_t)g + 1];
+                rc = make_uint2(__float_as_uint(r1.z), __float_as_uint(r1.w));
+            } else {
+                r0 = rec0[g]; const float4 t1 = rec1[g]; rc = rect[g];
+                r1 = make_float4(t1.x, t1.w, 0.f, 0.f);             // (conic c, skip threshold)
+            }
         }
         x0 = rc.x & 0xFFFFu;
         yh = (rc.x >> 16) | (((rc.y >> 16) - (rc.x >> 16)) << 16);

@@ -864,6 +864,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool cut_base = runbin && buckets_ok && o.cull != 0 && o.lpt != 0 && o.fwd_pixels_per_lane == 0 && bucket_sort && o.tile_clip != 0 && !o.no_list_cut &&
                           cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
     const bool cut = cut_base && (hints != nullptr || g_layer_cut.load() != 0);
+    // the 32-byte binning records (everything the run emission needs of a Gaussian in one line) are written where the emission gathers
+    // EVERY visible Gaussian; under the list cut it gathers one in eight, from the blend's records, and preprocess_fwd writes 96 MB less at 3 M
+    float4* binrec_p = cut ? nullptr : at<float4>(geom, GL.binrec);
     const int layer_mode = !cut || g_layer_cut.load() == 0 ? 0 : (hints ? 1 : 2);
     if (!cut && !o.no_list_cut) dec_to_zero(ctx->cut_pause);
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
@@ -953,12 +956,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
+                tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
                 zcut_used, T, scalars, host_found, pre_seq);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
-                tiles, rect, at<float4>(geom, GL.binrec), kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
+                tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
                 zcut_used, T, scalars, host_found, pre_seq);
         GS_LAUNCHED("preprocess_fwd");
     }
@@ -1065,32 +1068,32 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
             if (bucketed && mode == 1)
-                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e), at<float4>(geom, GL.binrec), W, H,
+                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e), binrec_p, W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), nbk, scalars,
-                                                            flag_alias, flag_seq, at<uint4>(geom, GL.bk_info));
+                                                            flag_alias, flag_seq, at<uint4>(geom, GL.bk_info), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect);
             else if (bucketed && mode == 2) {
                 // COMPLETION pass: only the CANDIDATES -- the Gaussians, early or late, whose rectangle touches a tile flagged by the
                 // blend -- are sorted (the buckets' non-early arrays are free) and listed, and only into flagged tiles
                 depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order),
                                                                                                    at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nullptr, pred,
                                                                                                    at<unsigned long long>(geom, GL.cand_bits));
-                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
+                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), binrec_p, W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, nullptr,
                                                             nullptr, 0, nullptr, pred, at<uint32_t>(img, IL.bucket_cnt), XCD_GROUPS * WORK_BUCKETS /* (the forward's order only: the backward's keeps the tiles that are final) */, hints,
                                                             rb_pre ? reinterpret_cast<unsigned long long*>(pre_alias) + RB_FALLBACK : nullptr, pre_seq,
-                                                            at<unsigned char>(img, IL.tile_flags), cam.gx, scalars + SC_PASS2); }
+                                                            at<unsigned char>(img, IL.tile_flags), cam.gx, scalars + SC_PASS2, rec0, rec1, rect); }
             else if (bucketed) {
                 if (cut) {      // (a list-cut forward sorted the early Gaussians only, and now everything is listed after all: the buckets are sorted again, whole)
                     depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(at<uint4>(geom, GL.bk_slab), at<uint32_t>(geom, GL.bk_count), nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order),
                                                                                                        at<uint32_t>(geom, GL.bk_wincl), at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
                     GS_LAUNCHED("depth_bucket_sort");
                 }
-                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), at<float4>(geom, GL.binrec), W, H,
+                emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), binrec_p, W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars,
-                                                            flag_alias, flag_seq);
+                                                            flag_alias, flag_seq, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect);
             } else
-                emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, at<float4>(geom, GL.binrec), W, H,
-                                                                       o.tile_clip, capQ_, rkA, rvA);
+                emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, binrec_p, W, H,
+                                                                       o.tile_clip, capQ_, rkA, rvA, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect);
             GS_LAUNCHED("emit_column_runs"); }
         if (bucketed && mode != 2) totals_pending = false;
         if (after_emit) { int rc = after_emit(); if (rc != GSRAST_OK) return rc; }

@@ -817,8 +817,12 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                 }
                 rc = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
                 // everything the binning needs about this Gaussian in ONE 32-byte record (it is gathered in depth order)
-                binrec[2 * (size_t)i] = make_float4(px, py, con0, con1);
-                binrec[2 * (size_t)i + 1] = make_float4(con2, thr, __uint_as_float(rc.x), __uint_as_float(rc.y));
+                // (null under the list cut: the emission then gathers the few Gaussians it lists from rec0 / rec1 / rect, and 32 bytes per
+                // Gaussian stay unwritten)
+                if (binrec) {
+                    binrec[2 * (size_t)i] = make_float4(px, py, con0, con1);
+                    binrec[2 * (size_t)i + 1] = make_float4(con2, thr, __uint_as_float(rc.x), __uint_as_float(rc.y));
+                }
             }
         }
     }
