@@ -323,14 +323,14 @@ def stage_table(_C, wl, st, P, deg, H):
     run_binning = _C.get_option("binning") == 0 and T <= 65536 and (H + 15) // 16 <= 256
     bucket_sort = run_binning and _C.get_option("depth_sort") == 0 and P >= 32768
     alg = {
-        "preprocess_fwd": P * (44 + 20) + Pv * 64,                # geometry half: in 44 B, out radii / tiles / rect / depth key 20 B + rec0, rec1, binrec 64 B per visible Gaussian (round 3: no cov3D / depth / sort value)
+        "preprocess_fwd": P * (44 + 20) + Pv * (32 if late_n else 64),   # geometry half: in 44 B, out radii / tiles / rect / depth key 20 B + rec0, rec1 32 B (+ binrec 32 B when the list cut is not in force) per visible Gaussian
         "preprocess_color": (Pe if late_n else P) * (12 + 12 * C + 17 + (36 if deg > 0 else 0)) + (P if late_n else 0),   # colour half (side stream, beside the binning): means + SH in, rec2 + clamp flags + the 9 direction derivatives out (list cut: early Gaussians only, + a flag byte each)
         # bucket depth sort (default): scatter reads key + rect + tiles (16 B), writes a 16-B slab element; the sort kernel reads it
         # (twice, the second time from L2) and writes id + width scan (8 B) -- per visible Gaussian; radix passes: 20 B x 4
         "sort_depth": (P * 16 + Pv * 40) if bucket_sort else P * 20 * 4,
         "scan_tiles": (0 if bucket_sort else P * 12) if run_binning else P * 24,   # bucket sort: totals by the run emission's last workgroup
         # run-compressed: Q column runs of 10 B emitted, sorted by column (one pass), expanded once into Rl instances
-        "emit_instances": (P * 40 + Q * 10) if run_binning else (P * 24 + R * 6),
+        "emit_instances": (((Pe * 48 + P * 8) if late_n else P * 40) + Q * 10) if run_binning else (P * 24 + R * 6),
         "sort_tile": (Q * 22 + Q * 16 + Rl * 4) if run_binning else R * 14 * passes_t,
         "tile_ranges": T * 8 if run_binning else R * 2 + T * 8,
         "blend_fwd": Re * 44 + N * 24,
