@@ -365,7 +365,14 @@ __device__ __forceinline__ void color_stage_rows(const float* __restrict__ shs, 
         const float4* src4 = reinterpret_cast<const float4*>(shs + (size_t)base * row);
         float4 v[PP_SH_MAX / 4];
 #pragma unroll
-        for (int u = 0; u < PP_SH_MAX / 4; u++) { const int q = threadIdx.x + u * PP_THREADS; v[u] = src4[q_of(q, n4, row)]; }
+        for (int u = 0; u < PP_SH_MAX / 4; u++) {
+            const int q = threadIdx.x + u * PP_THREADS;
+            // (non-temporal: 576 MB of SH rows at 3 M, each read once per forward -- they need not push the arrays that are read again out
+            // of the Infinity Cache: first-seen-pose step +1.4 % views/s)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src4) + q_of(q, n4, row));
+            v[u] = make_float4(t.x, t.y, t.z, t.w);
+        }
 #pragma unroll
         for (int u = 0; u < PP_SH_MAX / 4; u++) {
             const int q = threadIdx.x + u * PP_THREADS;
