@@ -42,7 +42,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -371,6 +371,24 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // views.  The reference-shaped entry points use a context private to the calling host thread.
 } // namespace
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
+// The list cut's completion pass OFF the critical path (round 4).  Its eleven predicated launches used to sit between the forward blend and
+// whatever the caller enqueues next: 55-80 us of dependent-launch latency in the steady state, where every one of them returns at once.
+// Now one tiny kernel behind the blend copies the blend's verdict into a word of the context's own (`pred`: the chain's predicate; the
+// forward's buffers may be gone by the time the chain's no-ops run) and, if the verdict is "nothing to complete", releases the caller's
+// stream at once (`done` = the call's sequence number, waited for with hipStreamWaitValue32); the chain runs on a second stream behind
+// that kernel and, if it had work to do, releases the caller's stream at its end.  Deadlock-free on in-order hardware queues however HIP
+// maps streams onto them: everything the wait can be released by is SUBMITTED before the wait (gate kernel, event, chain, last the wait).
+struct ChainGate { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; uint32_t* words = nullptr /* [64] done | [64] pred */; uint32_t seq = 0; bool failed = false; };
+__global__ void chain_gate_kernel(const uint32_t* __restrict__ undone, uint32_t* __restrict__ pred_copy, uint32_t* __restrict__ done, uint32_t seq)
+{
+    const uint32_t v = *undone;
+    *pred_copy = v;
+    if (v == 0u) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void chain_done_kernel(const uint32_t* __restrict__ pred_copy, uint32_t* __restrict__ done, uint32_t seq)
+{
+    if (*pred_copy != 0u) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 struct gsrast_context {
     std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0}, last_late{0}, last_Qe{0};
     std::atomic<uint32_t> Qe_hint{0};  // list cut: column runs of the early Gaussians in recent forwards (sizes the launches over the cut lists)
@@ -387,6 +405,7 @@ struct gsrast_context {
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
     std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
+    ChainGate gate[32];               // per device: the completion pass's own stream and release words (created on first use)
     struct Hints { HintTable* table = nullptr; uint32_t T = 0; uint64_t used = 0; } hints[32][4];   // (one table per image size in use, up to four: train / eval resolutions alternate)
     uint64_t hints_clock = 0;   // per device: launch-order hints of the forward blend (gsrast_common.h), device memory
     std::mutex mu;
@@ -418,6 +437,24 @@ SideStream* side_stream_of(gsrast_context* ctx)
         }
     }
     return &x;
+}
+ChainGate* chain_gate_of(gsrast_context* ctx)
+{
+    int device = 0, can = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ChainGate& g = ctx->gate[device];
+    if (g.failed) return nullptr;
+    if (!g.stream) {
+        g.failed = true;                      // (until everything below has worked)
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess || !can) return nullptr;
+        if (hipMalloc((void**)&g.words, 128 * sizeof(uint32_t)) != hipSuccess) { g.words = nullptr; return nullptr; }
+        if (hipMemset(g.words, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
+            hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
+        if (hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(g.stream); (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
+        g.failed = false;
+    }
+    return &g;
 }
 // The context's hint table on the current device for a T-tile image (allocated on first use, cleared when T changes); nullptr if
 // it cannot be had -- the forward then orders its blend by list length, as a first-seen pose does.
@@ -604,6 +641,11 @@ void gsrast_context_destroy(gsrast_context* c)
 {
     if (!c) return;
     for (auto& d : c->hints) for (auto& h : d) if (h.table) (void)hipFree(h.table);
+    for (ChainGate& g : c->gate) {
+        if (g.stream) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
+        if (g.ev) (void)hipEventDestroy(g.ev);
+        if (g.words) (void)hipFree(g.words);
+    }
     for (SideStream& x : c->side) {
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
@@ -645,6 +687,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "profile")) { g_profile = value; return 0; }  // bit k = time kernel id k; -1 = all
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "list_cut_always")) { g_list_cut_always = value ? 1 : 0; return 0; }   // the list cut also where it does not pay (tests)
+    if (!strcmp(name, "chain_gate")) { g_chain_gate = value ? 1 : 0; return 0; }               // 0: the completion pass's launches on the caller's stream (round 3)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
@@ -679,6 +722,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "bwd_transposed")) return g_bwd_transposed.load();
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
     if (!strcmp(name, "list_cut_always")) return g_list_cut_always.load();
+    if (!strcmp(name, "chain_gate")) return g_chain_gate.load();
     if (!strcmp(name, "layer_cut")) return g_layer_cut.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
@@ -1055,8 +1099,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // counts read on the device (speculative launch: grids and histogram strides follow the capacities)
     // mode (list cut): 0 = all Gaussians (as ever); 1 = the EARLY Gaussians only (counts_dev = scalars + SC_EARLY_COUNTS); 2 = all
     // Gaussians again behind a blend over cut lists, every kernel predicated on scalars[SC_REDO_PRED] (counts_dev = scalars)
+    const uint32_t* redo_pred = scalars + SC_REDO_PRED;      // the completion pass's predicate (the gate's copy of it when the pass runs on its own stream)
     auto launch_run_binning = [&](char* binb, uint32_t capR_, uint32_t capQ_, uint32_t nQ, const uint32_t* counts_dev, const std::function<int()>& after_emit = nullptr, int mode = 0) -> int {
-        const uint32_t* pred = mode == 2 ? scalars + SC_REDO_PRED : nullptr;
+        const uint32_t* pred = mode == 2 ? redo_pred : nullptr;
         const RunBinLayout RL = runbin_layout((size_t)capR_, (size_t)capQ_);
         uint16_t *rkA = at<uint16_t>(binb, RL.rkeyA), *rkB = at<uint16_t>(binb, RL.rkeyB);
         uint2 *rvA = at<uint2>(binb, RL.rvalA), *rvB = at<uint2>(binb, RL.rvalB);
@@ -1129,7 +1174,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (zero_in_blend && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
         if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; ba.tile_flags = at<unsigned char>(img, IL.tile_flags); }
-        if (mode == 2) ba.pred = scalars + SC_REDO_PRED;
+        if (mode == 2) ba.pred = redo_pred;
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && o.lpt) {
             if (buckets_ok && fwd_lists_built) { ba.from_buckets = 1; grid = (uint32_t)(XCD_GROUPS * xcd_group_tiles_host((size_t)cam.gx, (size_t)cam.gy)); }   // the tile-range kernel already bucketed the tiles
@@ -1291,15 +1336,42 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             // blend over ALL Gaussians, predicated on its verdict (gsrast_common.h).  Nothing of this runs in the steady state.
             ProfScope ps(K_CUT_REDO, s);
             struct Off { Off() { t_prof_off++; } ~Off() { t_prof_off--; } } off;
+            // the pass on its own stream behind a gate (ChainGate above), unless that cannot be had
+            ChainGate* gate = g_chain_gate.load() != 0 ? chain_gate_of(ctx) : nullptr;
+            const hipStream_t s_caller = s;
+            uint32_t gseq = 0, *gdone = nullptr;
+            if (gate) {
+                uint32_t slot;
+                { std::lock_guard<std::mutex> lk(ctx->mu); gseq = ++gate->seq; if (gseq == 0u) gseq = ++gate->seq; }
+                slot = gseq & 63u; gdone = gate->words + slot;
+                chain_gate_kernel<<<1, 1, 0, s>>>(scalars + SC_REDO_PRED, gate->words + 64 + slot, gdone, gseq);
+                GS_LAUNCHED("chain_gate");
+                GS_HIP(hipEventRecord(gate->ev, s));
+                GS_HIP(hipStreamWaitEvent(gate->stream, gate->ev, 0));
+                redo_pred = gate->words + 64 + slot;
+                s = gate->stream;                  // (the lambdas below launch on `s`)
+            }
+            struct Back { hipStream_t& s; hipStream_t v; const uint32_t*& p; const uint32_t* pv; ~Back() { s = v; p = pv; } } back{ s, s_caller, redo_pred, scalars + SC_REDO_PRED };
             // (round 4: a COMPLETION pass, not a second forward: the Gaussians that touch a flagged tile -- the candidates --, their
             // missing colours, their column runs through flagged tiles, and the flagged tiles' blend from their full lists)
             cut_candidates_kernel<<<std::min((P + 255) / 256, 2048), 256, 0, s>>>((uint32_t)P, tiles, rect, at<unsigned char>(img, IL.tile_flags), T, (uint32_t)cam.gx,
                                                                                 at<unsigned long long>(geom, GL.color_skip), at<unsigned long long>(geom, GL.cand_bits),
-                                                                                at<unsigned long long>(geom, GL.skip2), scalars + SC_REDO_PRED);
+                                                                                at<unsigned long long>(geom, GL.skip2), redo_pred);
             GS_LAUNCHED("cut_candidates");
-            int rc = cut_colors ? color_kernels(s, true, scalars + SC_REDO_PRED) : GSRAST_OK;      // (the late candidates' colours)
+            int rc = cut_colors ? color_kernels(s, true, redo_pred) : GSRAST_OK;      // (the late candidates' colours)
             if (rc == GSRAST_OK) rc = launch_run_binning(bin, cap, capQ, capQ, scalars + SC_PASS2, nullptr, 2);
             if (rc == GSRAST_OK) rc = launch_blend(at<uint32_t>(bin, 0), true, 2);
+            if (gate) {
+                // (also after an error above: the caller's stream must not wait for a release nobody sends)
+                chain_done_kernel<<<1, 1, 0, gate->stream>>>(redo_pred, gdone, gseq);
+                const hipError_t e1 = hipGetLastError();
+                const hipError_t e2 = hipStreamWaitValue32(s_caller, gdone, gseq, hipStreamWaitValueEq, 0xFFFFFFFFu);
+                if (e1 != hipSuccess || e2 != hipSuccess) {     // no gate after all: an ordinary join behind the chain, and never again
+                    { std::lock_guard<std::mutex> lk(ctx->mu); gate->failed = true; }
+                    (void)hipEventRecord(gate->ev, gate->stream);
+                    (void)hipStreamWaitEvent(s_caller, gate->ev, 0);
+                }
+            }
             if (rc != GSRAST_OK) return rc;
         }
         return (int)R;

@@ -975,6 +975,22 @@ def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu)
             _list_cut_body(orc, scenes, rast, gpu, _C, render2, same, sc, cam2, P, W, H, layer=True)
         finally:
             _C.set_option("layer_cut", 0)
+        # option "chain_gate" off: the completion pass's launches on the caller's stream (round 3's arrangement) instead of behind the gate
+        # on the context's second stream -- same results, a third pose
+        cam3 = scenes.camera(7, 9, W, H)
+
+        def render3(scene):
+            nonlocal cam
+            keep, cam = cam, cam3
+            try:
+                return render(scene)
+            finally:
+                cam = keep
+        _C.set_option("chain_gate", 0)
+        try:
+            _list_cut_body(orc, scenes, rast, gpu, _C, render3, same, sc, cam3, P, W, H)
+        finally:
+            _C.set_option("chain_gate", 1)
     finally:
         _C.set_option("list_cut_always", 0)
 
