@@ -373,18 +373,12 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
 // The list cut's completion pass OFF the critical path (round 4).  Its eleven predicated launches used to sit between the forward blend and
 // whatever the caller enqueues next: 55-80 us of dependent-launch latency in the steady state, where every one of them returns at once.
-// Now one tiny kernel behind the blend copies the blend's verdict into a word of the context's own (`pred`: the chain's predicate; the
+// Now the blend's LAST workgroup (gsrast_blend.h, GateArgs) copies the blend's verdict into a word of the context's own (`pred`: the chain's predicate; the
 // forward's buffers may be gone by the time the chain's no-ops run) and, if the verdict is "nothing to complete", releases the caller's
 // stream at once (`done` = the call's sequence number, waited for with hipStreamWaitValue32); the chain runs on a second stream behind
-// that kernel and, if it had work to do, releases the caller's stream at its end.  Deadlock-free on in-order hardware queues however HIP
+// the blend and, if it had work to do, releases the caller's stream at its end.  Deadlock-free on in-order hardware queues however HIP
 // maps streams onto them: everything the wait can be released by is SUBMITTED before the wait (gate kernel, event, chain, last the wait).
 struct ChainGate { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; uint32_t* words = nullptr /* [64] done | [64] pred */; uint32_t seq = 0; bool failed = false; };
-__global__ void chain_gate_kernel(const uint32_t* __restrict__ undone, uint32_t* __restrict__ pred_copy, uint32_t* __restrict__ done, uint32_t seq)
-{
-    const uint32_t v = *undone;
-    *pred_copy = v;
-    if (v == 0u) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 __global__ void chain_done_kernel(const uint32_t* __restrict__ pred_copy, uint32_t* __restrict__ done, uint32_t seq)
 {
     if (*pred_copy != 0u) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -577,6 +571,7 @@ struct BlendArgs {
     HintTable* hints = nullptr; const uint32_t* hint_sel = nullptr;   // forward: the context's launch-order hints, this call's slot
     const uint32_t* zcut_used = nullptr; uint32_t* cut_scalars = nullptr; const uint32_t* pred = nullptr;   // forward: list cut (gsrast_common.h)
     unsigned char* tile_flags = nullptr;                         // forward: tiles the completion pass lists and blends again
+    GateArgs gate{};                                             // forward, list cut's first pass: the completion pass's gate (ChainGate)
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -615,7 +610,7 @@ template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
     blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
-                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred, a.tile_flags);
+                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred, a.tile_flags, a.gate);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -1159,6 +1154,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             GS_LAUNCHED("rows_and_ranges"); }
         return GSRAST_OK;
     };
+    // the completion pass's gate (ChainGate): claimed when the cut forward's blend is launched -- its last workgroup is the gate
+    ChainGate* gate = nullptr; uint32_t gseq = 0, *gdone = nullptr, *gpred = nullptr;
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built, int mode = 0 /* list cut: as launch_run_binning */) -> int {
         { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }  // the other binning scheme / nothing to bin: not forked yet
         if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); if (zero_in_blend) side_guard.joined = true; }       // the colours (rec2) are the blend's input
@@ -1174,6 +1171,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (zero_in_blend && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
         if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; ba.tile_flags = at<unsigned char>(img, IL.tile_flags); }
+        if (mode == 1 && cull && g_chain_gate.load() != 0 && (gate = chain_gate_of(ctx)) != nullptr) {
+            { std::lock_guard<std::mutex> lk(ctx->mu); gseq = ++gate->seq; if (gseq == 0u) gseq = ++gate->seq; }
+            gdone = gate->words + (gseq & 63u); gpred = gate->words + 64 + (gseq & 63u);
+            ba.gate = GateArgs{ at<uint32_t>(img, IL.bucket_cnt) + (XCD_GROUPS + 1) * WORK_BUCKETS, gpred, gdone, gseq };
+        }
         if (mode == 2) ba.pred = redo_pred;
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
         if (cull && o.lpt) {
@@ -1337,18 +1339,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             ProfScope ps(K_CUT_REDO, s);
             struct Off { Off() { t_prof_off++; } ~Off() { t_prof_off--; } } off;
             // the pass on its own stream behind a gate (ChainGate above), unless that cannot be had
-            ChainGate* gate = g_chain_gate.load() != 0 ? chain_gate_of(ctx) : nullptr;
             const hipStream_t s_caller = s;
-            uint32_t gseq = 0, *gdone = nullptr;
-            if (gate) {
-                uint32_t slot;
-                { std::lock_guard<std::mutex> lk(ctx->mu); gseq = ++gate->seq; if (gseq == 0u) gseq = ++gate->seq; }
-                slot = gseq & 63u; gdone = gate->words + slot;
-                chain_gate_kernel<<<1, 1, 0, s>>>(scalars + SC_REDO_PRED, gate->words + 64 + slot, gdone, gseq);
-                GS_LAUNCHED("chain_gate");
+            if (gate) {      // (claimed with the blend's launch: its last workgroup has copied the verdict and, if there is nothing to do, released us)
                 GS_HIP(hipEventRecord(gate->ev, s));
                 GS_HIP(hipStreamWaitEvent(gate->stream, gate->ev, 0));
-                redo_pred = gate->words + 64 + slot;
+                redo_pred = gpred;
                 s = gate->stream;                  // (the lambdas below launch on `s`)
             }
             struct Back { hipStream_t& s; hipStream_t v; const uint32_t*& p; const uint32_t* pv; ~Back() { s = v; p = pv; } } back{ s, s_caller, redo_pred, scalars + SC_REDO_PRED };

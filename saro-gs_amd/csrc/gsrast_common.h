@@ -186,6 +186,8 @@ static inline int cut_cell_shift(size_t gx, size_t gy)      // 1, 2, 3, or 0 = n
 constexpr uint32_t LATE_BIT = 0x80000000u;      // in the width word of a bucket-slab element
 // words of GeomLayout::scalars used by the list cut
 constexpr int SC_ZBINS = 7 /* first | last << 16 occupied bin of the sampled depth histogram (0xFFFFFFFF: no sample) */;
+constexpr int GATE_WORDS = 80;      // 64 first-level counters of finished workgroups + 1 second-level (ImgLayout::bucket_cnt's tail)
+constexpr int SC_GATE_COUNT = 28 /* workgroups of the cut forward's blend that have finished (its last one is the completion pass's gate) */;
 constexpr int SC_PASS2 = 24 /* {instances (tile counts) lo, column runs, -, hi} of the completion pass's candidates */;
 constexpr int SC_Q_EARLY = 4, SC_N_LATE = 5, SC_UNDONE = 6, SC_EARLY_COUNTS = 20 /* {R lo, Q early, -, R hi} */, SC_REDO_PRED = SC_UNDONE /* the predicate of the second binning + blend: some tile's cut list was too short */;
 
@@ -302,7 +304,7 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     L.final_T = take(N * 4); L.n_contrib = take(N * 4); L.ranges = take(T * 8); L.tile_max = take(T * 4);
     L.order_fwd = take(T * 4); L.order_bwd = take(T * 4);
     const size_t Tg = xcd_group_tiles_host((W + TILE_X - 1) / TILE_X, (H + TILE_Y - 1) / TILE_Y);      // list capacity of one (group, bucket)
-    L.bucket_cnt = take((XCD_GROUPS + 1) * WORK_BUCKETS * 4);            // forward: per XCD group; backward: one global set
+    L.bucket_cnt = take(((XCD_GROUPS + 1) * WORK_BUCKETS + GATE_WORDS) * 4);   // forward: per XCD group; backward: one global set; + the completion pass's gate counters (gsrast_blend.h, GateArgs), zeroed with them
     L.bucket_list = take(T <= BUCKET_MAX_TILES ? (XCD_GROUPS * WORK_BUCKETS * (Tg ? Tg : 1) + WORK_BUCKETS * T) * 2 : 0);
     L.zcut_used = take(T * 4);
     L.tile_flags = take(T);

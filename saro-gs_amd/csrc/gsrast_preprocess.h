@@ -682,8 +682,8 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       unsigned long long* __restrict__ host_found = nullptr, uint32_t host_seq = 0 /* pinned host word: {this pose was in the table, the
                                                              call's sequence number} -- the host sizes the launches over the cut lists by it */)
 {
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS; i += blockDim.x) bucket_cnt[i] = 0u;
-    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; }      // (always: the backward reads them)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS + GATE_WORDS; i += blockDim.x) bucket_cnt[i] = 0u;
+    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; cut_scalars[SC_GATE_COUNT] = 0u; }      // (always: the backward reads them)
     // The camera pose's key: block 0 looks it up and claims its slot, or the least recently used one; the first blocks of the grid
     // look it up too and copy the slot's cut depths into this call's own image buffer -- the bucket scatter and the forward blend
     // must see the SAME values, whatever another forward of this context writes into the table meanwhile (a stale or torn snapshot
