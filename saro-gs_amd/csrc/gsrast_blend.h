@@ -380,7 +380,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         if (atomicAdd(gate.count + cls, 1u) == quota - 1u && atomicAdd(gate.count + 64, 1u) == (gridDim.x < 64u ? gridDim.x : 64u) - 1u) {
             const uint32_t v = __hip_atomic_load(cut_scalars + SC_UNDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *gate.pred = v;
-            if (v == 0u) __hip_atomic_store(gate.done, gate.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v == 0u) __hip_atomic_store(gate.done, gate.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (relaxed: the waiter is a later command of the same stream)
         }
     }
 }
