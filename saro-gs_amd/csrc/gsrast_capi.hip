@@ -442,9 +442,11 @@ ChainGate* chain_gate_of(gsrast_context* ctx)
     if (!g.stream) {
         g.failed = true;                      // (until everything below has worked)
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess || !can) return nullptr;
+        int prio_least = 0, prio_greatest = 0;      // (lowest priority: the pass's no-ops run beside the backward and must not stand in its workgroups' way)
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         if (hipMalloc((void**)&g.words, 128 * sizeof(uint32_t)) != hipSuccess) { g.words = nullptr; return nullptr; }
         if (hipMemset(g.words, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
-            hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
+            hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
         if (hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(g.stream); (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
         g.failed = false;
     }
