@@ -268,6 +268,10 @@ int gsrast_backward_ex(const gsrast_options* options,
  * "sh_grad_factors" see gsrast_sh_grad_combine;
  * "bwd_transposed" (process-wide A/B switch) 1 (default) = the one-pixel-per-lane backward blend sums across lanes once per
  * group of eight staged instances (blend_bwd_cull_t_kernel), 0 = nine wave reductions per surviving (wave, instance) pair.
+ * "chain_gate" (process-wide A/B switch) 1 (default) = the list cut's completion pass (no_list_cut above) is enqueued on the context's
+ * second stream and the caller's stream is released by the cut forward's blend itself (hipStreamWaitValue32 on a word of the
+ * context's own), 0 = its predicated launches on the caller's stream;  "layer_cut" 1 = a pose without remembered cut depths lists
+ * the nearest eighth of the Gaussians first (measured slower: default 0);  "list_cut_always" 1 = the cut also where it does not pay.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
  * last forward call of the CALLING THREAD's context, "redo_count" (= gsrast_context_query(NULL, name)). */
 int gsrast_set_option(const char* name, int value);
