@@ -1118,7 +1118,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                 r0 = binrec[2 * (size_t)g]; r1 = binrec[2 * (size_t)g + 1];
                 rc = make_uint2(__float_as_uint(r1.z), __float_as_uint(r1.w));
             } else {
-                r0 = rec0[g]; const float4 t1 = rec1[g]; rc = rect[g];
+                r0 = rec0[(size_t)REC_STRIDE * g]; const float4 t1 = rec1[(size_t)REC_STRIDE * g]; rc = rect[g];
                 r1 = make_float4(t1.x, t1.w, 0.f, 0.f);             // (conic c, skip threshold)
             }
         }

@@ -228,8 +228,8 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
         bool safe = false;
         if (t < FB && i < n) {
             const uint32_t g = point_list[range.x + i];
-            const float4 b1 = rec1[g];
-            s0[t] = rec0[g]; s1[t] = b1; s2[t] = rec2[g];
+            const float4 b1 = rec1[(size_t)REC_STRIDE * g];
+            s0[t] = rec0[(size_t)REC_STRIDE * g]; s1[t] = b1; s2[t] = rec2[(size_t)REC_STRIDE * g];
             safe = __float_as_uint(b1.z) <= zc;             // the list is in depth order: the safe entries are a prefix
         }
         uint32_t cnt = (n - base) < FB ? (n - base) : FB;
@@ -335,10 +335,10 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
             uint32_t znew = ZCUT_NONE;
             if (all_done) {
                 const uint32_t p = GSRAST_CUT_MARGIN_X4 * s_max / 4u + 32u;
-                if (p < n_safe) znew = __float_as_uint(rec1[point_list[range.x + p]].z);
+                if (p < n_safe) znew = __float_as_uint(rec1[(size_t)REC_STRIDE * point_list[range.x + p]].z);
                 else if (zc != ZCUT_NONE && n_safe > 0u) {
                     // the cut list does not reach that deep: position -> depth extrapolated linearly from the list's first entry
-                    const float z0 = rec1[point_list[range.x]].z, zcf = __uint_as_float(zc);
+                    const float z0 = rec1[(size_t)REC_STRIDE * point_list[range.x]].z, zcf = __uint_as_float(zc);
                     const float zn = z0 + (zcf - z0) * ((float)(p + 1u) / (float)n_safe);
                     znew = zn < 3.0e38f ? (zn > zcf ? __float_as_uint(zn) : zc) : ZCUT_NONE;
                 } else if (zc != ZCUT_NONE) znew = zc;
@@ -448,7 +448,7 @@ blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
             const uint32_t slot = t + r * NT, i = base + slot;
             if (i < n) {
                 const uint32_t g = point_list[range.x + i];
-                s0[slot] = rec0[g]; s1[slot] = rec1[g]; s2[slot] = rec2[g];
+                s0[slot] = rec0[(size_t)REC_STRIDE * g]; s1[slot] = rec1[(size_t)REC_STRIDE * g]; s2[slot] = rec2[(size_t)REC_STRIDE * g];
             }
         }
         __syncthreads();
@@ -595,7 +595,7 @@ blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
             if (i < n) {
                 const uint32_t g = point_list[range.x + (n - 1 - i)];
                 sid[slot] = g;
-                s0[slot] = rec0[g]; s1[slot] = rec1[g]; s2[slot] = rec2[g];
+                s0[slot] = rec0[(size_t)REC_STRIDE * g]; s1[slot] = rec1[(size_t)REC_STRIDE * g]; s2[slot] = rec2[(size_t)REC_STRIDE * g];
             }
 #pragma unroll
             for (int q = 0; q < 9; q++) acc[q][slot] = 0.0f;
@@ -794,7 +794,7 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
             if (i < n) {
                 const uint32_t g = point_list[range.x + (n - 1 - i)];
                 sid[slot] = g;
-                s0[slot] = rec0[g]; s1[slot] = rec1[g]; s2[slot] = rec2[g];
+                s0[slot] = rec0[(size_t)REC_STRIDE * g]; s1[slot] = rec1[(size_t)REC_STRIDE * g]; s2[slot] = rec2[(size_t)REC_STRIDE * g];
             }
         }
         for (uint32_t q4 = t; q4 < (uint32_t)(NS * BATCH * AS / 4); q4 += NT) reinterpret_cast<float4*>(&acc[0][0][0])[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1037,7 +1037,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
         return (wave < 3u && i < n) ? point_list[range.x + (n - 1 - i)] : 0xFFFFFFFFu;
     };
     uint32_t id_cur = staged_id(0), id_next = staged_id(BATCH);
-    float4 pre = id_cur != 0xFFFFFFFFu ? recw[id_cur] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pre = id_cur != 0xFFFFFFFFu ? recw[(size_t)REC_STRIDE * id_cur] : make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (uint32_t base = 0; base < n; base += BATCH) {
         __syncthreads();
@@ -1050,7 +1050,7 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
         }
         __syncthreads();
         id_cur = id_next;
-        if (id_cur != 0xFFFFFFFFu) pre = recw[id_cur];
+        if (id_cur != 0xFFFFFFFFu) pre = recw[(size_t)REC_STRIDE * id_cur];
         id_next = staged_id(base + 2 * BATCH);
         const uint32_t cnt = (n - base) < (uint32_t)BATCH ? (n - base) : (uint32_t)BATCH;
         uint64_t mk;

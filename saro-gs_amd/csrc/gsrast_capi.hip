@@ -514,7 +514,7 @@ export_geom_kernel(int P, const float4* __restrict__ rec0,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const bool vis = tiles_in[i] != 0;
-    const float4 a = rec0[i], b = rec1[i], c = rec2[i];
+    const float4 a = rec0[(size_t)REC_STRIDE * i], b = rec1[(size_t)REC_STRIDE * i], c = rec2[(size_t)REC_STRIDE * i];
     if (depths) depths[i] = vis ? b.z : 0.0f;
     if (means2D) { means2D[2 * i] = vis ? a.x : 0.f; means2D[2 * i + 1] = vis ? a.y : 0.f; }
     if (cov3D) for (int k = 0; k < 6; k++) cov3D[6 * i + k] = cov3D_in[6 * i + k];
@@ -546,7 +546,7 @@ export_keys_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // entry-by-entry comparisons run with tile_clip = 0, i.e. without the cut)
     for (uint32_t i = r.x + threadIdx.x; i < r.y && i < R; i += 256) {
         const uint32_t g = vals_sorted[i];
-        if (keys) keys[i] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__float_as_uint(rec1[g].z);
+        if (keys) keys[i] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__float_as_uint(rec1[(size_t)REC_STRIDE * g].z);
         if (point_list) point_list[i] = g;
     }
 }

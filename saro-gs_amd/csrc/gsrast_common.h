@@ -39,6 +39,12 @@ constexpr int WAVE = 64;            // CDNA4 wavefront
 //   grec     f32[16P]    backward only: per-Gaussian gradient record {dL/dmean2D.x, .y, dL/dconic a, b, c, dL/dopacity, dL/dr, dg, db,
 //                        7 unused}, one 64-byte line per Gaussian.  gsrast_backward zero-fills it, the blend backward adds the nine sums
 //                        of a (tile, Gaussian) pair with nine adjacent lanes, the per-Gaussian backward reads it with three 16-byte loads
+#ifndef GSRAST_REC_STRIDE
+#define GSRAST_REC_STRIDE 1
+#endif
+constexpr int REC_STRIDE = GSRAST_REC_STRIDE;      // float4 steps between two Gaussians' rec0 (rec1, rec2): 1 = three arrays, 4 = interleaved 64-byte records
+// (4 measured at 3 M: the blend forward stages one line per instance instead of three, 0.246 -> 0.238 ms, but the geometry kernel's 16-byte
+// stores at a 64-byte stride cost it 0.068 -> 0.118 ms: 1 stays)
 struct GeomLayout {
     size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
         hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zhist, bk_key, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base,
@@ -221,7 +227,8 @@ static inline GeomLayout geom_layout(size_t P)
     GeomLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     size_t Pp = P ? P : 1;
-    L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16);
+    if (REC_STRIDE == 4) { L.rec0 = take(Pp * 64); L.rec1 = L.rec0 + 16; L.rec2 = L.rec0 + 32; }      // one 64-byte record per Gaussian: {rec0, rec1, rec2, -}
+    else { L.rec0 = take(Pp * 16); L.rec1 = take(Pp * 16); L.rec2 = take(Pp * 16); }
     L.cov3D = take(Pp * 24); L.clamped = take(Pp); L.tiles = take(Pp * 4); L.rect = take(Pp * 8); L.binrec = take(Pp * 32);
     L.keyA = take(Pp * 4); L.keyB = take(Pp * 4); L.valA = take(Pp * 4); L.valB = take(Pp * 4);
     L.offsets = take(Pp * 4); L.woffsets = take(Pp * 4);

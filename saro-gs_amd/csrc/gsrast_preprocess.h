@@ -480,7 +480,7 @@ preprocess_color_kernel(int P, int D, int M, const float* __restrict__ means3D, 
             shdB[i] = make_float4(dy[1], dy[2], dz[0], dz[1]);
             shdC[i] = dz[2];
         }
-        rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+        rec2[(size_t)REC_STRIDE * i] = make_float4(col[0], col[1], col[2], 0.0f);
         clamped[i] = (unsigned char)cl;
     }
 }
@@ -524,7 +524,7 @@ preprocess_color_direct_kernel(int P, int D, int M, const float* __restrict__ me
 #pragma unroll
         for (int c = 0; c < 3; c++) col[c] = colors_precomp[3 * (size_t)i + c];
     }
-    rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+    rec2[(size_t)REC_STRIDE * i] = make_float4(col[0], col[1], col[2], 0.0f);
     clamped[i] = (unsigned char)cl;
 }
 
@@ -647,7 +647,7 @@ preprocess_color_compact_kernel(int P, int D, int M, const float* __restrict__ m
             pcc_wave_sync();                               // the next round overwrites the rows
         }
         if (lane < cnt) {
-            rec2[i] = make_float4(col[0], col[1], col[2], 0.0f);
+            rec2[(size_t)REC_STRIDE * i] = make_float4(col[0], col[1], col[2], 0.0f);
             clamped[i] = (unsigned char)cl;
         }
     }
@@ -791,8 +791,8 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                 // with a 2% margin, so skipping the exp for such pairs never changes a decision.
                 // (clamped at -80 so that exp() is only ever evaluated on [-80, 0]: gs_exp<., BOUNDED>)
                 const float thr = op > 0.0f ? fmaxf(logf(1.0f / (255.0f * op)) - 0.02f, -80.0f) : 1.0f;
-                rec0[i] = make_float4(px, py, con0, con1);      // (non-temporal stores here, measured: the kernel +10 us, its readers -12: nothing)
-                rec1[i] = make_float4(con2, op, pv[2], thr);
+                rec0[(size_t)REC_STRIDE * i] = make_float4(px, py, con0, con1);      // (non-temporal stores here, measured: the kernel +10 us, its readers -12: nothing)
+                rec1[(size_t)REC_STRIDE * i] = make_float4(con2, op, pv[2], thr);
                 rad_out = rad; ntiles = (uint32_t)area;
                 key = __float_as_uint(pv[2]);
                 if (clip_rect) {
