@@ -1313,7 +1313,7 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
     work = before1 > before0 ? before1 - before0 : 0u;
     // forward launch order: the prefix this tile consumed the last time this pose was rendered, if the context knows (never more than the list)
     if (hints && hint_sel[1] && work && y < (uint32_t)gy) {
-        const uint32_t h = hint_work(hints, 0u)[(size_t)hint_sel[0] * ((uint32_t)gx * (uint32_t)gy) + y * (uint32_t)gx + x];
+        const uint32_t h = hint_work(hints, 0u)[(size_t)hint_sel[2] * ((uint32_t)gx * (uint32_t)gy) + y * (uint32_t)gx + x];      // ([2]: the pose's own slot, or the near pose's it borrows from)
         work = h < work ? (h ? h : 1u) : work;
     }
     }

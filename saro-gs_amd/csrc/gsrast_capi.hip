@@ -42,7 +42,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -685,6 +685,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "list_cut_always")) { g_list_cut_always = value ? 1 : 0; return 0; }   // the list cut also where it does not pay (tests)
     if (!strcmp(name, "chain_gate")) { g_chain_gate = value ? 1 : 0; return 0; }               // 0: the completion pass's launches on the caller's stream (round 3)
+    if (!strcmp(name, "near_pose")) { g_near_pose = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }                 // 0: only the pose's own slot (round 3)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
@@ -720,6 +721,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
     if (!strcmp(name, "list_cut_always")) return g_list_cut_always.load();
     if (!strcmp(name, "chain_gate")) return g_chain_gate.load();
+    if (!strcmp(name, "near_pose")) return g_near_pose.load();
     if (!strcmp(name, "layer_cut")) return g_layer_cut.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
@@ -998,12 +1000,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars, host_found, pre_seq);
+                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load());
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars, host_found, pre_seq);
+                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load());
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort

@@ -158,10 +158,12 @@ struct HintTable {
     uint32_t key[HINT_SLOTS][2];   // 0, 0 = free
     uint32_t stamp[HINT_SLOTS];    // value of `clock` when the slot was last used
     uint32_t clock, cut_fallbacks /* forwards whose cut lists turned out too short and were binned and blended again (diagnostic) */, pad[2];
+    float cam[HINT_SLOTS][8];      // the slot's camera: position (3), viewing direction (3), -, - -- a pose the table does not know BORROWS the
+                                   // estimates and cut depths of a slot whose camera is close (a camera path: the previous frame); the cut is verified either way
     // followed by uint16_t work[HINT_SLOTS][T], then (4-byte aligned) uint32_t zcut[HINT_SLOTS][T]
 };
-// A forward's own choice -- {slot, "the slot held estimates of this pose when the forward began"} -- lives in ITS geometry buffer
-// (scalars[HINT_SEL], [HINT_SEL + 1]), so two forwards of one context in flight on two streams do not read each other's slot.
+// A forward's own choice -- {slot, 1 = "the slot held estimates of this pose when the forward began" / 2 = "estimates borrowed from
+// a near pose", the slot they are read from} -- lives in ITS geometry buffer (scalars[HINT_SEL], [HINT_SEL + 1], [HINT_SEL + 2]), so two forwards of one context in flight on two streams do not read each other's slot.
 constexpr int HINT_SEL = 16;
 __host__ __device__ inline uint16_t* hint_work(HintTable* h, uint32_t) { return reinterpret_cast<uint16_t*>(h + 1); }
 __host__ __device__ inline const uint16_t* hint_work(const HintTable* h, uint32_t) { return reinterpret_cast<const uint16_t*>(h + 1); }

@@ -680,7 +680,8 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       uint32_t* __restrict__ zcut_used /* or null; [ntiles_img]: this call's snapshot of the pose's cut depths (list cut, gsrast_common.h) */,
                       uint32_t ntiles_img, uint32_t* __restrict__ cut_scalars /* or null: GeomLayout::scalars, whose `undone` counter is zeroed here */,
                       unsigned long long* __restrict__ host_found = nullptr, uint32_t host_seq = 0 /* pinned host word: {this pose was in the table, the
-                                                             call's sequence number} -- the host sizes the launches over the cut lists by it */)
+                                                             call's sequence number} -- the host sizes the launches over the cut lists by it */,
+                      int borrow = 0 /* r > 0: a pose the table does not know takes the estimates and cut depths of a near pose's slot (HintTable::cam), the cut depths widened over (2 r + 1)^2 tiles */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS + GATE_WORDS; i += blockDim.x) bucket_cnt[i] = 0u;
     if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; cut_scalars[SC_GATE_COUNT] = 0u; }      // (always: the backward reads them)
@@ -703,26 +704,57 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
         }
         h0 = (h0 ^ (uint32_t)cam_args.W) * 16777619u; h1 = (h1 + (uint32_t)cam_args.H) * 0x85EBCA6Bu;
         h0 |= 1u;                                                   // (0, 0) means "free"
+        // this camera: position, viewing direction (third row of the world-to-view rotation; the matrices are stored transposed)
+        const float cpx = cam_args.campos[0], cpy = cam_args.campos[1], cpz = cam_args.campos[2];
+        const float fwx = cam_args.view[2], fwy = cam_args.view[6], fwz = cam_args.view[10];
+        __shared__ unsigned long long s_near;
+        if (threadIdx.x == 0) s_near = 0ull;
+        __syncthreads();
         for (int k = threadIdx.x; k < HINT_SLOTS; k += blockDim.x) {        // one lane per slot
+            const bool used = (hints->key[k][0] | hints->key[k][1]) != 0u;
             if (hints->key[k][0] == h0 && hints->key[k][1] == h1) s_slot = k;
             atomicMin(&s_lru, ((unsigned long long)hints->stamp[k] << 32) | (unsigned long long)k);      // least recently used, lowest index first
+            if (used && borrow) {
+                // a NEAR pose (a camera path's previous frame): within 12 % of the distance to the world origin and 12 degrees of the viewing
+                // direction; the closest direction wins, the lower index on a tie.  (Lookup blocks that read a slot while block 0 rewrites
+                // it may decide differently: a tile's snapshot then comes from another slot -- only a poorer speculation, verified like any.)
+                const float* c = hints->cam[k];
+                const float dx = c[0] - cpx, dy = c[1] - cpy, dz = c[2] - cpz;
+                const float d2 = dx * dx + dy * dy + dz * dz, r2 = fmaxf(cpx * cpx + cpy * cpy + cpz * cpz, 1e-12f);
+                const float dot = c[3] * fwx + c[4] * fwy + c[5] * fwz;
+                if (d2 <= 0.0144f * r2 && dot >= 0.978f)
+                    atomicMax(&s_near, ((unsigned long long)__float_as_uint(dot) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k));
+            }
         }
         __syncthreads();
+        const int near_slot = (s_slot < 0 && s_near != 0ull) ? (int)(0xFFFFFFFFu - (uint32_t)(s_near & 0xFFFFFFFFull)) : -1;
         if (threadIdx.x == 0 && blockIdx.x == 0) {
             int slot = s_slot;
             const uint32_t now = hints->clock + 1u;
-            const uint32_t found = slot >= 0 ? 1u : 0u;
+            const uint32_t found = slot >= 0 ? 1u : (near_slot >= 0 ? 2u : 0u);
             if (slot < 0) { slot = (int)(uint32_t)(s_lru & 0xFFFFFFFFull); hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
             hints->stamp[slot] = now; hints->clock = now;
-            hint_sel[0] = (uint32_t)slot; hint_sel[1] = found;
+            float* c = hints->cam[slot];
+            c[0] = cpx; c[1] = cpy; c[2] = cpz; c[3] = fwx; c[4] = fwy; c[5] = fwz;
+            hint_sel[0] = (uint32_t)slot; hint_sel[1] = found; hint_sel[2] = found == 2u ? (uint32_t)near_slot : (uint32_t)slot;
             if (host_found) __hip_atomic_store(host_found, ((unsigned long long)host_seq << 32) | (unsigned long long)found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (snap) {
-            const int slot = s_slot;
+            const int slot = s_slot >= 0 ? s_slot : near_slot;
             const uint32_t* zc = hint_zcut(hints, ntiles_img) + (size_t)(slot < 0 ? 0 : slot) * ntiles_img;
             const uint32_t nsb = gridDim.x < (unsigned)SNAP_BLOCKS ? gridDim.x : (unsigned)SNAP_BLOCKS;
-            for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles_img; t += nsb * blockDim.x)
-                zcut_used[t] = slot < 0 ? ZCUT_NONE : zc[t];
+            // (a BORROWED slot is another camera's: what a tile sees there, a tile a few columns or rows away sees here -- the cut depth is
+            // the deepest of the (2 borrow + 1)^2 tiles around it, none if one of them has none)
+            const int rad = s_slot >= 0 ? 0 : borrow, gxt = cam_args.gx, gyt = (int)ntiles_img / cam_args.gx;
+            for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles_img; t += nsb * blockDim.x) {
+                uint32_t z = slot < 0 ? ZCUT_NONE : zc[t];
+                if (slot >= 0 && rad > 0) {
+                    const int tx = (int)t % gxt, ty = (int)t / gxt;
+                    for (int y = max(ty - rad, 0); y <= min(ty + rad, gyt - 1); y++)
+                        for (int x = max(tx - rad, 0); x <= min(tx + rad, gxt - 1); x++) z = max(z, zc[y * gxt + x]);
+                }
+                zcut_used[t] = z;
+            }
         }
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;

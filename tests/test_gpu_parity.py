@@ -957,6 +957,7 @@ def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu)
         return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
 
     _C.set_option("list_cut_always", 1)               # (by default the cut is only applied where it pays: scenes of millions of column runs)
+    _C.set_option("near_pose", 0)                     # (a first render must find nothing to cut by: no borrowing from whatever pose another test left near this one)
     try:
         _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H)
         # option "layer_cut" (off by default, DESIGN.md: measured slower): a pose WITHOUT remembered cut depths lists the nearest
@@ -991,6 +992,52 @@ def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu)
             _list_cut_body(orc, scenes, rast, gpu, _C, render3, same, sc, cam3, P, W, H)
         finally:
             _C.set_option("chain_gate", 1)
+    finally:
+        _C.set_option("list_cut_always", 0)
+        _C.set_option("near_pose", 3)
+
+
+def test_near_pose_borrows_cut_depths_and_never_changes_a_result(orc, scenes, rast, gpu):
+    """A pose the context's table does not know takes the launch order and the cut depths (widened over 7 x 7 tiles) of a NEAR pose's slot
+    (option near_pose, gsrast_common.h HintTable::cam): along a camera path every frame after the first two is cut although no pose is
+    ever rendered twice -- with the same outputs bit for bit as without any cut, and as the oracle."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P, W, H, V = 60_000, 336, 256, 360               # (an image size no other test uses: this test's poses are the only ones in its table)
+    sc = scenes.synth(P, 811, scale_mul=1.3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+
+    def render(k):
+        cam = scenes.camera(k, V, W, H)
+        rs = settings_from(rast, cam, sc, gpu)
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return (R, color.clone(), depth.clone(), radii.clone(), st["n_contrib"].clone(), st["final_T"].clone()), _C.context_query("last_late")
+
+    same = lambda a, b: a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))  # noqa: E731
+    frames2 = list(range(200, 212))                   # one degree apart, no pose twice
+    _C.set_option("list_cut_always", 1)
+    try:
+        cut_frames = 0
+        outs = {}
+        for k in frames2:
+            outs[k], late = render(k)
+            cut_frames += 1 if late > 0 else 0
+        assert cut_frames >= len(frames2) - 2, cut_frames            # the first frame has nobody to borrow from, the second only a first estimate
+        _C.set_option("no_list_cut", 1)
+        try:
+            for k in frames2:
+                assert same(outs[k], render(k)[0]), k
+        finally:
+            _C.set_option("no_list_cut", 0)
+        k = frames2[-1]
+        o = orc.render(sc, scenes.camera(k, V, W, H))
+        assert outs[k][0] == o["R"] and np.array_equal(bits(outs[k][1].cpu().numpy()), bits(o["out_color"]))
     finally:
         _C.set_option("list_cut_always", 0)
 
