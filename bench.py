@@ -495,6 +495,36 @@ def eval_fps_row(rast, scenes, dev, P, W, H, deg):
         finally:
             if opt_name:
                 _C.set_option(opt_name, 0)
+    # a camera PATH: 60 frames 1.5 degrees apart, every pose rendered exactly once (a test trajectory / a video: what test.py does with a
+    # scene's test cameras) -- the table never holds the pose, but with option near_pose (default) it holds the previous frame's
+    VP, NF = 240, 60
+
+    def path(first, opts):
+        for k_, v_ in opts.items():
+            _C.set_option(k_, v_)
+        try:
+            rs = []
+            for k in range(first, first + NF):
+                cam = scenes.camera(k, VP, W, H)
+                rs.append(rast.GaussianRasterizer(rast.GaussianRasterizationSettings(
+                    image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
+                    viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)))
+            ds, cut = [], 0
+            with torch.no_grad():
+                for i, raster in enumerate(rs):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    raster(means3D=ten["means3D"], means2D=m2, opacities=ten["opacities"], shs=ten["shs"], scales=ten["scales"], rotations=ten["rotations"])
+                    torch.cuda.synchronize(dev)
+                    if i >= 10:
+                        ds.append(time.perf_counter() - t0)
+                        cut += 1 if int(_C.context_query("last_late")) > 0 else 0
+            return {"fps": round(1.0 / float(np.mean(ds)), 1), "ms_per_view": round(float(np.mean(ds)) * 1e3, 4), "frames_timed": len(ds), "frames_under_the_list_cut": cut}
+        finally:
+            for k_ in opts:
+                _C.set_option(k_, 3 if k_ == "near_pose" else 0)
+    out["camera_path_every_pose_new"] = {"pose_table_off": path(30, {"no_order_hint": 1}), "own_slot_only": path(100, {"near_pose": 0}), "near_pose_borrowing": path(170, {}),
+                                         "note": "60 frames 1.5 degrees apart on the orbit, each pose rendered once, the first 10 discarded; same timing protocol"}
     out["note"] = "forward only, torch.no_grad(), synchronised wall clock per call (test.py:155-168 protocol), P = %d at %dx%d; first_pass = views 12-20 of pass 1 (poses never seen before)" % (P, W, H)
     return out
 

@@ -271,7 +271,9 @@ int gsrast_backward_ex(const gsrast_options* options,
  * "chain_gate" (process-wide A/B switch) 1 (default) = the list cut's completion pass (no_list_cut above) is enqueued on the context's
  * second stream and the caller's stream is released by the cut forward's blend itself (hipStreamWaitValue32 on a word of the
  * context's own), 0 = its predicated launches on the caller's stream;  "layer_cut" 1 = a pose without remembered cut depths lists
- * the nearest eighth of the Gaussians first (measured slower: default 0);  "list_cut_always" 1 = the cut also where it does not pay.
+ * the nearest eighth of the Gaussians first (measured slower: default 0);  "list_cut_always" 1 = the cut also where it does not pay;
+ * "near_pose" r (default 3; 0 = off): a camera pose the context's table does not know takes the launch order and the cut depths of a
+ * NEAR pose's slot (a camera path's previous frame), the cut depths widened over (2 r + 1)^2 tiles -- verified like any cut.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
  * last forward call of the CALLING THREAD's context, "redo_count" (= gsrast_context_query(NULL, name)). */
 int gsrast_set_option(const char* name, int value);
