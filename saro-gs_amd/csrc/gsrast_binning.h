@@ -706,7 +706,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
                          const unsigned long long* __restrict__ keep_bits = nullptr)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
-    __shared__ uint32_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order
+    __shared__ uint16_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order (their running sum goes through s_grp, free by then: 26 KB of LDS = six workgroups per CU)
     __shared__ uint16_t s_wid[BK_WAVES][BK_CAP];                // widths, grouped like s_grp
     __shared__ uint32_t s_cnt[BK_WAVES][BK_SUB + 1];
     if (pred && *pred == 0u) return;
@@ -715,7 +715,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     if (b >= nb) return;
     const bool early_only = binfo_all != nullptr;
     unsigned long long* grp = s_grp[wave];
-    uint32_t* aux = s_aux[wave];
+    uint16_t* aux = s_aux[wave];
     uint16_t* wid = s_wid[wave];
     uint32_t* cnt = s_cnt[wave];
     // this bucket's key interval, cut into BK_SUB equal sub-intervals (an approximate interval is as good as the exact one: every
@@ -806,9 +806,10 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     const uint32_t wtot = __shfl(run + wsum, 63, 64);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { tsum += __shfl_xor(tsum, d, 64); wall += __shfl_xor(wall, d, 64); }
-    for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) { run += aux[t]; aux[t] = run; } }
+    uint32_t* scanbuf = reinterpret_cast<uint32_t*>(grp);        // (step 4 was the composites' last use)
+    for (uint32_t e = 0; e < E; e++) { const uint32_t t = lane * E + e; if (t < n) { run += aux[t]; scanbuf[t] = run; } }
     wave_sync();
-    for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = aux[t];
+    for (uint32_t t = lane; t < n; t += 64) bwincl[(size_t)b * BK_CAP + t] = scanbuf[t];
     if (lane == 0) {
         if (early_only) { binfo[b] = make_uint4(n, wtot, n_all - n, over); binfo_all[b] = make_uint4(n_all, wall, tsum, over); }
         else binfo[b] = make_uint4(n, wtot, tsum, over);
