@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--no-lpt", action="store_true", help="disable heaviest-tile-first launch order (A/B experiments)")
     ap.add_argument("--binning", type=int, default=None, help="0 run-compressed binning (default), 1 instance-level two-pass sort")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="--gpus 1 only: run the N > 1 gradient exchange through a one-rank RCCL process group (backend nccl: ReduceOp.AVG, "
+                         "the uint8 MAX and all_gather_into_tensor of the sparse exchange) instead of skipping it -- puts the collective "
+                         "library under the bench on a 1-GPU box; a profiling run, not the headline (sweep / training-like / CPU legs off)")
     ap.add_argument("--poses", type=int, default=8,
                     help="camera poses each rank renders round-robin (the reference's batch loop renders different cameras one after "
                          "the other, train.py:198-226); 1 = the repeated-pose protocol of rounds 1-3")
@@ -114,7 +118,7 @@ class Workload:
         color, radii, depth = raster(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"],
                                      shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)
-        if bucket is not None and world > 1:
+        if bucket is not None and (world > 1 or getattr(self, "force_exchange", False)):
             # the backward wrote the leaf gradients straight into the bucket (zero-copy GradArena)
             if getattr(bucket, "sh_factors", False):
                 # all-reduce 11 + all-gather 3 floats/Gaussian -- sparse: of the rows some rank touched only
@@ -377,6 +381,38 @@ def step_bytes(st, per_kernel, P, deg, ms_per_step):
     return out
 
 
+class Deformation:
+    """A stand-in for what SaRO-GS's deformation field hands the rasterizer at timestamp t (scene/saro_gaussian.py:get_deformation, :782-847, with
+    the shipped switches dx = drot = dopacity = True, arguments/__init__.py:68-72): per Gaussian a temporal position and a lifespan,
+        opacity  = sigmoid(_opacity) * exp(-4 ((t - pos) / lifespan)^2)                                   (:791-792, :824-829)
+        means3D  = _xyz + motion_residual(t),  rotations = normalize(_rotation + rot_residual[:, :4]),
+        scales   = exp(_scaling + rot_residual[:, 4:])                                                   (:805-822)
+    The residuals are smooth functions of (t - pos) with a fixed random direction per Gaussian: means move by up to 1.2 % of the scene's
+    extent, scales by +-10 %, quaternions by ~3 degrees -- the size of a learned deformation, none of its cost (the reference's MLP heads
+    are model code outside this path).  The tensors require a gradient, as the heads' outputs do: the backward writes their rows."""
+
+    def __init__(self, P, dev, seed=5, motion=True):
+        rng = np.random.default_rng(seed)
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
+        self.tpos = t(rng.uniform(0.0, 1.0, size=(P, 1)))
+        self.life = t(rng.uniform(0.2, 1.0, size=(P, 1)))
+        self.ts = rng.uniform(0.0, 1.0, size=4096)
+        self.motion = motion
+        if motion:
+            d = rng.normal(size=(P, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+            self.mdir = t(0.03 * d)
+            self.rdir = t(np.concatenate([0.05 * rng.normal(size=(P, 4)), 0.1 * rng.uniform(-1.0, 1.0, size=(P, 3))], axis=1))
+
+    def at(self, i):
+        """(motion_residual, rot_residual, trbfoutput) of call i."""
+        d = float(self.ts[i % len(self.ts)]) - self.tpos
+        trbf = torch.exp(-4.0 * (d / self.life) ** 2)
+        if not self.motion:
+            return None, None, trbf
+        s = torch.sin(6.283185307179586 * d)
+        return (self.mdir * s).requires_grad_(True), (self.rdir * s).requires_grad_(True), trbf
+
+
 def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
     """The reference's call pattern (train.py:198-226, scene/saro_gaussian.py:788-829): V poses dealt round-robin, every call followed by
     loss -> backward -> Adam step (the scene changes between two visits of a pose), and -- `dynamic_opacity` -- a per-call
@@ -389,10 +425,7 @@ def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
     sc = scenes.synth(P, 0, sh_degree=deg)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
     bg = t(sc["bg"])
-    rng = np.random.default_rng(5)
-    tpos = t(rng.uniform(0.0, 1.0, size=(P, 1)))
-    life = t(rng.uniform(0.2, 1.0, size=(P, 1)))
-    ts = rng.uniform(0.0, 1.0, size=4096)
+    deform = {"dynamic_opacity": Deformation(P, dev, motion=False), "dynamic_full": Deformation(P, dev, motion=True)}
     lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
     m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
     gt = torch.rand(3, H, W, device=dev)
@@ -405,7 +438,7 @@ def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
             viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
 
     out = {}
-    for dyn in (False, True):
+    for dyn in (None, "dynamic_opacity", "dynamic_full"):
         for V in Vs:
             rasters = [rast.GaussianRasterizerRaw(settings(k, V)) for k in range(V)]
             row = {}
@@ -417,10 +450,11 @@ def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
                 it = [0]
 
                 def step():
-                    trbf = torch.exp(-4.0 * ((float(ts[it[0] % len(ts)]) - tpos) / life) ** 2) if dyn else None
+                    mres, rres, trbf = deform[dyn].at(it[0]) if dyn else (None, None, None)
                     raster = rasters[it[0] % V]
                     it[0] += 1
-                    color, _, _ = raster(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"], trbfoutput=trbf)
+                    color, _, _ = raster(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"],
+                                         motion_residual=mres, rot_residual=rres, trbfoutput=trbf)
                     loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
                     opt.zero_grad(); m2.grad = None
                     loss.backward()
@@ -429,7 +463,7 @@ def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
                 if opt_name:
                     _C.set_option(opt_name, 1)
                 try:
-                    for _ in range(max(2 * V, 24)):         # every pose seen twice
+                    for _ in range(max((4 if dyn else 2) * V, 24)):         # every pose seen twice (four times where the scene varies with t: the remembered cut is a running maximum over visits)
                         step()
                     torch.cuda.synchronize(dev)
                     fb0 = _query(_C, "cut_fallbacks")
@@ -441,7 +475,7 @@ def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
                     torch.cuda.synchronize(dev)
                     dt = time.perf_counter() - t0
                     row[name] = {"iterations_per_s": round(n / dt, 1), "ms_per_iteration": round(dt / n * 1e3, 4), "calls": n,
-                                 "late_gaussians_per_call": int(late / n),
+                                 "late_gaussians_per_call": int(late / n), "cut_margin_x4": _query(_C, "cut_margin_x4"),
                                  "cut_fallbacks_per_100_calls": round(100.0 * ((_query(_C, "cut_fallbacks") or 0) - (fb0 or 0)) / n, 2)}
                 finally:
                     if opt_name:
@@ -449,9 +483,11 @@ def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
                 del opt, rc
                 torch.cuda.empty_cache()
             row["table_on_over_off"] = round(row["pose_table_on"]["iterations_per_s"] / row["pose_table_off"]["iterations_per_s"], 3)
-            out[("dynamic_opacity" if dyn else "static_opacity") + f"_V{V}"] = row
+            out[(dyn or "static_opacity") + f"_V{V}"] = row
     out["note"] = ("one iteration = GaussianRasterizerRaw forward -> fused L1 + D-SSIM -> backward -> GaussianAdam.step, P = %d at %dx%d; "
-                   "V poses round-robin; dynamic_opacity: opacity = sigmoid(.) * exp(-4 ((t - pos) / lifespan)^2), t ~ U(0, 1) per call" % (P, W, H))
+                   "V poses round-robin; dynamic_opacity: opacity = sigmoid(.) * exp(-4 ((t - pos) / lifespan)^2), t ~ U(0, 1) per call; "
+                   "dynamic_full: the same opacity AND means / rotations / scales moved by residuals that are functions of t "
+                   "(bench.py:Deformation -- what scene/saro_gaussian.py:get_deformation returns with dx = drot = dopacity = True)" % (P, W, H))
     return out
 
 
@@ -1010,6 +1046,11 @@ def main():
     if a.gpus > 1 and not single and torch.cuda.device_count() < a.gpus:
         print(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} device(s) are visible; refusing to run", file=sys.stderr)
         raise SystemExit(2)
+    if a.force_collectives:
+        if a.gpus != 1:
+            raise SystemExit("bench.py: --force-collectives is for --gpus 1 (N > 1 runs the collectives anyway)")
+        vp.force_collectives(True)
+        a.sweep, a.no_training_like, a.no_cpu_baseline = "", True, True
     rank, local, world = vp.init_from_env()
     assert world == a.gpus
     dev = torch.device("cuda", local if (world > 1 and not single) else 0)
@@ -1043,7 +1084,9 @@ def main():
     n_poses = max(a.poses, 1)
     wl = Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=max(world, 1) * n_poses, dev=dev, kind=a.scene, poses=n_poses, pose_stride=max(world, 1))
     bucket = None
-    if world > 1:
+    exchanging = world > 1 or a.force_collectives
+    if exchanging:
+        wl.force_exchange = a.force_collectives
         # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the backward writes
         # into it directly.  Default exchange: all-reduce of the 11 dense floats + all-gather of the 3-float factor of
         # dL/dsh, recombined locally (view_parallel.exchange_gradients); --exchange allreduce: ONE in-place all-reduce
@@ -1085,7 +1128,7 @@ def main():
     late_headline = _query(_C, "last_late")
     # the SAME protocol with one repeated pose (rounds 1-3's headline: the pose table's best case), for comparison
     repeated = None
-    if world == 1 and n_poses > 1:
+    if world == 1 and not exchanging and n_poses > 1:
         wl1 = Workload(rast, scenes, P, W, H, deg, view_k=0, n_views=n_poses, dev=dev, kind=a.scene)
         for k in ("means3D", "opacities", "shs", "scales", "rotations"):
             wl1.leaves[k] = wl.leaves[k]            # (the same scene tensors: no second copy of 3 M Gaussians)
@@ -1096,7 +1139,7 @@ def main():
     # the same protocol with the context's launch-order hints switched off (include/gsrast.h: options.no_order_hint): the bench repeats ONE
     # camera pose, the best case for them; a pose seen for the first time is ordered by list length
     no_hint = None
-    if world == 1:
+    if world == 1 and not exchanging:
         _C.set_option("no_order_hint", 1)
         try:
             d0 = timed(wl, a.steps, a.warmup, None, 1, vp, dev)
@@ -1106,7 +1149,7 @@ def main():
     # ... and with the LIST CUT switched off (options.no_list_cut; the launch-order hints stay on): a pose rendered before bins only the
     # Gaussians in front of its tiles' cut depths -- the same best case (one pose, an unchanged scene: the speculation always holds)
     no_cut = None
-    if world == 1:
+    if world == 1 and not exchanging:
         _C.set_option("no_list_cut", 1)
         try:
             d0 = timed(wl, a.steps, a.warmup, None, 1, vp, dev)
@@ -1117,7 +1160,7 @@ def main():
             wl.step(None, 1)        # (the statistics below describe the default path again)
     st = wl.stats()
     per_kernel, pk, exp2 = (None, None, None)
-    if world == 1:
+    if world == 1 and not exchanging:
         per_kernel, pk = stage_table(_C, wl, st, P, deg, H)
         exp2 = None if os.environ.get("BENCH_NO_EXP2") else exp_mode2_row(_C, wl, dev, kid)
     result = None
@@ -1133,12 +1176,16 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the SAME protocol with the context's pose table switched off -- what a camera pose costs that the context has never
+            # rendered, and the floor for a scene that changes too much between two visits of a pose for the table to help
+            "value_cold": no_hint["views_per_s"] if no_hint else None, "ms_per_step_cold": no_hint["ms_per_step"] if no_hint else None,
             "config": {"workload": f"BASELINE configs[4] stress-1080p: {scene_fn}(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
                                    + ((" + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
                                        + (" -- of the rows some rank touched only" if a.exchange == "sparse" else "")
-                                       if a.exchange != "allreduce" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if world > 1 else ""),
-                       "exchange": a.exchange if world > 1 else None,
-                       "exchange_bytes_per_rank_and_step": getattr(wl, "exchanged", None) if world > 1 else None,
+                                       if a.exchange != "allreduce" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if exchanging else ""),
+                       "exchange": a.exchange if exchanging else None,
+                       "exchange_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None) if exchanging else None,
+                       "exchange_bytes_per_rank_and_step": getattr(wl, "exchanged", None) if exchanging else None,
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
                        "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
                        "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],

@@ -150,7 +150,9 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
                       // round 4: a tile whose cut list was too short is flagged (tile_flags[tile] = 1) for the COMPLETION pass, which
                       // lists the Gaussians that touch such tiles -- all of them, late or not -- and blends those tiles again from
                       // their full lists (the launch with `pred`); every other tile is final after this launch
-                      unsigned char* __restrict__ tile_flags = nullptr)
+                      unsigned char* __restrict__ tile_flags = nullptr,
+                      uint32_t cut_margin_x4 = GSRAST_CUT_MARGIN_X4 /* round 5: the context's margin (6 = 1.5 x; it widens while completion passes are reported) */,
+                      unsigned long long* __restrict__ untouched = nullptr /* GeomLayout::untouched: bit i cleared = some pixel consumed Gaussian i */)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
     if (pred && *pred == 0u) return;
@@ -319,6 +321,17 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     const bool all_done = __syncthreads_and(alive == 0ull) != 0;    // every pixel of the tile inside the image has saturated
     if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
+    // Round 5: which Gaussians did anybody consume?  The backward walks this tile's list up to s_max and no further, so only those can
+    // receive a gradient: their bits are cleared (fire-and-forget atomics of a VALU-bound kernel), every other Gaussian's output rows are
+    // zeros that late_rows_zero_kernel writes beside the blend backward and the per-Gaussian backward skips -- for ANY forward, not only
+    // one that ran under a remembered cut.  (A tile the completion pass blends again clears a few bits too many here: harmless.)
+    if (untouched) {
+        const uint32_t smx = s_max;
+        for (uint32_t i = t; i < smx; i += 256u) {
+            const uint32_t g = point_list[range.x + i];
+            atomicAnd(&untouched[g >> 6], ~(1ull << (g & 63u)));
+        }
+    }
     if (t == 0) {
         tile_max[tile] = s_max;
         // list cut: the speculation failed for this tile if it had a cut and some pixel would have looked further
@@ -329,12 +342,13 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
             asm volatile("" :: "v"(before));
         }
         if (hints) {
-            hint_work(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
-            // the tile's next cut depth: that of the entry 1.5 x as deep (+ 32) as the deepest one consumed; none for a tile that did
-            // not saturate, or whose (full) list is shorter than that
+            const size_t hslot = (size_t)hint_sel[0] * ntiles + tile;
+            hint_work(hints, ntiles)[hslot] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
+            // the tile's next cut depth: that of the entry 1.5 x (cut_margin_x4 / 4) as deep (+ 32) as the deepest one consumed; none for
+            // a tile that did not saturate, or whose (full) list is shorter than that
             uint32_t znew = ZCUT_NONE;
             if (all_done) {
-                const uint32_t p = GSRAST_CUT_MARGIN_X4 * s_max / 4u + 32u;
+                const uint32_t p = cut_margin_x4 * s_max / 4u + 32u;
                 if (p < n_safe) znew = __float_as_uint(rec1[(size_t)REC_STRIDE * point_list[range.x + p]].z);
                 else if (zc != ZCUT_NONE && n_safe > 0u) {
                     // the cut list does not reach that deep: position -> depth extrapolated linearly from the list's first entry
@@ -343,7 +357,30 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
                     znew = zn < 3.0e38f ? (zn > zcf ? __float_as_uint(zn) : zc) : ZCUT_NONE;
                 } else if (zc != ZCUT_NONE) znew = zc;
             }
-            hint_zcut(hints, ntiles)[(size_t)hint_sel[0] * ntiles + tile] = znew;
+            uint32_t* const zslot = hint_zcut(hints, ntiles) + hslot;
+            // Round 5: the cut REMEMBERS.  SaRO-GS renders a camera at a different timestamp every time (opacity = sigmoid * trbf(t), means
+            // and scales moved by the deformation field: scene/saro_gaussian.py:791-829), so the depth at which a tile saturates varies
+            // from visit to visit; a cut that follows the last visit alone is too short every other time, and one short tile costs the
+            // call a completion pass.  A slot that already held THIS pose (hint_sel[1] == 1) keeps the deeper of its old cut and the new
+            // one, the old one moved an eighth of the way towards the new per visit -- a running maximum over roughly the last eight
+            // visits, which still follows a scene that gets more opaque for good.  A frozen scene's cut does not change.
+            if (znew != ZCUT_NONE && hint_sel[1] == 1u) {
+                const uint32_t zold = *zslot;
+                if (zold != ZCUT_NONE && zold > znew) {
+                    const float fo = __uint_as_float(zold), fn = __uint_as_float(znew);
+                    const float fm = fo - (fo - fn) * 0.125f;
+                    if (fm < 3.0e38f && fm > fn) znew = __float_as_uint(fm);
+                }
+            }
+            *zslot = znew;
+            // the pose's key and camera are published HERE, not by preprocess_fwd's block 0 while that kernel's other blocks look the
+            // table up (round 4's benign race): whoever blends tile 0 writes them (scalars[HINT_PUB ...] of this call's geometry buffer)
+            if (tile == 0u && hint_sel[HINT_PUB - HINT_SEL] == 1u) {
+                const uint32_t slot = hint_sel[0];
+                hints->key[slot][0] = hint_sel[HINT_PUB - HINT_SEL + 1]; hints->key[slot][1] = hint_sel[HINT_PUB - HINT_SEL + 2];
+#pragma unroll
+                for (int q = 0; q < 6; q++) hints->cam[slot][q] = __uint_as_float(hint_sel[HINT_PUB - HINT_SEL + 3 + q]);
+            }
         }
         // backward launch order: this tile's work there = the deepest list entry any of its pixels consumed (a tile that is blended
         // again enters the order then)
@@ -366,10 +403,10 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       uint32_t* __restrict__ bucket_cnt, uint16_t* __restrict__ bucket_list, int order_from_buckets,
                       float4* __restrict__ zero4, uint32_t n_zero4, HintTable* __restrict__ hints, const uint32_t* __restrict__ hint_sel,
                       const uint32_t* __restrict__ zcut_used, uint32_t* __restrict__ cut_scalars, const uint32_t* __restrict__ pred,
-                      unsigned char* __restrict__ tile_flags, GateArgs gate)
+                      unsigned char* __restrict__ tile_flags, GateArgs gate, uint32_t cut_margin_x4, unsigned long long* __restrict__ untouched)
 {
     blend_fwd_cull_body<EXPMODE>(ranges, point_list, order, W, H, gx, ntiles, rec0, rec1, rec2, bg, out_color, out_depth, final_T, n_contrib, tile_max,
-                                 bucket_cnt, bucket_list, order_from_buckets, zero4, n_zero4, hints, hint_sel, zcut_used, cut_scalars, pred, tile_flags);
+                                 bucket_cnt, bucket_list, order_from_buckets, zero4, n_zero4, hints, hint_sel, zcut_used, cut_scalars, pred, tile_flags, cut_margin_x4, untouched);
     // (no fence: a release fence here writes the L2 back once per workgroup -- measured: the launch 0.24 -> 0.62 ms.  None is needed: the
     // verdict travels in device-scope atomics, each workgroup's has returned before it counts itself out, and everything else the blend
     // wrote is ordered by the end of the kernel -- the wait behind it is a later command on the same stream)
@@ -937,8 +974,13 @@ blend_bwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 // per compute unit (27.1 KB of LDS, 76 VGPRs): 0.457 -> 0.478 at 3 M, 0.327 -> 0.340 at 1 M; s_setprio 3 for tiles of more than 256 / 768
 // consumed entries: nothing; and the launch is NOT the heavy tiles' serial chain: consuming at most 256 entries per tile (16 % of the
 // entries gone, wrong gradients) takes 0.455 -> 0.403 ms, in proportion.)
+#ifdef GSRAST_BWD_WAVES      // (A/B: cap the registers for that many waves per SIMD)
+#define GSRAST_BWD_OCC __attribute__((amdgpu_waves_per_eu(GSRAST_BWD_WAVES, GSRAST_BWD_WAVES)))
+#else
+#define GSRAST_BWD_OCC
+#endif
 template <int EXPMODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) GSRAST_BWD_OCC
 blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                         const uint32_t* __restrict__ order, int W, int H,
                         int gx, uint32_t ntiles, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
@@ -951,6 +993,12 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 #pragma clang fp contract(fast)
     constexpr int NT = 256, BATCH = 64, NW = 4;
     constexpr int GB = 8;            // instances per group
+    // (Round 5, measured and dropped: the pair's derivative FRONT TO BACK --  dC/dalpha_i . g = T_i (c_i . g) - R_i / (1 - alpha_i), R_i = what
+    // is left of colour_out . g behind contributor i: ONE scalar recurrence and the forward's own T update, 11 instructions where the
+    // reference's back-to-front form (T / (1 - alpha), the three-channel accum_rec: backward.cu:503-516) has 19.  0.398 -> 0.390 ms at 3 M, and
+    // the forward 18 us slower for the copy of its output colour the backward then needs; R is a difference from the pixel's TOTAL, whose
+    // absolute error (the forward's accumulated rounding, ~ n eps |colour . g|) does not shrink with T_i as the back-to-front form's does:
+    // tests/test_gpu_parity.py::test_golden_fixture failed the 1e-5 bar at 1.8e-5.)
     constexpr int PS = 72;           // float2 slots per instance row: 64 pixels + 8 of padding (row stride = 16 banks mod 64: the
                                      // transposed phase's ds_read_b64 of lanes (k, jj), jj = 0..3 within a 32-lane group, are conflict-free)
     constexpr int AS = 12;
@@ -1112,31 +1160,58 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 pbuf[wave][jb][lane] = make_float2(u, dch);
             }
             if (!alive) continue;
-            GS_COUNT(8, 1); GS_COUNT(9, __popc(alive));
+            GS_COUNT(8, 1); GS_COUNT(9, __popc(alive)); GS_COUNT(14, __popc(alive) == 1 ? 1 : 0); GS_COUNT(15, __popc(alive) == 2 ? 1 : 0);
             __builtin_amdgcn_wave_barrier();            // same wave: the LDS executes its accesses in order, no s_barrier needed
             // ---- transposed phase: lane (k, jj) sums pixels k, k + 8, ..., k + 56 of instance jj ----
             const uint32_t j = g * GB + jj;
             const float4 a = s0[j];
             const float4 b = s1[j];
-            const float dxa = a.x - pxk0, dxb = a.x - pxk1;
-            float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
+            float v8[8], Cb = 0.f;
             const float2* urow = &pbuf[wave][jj][k];
+            if constexpr (B8) {
+                // Round 5: SEPARABLE moments.  In the 8 x 8 block lane (k, jj) walks ONE column (pixel k + 8 i = column k of row i): dx is the
+                // same for its eight pixels and dy = (a.y - sy0) - i, so the five geometric sums are polynomials in (dx, by = a.y - sy0) of
+                // THREE row moments of u -- M0 = sum u, M1 = sum u i, M2 = sum u i^2, whose weights are compile-time constants:
+                //   sum u dx = dx M0, sum u dx^2 = dx^2 M0, sum u dy = by M0 - M1, sum u dx dy = dx (by M0 - M1), sum u dy^2 = by^2 M0 - 2 by M1 + M2
+                // Six FMA-class instructions per pixel (three moments, three colour sums) instead of twelve; the polynomials cost nine once
+                // per phase.  SQ_INSTS_VALU per launch at 3 M: 230 M -> see profiles/r05_*.  The rounding differs from summing u dx^2 term by
+                // term but is of the same size (both are relative to |by|^2 sum |u|); gradients stay within the 1e-5 bar of the fp64 oracle.
+                float M0 = 0.f, M1 = 0.f, M2 = 0.f, Cr = 0.f, Cg = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float2 ud = urow[i * 8];
-                asm volatile("" ::: "memory");                       // keeps the 8-byte reads apart: merged into ds_read2_b64 they cost 8 LDS cycles per pair, apart 2 each
-                const float uu = ud.x, dd = ud.y;
-                const float4 dp = make_float4(dpr[i][0], dpr[i][1], dpr[i][2], 0.f);
-                const float dx = B8 ? dxa : ((i & 1) ? dxb : dxa);      // (8 x 8 block: pixel k + 8 i = column k of row i)
-                const float dy = a.y - (sy0 + (float)(B8 ? i : (i >> 1)));
-                const float gxv = uu * dx, gyv = uu * dy;            // the opacity factor of dL/dG = opacity * dL/dalpha is applied once, below
-                Sx += gxv; Sy += gyv;
-                Sxx = __builtin_fmaf(gxv, dx, Sxx); Sxy = __builtin_fmaf(gxv, dy, Sxy); Syy = __builtin_fmaf(gyv, dy, Syy);
-                Su += uu;
-                Cr = __builtin_fmaf(dd, dp.x, Cr); Cg = __builtin_fmaf(dd, dp.y, Cg); Cb = __builtin_fmaf(dd, dp.z, Cb);
+                for (int i = 0; i < 8; i++) {
+                    const float2 ud = urow[i * 8];
+                    asm volatile("" ::: "memory");                       // keeps the 8-byte reads apart: merged into ds_read2_b64 they cost 8 LDS cycles per pair, apart 2 each
+                    const float uu = ud.x, dd = ud.y;
+                    M0 += uu;
+                    if (i == 1) { M1 += uu; M2 += uu; }
+                    else if (i > 1) { M1 = __builtin_fmaf(uu, (float)i, M1); M2 = __builtin_fmaf(uu, (float)(i * i), M2); }
+                    Cr = __builtin_fmaf(dd, dpr[i][0], Cr); Cg = __builtin_fmaf(dd, dpr[i][1], Cg); Cb = __builtin_fmaf(dd, dpr[i][2], Cb);
+                }
+                const float dx = a.x - pxk0, by = a.y - sy0;
+                const float m0 = M0 * b.y, m1 = M1 * b.y, m2 = M2 * b.y;  // the opacity factor of dL/dG = opacity * dL/dalpha, once
+                const float Sy = __builtin_fmaf(by, m0, -m1);
+                const float Syy = __builtin_fmaf(by, Sy, -__builtin_fmaf(by, m1, -m2));
+                const float Sx = dx * m0, Sxx = dx * Sx, Sxy = dx * Sy;
+                v8[0] = Sx * a.z + Sy * a.w; v8[1] = Sy * b.x + Sx * a.w; v8[2] = Sxx; v8[3] = Sxy; v8[4] = Syy; v8[5] = M0; v8[6] = Cr; v8[7] = Cg;
+            } else {
+                const float dxa = a.x - pxk0, dxb = a.x - pxk1;
+                float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, Cr = 0.f, Cg = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float2 ud = urow[i * 8];
+                    asm volatile("" ::: "memory");
+                    const float uu = ud.x, dd = ud.y;
+                    const float dx = (i & 1) ? dxb : dxa;
+                    const float dy = a.y - (sy0 + (float)(i >> 1));
+                    const float gxv = uu * dx, gyv = uu * dy;            // the opacity factor of dL/dG = opacity * dL/dalpha is applied once, below
+                    Sx += gxv; Sy += gyv;
+                    Sxx = __builtin_fmaf(gxv, dx, Sxx); Sxy = __builtin_fmaf(gxv, dy, Sxy); Syy = __builtin_fmaf(gyv, dy, Syy);
+                    Su += uu;
+                    Cr = __builtin_fmaf(dd, dpr[i][0], Cr); Cg = __builtin_fmaf(dd, dpr[i][1], Cg); Cb = __builtin_fmaf(dd, dpr[i][2], Cb);
+                }
+                Sx *= b.y; Sy *= b.y; Sxx *= b.y; Sxy *= b.y; Syy *= b.y;
+                v8[0] = Sx * a.z + Sy * a.w; v8[1] = Sy * b.x + Sx * a.w; v8[2] = Sxx; v8[3] = Sxy; v8[4] = Syy; v8[5] = Su; v8[6] = Cr; v8[7] = Cg;
             }
-            Sx *= b.y; Sy *= b.y; Sxx *= b.y; Sxy *= b.y; Syy *= b.y;
-            const float v8[8] = { Sx * a.z + Sy * a.w, Sy * b.x + Sx * a.w, Sxx, Sxy, Syy, Su, Cr, Cg };
             const float tot = group8_sum8_transposed(v8, lane);     // lane (k, jj): total of value k for instance jj
             const float tb = group8_sum(Cb);
             if ((alive >> jj) & 1u) {

@@ -42,7 +42,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_late_fill_min_p{1500000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -333,14 +333,15 @@ int read_flag_finish(Readback* rb, const uint32_t* dev, hipStream_t s, uint32_t*
     if (nwords > 11) { out[11] = (uint32_t)w[2]; out[SC_Q_EARLY] = (uint32_t)w[4]; out[SC_N_LATE] = (uint32_t)w[5]; out[SC_ZBINS] = (uint32_t)w[6]; }     // (list cut: early column runs, late Gaussians; the depth histogram's occupied bins)
     return GSRAST_OK;
 }
-// the pose-found word of preprocess_fwd (RB_FOUND): 1 / 0, or 1 ("size the launches as for a known pose") if it does not arrive
+// the pose-found word of preprocess_fwd (RB_FOUND): 1 / 0, or 0 ("size the launches as for an unknown pose": all column runs, the safe
+// sizing) if it does not arrive within 200 ms
 bool read_found(Readback* rb)
 {
     volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(rb->pinned) + RB_FOUND;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned long long w;
     for (uint64_t spins = 1; (uint32_t)((w = *p) >> 32) != rb->seq; spins++)
-        if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return true;
+        if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
     return (uint32_t)w != 0u;
 }
 // has the device reported a completion pass of the list cut this thread has not taken note of yet (RB_FALLBACK)?  Returns the number
@@ -378,7 +379,14 @@ struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, joi
 // stream at once (`done` = the call's sequence number, waited for with hipStreamWaitValue32); the chain runs on a second stream behind
 // the blend and, if it had work to do, releases the caller's stream at its end.  Deadlock-free on in-order hardware queues however HIP
 // maps streams onto them: everything the wait can be released by is SUBMITTED before the wait (gate kernel, event, chain, last the wait).
-struct ChainGate { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; uint32_t* words = nullptr /* [64] done | [64] pred */; uint32_t seq = 0; bool failed = false; };
+// The release / predicate words are a ring of GATE_RING slots indexed by the call's sequence number.  A slot may only be claimed again once
+// every launch that can still read it has run: the host records an event behind each chain (`tail`) and claims sequence number n only
+// if the chain of n - GATE_RING / 2 has completed (hipEventQuery, no wait) -- otherwise that call runs its completion pass inline on the
+// caller's stream, the round-3 form, which needs no slot.  So at most GATE_RING / 2 chains are ever pending and no slot is rewritten
+// under a chain (the gate stream has the lowest priority and nothing else bounded its backlog).
+constexpr uint32_t GATE_RING = 64;
+struct ChainGate { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; uint32_t* words = nullptr /* [64] done | [64] pred */; uint32_t seq = 0; bool failed = false;
+                   hipEvent_t tail[GATE_RING] = {}; uint32_t tail_seq[GATE_RING] = {} /* sequence number whose chain the slot's event follows; 0 = none */; uint32_t inline_calls = 0 /* forwards that found the ring's older half still pending (diagnostic) */; };
 __global__ void chain_done_kernel(const uint32_t* __restrict__ pred_copy, uint32_t* __restrict__ done, uint32_t seq)
 {
     if (*pred_copy != 0u) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -392,6 +400,10 @@ struct gsrast_context {
     // opacity): every fallback costs a whole second forward and is reported by the device (RB_FALLBACK); two in close succession pause
     // the cut, for twice as long each time (64 ... 1024 forwards; back on probation: one more such pass pauses again), 64 cut forwards without one forget
     std::atomic<int> cut_fb_score{0}, cut_fb_pause{0}, cut_ok_streak{0};
+    // round 5: how far behind the deepest consumed entry the next cut is put (quarters: 6 = 1.5 x).  Every reported completion pass widens
+    // it by half a step (a scene whose opacities vary from visit to visit needs more room than a frozen one), 128 cut forwards without
+    // one narrow it again by a quarter step; between CUT_MARGIN_MIN and CUT_MARGIN_MAX
+    std::atomic<int> cut_margin{6}, cut_margin_streak{0};
     // equalised depth buckets (gsrast_common.h): the key range the depth histogram's bins cover, learned from the previous forwards
     std::atomic<uint32_t> zh_klo{ZH_KLO_DEFAULT}; std::atomic<int> zh_shift{ZH_SHIFT_DEFAULT};
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
@@ -448,6 +460,11 @@ ChainGate* chain_gate_of(gsrast_context* ctx)
         if (hipMemset(g.words, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
             hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
         if (hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(g.stream); (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr; }
+        for (uint32_t k = 0; k < GATE_RING; k++)
+            if (hipEventCreateWithFlags(&g.tail[k], hipEventDisableTiming) != hipSuccess) {
+                for (uint32_t j = 0; j < k; j++) (void)hipEventDestroy(g.tail[j]);
+                (void)hipEventDestroy(g.ev); (void)hipStreamDestroy(g.stream); (void)hipFree(g.words); g = ChainGate{}; g.failed = true; return nullptr;
+            }
         g.failed = false;
     }
     return &g;
@@ -574,6 +591,8 @@ struct BlendArgs {
     const uint32_t* zcut_used = nullptr; uint32_t* cut_scalars = nullptr; const uint32_t* pred = nullptr;   // forward: list cut (gsrast_common.h)
     unsigned char* tile_flags = nullptr;                         // forward: tiles the completion pass lists and blends again
     GateArgs gate{};                                             // forward, list cut's first pass: the completion pass's gate (ChainGate)
+    uint32_t cut_margin_x4 = 6;                                  // forward: the next cut depth's margin (gsrast_context::cut_margin)
+    unsigned long long* untouched = nullptr;                     // forward (culling kernel): GeomLayout::untouched
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -612,7 +631,7 @@ template <int MODE>
 void launch_fwd_cull(uint32_t grid, hipStream_t s, const BlendArgs& a)
 {
     blend_fwd_cull_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.oc, a.od, a.fT, a.nc, a.tm,
-                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred, a.tile_flags, a.gate);
+                                                     a.bcnt, a.blist, a.from_buckets, a.zero4, a.n_zero4, a.hints, a.hint_sel, a.zcut_used, a.cut_scalars, a.pred, a.tile_flags, a.gate, a.cut_margin_x4, a.untouched);
 }
 template <int MODE>
 void dispatch_bwd(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -641,6 +660,7 @@ void gsrast_context_destroy(gsrast_context* c)
     for (ChainGate& g : c->gate) {
         if (g.stream) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
         if (g.ev) (void)hipEventDestroy(g.ev);
+        for (hipEvent_t e : g.tail) if (e) (void)hipEventDestroy(e);
         if (g.words) (void)hipFree(g.words);
     }
     for (SideStream& x : c->side) {
@@ -661,6 +681,11 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
     if (!strcmp(name, "last_late")) return (int)c->last_late.load();
     if (!strcmp(name, "last_early_runs")) return (int)c->last_Qe.load();
+    if (!strcmp(name, "cut_margin_x4")) return c->cut_margin.load();      // the list cut's current margin, in quarters (6 = 1.5 x)
+    if (!strcmp(name, "gate_inline_calls")) {     // cut forwards that ran their completion pass inline because the gate's ring was half full
+        int device = 0; if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return 0;
+        return (int)c->gate[device].inline_calls;
+    }
     if (!strcmp(name, "cut_pause")) return c->cut_pause.load();      // forwards the list cut still sits out (too little saved, or its lists kept failing)
     if (!strcmp(name, "cut_fallbacks")) {       // a device counter in the hint table of the current device (diagnostic: waits for the device)
         int device = 0;
@@ -685,6 +710,8 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "debug_sync")) { g_debug_sync = value ? 1 : 0; return 0; }
     if (!strcmp(name, "list_cut_always")) { g_list_cut_always = value ? 1 : 0; return 0; }   // the list cut also where it does not pay (tests)
     if (!strcmp(name, "chain_gate")) { g_chain_gate = value ? 1 : 0; return 0; }               // 0: the completion pass's launches on the caller's stream (round 3)
+    if (!strcmp(name, "touch_bits")) { g_touch_bits = value ? 1 : 0; return 0; }               // 0: only the list cut's late bits serve the backward (round 4)
+    if (!strcmp(name, "late_fill_min_p")) { g_late_fill_min_p = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "near_pose")) { g_near_pose = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }                 // 0: only the pose's own slot (round 3)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
@@ -721,6 +748,8 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "debug_sync")) return g_debug_sync.load();
     if (!strcmp(name, "list_cut_always")) return g_list_cut_always.load();
     if (!strcmp(name, "chain_gate")) return g_chain_gate.load();
+    if (!strcmp(name, "touch_bits")) return g_touch_bits.load();
+    if (!strcmp(name, "late_fill_min_p")) return g_late_fill_min_p.load();
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
     if (!strcmp(name, "layer_cut")) return g_layer_cut.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
@@ -804,6 +833,14 @@ int gsrast_forward(gsrast_alloc_fn geometry_alloc, void* geometry_ctx, gsrast_al
                              radii, stream);
 }
 
+static int prefilter_verdict(const uint32_t* word, hipStream_t s)
+{
+    uint32_t v = 0;
+    GS_HIP(hipMemcpyAsync(&v, word, sizeof v, hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    return v ? fail(GSRAST_E_ARG, "forward: a Gaussian passed as prefiltered was culled by the near plane (the reference traps: auxiliary.h:156-160)") : GSRAST_OK;
+}
+
 // The forward behind gsrast_forward_ex (rawin == nullptr) and gsrast_forward_raw (rawin: means3D / opacities / scales / rotations
 // are then the model's raw leaves, shs a non-null placeholder; the per-Gaussian kernels run as their RAW instantiations).
 static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
@@ -816,13 +853,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                       float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream,
                       const gsrast_raw_inputs* rawin)
 {
-    (void)prefiltered;
     RoctxRange range_fwd(rawin ? "gsrast_forward_raw" : "gsrast_forward");
     RawArgs raw{};
     if (rawin) {
         raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
         raw.features_dc = rawin->features_dc; raw.features_rest = rawin->features_rest; raw.shs_res = rawin->shs_res;
-    } // the reference only traps when a prefiltered point is culled (auxiliary.h:156-160)
+    }
     const gsrast_options o = options ? *options : snapshot_defaults();
     if (!options_valid(o)) return fail(GSRAST_E_ARG, "forward: bad option value");
     if (!ctx) ctx = thread_context();
@@ -862,7 +898,19 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     uint32_t* hist = at<uint32_t>(geom, GL.hist);
     uint32_t* scan_tmp = at<uint32_t>(geom, GL.scan_tmp);
     uint32_t* scalars = at<uint32_t>(geom, GL.scalars);
-
+    // `prefiltered` is the caller's promise that no Gaussian will be culled by the near plane; the reference prints and traps when one is
+    // (auxiliary.h:156-160).  Here preprocess_fwd raises a word and this call returns GSRAST_E_ARG after it has waited for the device
+    // (SaRO-GS always passes False, renderer/__init__.py:63: the promise costs a synchronisation, nobody makes it on a hot path).
+    uint32_t* prefilter_word = prefiltered ? scalars + SC_PREFILTER : nullptr;
+    if (prefilter_word) GS_HIP(hipMemsetAsync(prefilter_word, 0, sizeof(uint32_t), s));
+    // near-pose borrowing (HintTable::cam): the position tolerance is relative to the camera's distance from the scene = the middle of the
+    // depth range the context has learned (0: nothing learned yet, the kernel falls back to the distance from the origin)
+    float near_scale2 = 0.0f;
+    {   const uint32_t klo = ctx->zh_klo.load(); const int sh = ctx->zh_shift.load();
+        if (!(klo == ZH_KLO_DEFAULT && sh == ZH_SHIFT_DEFAULT)) {
+            const uint64_t kmid = (uint64_t)klo + (((uint64_t)ZH_MID << sh) >> 1);
+            if (kmid < (uint64_t)ZH_KEY_TOP) { const uint32_t kb = (uint32_t)kmid; float z; memcpy(&z, &kb, sizeof z); if (z > 0.0f && z < 1e18f) near_scale2 = z * z; }
+        } }
     // Run-compressed binning needs one 8-bit pass over tile rows and 16-bit tile ids.
     const bool runbin = o.binning == 0 && cam.gy <= 256 && T <= 65536u;
     const bool buckets_ok = T <= BUCKET_MAX_TILES;      // launch order of the blend kernels from work buckets (u16 tile ids)
@@ -894,6 +942,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // runs, and paused for CUT_PAUSE forwards whenever a cut forward removed fewer than that (a surface-like scene; measured
     // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
     constexpr uint32_t CUT_MIN_RUNS = 1500000u; constexpr int CUT_PAUSE = 64;
+    constexpr int CUT_MARGIN_MIN = 6, CUT_MARGIN_MAX = 16;      // 1.5 x ... 4 x (gsrast_context::cut_margin)
     {   // (a pause belongs to the scene that earned it: a context that moves on to a scene of another size starts afresh)
         const uint32_t pp = ctx->cut_pause_P.load();
         if (ctx->cut_pause.load() > 0 && (pp > (uint32_t)P ? pp - (uint32_t)P : (uint32_t)P - pp) > pp / 8) ctx->cut_pause = 0;
@@ -916,6 +965,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
     const bool zero_in_blend = o.cull != 0 && o.fwd_pixels_per_lane == 0 && (size_t)P * 4 <= 0xFFFFFFFFull;
+    // ... and it keeps the "no pixel consumed this Gaussian" bits for the backward (GeomLayout::untouched), unless no backward will follow
+    unsigned long long* untouched = (o.cull != 0 && o.fwd_pixels_per_lane == 0 && !o.forward_only && g_touch_bits.load() != 0) ? at<unsigned long long>(geom, GL.untouched) : nullptr;
     bool color_launched = false;
     // Every exit after the fork must order the caller's stream behind the side stream: the colour kernel and the zero-fill write
     // into the geometry buffer, which the caller is free to release (on `s`) as soon as this function has returned -- an error
@@ -1000,12 +1051,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load());
+                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load());
+                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched);
         GS_LAUNCHED("preprocess_fwd");
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
@@ -1174,11 +1225,28 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
         if (zero_in_blend && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
+        ba.cut_margin_x4 = (uint32_t)ctx->cut_margin.load();
+        ba.untouched = untouched;
         if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; ba.tile_flags = at<unsigned char>(img, IL.tile_flags); }
         if (mode == 1 && cull && g_chain_gate.load() != 0 && (gate = chain_gate_of(ctx)) != nullptr) {
-            { std::lock_guard<std::mutex> lk(ctx->mu); gseq = ++gate->seq; if (gseq == 0u) gseq = ++gate->seq; }
-            gdone = gate->words + (gseq & 63u); gpred = gate->words + 64 + (gseq & 63u);
-            ba.gate = GateArgs{ at<uint32_t>(img, IL.bucket_cnt) + (XCD_GROUPS + 1) * WORK_BUCKETS, gpred, gdone, gseq };
+            {   std::lock_guard<std::mutex> lk(ctx->mu);
+                uint32_t n = gate->seq + 1u; if (n == 0u) n = 1u;
+                // the slot of n was last used by n - GATE_RING; it is free once the chain of n - GATE_RING / 2 (enqueued later on the same
+                // in-order stream) has run.  Not yet?  Then this call does without the gate (inline chain below).
+                // (a call that claimed a number but never enqueued a chain recorded no event: the youngest recorded chain among
+                // n - GATE_RING / 2 ... n - GATE_RING answers for all older ones)
+                bool free_slot = true;
+                for (uint32_t back = GATE_RING / 2u; back <= GATE_RING; back++) {
+                    const uint32_t k = n - back;
+                    if (k != 0u && gate->tail_seq[k % GATE_RING] == k) { free_slot = hipEventQuery(gate->tail[k % GATE_RING]) == hipSuccess; break; }
+                }
+                if (!free_slot) { gate->inline_calls++; gate = nullptr; }
+                else { gate->seq = n; gseq = n; gate->tail_seq[n % GATE_RING] = 0u; }
+            }
+            if (gate) {
+                gdone = gate->words + (gseq % GATE_RING); gpred = gate->words + GATE_RING + (gseq % GATE_RING);
+                ba.gate = GateArgs{ at<uint32_t>(img, IL.bucket_cnt) + (XCD_GROUPS + 1) * WORK_BUCKETS, gpred, gdone, gseq };
+            }
         }
         if (mode == 2) ba.pred = redo_pred;
         if (buckets_ok) { ba.bcnt = at<uint32_t>(img, IL.bucket_cnt); ba.blist = at<uint16_t>(img, IL.bucket_list); }   // backward order: always appended
@@ -1326,6 +1394,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (trace) fprintf(stderr, "[gsrast] completion pass reported: %u column runs of %u, %d points on a score of %d\n", q2, qall, pts, ctx->cut_fb_score.load());
         if (pts == 0 && ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
         if (pts >= 4) ctx->cut_ok_streak = 0;
+        { const int m = ctx->cut_margin.load(); if (m < CUT_MARGIN_MAX) ctx->cut_margin = std::min(CUT_MARGIN_MAX, m + 2); ctx->cut_margin_streak = 0; }
         if ((ctx->cut_fb_score += pts) >= 16 && !g_list_cut_always.load()) {
             // (on probation after the pause: the score restarts at half the bar, ONE more pass of that size pauses again, twice as long)
             const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 64 : (prev >= 512 ? 1024 : prev * 2);
@@ -1334,14 +1403,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     } else if (cut && counts[SC_N_LATE] != 0u) {
         if (ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
         if (++ctx->cut_ok_streak >= 64) ctx->cut_fb_pause = 0;
+        if (++ctx->cut_margin_streak >= 128) { ctx->cut_margin_streak = 0; const int m = ctx->cut_margin.load(); if (m > CUT_MARGIN_MIN) ctx->cut_margin = m - 1; }
     }
     const bool early_fits = !cut || counts[SC_Q_EARLY] <= nQ1;
     if (speculative && !sort_redone && R <= cap && Q <= capQ && early_fits) {          // everything is already in flight
         if (cut && counts[SC_N_LATE] != 0u) {
             // List cut: the lists in flight hold the early Gaussians only.  The blend verifies them; behind it, the whole binning and
             // blend over ALL Gaussians, predicated on its verdict (gsrast_common.h).  Nothing of this runs in the steady state.
-            ProfScope ps(K_CUT_REDO, s);
-            struct Off { Off() { t_prof_off++; } ~Off() { t_prof_off--; } } off;
             // the pass on its own stream behind a gate (ChainGate above), unless that cannot be had
             const hipStream_t s_caller = s;
             if (gate) {      // (claimed with the blend's launch: its last workgroup has copied the verdict and, if there is nothing to do, released us)
@@ -1351,6 +1419,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 s = gate->stream;                  // (the lambdas below launch on `s`)
             }
             struct Back { hipStream_t& s; hipStream_t v; const uint32_t*& p; const uint32_t* pv; ~Back() { s = v; p = pv; } } back{ s, s_caller, redo_pred, scalars + SC_REDO_PRED };
+            ProfScope ps(K_CUT_REDO, s);           // (on the stream the pass runs on: its events bracket the chain, not an empty interval of the caller's stream)
+            struct Off { Off() { t_prof_off++; } ~Off() { t_prof_off--; } } off;
             // (round 4: a COMPLETION pass, not a second forward: the Gaussians that touch a flagged tile -- the candidates --, their
             // missing colours, their column runs through flagged tiles, and the flagged tiles' blend from their full lists)
             cut_candidates_kernel<<<std::min((P + 255) / 256, 2048), 256, 0, s>>>((uint32_t)P, tiles, rect, at<unsigned char>(img, IL.tile_flags), T, (uint32_t)cam.gx,
@@ -1364,6 +1434,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 // (also after an error above: the caller's stream must not wait for a release nobody sends)
                 chain_done_kernel<<<1, 1, 0, gate->stream>>>(redo_pred, gdone, gseq);
                 const hipError_t e1 = hipGetLastError();
+                {   std::lock_guard<std::mutex> lk(ctx->mu);      // the chain's tail: whoever wants this slot's successor asks this event
+                    if (hipEventRecord(gate->tail[gseq % GATE_RING], gate->stream) == hipSuccess) gate->tail_seq[gseq % GATE_RING] = gseq; }
                 const hipError_t e2 = hipStreamWaitValue32(s_caller, gdone, gseq, hipStreamWaitValueEq, 0xFFFFFFFFu);
                 if (e1 != hipSuccess || e2 != hipSuccess) {     // no gate after all: an ordinary join behind the chain, and never again
                     { std::lock_guard<std::mutex> lk(ctx->mu); gate->failed = true; }
@@ -1373,6 +1445,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             }
             if (rc != GSRAST_OK) return rc;
         }
+        if (prefilter_word) { int rc = prefilter_verdict(prefilter_word, s); if (rc != GSRAST_OK) return rc; }
         return (int)R;
     }
     if (speculative && !sort_redone) ctx->redo_count++;
@@ -1429,6 +1502,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         }
     }
     { int rc = launch_blend(plist, runbin && R > 0 && Q > 0); if (rc != GSRAST_OK) return rc; }
+    if (prefilter_word) { int rc = prefilter_verdict(prefilter_word, s); if (rc != GSRAST_OK) return rc; }
     return (int)R;
 }
 
@@ -1887,7 +1961,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // backward; preprocess_bwd then neither reads nor writes them.  Both kernels check on the device that the forward's cut was in force
     // and held.  Only where it pays for the two events (large scenes), with the sparse per-Gaussian backward, in a one-phase call.
     bool late_fill = false;
-    if (do_blend && do_geom && R > 0 && !o.dense_backward && o.side_stream && (P >= 1500000 || g_list_cut_always.load() != 0)) {
+    if (do_blend && do_geom && R > 0 && !o.dense_backward && o.side_stream && (P >= g_late_fill_min_p.load() || g_list_cut_always.load() != 0)) {
         if (!side) {
             side = side_stream_of(thread_context());
             if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); }
@@ -1901,7 +1975,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
             else if (use_sh && !o.sh_grad_factors) add(dL_dsh, M * 3);
             la.n = n;
             {   ProfScope ps(K_LATE_ZERO, side->stream);
-                late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la); }
+                late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la, at<unsigned long long>(geom, GL.untouched)); }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
             GS_HIP(hipEventRecord(side->join, side->stream));
@@ -1956,7 +2030,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         const int factors = (use_sh && o.sh_grad_factors) ? 1 : 0;
 #define GS_PB_ARGS P, D, M, means3D, radii, raw, rawg, sh_in, at<unsigned char>(geom, GL.clamped), at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), \
                    at<float>(geom, GL.shdC), sc_in, ro_in, cov, cam, reinterpret_cast<const float4*>(grec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,  \
-                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars)
+                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars), (late_fill ? at<unsigned long long>(geom, GL.untouched) : nullptr)
         const bool skip = !o.dense_backward;        // Gaussians with an all-zero gradient record are not read
         if (late_fill) {       // (late_fill implies skip) grouped: 1024 Gaussians per workgroup, the ones late_rows_zero_kernel does not write compacted
             const int gg = (P + PB_GROUP - 1) / PB_GROUP;

@@ -51,7 +51,10 @@ struct GeomLayout {
         bk_order_e, bk_wincl_e, bk_info_e, bk_base_e /* the same four over the EARLY Gaussians only, compact (list cut, below) */,
         color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */,
         cand_bits /* u64[ceil(P / 64)]: bit i = Gaussian i touches a tile the completion pass lists again */,
-        skip2 /* u64[ceil(P / 64)]: bit i = the completion pass need NOT evaluate Gaussian i's colour (it is not a late candidate) */, total;
+        skip2 /* u64[ceil(P / 64)]: bit i = the completion pass need NOT evaluate Gaussian i's colour (it is not a late candidate) */,
+        untouched /* u64[ceil(P / 64)]: bit i = NO pixel consumed Gaussian i (round 5, stateless: set by preprocess_fwd, cleared by the forward
+                     blend for the list prefix each tile consumed): the backward's rows of such a Gaussian are zero -- written beside the
+                     blend backward, skipped by the per-Gaussian backward, whatever the pose table knows */, total;
 };
 constexpr int GREC = 16;            // floats per gradient record
 constexpr size_t BUCKET_SORT_MIN_P = 32768;     // below this the depth sort is one or two self-scanned radix passes anyway
@@ -165,6 +168,12 @@ struct HintTable {
 // A forward's own choice -- {slot, 1 = "the slot held estimates of this pose when the forward began" / 2 = "estimates borrowed from
 // a near pose", the slot they are read from} -- lives in ITS geometry buffer (scalars[HINT_SEL], [HINT_SEL + 1], [HINT_SEL + 2]), so two forwards of one context in flight on two streams do not read each other's slot.
 constexpr int HINT_SEL = 16;
+// ... and what the forward blend PUBLISHES into a newly claimed slot once the call's lists exist (round 5: preprocess_fwd's block 0 used to
+// write the key while the kernel's other lookup blocks read the table): scalars[HINT_PUB] = 1 "publish", [+1, +2] the pose's key,
+// [+3 .. +8] its camera (position, viewing direction)
+constexpr int HINT_PUB = 32;
+constexpr int SC_TOUCH_VALID = 45;    // scalars: 1 = this forward's blend kept GeomLayout::untouched (the backward trusts the bits)
+constexpr int SC_PREFILTER = 44;      // scalars: set by preprocess_fwd when a Gaussian is culled although the caller passed prefiltered = 1
 __host__ __device__ inline uint16_t* hint_work(HintTable* h, uint32_t) { return reinterpret_cast<uint16_t*>(h + 1); }
 __host__ __device__ inline const uint16_t* hint_work(const HintTable* h, uint32_t) { return reinterpret_cast<const uint16_t*>(h + 1); }
 static inline size_t hint_zcut_offset(size_t T) { return (sizeof(HintTable) + (size_t)HINT_SLOTS * T * 2 + 255) & ~(size_t)255; }
@@ -256,6 +265,7 @@ static inline GeomLayout geom_layout(size_t P)
     L.color_skip = take(((Pp + 63) / 64) * 8 + 256);
     L.cand_bits = take(((Pp + 63) / 64) * 8 + 256);
     L.skip2 = take(((Pp + 63) / 64) * 8 + 256);
+    L.untouched = take(((Pp + 63) / 64) * 8 + 256);
     L.total = o + 256;
     return L;
 }

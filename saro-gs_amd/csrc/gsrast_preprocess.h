@@ -681,10 +681,13 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       uint32_t ntiles_img, uint32_t* __restrict__ cut_scalars /* or null: GeomLayout::scalars, whose `undone` counter is zeroed here */,
                       unsigned long long* __restrict__ host_found = nullptr, uint32_t host_seq = 0 /* pinned host word: {this pose was in the table, the
                                                              call's sequence number} -- the host sizes the launches over the cut lists by it */,
-                      int borrow = 0 /* r > 0: a pose the table does not know takes the estimates and cut depths of a near pose's slot (HintTable::cam), the cut depths widened over (2 r + 1)^2 tiles */)
+                      int borrow = 0 /* r > 0: a pose the table does not know takes the estimates and cut depths of a near pose's slot (HintTable::cam), the cut depths widened over (2 r + 1)^2 tiles */,
+                      float near_scale2 = 0.0f /* (camera-to-scene distance)^2 the near-pose tolerance is relative to; 0: the camera's distance from the origin */,
+                      uint32_t* __restrict__ prefilter_violation = nullptr /* or a word that is set when a Gaussian is culled although the caller said `prefiltered` (auxiliary.h:156-160) */,
+                      unsigned long long* __restrict__ untouched = nullptr /* or GeomLayout::untouched: every bit set here, cleared by the forward blend */)
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS + GATE_WORDS; i += blockDim.x) bucket_cnt[i] = 0u;
-    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; cut_scalars[SC_GATE_COUNT] = 0u; }      // (always: the backward reads them)
+    if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; cut_scalars[SC_GATE_COUNT] = 0u; cut_scalars[SC_TOUCH_VALID] = untouched ? 1u : 0u; }      // (always: the backward reads them)
     // The camera pose's key: block 0 looks it up and claims its slot, or the least recently used one; the first blocks of the grid
     // look it up too and copy the slot's cut depths into this call's own image buffer -- the bucket scatter and the forward blend
     // must see the SAME values, whatever another forward of this context writes into the table meanwhile (a stale or torn snapshot
@@ -713,14 +716,17 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
         for (int k = threadIdx.x; k < HINT_SLOTS; k += blockDim.x) {        // one lane per slot
             const bool used = (hints->key[k][0] | hints->key[k][1]) != 0u;
             if (hints->key[k][0] == h0 && hints->key[k][1] == h1) s_slot = k;
-            atomicMin(&s_lru, ((unsigned long long)hints->stamp[k] << 32) | (unsigned long long)k);      // least recently used, lowest index first
+            if (blockIdx.x == 0) atomicMin(&s_lru, ((unsigned long long)hints->stamp[k] << 32) | (unsigned long long)k);      // least recently used, lowest index first (block 0 alone reads and writes the stamps)
             if (used && borrow) {
                 // a NEAR pose (a camera path's previous frame): within 12 % of the distance to the world origin and 12 degrees of the viewing
                 // direction; the closest direction wins, the lower index on a tie.  (Lookup blocks that read a slot while block 0 rewrites
                 // it may decide differently: a tile's snapshot then comes from another slot -- only a poorer speculation, verified like any.)
                 const float* c = hints->cam[k];
                 const float dx = c[0] - cpx, dy = c[1] - cpy, dz = c[2] - cpz;
-                const float d2 = dx * dx + dy * dy + dz * dz, r2 = fmaxf(cpx * cpx + cpy * cpy + cpz * cpz, 1e-12f);
+                // (the tolerance is relative to the camera's distance from the SCENE -- the middle of the depth range this context has
+                // learned from its forwards, near_scale2 --, not from the world origin, which a scene need not be centred on; a context's
+                // first forwards have learned nothing yet and fall back to the distance from the origin)
+                const float d2 = dx * dx + dy * dy + dz * dz, r2 = near_scale2 > 0.0f ? near_scale2 : fmaxf(cpx * cpx + cpy * cpy + cpz * cpz, 1e-12f);
                 const float dot = c[3] * fwx + c[4] * fwy + c[5] * fwz;
                 if (d2 <= 0.0144f * r2 && dot >= 0.978f)
                     atomicMax(&s_near, ((unsigned long long)__float_as_uint(dot) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k));
@@ -732,10 +738,15 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
             int slot = s_slot;
             const uint32_t now = hints->clock + 1u;
             const uint32_t found = slot >= 0 ? 1u : (near_slot >= 0 ? 2u : 0u);
-            if (slot < 0) { slot = (int)(uint32_t)(s_lru & 0xFFFFFFFFull); hints->key[slot][0] = h0; hints->key[slot][1] = h1; }
+            // A pose the table does not hold takes the least recently used slot.  Its key and camera are NOT written here: this kernel's
+            // other lookup blocks are reading the table right now (round 4 left that race in as benign); they travel in the call's own
+            // scalars (HINT_PUB) and the forward blend -- a later kernel of the same stream -- publishes them with the slot's new contents.
+            if (slot < 0) slot = (int)(uint32_t)(s_lru & 0xFFFFFFFFull);
             hints->stamp[slot] = now; hints->clock = now;
-            float* c = hints->cam[slot];
-            c[0] = cpx; c[1] = cpy; c[2] = cpz; c[3] = fwx; c[4] = fwy; c[5] = fwz;
+            uint32_t* pub = hint_sel + (HINT_PUB - HINT_SEL);
+            pub[0] = found == 1u ? 0u : 1u; pub[1] = h0; pub[2] = h1;
+            pub[3] = __float_as_uint(cpx); pub[4] = __float_as_uint(cpy); pub[5] = __float_as_uint(cpz);
+            pub[6] = __float_as_uint(fwx); pub[7] = __float_as_uint(fwy); pub[8] = __float_as_uint(fwz);
             hint_sel[0] = (uint32_t)slot; hint_sel[1] = found; hint_sel[2] = found == 2u ? (uint32_t)near_slot : (uint32_t)slot;
             if (host_found) __hip_atomic_store(host_found, ((unsigned long long)host_seq << 32) | (unsigned long long)found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -759,6 +770,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (untouched && i < P && (i & 63) == 0) untouched[i >> 6] = ~0ull;      // (one word per wave; the blend clears what it consumes)
     // Every per-Gaussian input is requested up front: loads issued where they are first used (inside the visibility / area
     // branches) put three more memory round trips into a latency-bound kernel.  Clamped index: lanes past P load a valid
     // element and never use it.
@@ -865,6 +877,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
             }
         }
     }
+    else if (prefilter_violation) *prefilter_violation = 1u;      // (the reference prints and traps: auxiliary.h:156-160; here the host returns GSRAST_E_ARG)
     radii[i] = rad_out; tiles[i] = ntiles; rect[i] = rc;
     sort_key[i] = key;
     if (sort_val) sort_val[i] = (uint32_t)i;        // the radix depth sort's values; the bucket sort carries the index in its slab element
@@ -1026,7 +1039,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       // order) and works through them densely (3 M cube: 0.4 M of 3 M), their dL/dsh rows leaving one by one.  Both
                       // kernels trust the bits only if the forward's scalars say that the cut was in force (SC_N_LATE != 0) and held
                       // (SC_UNDONE == 0: no second binning over all Gaussians); otherwise the rounds are the group's eight blocks of 128
-                      const unsigned long long* __restrict__ late_bits = nullptr, const uint32_t* __restrict__ cut_scalars = nullptr)
+                      // Round 5: `untouched` (GeomLayout::untouched, kept by the forward blend whenever scalars[SC_TOUCH_VALID] says so) takes
+                      // the bits' place -- "no pixel consumed this Gaussian", a superset of "culled or late" that needs no pose table
+                      const unsigned long long* __restrict__ late_bits = nullptr, const uint32_t* __restrict__ cut_scalars = nullptr,
+                      const unsigned long long* __restrict__ untouched = nullptr)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     __shared__ uint32_t s_list[GROUPED ? PB_GROUP : 1];
@@ -1034,7 +1050,9 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const int ncoef = (D + 1) * (D + 1);
     const bool staged = shs && M * 3 <= PP_SH_MAX;
     float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
-    const bool late_rows = GROUPED && late_bits && cut_scalars[SC_N_LATE] != 0u;      // (uniform; the completion pass has taken the Gaussians it listed after all out of the bits)
+    const bool touch_ok = GROUPED && untouched && cut_scalars[SC_TOUCH_VALID] != 0u;  // (uniform)
+    if (touch_ok) late_bits = untouched;
+    const bool late_rows = GROUPED && late_bits && (touch_ok || cut_scalars[SC_N_LATE] != 0u);      // (uniform; the completion pass has taken the Gaussians it listed after all out of the cut's bits)
     const int gbase = blockIdx.x * (GROUPED ? PB_GROUP : PP_THREADS);
     int nround = 1;
     uint32_t total = 0;
@@ -1311,9 +1329,11 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 // WHILE that VALU-bound kernel runs.  One wave per 64 consecutive Gaussians (one word of bits), every output array in turn, coalesced.
 struct LateRowsArgs { float* ptr[12]; int rowlen[12]; int n; };
 __global__ void __launch_bounds__(256)
-late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, const uint32_t* __restrict__ cut_scalars, LateRowsArgs a)
+late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, const uint32_t* __restrict__ cut_scalars, LateRowsArgs a,
+                      const unsigned long long* __restrict__ untouched)
 {
-    if (cut_scalars[SC_N_LATE] == 0u) return;       // the same verdict as preprocess_bwd_kernel's
+    if (untouched && cut_scalars[SC_TOUCH_VALID] != 0u) late_bits = untouched;      // the same verdict as preprocess_bwd_kernel's
+    else if (cut_scalars[SC_N_LATE] == 0u) return;
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t nw = ((uint32_t)P + 63u) / 64u;
     for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4u) {

@@ -22,21 +22,47 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE_COLLECTIVES = os.environ.get("GSRAST_FORCE_COLLECTIVES", "") == "1"
+
+
+def force_collectives(on: bool = True) -> None:
+    """Run every collective of this module even in a process group of ONE rank (default: a single rank short-circuits them).
+    A 1-GPU box can then drive the exchange through RCCL itself -- `backend="nccl"`, world size 1: ReduceOp.AVG, the uint8 MAX of the
+    sparse exchange, all_gather_into_tensor, the asynchronous all-reduce of distributed_step -- which is the library that runs them
+    on the 8-GPU node (tests/test_gpu_rccl.py, `bench.py --gpus 1 --force-collectives`).  Also: GSRAST_FORCE_COLLECTIVES=1."""
+    global _FORCE_COLLECTIVES
+    _FORCE_COLLECTIVES = bool(on)
+
+
+def collectives_active() -> bool:
+    """Is there a process group whose collectives this module should call (more than one rank, or forced)?"""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
-    Returns (rank, local_rank, world).  A single process (WORLD_SIZE unset or 1) needs no group."""
+    Returns (rank, local_rank, world).  A single process (WORLD_SIZE unset or 1) needs no group -- unless force_collectives()."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE_COLLECTIVES) and not dist.is_initialized():
         if backend is None:
             # GSRAST_DIST_BACKEND=gloo lets a 1-GPU box exercise the multi-rank code path (tests only)
             backend = os.environ.get("GSRAST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def views_of_rank(n_views: int, rank: int, world: int) -> List[int]:
@@ -74,7 +100,7 @@ class FlatGradBucket:
         """SUM over ranks, then / batch.  batch = number of views in the iteration (== world when
         every rank renders one view)."""
         work = None
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collectives_active():
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if work is None or not async_op:
             self.flat.mul_(1.0 / batch)
@@ -94,7 +120,7 @@ _AVG_OK = True
 def allreduce_mean_inplace(flat: torch.Tensor, batch: int) -> None:
     """Mean over the batch of one flat gradient buffer, in place.  RCCL's AVG does the division inside
     the collective (no extra pass over the buffer); gloo has no AVG, so SUM then scale."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not collectives_active():
         if batch != 1:
             flat.mul_(1.0 / batch)
         return
@@ -133,19 +159,30 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
     from diff_gaussian_rasterization_ch3 import _C
     if not getattr(arena, "sh_factors", False):
         raise ValueError("exchange_gradients needs GradArena(..., sh_factors=True)")
-    multi = dist.is_initialized() and dist.get_world_size() > 1
+    multi = collectives_active()
     n_views = dist.get_world_size() if multi else 1
     if n_views != arena.world:
         raise ValueError(f"arena was built for {arena.world} ranks, the process group has {n_views}")
     P = arena.P
     pending = getattr(arena, "_gather_work", None)
+    if sparse and pending is not None:
+        # (the asynchronous gather moves EVERY row's factor: the two forms do not combine -- say so instead of silently paying for both)
+        import warnings
+        warnings.warn("exchange_gradients(sparse=True) with overlap_factor_exchange() in force: the dense factor gather has already "
+                      "been started inside the backward, the exchange falls back to the dense form; switch the overlap off "
+                      "(overlap_factor_exchange(False)) to send only the touched rows", RuntimeWarning, stacklevel=2)
     if sparse and multi and pending is None and P > 0:
         segs = arena.dense_segments()
         fac = arena.factor[: 3 * P].view(P, 3)
-        touched = (fac != 0).any(dim=1)
+        # "touched" = any of the row's 14 floats is non-zero (all five arrays are looked at: a sum can cancel to exactly zero in one of
+        # them); the flag and the row map live on the arena, not in fresh [P] tensors every step
+        touched = getattr(arena, "_touched", None)
+        if touched is None or touched.numel() != P:
+            touched = arena._touched = torch.empty(P, dtype=torch.uint8, device=fac.device)
+            arena._row_of = torch.empty(P, dtype=torch.int32, device=fac.device)
+        torch.any(fac != 0, dim=1, out=touched.view(torch.bool))
         for sg in segs:
-            touched |= (sg != 0).any(dim=1)
-        touched = touched.to(torch.uint8)
+            touched |= (sg != 0).any(dim=1).view(torch.uint8)
         dist.all_reduce(touched, op=dist.ReduceOp.MAX)
         idx = torch.nonzero(touched, as_tuple=False).squeeze(1)          # (host synchronisation: every rank learns the same n)
         n = int(idx.numel())
@@ -161,7 +198,8 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
         mine[3 * n: 3 * n + 3] = arena.factor[3 * P: 3 * P + 3]
         gathered = torch.empty(n_views * stride, dtype=torch.float32, device=fac.device)
         dist.all_gather_into_tensor(gathered, mine)
-        row_of = torch.full((P,), -1, dtype=torch.int32, device=fac.device)
+        row_of = arena._row_of                     # (cached on the arena: no fresh [P] tensor per step)
+        row_of.fill_(-1)
         row_of[idx] = torch.arange(n, dtype=torch.int32, device=fac.device)
         _C.sh_grad_combine(arena, means3D, gathered, n_views, 1.0 / batch, rows=n, row_of=row_of, chunk_stride=stride)
         return {"allreduce": comp.numel() * 4 + P, "allgather": stride * 4, "rows": n}
@@ -186,7 +224,7 @@ def overlap_factor_exchange(enable: bool = True) -> None:
     from diff_gaussian_rasterization_ch3 import _C
 
     def hook(arena):
-        if dist.is_initialized() and dist.get_world_size() > 1 and getattr(arena, "world", 1) == dist.get_world_size():
+        if collectives_active() and getattr(arena, "world", 1) == dist.get_world_size():
             arena._gather_work = dist.all_gather_into_tensor(arena.gathered, arena.factor, async_op=True)
     _C.set_factor_ready_hook(hook if enable else None)
 
@@ -195,14 +233,14 @@ def reduce_densification_stats(point_grad_norm: torch.Tensor, visible_count: tor
                                max_radii: torch.Tensor) -> None:
     """In-place cross-rank reduction of the densification statistics of train.py:282-292:
     SUM of the screen-space gradient norms and visibility counts, MAX of the radii."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.all_reduce(point_grad_norm, op=dist.ReduceOp.SUM)
         dist.all_reduce(visible_count, op=dist.ReduceOp.SUM)
         dist.all_reduce(max_radii, op=dist.ReduceOp.MAX)
 
 
 def max_over_ranks(x: float, device: torch.device) -> float:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         t = torch.tensor([x], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -210,7 +248,7 @@ def max_over_ranks(x: float, device: torch.device) -> float:
 
 
 def barrier() -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.barrier()
 
 
@@ -330,7 +368,7 @@ def distributed_step(bucket: StepBucket, views: Sequence, render_loss_fn, batch:
     Memory: every view in flight holds its own rasterizer state until its backward has run -- ~320-350 B per Gaussian of geometry
     state (0.35 GB at 1e6 Gaussians, 0.95 GB at 3e6, gsrast_geometry_bytes), 4 B per listed instance + 20 B per column run of
     binning state (0.1-0.3 GB) and 19 MB per 1080p image -- plus one partial gradient cache (the size of the bucket) per extra lane."""
-    multi = dist.is_initialized() and dist.get_world_size() > 1
+    multi = collectives_active()
     rank = dist.get_rank() if multi else 0
     world = dist.get_world_size() if multi else 1
     batch = len(views) if batch is None else batch

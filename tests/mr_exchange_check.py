@@ -93,7 +93,8 @@ def main():
     other = flat.clone()
     torch.distributed.broadcast(other, src=0)
     same = bool(((flat - other).abs() <= 1e-7 + 1e-5 * other.abs()).all())
-    print(f"EXCHANGE_CHECK rank {rank} worst {worst:.3f} same_on_all_ranks {same}", flush=True)
+    avg_ok = getattr(vp, "_AVG_OK", None)        # (False: the collective library rejected ReduceOp.AVG and SUM + scale took over)
+    print(f"EXCHANGE_CHECK rank {rank} worst {worst:.3f} same_on_all_ranks {same} backend {torch.distributed.get_backend()} world {world} avg_ok {avg_ok}", flush=True)
     if worst > 1.0 or not same:
         sys.exit(3)
 

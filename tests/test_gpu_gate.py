@@ -1,0 +1,117 @@
+"""-m gpu: the list cut's completion pass behind its stream gate (gsrast_capi.hip: ChainGate) under load, and the `prefiltered` promise.
+
+The gate and the pose table are the only parts of the library that could hang (a stream waiting for a word nobody writes) or read
+torn state (a ring slot claimed again under a pending chain), so they get a soak of their own: two host threads,
+each with its own context and stream, render 3 poses round-robin while the scene's opacity changes between calls -- every few calls a
+tile's remembered cut turns out too short and the completion pass runs for real -- and every call is compared with the same call
+without the list cut.  A wall-clock bound turns a hang into a failure."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import settings_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(900)
+def test_gate_soak_two_threads_two_contexts(scenes, rast, gpu):
+    _C = rast._C
+    P, W, H, N = 1_000_000, 1920, 1080, 400
+    sc = scenes.synth(P, 0)
+    cams = [scenes.camera(k, 8, W, H) for k in range(3)]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    base = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    g = t(scenes.upstream_grad(H, W, 1))
+    result = {}
+
+    def worker(tid):
+        try:
+            rss = [settings_from(rast, c, sc, gpu) for c in cams]
+            L = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+            rng = np.random.default_rng(100 + tid)
+            bad = torch.zeros((), dtype=torch.int64, device=gpu)       # mismatching calls, counted on the device (no per-call sync)
+            stream = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(stream):
+                def render(rs):
+                    for p in list(L.values()) + [m2]:
+                        p.grad = None
+                    color, radii, depth = rast.GaussianRasterizer(rs)(means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"],
+                                                                      scales=L["scales"], rotations=L["rotations"])
+                    color.backward(g)
+                    return color.detach(), depth.detach(), radii, [L[k].grad for k in ("means3D", "opacities", "scales", "rotations", "shs")] + [m2.grad]
+
+                late_calls = 0
+                for i in range(N):
+                    with torch.no_grad():        # the scene turns more or less transparent between calls
+                        L["opacities"].copy_(base["opacities"] * float(rng.uniform(0.05, 1.0)))
+                    rs = rss[(i + tid) % 3]
+                    _C.set_option("no_list_cut", 0)
+                    a = render(rs)
+                    late_calls += int(_C.context_query("last_late") > 0)
+                    _C.set_option("no_list_cut", 1)
+                    b = render(rs)
+                    # (compared on the device: a host-side torch.equal would synchronise every call)
+                    ok = (a[0] == b[0]).all() & (a[1] == b[1]).all() & (a[2] == b[2]).all()
+                    for ga, gb in zip(a[3], b[3]):      # float-atomic order differs between two backwards: not bit-identical
+                        ok = ok & ((ga - gb).abs() <= 1e-6 + 1e-3 * gb.abs()).all()
+                    bad += (~ok).to(torch.int64)
+                _C.set_option("no_list_cut", 0)
+                stream.synchronize()
+            result[tid] = dict(bad=int(bad.item()), late_calls=late_calls, passes=int(_C.context_query("cut_fallbacks")),
+                               inline=int(_C.context_query("gate_inline_calls")), pause=int(_C.context_query("cut_pause")))
+        except Exception as e:      # noqa: BLE001
+            result[tid] = e
+
+    _C.set_option("list_cut_always", 1)      # (the cut also where it does not pay, and no pause)
+    try:
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(2)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=600)
+        assert not any(th.is_alive() for th in threads), "a worker is stuck: the gate (or its inline fallback) hangs"
+        wall = time.perf_counter() - t0
+    finally:
+        _C.set_option("list_cut_always", 0)
+    for tid in (0, 1):
+        assert not isinstance(result.get(tid), Exception), result.get(tid)
+    print("gate soak:", result, f"{wall:.1f} s")
+    assert all(result[k]["bad"] == 0 for k in (0, 1)), result
+    assert all(result[k]["late_calls"] >= N // 2 for k in (0, 1)), result            # the cut was in force
+    assert sum(result[k]["passes"] for k in (0, 1)) >= 100, result                   # ... and kept failing: completion passes ran for real
+    assert wall < 400.0, wall
+
+
+def test_prefiltered_promise_is_checked(orc, scenes, rast, gpu):
+    """`prefiltered=True` promises that no Gaussian is culled by the near plane; the reference traps the kernel when one is
+    (cuda_rasterizer/auxiliary.h:156-160).  Here the call fails with a RuntimeError instead of killing the context; a promise that
+    holds changes nothing."""
+    P, W, H = 4000, 200, 150
+    sc = scenes.synth(P, 33, scale_mul=0.8)
+    cam = scenes.camera(0, 4, W, H)                    # radius 4: the whole cube lies in front of the camera
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+
+    def render(scene, prefiltered):
+        rs = settings_from(rast, cam, scene, gpu)
+        rs = rs._replace(prefiltered=prefiltered)
+        return rast.GaussianRasterizer(rs)(means3D=t(scene["means3D"]), means2D=torch.zeros((P, 3), device=gpu), opacities=t(scene["opacities"]),
+                                           shs=t(scene["shs"]), scales=t(scene["scales"]), rotations=t(scene["rotations"]))
+
+    a = render(sc, False)
+    b = render(sc, True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    behind = dict(sc)
+    behind["means3D"] = sc["means3D"].copy()
+    behind["means3D"][7] = cam["campos"] * 1.5          # one Gaussian behind the camera
+    c = render(behind, False)                           # not promised: simply culled
+    assert int(c[1][7]) == 0
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        render(behind, True)
+    d = render(sc, True)                                # the library is fine afterwards
+    assert all(torch.equal(x, y) for x, y in zip(a, d))

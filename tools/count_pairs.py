@@ -28,6 +28,6 @@ try:
     if v[10]:
         print("bwd blend: longest workgroup %.1f us (list prefix walked: %d entries), launch first start -> last end %.1f us" % (v[10] / 100.0, v[13], (v[12] - v[11]) / 100.0))
     if v[8]:
-        print("bwd transposed phases %d, live instances in them %d (%.2f of 8)" % (v[8], v[9], v[9] / v[8]))
+        print("bwd transposed phases %d, live instances in them %d (%.2f of 8); phases with ONE live instance %d (%.1f %%), with TWO %d (%.1f %%)" % (v[8], v[9], v[9] / v[8], v[14], 100.0 * v[14] / v[8], v[15], 100.0 * v[15] / v[8]))
 finally:
     shutil.copy("/tmp/orig.so", lib)

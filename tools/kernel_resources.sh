@@ -1,13 +1,13 @@
 #!/bin/bash
 # Registers / LDS / scratch of every kernel of the library (no GPU needed): compiles csrc/gsrast_capi.hip with -save-temps into a
 # temporary directory and prints the resource lines of the kernels whose name matches $1 (default: all).
-# usage: tools/kernel_resources.sh [pattern]
+# usage: [EXTRA="-DFOO=1"] tools/kernel_resources.sh [pattern]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 D=$(mktemp -d /tmp/gsres.XXXXXX)
 cd "$D"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics \
-    -fno-slp-vectorize -save-temps -c "$ROOT/saro-gs_amd/csrc/gsrast_capi.hip" -o gs.o 2>/dev/null
+    -fno-slp-vectorize $EXTRA -save-temps -c "$ROOT/saro-gs_amd/csrc/gsrast_capi.hip" -o gs.o 2>/dev/null
 S=$(ls *gfx950*.s | head -1)
 python3 - "$S" "${1:-.}" <<'PY'
 import re, sys

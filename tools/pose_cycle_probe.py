@@ -116,13 +116,12 @@ def carry():
 
 
 def train():
+    import bench
     import fused_adam
     import fused_loss
     sc = scenes.synth(P, 0, sh_degree=deg)
     bg = t(sc["bg"])
-    rng = np.random.default_rng(5)
-    tpos = t(rng.uniform(0.0, 1.0, size=(P, 1)))
-    life = t(rng.uniform(0.2, 1.0, size=(P, 1)))
+    deform = {"dynamic_opacity": bench.Deformation(P, dev, motion=False), "dynamic_full": bench.Deformation(P, dev, motion=True)}
 
     def raw():
         d = dict(xyz=t(sc["means3D"]), rotation=t(sc["rotations"]), scaling=torch.log(t(sc["scales"])),
@@ -132,10 +131,10 @@ def train():
     lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
     m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
     gt = torch.rand(3, H, W, device=dev)
-    for dyn in (False, True):
+    legs = [x for x in os.environ.get("LEGS", "static,dynamic_opacity,dynamic_full").split(",") if x]
+    for dyn in legs:
         for V in Vs:
             poses = [settings(k, max(V, 8), bg) for k in range(V)]
-            ts = rng.uniform(0.0, 1.0, size=4096)
             for name, opts in MODES:
                 rc = raw()
                 inv = torch.ones(P, 1, device=dev)
@@ -145,23 +144,22 @@ def train():
                 it = [0]
 
                 def step(rs):
-                    trbf = None
-                    if dyn:
-                        trbf = torch.exp(-4.0 * ((float(ts[it[0] % len(ts)]) - tpos) / life) ** 2)
+                    mres, rres, trbf = deform[dyn].at(it[0]) if dyn != "static" else (None, None, None)
                     it[0] += 1
                     color, _, _ = rast.GaussianRasterizerRaw(rs)(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"],
-                                                                 trbfoutput=trbf)
+                                                                 motion_residual=mres, rot_residual=rres, trbfoutput=trbf)
                     loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
                     opt.zero_grad(); m2.grad = None
                     loss.backward()
                     opt.step()
 
-                warm = max(2, (20 + V - 1) // V)
+                warm = max(4 if dyn != "static" else 2, (20 + V - 1) // V)
                 timed = max(2, (100 + V - 1) // V)
                 r = run_cycle(step, poses, warm, timed)
+                r["cut_margin_x4"] = q("cut_margin_x4"); r["cut_pause"] = q("cut_pause")
                 for k_ in opts:
                     _C.set_option(k_, 0)
-                print(json.dumps(dict(leg="train", dynamic_opacity=dyn, P=P, V=V, mode=name, **r)), flush=True)
+                print(json.dumps(dict(leg="train", scene=dyn, P=P, V=V, mode=name, **r)), flush=True)
                 del opt, rc
                 torch.cuda.empty_cache()
 
