@@ -118,7 +118,7 @@ class Workload:
         color, radii, depth = raster(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"],
                                      shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)
-        if bucket is not None and (world > 1 or getattr(self, "force_exchange", False)):
+        if bucket is not None and (world > 1 or self.vp.collectives_active()):      # (a one-rank group with forced collectives: tests/test_gpu_rccl.py)
             # the backward wrote the leaf gradients straight into the bucket (zero-copy GradArena)
             if getattr(bucket, "sh_factors", False):
                 # all-reduce 11 + all-gather 3 floats/Gaussian -- sparse: of the rows some rank touched only
@@ -227,26 +227,29 @@ def _profile_json(name):
         return None
 
 
-def roofline_of(st, bwd_ms, P, exp2=None):
-    """The roofline object of the dominant kernel, blend_bwd_cull_t_kernel.
+def roofline_of(st, bwd_ms, P, exp2=None, kernel="blend_bwd_cull_t_kernel"):
+    """The roofline object of a blend kernel: the dominant one, blend_bwd_cull_t_kernel (`roofline`), or the forward blend_fwd_cull_kernel
+    (`roofline_fwd`: north_star's "per-tile blend kernel", reference forward.cu:261-393; algorithmic bytes R_eff*44 + N*24).
 
     The kernel is VALU-issue bound, so `bound` says "valu" and the binding pair is `valu.achieved / valu.peak` in
     wave64 instructions per second; the contract's HBM pair stays in `achieved / peak / frac` (ALGORITHMIC bytes, SURVEY.md 8d:
     N*20 + R_eff*40 + R_eff*36 per launch, / this run's mean launch duration / 8 TB/s).  `provenance` says for every field whether
     it was measured in this run (HIP events on the launch stream inside the timed region) or read from the committed rocprofv3 PMC
     passes of the same workload (profiles/pmc_blend_bwd*.json, tools/collect_profiles.sh)."""
-    bwd_bytes = st["N"] * 20 + st["R_eff"] * 76
+    fwd = kernel == "blend_fwd_cull_kernel"
+    bwd_bytes = st["N"] * 24 + st["R_eff"] * 44 if fwd else st["N"] * 20 + st["R_eff"] * 76
+    stem = "pmc_blend_fwd" if fwd else "pmc_blend_bwd"
     achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
     traffic, valu, src = None, None, None
-    for name in ("pmc_blend_bwd_3M.json", "pmc_blend_bwd.json"):
+    for name in (stem + "_3M.json", stem + ".json"):
         pj = _profile_json(name)
         if pj and pj.get("gaussians", 3_000_000 if "3M" in name else 1_000_000) == P:
             traffic, src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
             vi = pj.get("valu_wave_insts_per_launch")
-            mix = _profile_json("r04_valu_mix.json") or _profile_json("r03_valu_mix.json") or _profile_json("r02_valu_mix.json")
+            mix = _profile_json("r05_valu_mix.json") or _profile_json("r04_valu_mix.json") or _profile_json("r03_valu_mix.json") or _profile_json("r02_valu_mix.json")
             cal = _profile_json("r02_valu_calib.json")
             if vi and bwd_ms > 0 and mix and cal:
-                cyc = mix["kernels"]["blend_bwd_cull_t_kernel"]["avg_cycles_per_valu_inst"]
+                cyc = mix["kernels"][kernel]["avg_cycles_per_valu_inst"]
                 fma = max(r["wave_insts_per_s"] for r in cal["results"] if r["op"] == "v_fma_f32")
                 rate = vi / (bwd_ms * 1e-3)
                 peak = 1024 * 2.4e9 / cyc           # wave64 instructions/s the chip can issue at this kernel's mix
@@ -260,7 +263,7 @@ def roofline_of(st, bwd_ms, P, exp2=None):
                                 "2.4 cycles per wave64 instruction and SIMD, half-rate dpp/cmp/cndmask/min/cvt/ldexp 4.1, quarter-rate rcp/exp "
                                 "8.1: tools/valu_calib.hip, tools/valu_mix.py)"}
             break
-    out = {"kernel": "blend_bwd_cull_t_kernel", "bound": "valu" if valu else "hbm",
+    out = {"kernel": kernel, "bound": "valu" if valu else "hbm",
            # (flat copies of the binding pair: a parser that keeps only scalars still sees them)
            "valu_issue_slot_frac": valu["issue_slot_frac"] if valu else None,
            "valu_wave_insts_per_launch": valu["wave_insts_per_launch"] if valu else None,
@@ -270,7 +273,7 @@ def roofline_of(st, bwd_ms, P, exp2=None):
            "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
            "valu": valu,
            "provenance": {"avg_launch_ms / achieved / frac / gpairs_per_s": "measured in this run (HIP events on the launch stream, timed region)",
-                          "algorithmic_bytes_per_launch": "SURVEY.md 8d formula with this run's measured R_eff (tile_clip=0 lists)",
+                          "algorithmic_bytes_per_launch": "SURVEY.md 8d formula (" + ("R_eff*44 + N*24" if fwd else "N*20 + R_eff*76") + ") with this run's measured R_eff (tile_clip=0 lists)",
                           "traffic / traffic_ratio": (src + ": rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 units per MI355X_MICROARCH.md), committed pass, not this run") if src else None,
                           "valu.wave_insts_per_launch": (src + ": SQ_INSTS_VALU per launch, committed pass, not this run") if src else None,
                           "valu.avg_cycles_per_inst": "profiles/r0x_valu_mix.json over profiles/r02_valu_calib.json (measured issue costs)"},
@@ -1198,6 +1201,9 @@ def main():
                        "list_cut_late_gaussians": st.get("late"), "column_runs_early": st.get("Q_early"),
                        "pose_table_switched_off": no_hint, "list_cut_switched_off": no_cut, "one_repeated_pose": repeated},
             "roofline": roofline_of(st, bwd_ms, P, exp2),
+            # the forward blend -- the kernel north_star's 60 % figure names -- with the same fields; its launch duration comes from the
+            # event-bracketed stage pass behind the timed region (the timed region brackets the dominant kernel only)
+            "roofline_fwd": roofline_of(st, fwd_ms, P, None, kernel="blend_fwd_cull_kernel") if fwd_ms > 0 else None,
             "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
                            "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
             "per_stage": per_kernel,

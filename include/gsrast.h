@@ -233,6 +233,23 @@ void gsrast_context_destroy(gsrast_context* ctx);
  * (speculative launches / depth sorts that had to be repeated), "bucket_skip" (forwards that will still go straight to the radix
  * depth sort after a bucket overflow); ctx NULL = the calling thread's context. */
 int gsrast_context_query(const gsrast_context* ctx, const char* name);
+/* Round 5: also "completion_passes" (completion passes of the list cut the device has reported to this context), "cut_margin_x4" (the remembered
+ * cut's margin in quarters: 6 = 1.5 x), "tau_req" / "tau_force" (the predicted cut's requirement / forwards that still use predicted cut depths for
+ * every pose), "gate_inline_calls".
+ *
+ * The host-side decisions of a context (csrc/gsrast_policy.h: when the list cut is applied, paused and widened; how the speculative launch is
+ * sized) can be driven WITHOUT a device -- a context that never renders touches no GPU.  One event per call, the return value is the
+ * decision (or GSRAST_E_ARG for an unknown event):
+ *   "begin"  (a = Gaussians P, b = column runs of the previous forward, c = 1: option list_cut_always) -> 1: the cut pays for this forward; 0: it sits out
+ *   "counts" (a = all column runs Q, b = early column runs, c = bit 0: predicted cut depths available, bit 1: some Gaussian was late; P = the last "begin"'s) -> forwards of pause now pending
+ *   "pass"   (a = column runs of the completion pass's candidates, b = column runs of the forward, c = 1: predicted cut depths available) -> the pass's points (0 ... 8)
+ *   "clean"  (a cut forward behind which no pass was reported) -> the score
+ *   "size"   (a = early-run hint, b = capacity in column runs, c = 1: an early set is expected) -> column runs the launches over the cut lists are sized for
+ *   "grow"   (a = count) -> the capacity requested for it;   "follow" (a = hint, b = this forward's count, c = shift) -> the next hint
+ *   "get"    (a = 0 pause, 1 score, 2 margin x 4, 3 tau_req, 4 tau_force, 5 length of the last fallback pause)
+ *   "reset"  (a fresh policy: tests);   "tau_min" (a = the predicted cut's requirement and its floor: experiments)
+ * ctx NULL = the calling thread's context. */
+int gsrast_policy_event(gsrast_context* ctx, const char* what, int a, int b, int c);
 int gsrast_forward_ex(gsrast_context* ctx, const gsrast_options* options,
                       gsrast_alloc_fn geometry_alloc, void* geometry_ctx,
                       gsrast_alloc_fn binning_alloc, void* binning_ctx,

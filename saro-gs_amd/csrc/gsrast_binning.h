@@ -404,6 +404,55 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
 // A scene whose depths pile up beyond the histogram's resolution (more Gaussians in one bucket than its slab holds: thousands at
 // one depth) raises a flag the host reads back with the instance counts; the
 // forward then repeats the sort with the radix passes and the context uses those for its next calls (gsrast_forward).
+// PREDICTED CUT (gsrast_common.h): every tile's cut depth from this call's own opacity mass.  One workgroup = a 16 x 16 block of tiles of which
+// the inner 14 x 14 are written (the ring around them only feeds the 3 x 3 maxima), one lane per tile: TAU_COPIES x TAU_BINS / 4 = 32
+// sixteen-byte loads, a running sum, the first bin whose far edge lies behind tau_req of mean alpha mass.
+constexpr int TAU_TILE = 14;
+__global__ void __launch_bounds__(256)
+tau_cut_kernel(const uint32_t* __restrict__ tau_hist /* [TAU_COPIES][ntiles][TAU_BINS] */, uint32_t ntiles, int gx, int gy,
+               TauBins tau_bins, uint32_t tau_req_x256 /* tau_req in the table's unit: pixels^2 of alpha mass per tile = 256 x the mean */,
+               const uint32_t* __restrict__ hint_sel /* or null (no pose table): [1] = 1: the pose has remembered cut depths */, int force /* 1: predicted cuts also for a pose the table knows */,
+               uint32_t* __restrict__ zcut_used /* [ntiles] out */, int coarse_range /* 1: the depth histogram has no learned range (a context's first forward): no prediction */)
+{
+    __shared__ int s_bin[16][16];
+    const bool known = hint_sel && hint_sel[1] != 0u;      // (1: the pose's own slot, 2: a near pose's, widened -- both tighter than a prediction)
+    if (known && !force) return;                                   // (uniform) the remembered cut depths are already in zcut_used
+    const int lx = (int)(threadIdx.x & 15u), ly = (int)(threadIdx.x >> 4);
+    const int tx = (int)blockIdx.x * TAU_TILE - 1 + lx, ty = (int)blockIdx.y * TAU_TILE - 1 + ly;
+    int cb = -1;                                                    // -1: not a tile of the image (ignored by its neighbours)
+    if (tx >= 0 && ty >= 0 && tx < gx && ty < gy) {
+        const uint32_t t = (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+        uint32_t h[TAU_BINS];
+#pragma unroll
+        for (int b = 0; b < TAU_BINS; b++) h[b] = 0u;
+#pragma unroll
+        for (int c = 0; c < TAU_COPIES; c++) {
+            const uint4* src = reinterpret_cast<const uint4*>(tau_hist + ((size_t)c * ntiles + t) * TAU_BINS);
+#pragma unroll
+            for (int q = 0; q < TAU_BINS / 4; q++) { const uint4 v = src[q]; h[4 * q] += v.x; h[4 * q + 1] += v.y; h[4 * q + 2] += v.z; h[4 * q + 3] += v.w; }
+        }
+        cb = TAU_BINS;                                              // TAU_BINS: the tile does not saturate inside the table (no cut)
+        uint32_t run = 0;
+#pragma unroll
+        for (int b = 0; b < TAU_BINS - 1; b++) {                    // (the far tail bin has no far edge)
+            run += h[b];
+            if (run >= tau_req_x256 && cb == TAU_BINS) cb = b;
+        }
+        if (coarse_range) cb = TAU_BINS;
+    }
+    s_bin[ly][lx] = cb;
+    __syncthreads();
+    if (cb < 0 || lx == 0 || ly == 0 || lx == 15 || ly == 15) return;
+    int m = cb;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) { const int v = s_bin[ly + dy][lx + dx]; m = v > m ? v : m; }
+    uint32_t z = ZCUT_NONE;
+    if (m < TAU_BINS) z = tau_bin_far_edge((uint32_t)m, tau_bins);
+    zcut_used[(uint32_t)ty * (uint32_t)gx + (uint32_t)tx] = z;
+}
+
 constexpr int BK_CAP = GSRAST_BK_CAP;    // slots per bucket = the largest bucket the LDS sort takes
 constexpr int BK_XCD = 8;                // counter / slab sets
 constexpr int BK_CAPX = BK_CAP / BK_XCD; // slots per (bucket, XCD) sub-slab
@@ -703,13 +752,17 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
                          const uint32_t* __restrict__ pred = nullptr /* the predicated launch among the ones behind the forward blend */,
                          // completion pass of the list cut: only the Gaussians whose bit is set are sorted (the CANDIDATES: their rectangle
                          // touches a tile whose cut list was too short); binfo = their {elements, column runs, tiles, overflow}
-                         const unsigned long long* __restrict__ keep_bits = nullptr)
+                         const unsigned long long* __restrict__ keep_bits = nullptr,
+                         // round 5: the sampled depth histogram lives in the CONTEXT and is zeroed HERE for the context's next forward (every
+                         // workgroup of the scatter in front of this kernel has read it): no memset launch in front of preprocess_fwd
+                         uint32_t* __restrict__ zero_words = nullptr, uint32_t n_zero_words = 0)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
     __shared__ uint16_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order (their running sum goes through s_grp, free by then: 26 KB of LDS = six workgroups per CU)
     __shared__ uint16_t s_wid[BK_WAVES][BK_CAP];                // widths, grouped like s_grp
     __shared__ uint32_t s_cnt[BK_WAVES][BK_SUB + 1];
     if (pred && *pred == 0u) return;
+    if (zero_words) for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * BK_WAVES + wave;
     if (b >= nb) return;
@@ -1283,7 +1336,8 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
                              const uint32_t* __restrict__ hint_sel /* [2]: slot, valid */,
                              // completion pass of the list cut: only the tiles listed again (need2 != 0) get a range -- into the point list's
                              // second half (list_offset) -- and a place in the launch order; the others keep the first pass's
-                             const unsigned char* __restrict__ need2 = nullptr, uint32_t list_offset = 0)
+                             const unsigned char* __restrict__ need2 = nullptr, uint32_t list_offset = 0,
+                             const uint32_t* __restrict__ zcut_pred = nullptr /* or this call's cut depths when they are PREDICTED ones (gsrast_common.h) */)
 {
     __shared__ int diff[257];
     __shared__ uint32_t lcnt[XCD_GROUPS * WORK_BUCKETS], lbase[XCD_GROUPS * WORK_BUCKETS];
@@ -1316,6 +1370,13 @@ tile_ranges_from_runs_body(uint32_t column, const uint16_t* __restrict__ run_key
     if (hints && hint_sel[1] && work && y < (uint32_t)gy) {
         const uint32_t h = hint_work(hints, 0u)[(size_t)hint_sel[2] * ((uint32_t)gx * (uint32_t)gy) + y * (uint32_t)gx + x];      // ([2]: the pose's own slot, or the near pose's it borrows from)
         work = h < work ? (h ? h : 1u) : work;
+    } else if (zcut_pred && work && y < (uint32_t)gy && zcut_pred[y * (uint32_t)gx + x] != ZCUT_NONE) {
+        // Under PREDICTED cut depths nobody knows what the tile consumed last time, but a tile that got a cut is one whose pixels saturate
+        // well in front of it (the prediction is conservative: the 3 M cube's interior tiles consume a seventh of their cut lists), while a
+        // tile without one -- a silhouette -- may walk its whole list: two octaves down, so that the tiles without a cut of the same
+        // length start first (they shared the half-octave work buckets with thousands of light tiles: blend_fwd 0.35 ms against 0.27 in
+        // the exact order)
+        work = work >> 2 ? work >> 2 : 1u;
     }
     }
     if (bucket_cnt) {
@@ -1481,12 +1542,13 @@ rows_and_ranges_kernel(const uint16_t* __restrict__ run_keys, const uint2* __res
                        uint32_t nblk, uint32_t* __restrict__ point_list, uint32_t* __restrict__ total_out, uint2* __restrict__ ranges,
                        uint32_t* __restrict__ bucket_cnt, uint16_t* __restrict__ bucket_list, const HintTable* __restrict__ hints,
                        const uint32_t* __restrict__ hint_sel, const uint32_t* __restrict__ pred /* or null: predicated launch */,
-                       const unsigned char* __restrict__ need2 = nullptr, uint32_t list_offset = 0 /* completion pass: see tile_ranges_from_runs_body (point_list is then the second half) */)
+                       const unsigned char* __restrict__ need2 = nullptr, uint32_t list_offset = 0 /* completion pass: see tile_ranges_from_runs_body (point_list is then the second half) */,
+                       const uint32_t* __restrict__ zcut_pred = nullptr)
 {
     static_assert(RS_THREADS == 256, "one lane per tile row in the ranges part");
     if (pred && *pred == 0u) return;
     if (blockIdx.x < nblk) run_scatter_rows_body(blockIdx.x, run_vals, Q, counts_dev ? counts_dev + 1 : nullptr, capR, ybits, (uint32_t)gy, hist_scanned, digit_total, nblk, point_list, total_out);
-    else tile_ranges_from_runs_body(blockIdx.x - nblk, run_keys, run_vals, Q, counts_dev, capR, gx, gy, hist_scanned, digit_total, nblk, ranges, bucket_cnt, bucket_list, hints, hint_sel, need2, list_offset);
+    else tile_ranges_from_runs_body(blockIdx.x - nblk, run_keys, run_vals, Q, counts_dev, capR, gx, gy, hist_scanned, digit_total, nblk, ranges, bucket_cnt, bucket_list, hints, hint_sel, need2, list_offset, zcut_pred);
 }
 
 // Launch order of the blend kernels: tiles sorted by descending work (bucketed counting sort,

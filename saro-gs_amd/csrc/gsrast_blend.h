@@ -198,6 +198,13 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     // (a call in which the scatter marked NO Gaussian late has full lists whatever the snapshot says: nothing may be cut short, and
     // the host enqueues no second pass for it -- cut_scalars[SC_N_LATE] is final, the scatter ran before the binning)
     const uint32_t zc = (zcut_used && cut_scalars[SC_N_LATE] != 0u) ? zcut_used[tile] : ZCUT_NONE;       // uniform
+    // (what the hint writer at the kernel's end needs of the table, requested HERE: a load behind the last barrier is a memory round trip during
+    // which the workgroup holds its slot for nothing)
+    uint32_t h_slot = 0u, h_found = 0u, h_zold = ZCUT_NONE;
+    if (hints && t == 0) {
+        h_slot = hint_sel[0]; h_found = hint_sel[1];
+        if (h_found == 1u) h_zold = hint_zcut(hints, ntiles)[(size_t)h_slot * ntiles + tile];
+    }
     uint32_t n_safe = n;                          // entries of the list known to be ALL the tile's Gaussians up to their depth
     bool cut_here = false;
 
@@ -224,12 +231,19 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     // DECOUPLED waves (every wave stages its own 64-instance batches with a register double buffer, no workgroup barrier in the
     // loop, bit-identical): +0.3 ... +0.8 % on the cube at 0.1 / 1 / 3 M, -6.5 % on the shell scene, whose long consumed lists are then
     // staged four times -- the barriers are not what the waves wait for.)
+    // (GeomLayout::untouched) the Gaussian this lane staged in the previous batch, and that batch's first list position: a batch the tile
+    // moves on from was consumed to its end -- its bits are cleared right here, from the register, with nothing to wait for; the last batch's
+    // consumed prefix follows behind the loop
+    uint32_t g_prev = 0xFFFFFFFFu, base_prev = 0u;
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
+        if (untouched && g_prev != 0xFFFFFFFFu) atomicAnd(&untouched[g_prev >> 6], ~(1ull << (g_prev & 63u)));
+        g_prev = 0xFFFFFFFFu; base_prev = base;
         const uint32_t i = base + t;
         bool safe = false;
         if (t < FB && i < n) {
             const uint32_t g = point_list[range.x + i];
+            g_prev = g;
             const float4 b1 = rec1[(size_t)REC_STRIDE * g];
             s0[t] = rec0[(size_t)REC_STRIDE * g]; s1[t] = b1; s2[t] = rec2[(size_t)REC_STRIDE * g];
             safe = __float_as_uint(b1.z) <= zc;             // the list is in depth order: the safe entries are a prefix
@@ -322,16 +336,12 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
     // Round 5: which Gaussians did anybody consume?  The backward walks this tile's list up to s_max and no further, so only those can
-    // receive a gradient: their bits are cleared (fire-and-forget atomics of a VALU-bound kernel), every other Gaussian's output rows are
-    // zeros that late_rows_zero_kernel writes beside the blend backward and the per-Gaussian backward skips -- for ANY forward, not only
-    // one that ran under a remembered cut.  (A tile the completion pass blends again clears a few bits too many here: harmless.)
-    if (untouched) {
-        const uint32_t smx = s_max;
-        for (uint32_t i = t; i < smx; i += 256u) {
-            const uint32_t g = point_list[range.x + i];
-            atomicAnd(&untouched[g >> 6], ~(1ull << (g & 63u)));
-        }
-    }
+    // receive a gradient: their bits are cleared (fire-and-forget atomics of a VALU-bound kernel, from the registers the staging left the
+    // ids in: a loop over the list behind the kernel's last barrier cost every workgroup a memory round trip, blend_fwd 0.246 -> 0.274 ms at
+    // 3 M), every other Gaussian's output rows are zeros that late_rows_zero_kernel writes beside the blend backward and the per-Gaussian
+    // backward skips -- for ANY forward, not only one that ran under a remembered cut.  (Batches in front of the last one are cleared whole, a
+    // tile the completion pass blends again clears a few bits too many: harmless, a cleared bit only means "look at the record".)
+    if (untouched && g_prev != 0xFFFFFFFFu && base_prev + t < s_max) atomicAnd(&untouched[g_prev >> 6], ~(1ull << (g_prev & 63u)));
     if (t == 0) {
         tile_max[tile] = s_max;
         // list cut: the speculation failed for this tile if it had a cut and some pixel would have looked further
@@ -342,7 +352,7 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
             asm volatile("" :: "v"(before));
         }
         if (hints) {
-            const size_t hslot = (size_t)hint_sel[0] * ntiles + tile;
+            const size_t hslot = (size_t)h_slot * ntiles + tile;
             hint_work(hints, ntiles)[hslot] = (uint16_t)(s_max < 65535u ? s_max : 65535u);
             // the tile's next cut depth: that of the entry 1.5 x (cut_margin_x4 / 4) as deep (+ 32) as the deepest one consumed; none for
             // a tile that did not saturate, or whose (full) list is shorter than that
@@ -364,8 +374,8 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
             // call a completion pass.  A slot that already held THIS pose (hint_sel[1] == 1) keeps the deeper of its old cut and the new
             // one, the old one moved an eighth of the way towards the new per visit -- a running maximum over roughly the last eight
             // visits, which still follows a scene that gets more opaque for good.  A frozen scene's cut does not change.
-            if (znew != ZCUT_NONE && hint_sel[1] == 1u) {
-                const uint32_t zold = *zslot;
+            if (znew != ZCUT_NONE && h_found == 1u) {
+                const uint32_t zold = h_zold;
                 if (zold != ZCUT_NONE && zold > znew) {
                     const float fo = __uint_as_float(zold), fn = __uint_as_float(znew);
                     const float fm = fo - (fo - fn) * 0.125f;

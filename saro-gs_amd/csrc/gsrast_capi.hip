@@ -12,6 +12,7 @@
 // options.binning = 1; repeated binning + blend with exact sizes when the speculative capacities did not fit.
 #include "../../include/gsrast.h"
 #include "gsrast_common.h"
+#include "gsrast_policy.h"
 #include "gsrast_preprocess.h"
 #include "gsrast_binning.h"
 #include "gsrast_blend.h"
@@ -36,13 +37,15 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 using namespace gsrast;
 
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_late_fill_min_p{1500000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */;      // process-wide diagnostics (not per-call behaviour)
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_late_fill_min_p{750000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */,
+                 g_tau_sample{1} /* the predicted cut's opacity mass comes from one wave in 2^this of preprocess_fwd */, g_tau_cut{1} /* 1: a pose without (trustworthy) remembered cut depths gets PREDICTED ones from this call's own opacity mass (gsrast_common.h) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
 // snapshot the process defaults (gsrast_set_option) once at entry, so a call never sees a half-changed set and two host
@@ -394,31 +397,30 @@ __global__ void chain_done_kernel(const uint32_t* __restrict__ pred_copy, uint32
 struct gsrast_context {
     std::atomic<uint32_t> R_hint{0}, Q_hint{0}, last_R{0}, last_Q{0}, last_late{0}, last_Qe{0};
     std::atomic<uint32_t> Qe_hint{0};  // list cut: column runs of the early Gaussians in recent forwards (sizes the launches over the cut lists)
-    std::atomic<int> cut_pause{0};     // list cut: > 0 = a recent cut forward saved too few column runs to pay for itself; that many forwards go without
-    std::atomic<uint32_t> cut_pause_P{0};   // ... in a scene of this many Gaussians (another scene: the pause is void)
-    // ... or its cut lists keep turning out too short (a scene that changes between two visits of a pose: SaRO-GS's time-varying
-    // opacity): every fallback costs a whole second forward and is reported by the device (RB_FALLBACK); two in close succession pause
-    // the cut, for twice as long each time (64 ... 1024 forwards; back on probation: one more such pass pauses again), 64 cut forwards without one forget
-    std::atomic<int> cut_fb_score{0}, cut_fb_pause{0}, cut_ok_streak{0};
-    // round 5: how far behind the deepest consumed entry the next cut is put (quarters: 6 = 1.5 x).  Every reported completion pass widens
-    // it by half a step (a scene whose opacities vary from visit to visit needs more room than a frozen one), 128 cut forwards without
-    // one narrow it again by a quarter step; between CUT_MARGIN_MIN and CUT_MARGIN_MAX
-    std::atomic<int> cut_margin{6}, cut_margin_streak{0};
+    std::atomic<uint32_t> Qe_hint_tau{0};  // ... of the forwards that ran under PREDICTED cut depths (they keep more: their own hint)
+    CutPolicy pol;                     // list cut: when it is applied, paused, widened (gsrast_policy.h)
+    // a HINT, nothing more: "the last forward whose view matrix lived at this device address found its pose in the table".  Callers keep
+    // a camera's matrices in one tensor for its lifetime (scene/cameras.py:90-101), so a forward can tell BEFORE it launches anything
+    // whether it will need predicted cut depths: a pose the table knows skips the opacity-mass histogram and its kernel.  A wrong guess
+    // costs one forward its cut (an address reused for another camera: the snapshot finds no slot, nothing is predicted), never a result.
+    std::unordered_map<const void*, uint8_t> pose_seen;
     // equalised depth buckets (gsrast_common.h): the key range the depth histogram's bins cover, learned from the previous forwards
     std::atomic<uint32_t> zh_klo{ZH_KLO_DEFAULT}; std::atomic<int> zh_shift{ZH_SHIFT_DEFAULT};
+    std::atomic<uint32_t> zh_khi{0};   // ... and its upper end BEFORE the bins' width was rounded up to a power of two (0: nothing learned): the predicted cut's bins span [zh_klo, zh_khi]
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
     std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
     ChainGate gate[32];               // per device: the completion pass's own stream and release words (created on first use)
+    uint32_t* zhist_dev[32] = {};     // per device: the sampled depth histogram of the bucket depth sort [ZH_COPIES][ZH_BINS] -- filled by preprocess_fwd, read by the
+                                      // scatter, zeroed again by the bucket sort behind it (no memset launch per forward).  Two forwards of one context in flight on two
+                                      // streams mix their samples: the bucket map stays monotone whatever the histogram holds (gsrast_common.h), only the balance suffers
     struct Hints { HintTable* table = nullptr; uint32_t T = 0; uint64_t used = 0; } hints[32][4];   // (one table per image size in use, up to four: train / eval resolutions alternate)
     uint64_t hints_clock = 0;   // per device: launch-order hints of the forward blend (gsrast_common.h), device memory
     std::mutex mu;
 };
 namespace {
-// counters of "that many forwards go without ..." shared by the lanes of a view-parallel caller: never below zero
-inline void dec_to_zero(std::atomic<int>& a) { int v = a.load(); while (v > 0 && !a.compare_exchange_weak(v, v - 1)) { } }
 // The context's side stream on the current device (created on first use, lowest priority: its bandwidth-heavy kernels should fill
 // the gaps the critical path leaves, not compete with it for compute units).  nullptr if it cannot be had.
 SideStream* side_stream_of(gsrast_context* ctx)
@@ -663,6 +665,7 @@ void gsrast_context_destroy(gsrast_context* c)
         for (hipEvent_t e : g.tail) if (e) (void)hipEventDestroy(e);
         if (g.words) (void)hipFree(g.words);
     }
+    for (uint32_t* z : c->zhist_dev) if (z) (void)hipFree(z);
     for (SideStream& x : c->side) {
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
@@ -681,12 +684,15 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
     if (!strcmp(name, "last_late")) return (int)c->last_late.load();
     if (!strcmp(name, "last_early_runs")) return (int)c->last_Qe.load();
-    if (!strcmp(name, "cut_margin_x4")) return c->cut_margin.load();      // the list cut's current margin, in quarters (6 = 1.5 x)
+    if (!strcmp(name, "completion_passes")) return (int)c->pol.passes_reported.load();
+    if (!strcmp(name, "tau_req")) return c->pol.tau_req.load();
+    if (!strcmp(name, "tau_force")) return c->pol.tau_force.load();
+    if (!strcmp(name, "cut_margin_x4")) return c->pol.margin.load();      // the list cut's current margin, in quarters (6 = 1.5 x)
     if (!strcmp(name, "gate_inline_calls")) {     // cut forwards that ran their completion pass inline because the gate's ring was half full
         int device = 0; if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return 0;
         return (int)c->gate[device].inline_calls;
     }
-    if (!strcmp(name, "cut_pause")) return c->cut_pause.load();      // forwards the list cut still sits out (too little saved, or its lists kept failing)
+    if (!strcmp(name, "cut_pause")) return c->pol.pause.load();      // forwards the list cut still sits out (too little saved, or its lists kept failing)
     if (!strcmp(name, "cut_fallbacks")) {       // a device counter in the hint table of the current device (diagnostic: waits for the device)
         int device = 0;
         if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) return 0;
@@ -702,6 +708,33 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     return GSRAST_E_ARG;
 }
 
+int gsrast_policy_event(gsrast_context* c, const char* what, int a, int b, int c3)
+{
+    if (!what) return GSRAST_E_ARG;
+    if (!c) c = thread_context();
+    CutPolicy& pol = c->pol;
+    if (!strcmp(what, "begin")) {
+        pol.begin_forward((uint32_t)a);
+        c->last_R = (uint32_t)a;       // (the P the "counts" / "pass" events below refer to)
+        const bool pays = pol.pays((uint32_t)b, c3 != 0);
+        if (!pays) pol.sits_out();
+        return pays ? 1 : 0;
+    }
+    if (!strcmp(what, "counts")) { pol.forward_counts((c3 & 1) != 0, (c3 & 2) ? 1u : 0u, (uint32_t)a, (uint32_t)b, c->last_R.load(), false); return pol.pause.load(); }
+    if (!strcmp(what, "pass")) return pol.completion_pass((uint32_t)a, (uint32_t)b, c->last_R.load(), false, c3 != 0);
+    if (!strcmp(what, "clean")) { pol.clean_cut_forward(); return pol.fb_score.load(); }
+    if (!strcmp(what, "size")) return (int)early_launch_runs((uint32_t)a, (uint32_t)b, c3 != 0);
+    if (!strcmp(what, "grow")) return (int)grow_capacity((uint32_t)a);
+    if (!strcmp(what, "follow")) return (int)follow_hint((uint32_t)a, (uint32_t)b, c3);
+    if (!strcmp(what, "reset")) { c->pol.~CutPolicy(); new (&c->pol) CutPolicy(); return 0; }      // (tests: a fresh policy, whatever earlier calls left)
+    if (!strcmp(what, "tau_min")) { pol.tau_min = std::max(1, a); pol.tau_req = std::max(1, a); return a; }      // (experiments: the predicted cut's requirement and its floor)
+    if (!strcmp(what, "get")) {
+        switch (a) { case 0: return pol.pause.load(); case 1: return pol.fb_score.load(); case 2: return pol.margin.load(); case 3: return pol.tau_req.load();
+                     case 4: return pol.tau_force.load(); case 5: return pol.fb_pause.load(); default: return GSRAST_E_ARG; }
+    }
+    return GSRAST_E_ARG;
+}
+
 int gsrast_set_option(const char* name, int value)
 {
     if (!name) return GSRAST_E_ARG;
@@ -713,6 +746,8 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "touch_bits")) { g_touch_bits = value ? 1 : 0; return 0; }               // 0: only the list cut's late bits serve the backward (round 4)
     if (!strcmp(name, "late_fill_min_p")) { g_late_fill_min_p = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "near_pose")) { g_near_pose = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }                 // 0: only the pose's own slot (round 3)
+    if (!strcmp(name, "tau_sample")) { g_tau_sample = value < 0 ? 0 : (value > 6 ? 6 : value); return 0; }
+    if (!strcmp(name, "tau_cut")) { g_tau_cut = value ? 1 : 0; return 0; }                    // 0: only poses with remembered cut depths are cut (round 4's behaviour)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
@@ -751,6 +786,8 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "touch_bits")) return g_touch_bits.load();
     if (!strcmp(name, "late_fill_min_p")) return g_late_fill_min_p.load();
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
+    if (!strcmp(name, "tau_sample")) return g_tau_sample.load();
+    if (!strcmp(name, "tau_cut")) return g_tau_cut.load();
     if (!strcmp(name, "layer_cut")) return g_layer_cut.load();
     if (!strcmp(name, "debug_state")) return g_debug_state.load();
     if (!strcmp(name, "pixels_per_lane") || !strcmp(name, "fwd_pixels_per_lane")) return g_def.fwd_ppl.load();
@@ -941,13 +978,9 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // and saves ~50 us per million column runs it removes: it is used when the context's last forward had at least CUT_MIN_RUNS column
     // runs, and paused for CUT_PAUSE forwards whenever a cut forward removed fewer than that (a surface-like scene; measured
     // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
-    constexpr uint32_t CUT_MIN_RUNS = 1500000u; constexpr int CUT_PAUSE = 64;
-    constexpr int CUT_MARGIN_MIN = 6, CUT_MARGIN_MAX = 16;      // 1.5 x ... 4 x (gsrast_context::cut_margin)
-    {   // (a pause belongs to the scene that earned it: a context that moves on to a scene of another size starts afresh)
-        const uint32_t pp = ctx->cut_pause_P.load();
-        if (ctx->cut_pause.load() > 0 && (pp > (uint32_t)P ? pp - (uint32_t)P : (uint32_t)P - pp) > pp / 8) ctx->cut_pause = 0;
-    }
-    const bool cut_pays = g_list_cut_always.load() != 0 || (ctx->last_Q.load() >= CUT_MIN_RUNS && ctx->cut_pause.load() == 0);
+    CutPolicy& pol = ctx->pol;          // (the decisions: gsrast_policy.h)
+    pol.begin_forward((uint32_t)P);     // (a pause belongs to the scene that earned it: a context that moves on to a scene of another size starts afresh)
+    const bool cut_pays = pol.pays(ctx->last_Q.load(), g_list_cut_always.load() != 0);
     const int cut_cs = cut_cell_shift((size_t)cam.gx, (size_t)cam.gy);
     // Round 4: the cut no longer needs the pose table.  With remembered cut depths (a pose the table knows) the first pass lists what lies
     // in front of them; WITHOUT -- a first-seen pose, the table switched off -- it lists the nearest eighth of the Gaussians (one cut
@@ -955,12 +988,21 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // tiles that did not saturate inside that layer.  Either way the result is exact, and a pause (the passes did not pay) stops both.
     const bool cut_base = runbin && buckets_ok && o.cull != 0 && o.lpt != 0 && o.fwd_pixels_per_lane == 0 && bucket_sort && o.tile_clip != 0 && !o.no_list_cut &&
                           cut_cs != 0 && o.speculative != 0 && ctx->R_hint.load() != 0 && cut_pays;
-    const bool cut = cut_base && (hints != nullptr || g_layer_cut.load() != 0);
+    const bool tau_mode = g_tau_cut.load() != 0 && g_layer_cut.load() == 0;
+    const bool cut = cut_base && (hints != nullptr || g_layer_cut.load() != 0 || tau_mode);
     // the 32-byte binning records (everything the run emission needs of a Gaussian in one line) are written where the emission gathers
     // EVERY visible Gaussian; under the list cut it gathers one in eight, from the blend's records, and preprocess_fwd writes 96 MB less at 3 M
     float4* binrec_p = cut ? nullptr : at<float4>(geom, GL.binrec);
     const int layer_mode = !cut || g_layer_cut.load() == 0 ? 0 : (hints ? 1 : 2);
-    if (!cut && !o.no_list_cut) dec_to_zero(ctx->cut_pause);
+    if (!cut && !o.no_list_cut) pol.sits_out();
+    const int tau_forced = cut && tau_mode && pol.forced_prediction() ? 1 : 0;
+    bool pose_expected = false;         // (see gsrast_context::pose_seen)
+    if (cut && tau_mode && hints && !tau_forced) { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->pose_seen.find(viewmatrix); pose_expected = it != ctx->pose_seen.end() && it->second != 0; }
+    const bool tau_on = cut && tau_mode && !pose_expected;
+    uint32_t* tau_hist = tau_on ? at<uint32_t>(img, IL.tau_hist) : nullptr;
+    TauBins tau_bins{0u, 0.0f, 0.0f, (1u << g_tau_sample.load()) - 1u};      // (scale 0: the context has not learned a depth range yet -- no prediction in this call)
+    {   const uint32_t klo = ctx->zh_klo.load(), khi = ctx->zh_khi.load();
+        if (tau_on && khi > klo + (uint32_t)TAU_BINS) { tau_bins.lo = klo; tau_bins.scale = (float)TAU_BINS / (float)(khi - klo); tau_bins.inv_scale = (float)(khi - klo) / (float)TAU_BINS; } }
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
@@ -1035,6 +1077,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // list cut: the device says at once whether the pose has a slot in the table (RB_FOUND); the launches over the cut lists of a pose
     // that has none -- everything is early -- are sized for all column runs, not for the early runs of recent forwards (a launch
     // that turned out too small cost a first-seen pose a whole second forward: 1.35 instead of 1.05 ms forward-only at 3 M)
+    uint32_t* zhist_call = nullptr; bool zhist_ctx = false;      // the depth histogram this call fills and reads: the context's (zeroed by the bucket sort) or the call's own
     Readback* rb_pre = nullptr; uint32_t* pre_alias = nullptr; uint32_t pre_seq = 0;
     if (cut) rb_pre = read_flag_prepare(&pre_alias, &pre_seq);
     unsigned long long* host_found = rb_pre ? reinterpret_cast<unsigned long long*>(pre_alias) + RB_FOUND : nullptr;
@@ -1044,20 +1087,45 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         float* cov_dbg = g_debug_state.load() ? at<float>(geom, GL.cov3D) : nullptr;     // 24 B / Gaussian nobody but gsrast_debug_export reads
         const int clip = (runbin && o.tile_clip) ? 1 : 0;
         // equalised depth buckets (gsrast_common.h): the sampled depth histogram, zeroed in front of the kernel that fills it
-        uint32_t* zr = bucket_sort ? at<uint32_t>(geom, GL.zhist) : nullptr;
-        if (zr) GS_HIP(hipMemsetAsync(zr, 0, ZH_COPIES * ZH_BINS * sizeof(uint32_t), s));
+        uint32_t* zr = nullptr;
+        if (bucket_sort) {
+            int device = 0;
+            if (hipGetDevice(&device) == hipSuccess && device >= 0 && device < 32) {
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                if (!ctx->zhist_dev[device]) {
+                    uint32_t* z = nullptr;
+                    if (hipMalloc((void**)&z, ZH_COPIES * ZH_BINS * sizeof(uint32_t)) == hipSuccess) {
+                        if (hipMemset(z, 0, ZH_COPIES * ZH_BINS * sizeof(uint32_t)) == hipSuccess) ctx->zhist_dev[device] = z; else (void)hipFree(z);
+                    }
+                }
+                zr = ctx->zhist_dev[device];
+            }
+            zhist_ctx = zr != nullptr;
+            if (!zr) {      // (no context memory to be had: the call's own table and a memset, as before)
+                zr = at<uint32_t>(geom, GL.zhist);
+                GS_HIP(hipMemsetAsync(zr, 0, ZH_COPIES * ZH_BINS * sizeof(uint32_t), s));
+            }
+        }
+        zhist_call = zr;
+        if (tau_hist) GS_HIP(hipMemsetAsync(tau_hist, 0, (size_t)TAU_COPIES * T * TAU_BINS * sizeof(uint32_t), s));
         const int nzero = bucket_sort ? (int)nbk * BK_XCD : 0;
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched);
+                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched, tau_hist, tau_bins);
         else
             preprocess_fwd_kernel<false><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
-                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched);
+                zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched, tau_hist, tau_bins);
         GS_LAUNCHED("preprocess_fwd");
+        if (tau_hist) {       // the predicted cut depths of a pose without remembered ones (a no-op for a pose the table knows, unless forced)
+            const dim3 tg((unsigned)((cam.gx + TAU_TILE - 1) / TAU_TILE), (unsigned)((cam.gy + TAU_TILE - 1) / TAU_TILE));
+            tau_cut_kernel<<<tg, 256, 0, s>>>(tau_hist, T, cam.gx, cam.gy, tau_bins, (uint32_t)pol.tau_req.load() * 256u, hints ? hint_sel : nullptr, tau_forced,
+                                              zcut_used, tau_bins.scale > 0.0f ? 0 : 1);
+            GS_LAUNCHED("tau_cut");
+        }
     }
     const bool adaptive_sort = rs_blocks_n((size_t)P, GSRAST_DEPTH_ITEMS) > RS_SELF_SCAN_BLOCKS;      // see radix_sort
     const bool assume_short = adaptive_sort && g_sort_hint.load() != 0 && ctx->depth_short.load() != 0;
@@ -1072,7 +1140,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             {   ProfScope ps(K_SORT_DEPTH, s);
                 const int items = depth_scatter_items((size_t)P);       // (elements per lane: whatever makes the launch ONE round of workgroups)
                 auto scatter = items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE> : depth_bucket_scatter_kernel<BK_ITEMS>;
-                scatter<<<(P + 256 * items - 1) / (256 * items), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, at<uint32_t>(geom, GL.zhist), zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
+                scatter<<<(P + 256 * items - 1) / (256 * items), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, zhist_call, zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
                                                                                zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
                                                                                cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs,
                                                                                layer_mode, hint_sel, 0.125f, zcut_used);
@@ -1081,9 +1149,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)
                 // list cut: only the bucket's EARLY Gaussians are sorted (into the early set); the late ones count into bk_info's totals
                 if (cut) depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e),
-                                                                                                            at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), at<uint4>(geom, GL.bk_info));
+                                                                                                            at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), at<uint4>(geom, GL.bk_info),
+                                                                                                            nullptr, nullptr, zhist_ctx ? zhist_call : nullptr, ZH_COPIES * ZH_BINS);
                 else depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl),
-                                                                                                        at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base));
+                                                                                                        at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base),
+                                                                                                        nullptr, nullptr, nullptr, zhist_ctx ? zhist_call : nullptr, ZH_COPIES * ZH_BINS);
                 GS_LAUNCHED("depth_bucket_sort"); }
             totals_pending = true;      // by the run emission's last workgroup, or by launch_bucket_totals() if the host needs them first
             return GSRAST_OK;
@@ -1120,7 +1190,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // (a pose without a slot in the table has no cut depths: every visible Gaussian is early and the plain colour kernel, not the
     // compacting one, evaluates them -- the device said so at the very start of preprocess_fwd, long before this point)
     const bool pose_known = !(cut && rb_pre && hints) || read_found(rb_pre);
-    if (!pose_known && layer_mode == 0) cut_colors = false;
+    if (cut && tau_mode && hints && rb_pre) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (ctx->pose_seen.size() > 4096) ctx->pose_seen.clear();
+        ctx->pose_seen[viewmatrix] = pose_known ? 1 : 0;
+    }
+    if (!pose_known && layer_mode == 0 && !tau_on) cut_colors = false;
     { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
@@ -1130,7 +1205,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     auto bin_bytes = [&](uint32_t capR, uint32_t capQ) {
         return runbin ? runbin_layout((size_t)capR, (size_t)capQ).total : bin_layout((size_t)capR).total;
     };
-    auto grow = [](uint32_t v) { const uint64_t w = (uint64_t)v + v / 4 + 4096; return w > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)w; };
+    auto grow = [](uint32_t v) { return grow_capacity(v); };
     uint32_t cap = 0, capQ = 0;
     char* bin = nullptr;
     Readback* rb_flag = nullptr;                 // the counts arrive by the emission kernel's own store into pinned memory (no copy enqueued)
@@ -1205,7 +1280,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             rows_and_ranges_kernel<<<nblk + (uint32_t)cam.gx, RS_THREADS, 0, s>>>(rkA, rvA, nQ, counts_dev, capR_, tile_bits((size_t)cam.gy), cam.gx, cam.gy, hist_y, rscan, nblk,
                                                                                  mode == 2 ? plist_w + capR_ : plist_w, mode == 2 ? scalars + SC_PASS2 + 2 : scalars + 2, ranges,
                                                                                  buckets_ok ? at<uint32_t>(img, IL.bucket_cnt) : nullptr, at<uint16_t>(img, IL.bucket_list), hints, hint_sel, pred,
-                                                                                 mode == 2 ? at<unsigned char>(img, IL.tile_flags) : nullptr, mode == 2 ? capR_ : 0u);
+                                                                                 mode == 2 ? at<unsigned char>(img, IL.tile_flags) : nullptr, mode == 2 ? capR_ : 0u,
+                                                                                 (mode == 1 && tau_on) ? zcut_used : nullptr);
             GS_LAUNCHED("rows_and_ranges"); }
         return GSRAST_OK;
     };
@@ -1225,7 +1301,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
         if (zero_in_blend && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
-        ba.cut_margin_x4 = (uint32_t)ctx->cut_margin.load();
+        ba.cut_margin_x4 = (uint32_t)pol.margin.load();
         ba.untouched = untouched;
         if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; ba.tile_flags = at<unsigned char>(img, IL.tile_flags); }
         if (mode == 1 && cull && g_chain_gate.load() != 0 && (gate = chain_gate_of(ctx)) != nullptr) {
@@ -1297,10 +1373,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         // the recent forwards)
         // (LAYER mode -- an unknown pose, or no table: the nearest eighth of the Gaussians owns about a fifth of the column runs)
         if (cut) {
-            const uint32_t qe = ctx->Qe_hint.load();
+            // (a forward under predicted cut depths keeps two or three times the early set of one under remembered ones: each kind is sized by its own history)
+            const bool predicted_call = tau_on && (tau_forced || !pose_known || !hints);
+            const uint32_t qe = predicted_call ? ctx->Qe_hint_tau.load() : ctx->Qe_hint.load();
             const bool layer_call = layer_mode == 2 || (layer_mode == 1 && !pose_known);
-            const uint64_t want = layer_call ? std::max<uint64_t>((uint64_t)qe + qe / 2, (uint64_t)ctx->Q_hint.load() / 3) + 4096 : (uint64_t)qe + qe / 2 + 4096;
-            nQ1 = (qe && (pose_known || layer_mode != 0)) ? std::min<uint64_t>(capQ, want) : capQ;
+            const bool early_set_expected = pose_known || layer_mode != 0 || tau_on;
+            if (layer_call) nQ1 = (qe && early_set_expected) ? (uint32_t)std::min<uint64_t>(capQ, std::max<uint64_t>((uint64_t)qe + qe / 2, (uint64_t)ctx->Q_hint.load() / 3) + 4096) : capQ;
+            else nQ1 = early_launch_runs(qe, capQ, early_set_expected);
         }
         int rc = launch_run_binning(bin, cap, capQ, cut ? nQ1 : capQ, cut ? scalars + SC_EARLY_COUNTS : scalars, (late && !rb_flag) ? std::function<int()>(begin_readback) : std::function<int()>(), cut ? 1 : 0);
         flag_alias = nullptr;                    // (a repeated emission below reads its counts back the ordinary way)
@@ -1323,13 +1402,17 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const long long pad_lo = first == 0u ? 4 * span : span / 8 + 1, pad_hi = last >= (uint32_t)ZH_BINS - 1u ? 4 * span : span / 8 + 1;
         long long lo = std::max(kmin - pad_lo, bot), hi = std::min(kmax + pad_hi, top);
         if (!coarse) {      // (the middle of the previous table)
-            const long long plo = zh_klo, phi = (long long)zh_klo + ((long long)ZH_MID << zh_shift);
+            // (the previous range's upper end BEFORE its bins were rounded up to a power of two, if known: measured against the rounded one
+            // the range never narrowed below half the table -- harmless for the depth buckets, which follow the histogram's shape, but
+            // the predicted cut's 32 bins span [klo, khi] and a bin's width is what its prediction gives away)
+            const uint32_t khi_prev = ctx->zh_khi.load();
+            const long long plo = zh_klo, phi = khi_prev > zh_klo ? (long long)khi_prev : (long long)zh_klo + ((long long)ZH_MID << zh_shift);
             lo = lo < plo ? lo : plo + (lo - plo) / 8;
             hi = hi > phi ? hi : phi - (phi - hi) / 8;
         }
         int sh = 0;
         while (((hi - lo) >> sh) >= (long long)ZH_MID) sh++;
-        ctx->zh_klo = (uint32_t)lo; ctx->zh_shift = sh;
+        ctx->zh_klo = (uint32_t)lo; ctx->zh_shift = sh; ctx->zh_khi = (uint32_t)hi;
         return !coarse && !clipped;
     };
     bool sort_redone = false;
@@ -1370,41 +1453,30 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     auto t2 = std::chrono::steady_clock::now();
     if (trace) fprintf(stderr, "[gsrast] alloc(spec) %.1f us, readback wait %.1f us, cap %u R %u Q %u%s | cut %d (pays %d: last_Q %u pause %d) late %u Q_early %u nQ1 %u capQ %u bucket_sort %d (over %u) hints %d zh %08x >> %d bins %u-%u\n",
                        std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), cap, counts[0], counts[1],
-                       speculative ? " (speculative)" : "", (int)cut, (int)cut_pays, ctx->last_Q.load(), ctx->cut_pause.load(), counts[SC_N_LATE], counts[SC_Q_EARLY], nQ1, capQ,
+                       speculative ? " (speculative)" : "", (int)cut, (int)cut_pays, ctx->last_Q.load(), pol.pause.load(), counts[SC_N_LATE], counts[SC_Q_EARLY], nQ1, capQ,
                        (int)bucket_sort, counts[11], hints ? 1 : 0, zh_klo, zh_shift, counts[SC_ZBINS] & 0xFFFFu, counts[SC_ZBINS] >> 16);
     if (counts[0] > 0x7FFFFFFFu) return fail(GSRAST_E_OVERFLOW, "forward: more than 2^31-1 instances");
     const uint32_t R = counts[0], Q = counts[1];
     if (bucket_sort && !sort_redone) (void)learn_depth_range(counts[SC_ZBINS]);
     // capacity hints decay slowly: consecutive calls render different views, a buffer sized for the largest recent one
     // keeps the speculative launch valid
-    { const uint32_t hr = ctx->R_hint.load(), hq = ctx->Q_hint.load();
-      ctx->R_hint = R > hr - hr / 16 ? R : hr - hr / 16; ctx->Q_hint = Q > hq - hq / 16 ? Q : hq - hq / 16; }
+    ctx->R_hint = follow_hint(ctx->R_hint.load(), R, 4); ctx->Q_hint = follow_hint(ctx->Q_hint.load(), Q, 4);
     ctx->last_R = R; ctx->last_Q = Q;
     ctx->last_late = cut ? counts[SC_N_LATE] : 0u; ctx->last_Qe = cut ? counts[SC_Q_EARLY] : counts[1];
-    if (cut && counts[SC_N_LATE] != 0u && counts[1] - counts[SC_Q_EARLY] < CUT_MIN_RUNS && !g_list_cut_always.load()) { ctx->cut_pause = CUT_PAUSE; ctx->cut_pause_P = (uint32_t)P; }
-    if (cut && speculative && !sort_redone) { const uint32_t qe = counts[SC_Q_EARLY], hq = ctx->Qe_hint.load(); ctx->Qe_hint = qe > hq - hq / 32 ? qe : hq - hq / 32; }
+    // (a cut forward that removed too little to pay for itself; round 5: FOUR in a row before the context sits out)
+    if (cut) pol.forward_counts(tau_on, counts[SC_N_LATE], counts[1], counts[SC_Q_EARLY], (uint32_t)P, g_list_cut_always.load() != 0);
+    if (cut && speculative && !sort_redone) {
+        std::atomic<uint32_t>& hint = (tau_on && (tau_forced || !pose_known || !hints)) ? ctx->Qe_hint_tau : ctx->Qe_hint;
+        hint = follow_hint(hint.load(), counts[SC_Q_EARLY], 5); }
     // fallbacks of this thread's earlier cut forwards, as the device reported them (everything enqueued before this forward's counts has run)
     // (a completion pass over a few tiles is cheap and expected; its cost grows with the tiles it lists again: one over an eighth of
     // the image counts like rounds 3's whole second forward, smaller ones in proportion)
     if (const uint32_t q2 = take_fallback_event()) {       // (the column runs of the pass's candidates)
-        // up to an eighth of all column runs is what a pass is expected to cost (LAYER mode lists a few per cent again on every
-        // call); a quarter and more counts like round 3's whole second forward, in between in proportion
-        const uint32_t qall = std::max(ctx->last_Q.load(), 8u), lo = qall / 8u;
-        const int pts = q2 <= lo ? 0 : (int)std::min<uint64_t>(8u, ((uint64_t)(q2 - lo) * 8u + lo - 1u) / lo);
-        if (trace) fprintf(stderr, "[gsrast] completion pass reported: %u column runs of %u, %d points on a score of %d\n", q2, qall, pts, ctx->cut_fb_score.load());
-        if (pts == 0 && ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
-        if (pts >= 4) ctx->cut_ok_streak = 0;
-        { const int m = ctx->cut_margin.load(); if (m < CUT_MARGIN_MAX) ctx->cut_margin = std::min(CUT_MARGIN_MAX, m + 2); ctx->cut_margin_streak = 0; }
-        if ((ctx->cut_fb_score += pts) >= 16 && !g_list_cut_always.load()) {
-            // (on probation after the pause: the score restarts at half the bar, ONE more pass of that size pauses again, twice as long)
-            const int prev = ctx->cut_fb_pause.load(), len = prev <= 0 ? 64 : (prev >= 512 ? 1024 : prev * 2);
-            ctx->cut_fb_pause = len; ctx->cut_pause = len; ctx->cut_pause_P = (uint32_t)P; ctx->cut_fb_score = 8;
-        }
-    } else if (cut && counts[SC_N_LATE] != 0u) {
-        if (ctx->cut_fb_score.load() > 0) ctx->cut_fb_score--;
-        if (++ctx->cut_ok_streak >= 64) ctx->cut_fb_pause = 0;
-        if (++ctx->cut_margin_streak >= 128) { ctx->cut_margin_streak = 0; const int m = ctx->cut_margin.load(); if (m > CUT_MARGIN_MIN) ctx->cut_margin = m - 1; }
-    }
+        const int before = pol.fb_score.load();
+        const int pts = pol.completion_pass(q2, ctx->last_Q.load(), (uint32_t)P, g_list_cut_always.load() != 0, tau_mode);
+        if (trace) fprintf(stderr, "[gsrast] completion pass reported: %u column runs of %u, %d points on a score of %d; margin %d / 4, tau_req %d, pause %d\n", q2, ctx->last_Q.load(), pts, before,
+                           pol.margin.load(), pol.tau_req.load(), pol.pause.load());
+    } else if (cut && counts[SC_N_LATE] != 0u) pol.clean_cut_forward();
     const bool early_fits = !cut || counts[SC_Q_EARLY] <= nQ1;
     if (speculative && !sort_redone && R <= cap && Q <= capQ && early_fits) {          // everything is already in flight
         if (cut && counts[SC_N_LATE] != 0u) {

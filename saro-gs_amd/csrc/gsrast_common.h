@@ -134,7 +134,8 @@ struct BinLayout {
 //   kernel finds its tile from the prefix sums of the 64 counts.  [0] = forward, [1] = backward.
 struct ImgLayout {
     size_t final_T, n_contrib, ranges, tile_max, order_fwd, order_bwd, bucket_cnt, bucket_list, zcut_used /* u32[T]: this call's snapshot of the pose's cut depths (list cut, below) */,
-        tile_flags /* u8[T]: 1 = the tile's cut list was too short: the completion pass lists and blends it again (list cut, below) */, total;
+        tile_flags /* u8[T]: 1 = the tile's cut list was too short: the completion pass lists and blends it again (list cut, below) */,
+        tau_hist /* u32[TAU_COPIES][T][TAU_BINS]: opacity mass per tile and depth bin (predicted cut, below) */, total;
 };
 constexpr int WORK_BUCKETS = 64;
 constexpr size_t BUCKET_MAX_TILES = 65535;     // tile ids are stored as u16
@@ -199,6 +200,35 @@ static inline int cut_cell_shift(size_t gx, size_t gy)      // 1, 2, 3, or 0 = n
     if (gx >= 32768) return 0;
     for (int cs = 1; cs <= 3; cs++) { const size_t c = (size_t)1 << cs; if (((gx + c - 1) >> cs) * ((gy + c - 1) >> cs) <= CUT_MAX_CELLS) return cs; }
     return 0;
+}
+// PREDICTED CUT (round 5): a cut depth for a pose the context has never rendered -- or whose remembered cut keeps failing because the scene
+// is another one at every visit (SaRO-GS: opacity, means and scales are functions of the timestamp) -- from THIS call's own Gaussians.
+// preprocess_fwd adds a visible Gaussian's OPTICAL-DEPTH mass -- the integral over the image plane of -ln(1 - alpha(x)) = 2 pi sqrt(det cov2D)
+// Li2(opacity), in pixels^2, capped at what it can lay on one tile -- to the bin (tile of its centre, depth bin); mass / 256 estimates the
+// tile's MEAN optical depth from below (series cut short, wide Gaussians capped, one wave in two sampled and doubled).  tau_cut_kernel walks
+// every tile's bins front to back: the far edge of the bin where the running mean reaches tau_req (default 10; T < 1e-4 needs 9.2 at EVERY
+// pixel -- the far edge and the 3 x 3 maximum are the slack) is the tile's predicted cut -- the deepest over the 3 x 3 tiles
+// around it, none if one of those has none: silhouette tiles, whose pixels do not all saturate, get the full list straight away.  The
+// prediction is verified like a remembered cut (the blend flags a tile whose cut list ended before it saturated, the completion pass lists
+// it again), so it can only cost time; every reported pass raises tau_req.  Depth bins: TAU_BINS equal steps of the depth KEY (float bits:
+// piecewise linear in log depth) over the key range [lo, hi] the context has learned from its forwards (the occupied range padded by an
+// eighth, gsrast_capi.hip: learn_depth_range) -- the depth histogram's own bins are powers of two of key steps and cover up to twice
+// that range, too coarse here: a tile's cut lands on a bin's FAR edge, so a bin's width is what the prediction gives away.  The last
+// bin also takes everything behind hi and has no far edge (no cut there).
+constexpr int TAU_BINS = 32, TAU_COPIES = 4;      // (copies: workgroup b adds into copy b mod 4)
+struct TauBins { uint32_t lo; float scale /* bins per key step */; float inv_scale; uint32_t wave_mask /* wave w of preprocess_fwd adds its Gaussians iff (hash(w) & mask) == 0, each (mask + 1) times its mass */; };
+__host__ __device__ inline uint32_t tau_bin_of(uint32_t key, const TauBins& tb)
+{
+    if (key <= tb.lo) return 0u;
+    const float f = (float)(key - tb.lo) * tb.scale;
+    return f >= (float)(TAU_BINS - 1) ? (uint32_t)(TAU_BINS - 1) : (uint32_t)f;
+}
+// a key that is certainly not in front of bin b's far edge, whatever the float rounding in tau_bin_of did (two key steps of slack per bin index)
+__host__ __device__ inline uint32_t tau_bin_far_edge(uint32_t b, const TauBins& tb)
+{
+    const float e = (float)(b + 1u) * tb.inv_scale;
+    const unsigned long long k = (unsigned long long)tb.lo + (unsigned long long)e + 2ull * (b + 2u);
+    return k >= (unsigned long long)ZH_KEY_TOP ? ZCUT_NONE : (uint32_t)k;
 }
 constexpr uint32_t LATE_BIT = 0x80000000u;      // in the width word of a bucket-slab element
 // words of GeomLayout::scalars used by the list cut
@@ -327,6 +357,7 @@ static inline ImgLayout img_layout(size_t W, size_t H)
     L.bucket_list = take(T <= BUCKET_MAX_TILES ? (XCD_GROUPS * WORK_BUCKETS * (Tg ? Tg : 1) + WORK_BUCKETS * T) * 2 : 0);
     L.zcut_used = take(T * 4);
     L.tile_flags = take(T);
+    L.tau_hist = take((size_t)TAU_COPIES * T * TAU_BINS * 4);
     L.total = o + 256;
     return L;
 }

@@ -684,7 +684,9 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       int borrow = 0 /* r > 0: a pose the table does not know takes the estimates and cut depths of a near pose's slot (HintTable::cam), the cut depths widened over (2 r + 1)^2 tiles */,
                       float near_scale2 = 0.0f /* (camera-to-scene distance)^2 the near-pose tolerance is relative to; 0: the camera's distance from the origin */,
                       uint32_t* __restrict__ prefilter_violation = nullptr /* or a word that is set when a Gaussian is culled although the caller said `prefiltered` (auxiliary.h:156-160) */,
-                      unsigned long long* __restrict__ untouched = nullptr /* or GeomLayout::untouched: every bit set here, cleared by the forward blend */)
+                      unsigned long long* __restrict__ untouched = nullptr /* or GeomLayout::untouched: every bit set here, cleared by the forward blend */,
+                      uint32_t* __restrict__ tau_hist = nullptr /* or ImgLayout::tau_hist [TAU_COPIES][ntiles_img][TAU_BINS] (zeroed by a memset): the predicted cut's opacity mass */,
+                      TauBins tau_bins = TauBins{0u, 0.0f, 0.0f, 0u})
 {
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (XCD_GROUPS + 1) * WORK_BUCKETS + GATE_WORDS; i += blockDim.x) bucket_cnt[i] = 0u;
     if (cut_scalars && blockIdx.x == 0 && threadIdx.x == 0) { cut_scalars[SC_UNDONE] = 0u; cut_scalars[SC_N_LATE] = 0u; cut_scalars[SC_GATE_COUNT] = 0u; cut_scalars[SC_TOUCH_VALID] = untouched ? 1u : 0u; }      // (always: the backward reads them)
@@ -792,6 +794,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     }
     const Cam cam = load_cam(cam_args);
     int rad_out = 0; uint32_t ntiles = 0; uint32_t key = 0xFFFFFFFFu; uint2 rc = make_uint2(0u, 0u);
+    float tau_mass = 0.0f; int tau_tile = -1;          // predicted cut (gsrast_common.h): this Gaussian's opacity mass and the tile of its centre
     if (i < P) {
 
     float ph[4], pv[3];
@@ -839,6 +842,16 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                 rec1[(size_t)REC_STRIDE * i] = make_float4(con2, op, pv[2], thr);
                 rad_out = rad; ntiles = (uint32_t)area;
                 key = __float_as_uint(pv[2]);
+                if (tau_hist && px >= 0.0f && py >= 0.0f && px < (float)cam.W && py < (float)cam.H) {
+                    tau_tile = ((int)py >> 4) * cam.gx + ((int)px >> 4);
+                    // the Gaussian's OPTICAL-DEPTH mass: integral over the plane of -ln(1 - a(x)), a(x) = o exp(-q(x) / 2)  =  2 pi sqrt(det cov2D) Li2(o),
+                    // Li2 the dilogarithm, here its series cut after six terms (a lower bound: the estimate stays conservative)
+                    const float oc = fminf(op, 0.99f);
+                    const float li2 = oc * (1.0f + oc * (0.25f + oc * (0.111111f + oc * (0.0625f + oc * (0.04f + oc * 0.0277778f)))));
+                    // ... but never more than it can lay on ONE tile (its peak over all 256 pixels): a Gaussian wider than a tile hands the tile of
+                    // its centre that much and its neighbours nothing, which only lowers their estimates
+                    tau_mass = fminf(li2 * 6.28318531f * sqrtf(fmaxf(det, 0.0f)), -logf(1.0f - oc) * 256.0f);
+                }
                 if (clip_rect) {
                     // Bounding box of the ellipse the alpha >= 1/255 pixels lie in (same construction and margins as the
                     // per-column clipping in emit_column_runs_kernel, gsrast_binning.h): whole tile columns / rows of the
@@ -888,6 +901,12 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
         uint32_t bin, pos; int wlog;
         zh_locate(key, zh_klo, zh_shift, bin, pos, wlog);
         atomicAdd(&zhist[(blockIdx.x & (unsigned)(ZH_COPIES - 1)) * (unsigned)ZH_BINS + bin], 1u);
+    }
+    // predicted cut: one fire-and-forget atomic per small visible Gaussian (the workgroup's XCD's own copy of the table)
+    // (a pseudo-random subset of the waves, their mass scaled up: three million atomics cost the kernel 40 us at 3 M, a quarter of them 10)
+    if (tau_tile >= 0 && ((((uint32_t)i >> 6) * 0x9E3779B1u >> 14) & tau_bins.wave_mask) == 0u) {
+        const uint32_t q = (uint32_t)(tau_mass * (float)(tau_bins.wave_mask + 1u) + 0.5f);
+        if (q) atomicAdd(&tau_hist[((size_t)(blockIdx.x & (unsigned)(TAU_COPIES - 1)) * ntiles_img + (uint32_t)tau_tile) * TAU_BINS + tau_bin_of(key, tau_bins)], q);
     }
 }
 

@@ -37,7 +37,7 @@ EXPORTS = (
     "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
-    "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query",
+    "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query", "gsrast_policy_event",
     "gsrast_forward_ex", "gsrast_backward_ex", "gsrast_forward_raw", "gsrast_backward_raw",
 )
 
@@ -141,6 +141,8 @@ def lib() -> C.CDLL:
     L.gsrast_context_destroy.argtypes = [vp]
     L.gsrast_context_query.restype = ci
     L.gsrast_context_query.argtypes = [vp, C.c_char_p]
+    L.gsrast_policy_event.restype = ci
+    L.gsrast_policy_event.argtypes = [vp, C.c_char_p, ci, ci, ci]
     L.gsrast_mark_visible.restype = ci
     L.gsrast_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
     for name in ("gsrast_geometry_bytes",):
@@ -365,7 +367,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             rendered = L.gsrast_forward_ex(
-                None, C.byref(_options_struct(forward_only=forward_only)),       # context: the calling thread's own (capacity hints of the speculative launch)
+                _current_context(), C.byref(_options_struct(forward_only=forward_only)),       # context: the innermost `with Context()` of the calling thread, else the thread's own
                 arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
                 P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
@@ -513,7 +515,7 @@ def rasterize_gaussians_raw(background, raw: dict, scale_modifier, viewmatrix, p
     try:
         with torch.cuda.device(dev):
             rendered = L.gsrast_forward_raw(
-                None, C.byref(_options_struct(forward_only=forward_only)),
+                _current_context(), C.byref(_options_struct(forward_only=forward_only)),
                 arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
                 P, int(degree), M, _ptr(background), W, H, C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii),
@@ -671,10 +673,85 @@ def get_option(name: str) -> int:
     return int(lib().gsrast_get_option(name.encode()))
 
 
+class Context:
+    """A caller-owned gsrast_context (include/gsrast.h: gsrast_context_create / _destroy): the state a sequence of similar views shares --
+    capacity hints of the speculative launch, the depth sort's history, the pose table with its launch-order hints and cut depths, the
+    side streams.  By default every host thread has one of its own; a caller that keeps SEVERAL views in flight on several streams of one
+    thread (view_parallel.distributed_step(views_in_flight=n)) gives each lane its own, so that the lanes' forwards do not share side
+    streams, gate words and adaptive state:
+
+        ctx = _C.Context()
+        with ctx:                      # forwards issued by this thread inside the block use ctx
+            color, radii, depth = GaussianRasterizer(settings)(...)
+        ctx.close()                    # frees its device memory (or let the object die)
+
+    Results never depend on which context a call runs in."""
+
+    def __init__(self):
+        self._h = lib().gsrast_context_create()
+        if not self._h:
+            raise MemoryError("gsrast_context_create failed")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("gsrast: the context has been closed")
+        return self._h
+
+    def query(self, name: str) -> int:
+        v = int(lib().gsrast_context_query(self.handle, name.encode()))
+        if v < 0:
+            raise ValueError(f"gsrast: unknown context query: {name}")
+        return v
+
+    def policy_event(self, what: str, a: int = 0, b: int = 0, c: int = 0) -> int:
+        """gsrast_policy_event (include/gsrast.h): one host-side decision of the context, no device involved."""
+        v = int(lib().gsrast_policy_event(self.handle, what.encode(), int(a), int(b), int(c)))
+        if v < 0:
+            raise ValueError(f"gsrast: unknown policy event: {what}")
+        return v
+
+    def close(self) -> None:
+        h, self._h = self._h, None
+        if h:
+            lib().gsrast_context_destroy(h)     # (waits for the context's own streams)
+
+    def __enter__(self):
+        stack = getattr(_tls, "contexts", None)
+        if stack is None:
+            stack = _tls.contexts = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.contexts.pop()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def policy_event(what: str, a: int = 0, b: int = 0, c: int = 0) -> int:
+    """gsrast_policy_event on the calling thread's current context."""
+    v = int(lib().gsrast_policy_event(_current_context(), what.encode(), int(a), int(b), int(c)))
+    if v < 0:
+        raise ValueError(f"gsrast: unknown policy event: {what}")
+    return v
+
+
+def _current_context():
+    """The handle of the innermost `with Context():` block of the calling thread, or None = the thread's own default context."""
+    stack = getattr(_tls, "contexts", None)
+    return stack[-1].handle if stack else None
+
+
 def context_query(name: str) -> int:
-    """gsrast_context_query on the calling thread's context (include/gsrast.h): "last_instances", "last_runs", "redo_count",
-    "bucket_skip", "last_late", "last_early_runs", "cut_pause", "cut_fallbacks"."""
-    v = int(lib().gsrast_context_query(None, name.encode()))
+    """gsrast_context_query on the calling thread's current context (include/gsrast.h): "last_instances", "last_runs", "redo_count",
+    "bucket_skip", "last_late", "last_early_runs", "cut_pause", "cut_fallbacks", "completion_passes", "cut_margin_x4", "tau_req", ..."""
+    v = int(lib().gsrast_context_query(_current_context(), name.encode()))
     if v < 0:
         raise ValueError(f"gsrast: unknown context query: {name}")
     return v

@@ -329,6 +329,19 @@ class StepBucket:
 
 
 _LANE_STREAMS: Dict[tuple, list] = {}
+_LANE_CONTEXTS: Dict[tuple, list] = {}
+
+
+def _lane_contexts(dev: torch.device, n: int) -> list:
+    """One rasterizer context per lane (diff_gaussian_rasterization_ch3._C.Context), made once per device: views in flight on different
+    streams must not share a context's side streams, completion-pass gate and adaptive state (capacity hints, pose table)."""
+    if dev.type != "cuda":
+        return [contextlib.nullcontext()] * n
+    from diff_gaussian_rasterization_ch3 import _C
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _LANE_CONTEXTS:
+        _LANE_CONTEXTS[key] = [_C.Context() for _ in range(n)]
+    return _LANE_CONTEXTS[key]
 
 
 def _lane_streams(dev: torch.device, n: int) -> list:
@@ -380,13 +393,14 @@ def distributed_step(bucket: StepBucket, views: Sequence, render_loss_fn, batch:
         n = min(int(views_in_flight), len(mine))
         dev = bucket.flat.device
         streams = _lane_streams(dev, n)
+        lane_ctx = _lane_contexts(dev, n)
         main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         partial = bucket.partials(n)                            # lane 0 adds into the cache itself
         stats = [None] * n
         for j, i in enumerate(mine):
             k = j % n
             ctx = torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()
-            with ctx:
+            with ctx, lane_ctx[k]:
                 if streams[k] is not None and j < n:
                     streams[k].wait_stream(main)                # the parameters (and the zeroed cache) are ordered on the caller's stream
                 out = render_loss_fn(views[i])

@@ -19,6 +19,27 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "remembered_cut_only: the test pins the bookkeeping of the list cut's REMEMBERED cut depths (late counts, "
+                            "fallbacks, redo counts): it runs with the predicted cut (option tau_cut, round 5) switched off")
+
+
+@pytest.fixture(autouse=True)
+def _predicted_cut_switch(request):
+    """Tests marked `remembered_cut_only` run with gsrast_set_option("tau_cut", 0): a pose without remembered cut depths is then not cut at
+    all (round 4's behaviour), which is what their exact counts of late Gaussians / completion passes / redone forwards assume."""
+    gpu_test = request.node.get_closest_marker("gpu") is not None
+    if gpu_test:         # the list cut's policy state (pauses, widened margins) of the calling thread's context must not leak from test to test
+        import diff_gaussian_rasterization_ch3 as _r
+        _r._C.policy_event("reset")
+    if request.node.get_closest_marker("remembered_cut_only") is None:
+        yield
+        return
+    import diff_gaussian_rasterization_ch3 as _r
+    _r._C.set_option("tau_cut", 0)
+    try:
+        yield
+    finally:
+        _r._C.set_option("tau_cut", 1)
 
 
 @pytest.fixture(scope="session")

@@ -56,7 +56,14 @@ def _run_hip(rast, scene, cam, device, dL_dcolor, colors_precomp, cov3D_precomp)
             kw.get("scales", empty).detach(), kw.get("rotations", empty).detach(), rs.scale_modifier,
             kw.get("cov3D_precomp", empty).detach(), rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
             rs.image_height, rs.image_width, kw.get("shs", empty).detach(), rs.sh_degree, rs.campos, False)
-    R, color0, radii0, gb, bb, ib, depth0 = _C.rasterize_gaussians(*args)
+    # (the state that is exported comes from a forward WITHOUT the list cut: under a cut -- remembered or, round 5, predicted -- the lists hold
+    # the early Gaussians only and a completed tile's range lies in the point list's second half; the module call below may run under one,
+    # and must produce the same image bit for bit)
+    _C.set_option("no_list_cut", 1)
+    try:
+        R, color0, radii0, gb, bb, ib, depth0 = _C.rasterize_gaussians(*args)
+    finally:
+        _C.set_option("no_list_cut", 0)
     out = {"R": R}
     if P > 0:
         st = _C.debug_export(P, R, rs.image_width, rs.image_height, gb, bb, ib)

@@ -50,7 +50,8 @@ def test_state_buffer_sizes(L):
     assert all(y >= x for x, y in zip(b, b[1:])) and b[2] > b[1]
     assert b[-1] / (5 * 10**7) < 20       # 16 B per instance + histograms
     i = L.gsrast_image_bytes(1920, 1080)
-    assert 8 * 1920 * 1080 <= i <= 10 * 1920 * 1080     # 8 B per pixel + per-tile arrays (ranges, work-bucket lists)
+    assert 8 * 1920 * 1080 <= i <= 12 * 1920 * 1080     # 8 B per pixel + per-tile arrays (ranges, work-bucket lists; round 5: the predicted cut's
+                                                         # opacity-mass table, 8 copies x 16 depth bins x 4 B per tile = 2 B per pixel)
     assert all(x % 256 == 0 for x in g + b + [i])
 
 

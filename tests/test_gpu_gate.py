@@ -17,6 +17,7 @@ from conftest import settings_from
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.remembered_cut_only          # (with predicted cut depths the first wide failure switches the context to them, and they hold: the gate would idle)
 @pytest.mark.timeout(900)
 def test_gate_soak_two_threads_two_contexts(scenes, rast, gpu):
     _C = rast._C
@@ -115,3 +116,39 @@ def test_prefiltered_promise_is_checked(orc, scenes, rast, gpu):
         render(behind, True)
     d = render(sc, True)                                # the library is fine afterwards
     assert all(torch.equal(x, y) for x, y in zip(a, d))
+
+
+def test_python_context_handle(scenes, rast, gpu):
+    """_C.Context (gsrast_context_create / _destroy behind a Python handle): forwards inside `with ctx:` run in that context -- its own
+    capacity hints, pose table and streams -- and results do not depend on the context; closing it frees its device memory."""
+    _C = rast._C
+    P, W, H = 40_000, 320, 240
+    sc = scenes.synth(P, 41, scale_mul=1.2)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    rs_a, rs_b = (settings_from(rast, scenes.camera(k, 6, W, H), sc, gpu) for k in (0, 3))
+
+    def render(rs):
+        return rast.GaussianRasterizer(rs)(means3D=ten["means3D"], means2D=torch.zeros((P, 3), device=gpu), opacities=ten["opacities"], shs=ten["shs"],
+                                           scales=ten["scales"], rotations=ten["rotations"])
+
+    want_a, want_b = render(rs_a), render(rs_b)
+    c1, c2 = _C.Context(), _C.Context()
+    assert c1.query("last_instances") == 0 and c2.query("last_instances") == 0
+    for _ in range(3):
+        with c1:
+            got = render(rs_a)
+            assert _C.context_query("last_instances") == c1.query("last_instances") > 0
+        assert all(torch.equal(x, y) for x, y in zip(got, want_a))
+        with c2:
+            got = render(rs_b)
+            with c1:                                    # nesting: the innermost block decides
+                inner = render(rs_a)
+            assert all(torch.equal(x, y) for x, y in zip(inner, want_a))
+        assert all(torch.equal(x, y) for x, y in zip(got, want_b))
+    assert c1.query("last_instances") != c2.query("last_instances")      # two poses, two contexts: each remembers its own last forward
+    torch.cuda.synchronize()
+    c1.close(); c2.close()
+    with pytest.raises(RuntimeError):
+        c1.query("last_instances")
+    assert all(torch.equal(x, y) for x, y in zip(render(rs_a), want_a))  # the thread's own context is untouched

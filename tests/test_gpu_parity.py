@@ -443,6 +443,7 @@ def test_state_buffers_are_not_overrun(scenes, rast, gpu, monkeypatch):
         _C.set_option("binning", 0)
 
 
+@pytest.mark.remembered_cut_only
 @pytest.mark.parametrize("speculative", [1, 0])
 def test_speculative_launch_overflow_and_shrink(speculative, orc, scenes, rast, gpu):
     """The forward enqueues binning + blend against a capacity remembered from earlier calls, before it knows R and Q.
@@ -930,6 +931,7 @@ def test_launch_order_hints_never_change_a_result(orc, scenes, rast, gpu):
         _C.set_option("list_cut_always", 0)
 
 
+@pytest.mark.remembered_cut_only
 def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu):
     """List cut (include/gsrast.h: options.no_list_cut): the second forward of a pose gives column runs only to the Gaussians in front
     of the cut depth of some tile they cover.  The speculation is verified on the device: same outputs and state bit for bit, the same
@@ -997,6 +999,7 @@ def test_list_cut_is_verified_and_never_changes_a_result(orc, scenes, rast, gpu)
         _C.set_option("near_pose", 3)
 
 
+@pytest.mark.remembered_cut_only
 def test_near_pose_borrows_cut_depths_and_never_changes_a_result(orc, scenes, rast, gpu):
     """A pose the context's table does not know takes the launch order and the cut depths (widened over 7 x 7 tiles) of a NEAR pose's slot
     (option near_pose, gsrast_common.h HintTable::cam): along a camera path every frame after the first two is cut although no pose is
@@ -1088,6 +1091,7 @@ def _list_cut_body(orc, scenes, rast, gpu, _C, render, same, sc, cam, P, W, H, l
     _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
 
 
+@pytest.mark.remembered_cut_only
 def test_list_cut_on_a_large_image(scenes, rast, gpu):
     """An image of more than 3072 cells of 2 x 2 tiles (here 2048 x 1600: 128 x 100 tiles) keeps its cut depths in 4 x 4-tile cells
     (gsrast_common.h: cut_cell_shift): same results with and without the cut, also after the scene turned transparent."""
@@ -1138,6 +1142,7 @@ def test_list_cut_on_a_large_image(scenes, rast, gpu):
         _C.set_option("list_cut_always", 0)
 
 
+@pytest.mark.remembered_cut_only
 def test_list_cut_survives_alternating_image_sizes(scenes, rast, gpu):
     """a context keeps one pose table per image size (up to four): train and eval resolutions that alternate call by
     call each keep their poses' cut depths -- the cut is in force on every visit after a size's first, with the same results as without."""
@@ -1176,6 +1181,7 @@ def test_list_cut_survives_alternating_image_sizes(scenes, rast, gpu):
         _C.set_option("list_cut_always", 0)
 
 
+@pytest.mark.remembered_cut_only
 def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
     """a pose may hold cut depths while the scatter marks NO Gaussian late (rectangles of more than 64 tiles are
     never late; a Gaussian over a tile without a cut stays early).  The host then enqueues no second pass, so the blend must not
@@ -1226,6 +1232,7 @@ def test_list_cut_with_cut_depths_but_no_late_gaussian(orc, scenes, rast, gpu):
         _C.set_option("list_cut_always", 0)
 
 
+@pytest.mark.remembered_cut_only
 def test_list_cut_under_a_changing_scene(orc, scenes, rast, gpu):
     """A training run changes the scene between two renders of a pose.  A fixed pose, twelve random edits in a row -- opacities scaled
     up or down, a tenth of the Gaussians pruned, the scene pushed away from / pulled towards the camera, a transparent and an opaque
@@ -1342,3 +1349,118 @@ def test_backward_writes_every_row_of_poisoned_outputs(path, orc, scenes, rast, 
         assert dead.sum() >= 400
         for k in names:
             assert not np.asarray(h[k]).reshape(P, -1)[dead].any(), (dense, k)
+
+
+@pytest.mark.parametrize("table", [0, 1], ids=["pose_table_off", "pose_table_on"])
+@pytest.mark.parametrize("W,H", [(320, 240), (437, 251), (304, 528)])
+def test_predicted_cut_is_verified_and_never_changes_a_result(table, W, H, orc, scenes, rast, gpu):
+    """Round 5, option "tau_cut" (default on): a pose WITHOUT remembered cut depths -- one the context has never rendered, or any pose when
+    the pose table is switched off -- gets PREDICTED cut depths from the call's own opacity mass per tile and coarse depth bin
+    (gsrast_common.h: preprocess_fwd's histogram, tau_cut_kernel).  A prediction is a speculation like a remembered cut: the blend verifies it,
+    a tile whose pixels do not all saturate in front of it is listed and blended again by the completion pass.  So: forwards under a predicted cut
+    equal their cut-less twins bit for bit (state included) and the oracle; a scene built to fool the predictor -- dense on average, with an
+    empty shaft along the view axis through the middle of the image, whose pixels never saturate -- is completed and equals the oracle too;
+    gradients through a predicted-cut forward meet the oracle bar."""
+    import torch
+    from conftest import settings_from
+    _C = rast._C
+    P = 60_000
+    sc = scenes.synth(P, 815, scale_mul=1.3)
+    cam = scenes.camera(1, 7, W, H)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    e = torch.empty(0)
+
+    def render(scene, camera=cam):
+        rs = settings_from(rast, camera, scene, gpu)
+        ten = {k: t(scene[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        R, color, radii, gb, bb, ib, depth = _C.rasterize_gaussians(
+            rs.bg, ten["means3D"], e, ten["opacities"], ten["scales"], ten["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, H, W, ten["shs"], 3, rs.campos, False)
+        st = _C.debug_export(P, R, W, H, gb, bb, ib)
+        return (R, color.clone(), depth.clone(), radii.clone(), st["n_contrib"].clone(), st["final_T"].clone()), _C.context_query("last_late")
+
+    def same(a, b):
+        return a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+    def twin(scene, camera=cam):
+        _C.set_option("no_list_cut", 1)
+        try:
+            return render(scene, camera)[0]
+        finally:
+            _C.set_option("no_list_cut", 0)
+
+    _C.set_option("list_cut_always", 1)
+    _C.set_option("near_pose", 0)
+    _C.set_option("no_order_hint", 0 if table else 1)
+    try:
+        for k in range(3):                            # the context learns its depth range and launch sizes on other poses of the ring
+            render(sc, scenes.camera(3 + k, 7, W, H))
+        full = twin(sc)
+        o = orc.render(sc, cam)
+        assert full[0] == o["R"] and np.array_equal(bits(full[1].cpu().numpy()), bits(o["out_color"]))
+        p0 = _C.context_query("completion_passes")
+        first, late_first = render(sc)                # never rendered by this context: PREDICTED cut depths
+        assert late_first > P // 8, late_first       # the cube is opaque after a fraction of its depth, and the prediction sees that
+        assert same(first, full)
+        again, late_again = render(sc)                # (with the table on: the pose's remembered cut from now on)
+        assert late_again > P // 8 and same(again, full)
+        # an empty shaft along the view axis: the tiles in the middle of the image are dense ON AVERAGE, the pixels on the axis see nothing
+        cpos = np.asarray(cam["campos"], dtype=np.float64)
+        axis = -cpos / np.linalg.norm(cpos)
+        rel = sc["means3D"].astype(np.float64) - cpos
+        along = rel @ axis
+        perp = np.linalg.norm(rel - np.outer(along, axis), axis=1)
+        hole = dict(sc)
+        hole["opacities"] = np.where((perp < 0.035 * along)[:, None], 1e-4, sc["opacities"]).astype(np.float32)
+        oh = orc.render(hole, cam)
+        got, late_h = render(hole, scenes.camera(1, 7, W, H))
+        assert late_h > 0
+        assert got[0] == oh["R"] and np.array_equal(bits(got[1].cpu().numpy()), bits(oh["out_color"])) and np.array_equal(bits(got[2].cpu().numpy()), bits(oh["out_depth"]))
+        assert same(got, twin(hole))
+        torch.cuda.synchronize()
+        render(sc, scenes.camera(2, 7, W, H))         # (the report of a completion pass reaches the host with a later forward)
+        print("completion passes:", _C.context_query("completion_passes") - p0, "tau_req", _C.context_query("tau_req"))
+        # gradients through a forward under a predicted cut (another unseen pose), oracle bar
+        cam_g = scenes.camera(6, 7, W, H)
+        g = scenes.upstream_grad(H, W, 816) * (H * W)
+        o32 = orc.render(sc, cam_g, g)
+        o64 = orc.render(sc, cam_g, g, f64=True)
+        h = run_hip(rast, sc, cam_g, gpu, dL_dcolor=g, tile_clip=1)
+        assert np.array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+        _check_grads(o64, o32, h, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    finally:
+        _C.set_option("list_cut_always", 0)
+        _C.set_option("near_pose", 3)
+        _C.set_option("no_order_hint", 0)
+
+
+@pytest.mark.parametrize("P,W,H,deg", [(20000, 256, 192, 3), (5000, 97, 83, 1)])
+def test_untouched_rows_are_zero_rows(P, W, H, deg, orc, scenes, rast, gpu):
+    """Round 5: the forward blend keeps one bit per Gaussian, "no pixel consumed it" (GeomLayout::untouched); the backward writes those
+    Gaussians' rows as zeros beside the blend backward and its per-Gaussian kernel works through the others only -- stateless, for every
+    forward.  Forced on at test size (option late_fill_min_p = 0): every gradient at the oracle bar, untouched rows exactly zero, and the
+    same gradients as with the bits switched off."""
+    import torch
+    _C = rast._C
+    sc = scenes.synth(P, 820, sh_degree=deg, scale_mul=1.2)
+    cam = scenes.camera(2, 5, W, H)
+    g = scenes.upstream_grad(H, W, 821) * (H * W)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    names = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"]
+    _C.set_option("late_fill_min_p", 0)
+    try:
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+        _C.set_option("touch_bits", 0)
+        try:
+            h0 = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+        finally:
+            _C.set_option("touch_bits", 1)
+    finally:
+        _C.set_option("late_fill_min_p", 750000)
+    assert np.array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+    _check_grads(o64, o32, h, names)
+    for k in names:          # float-atomic order differs between two backwards: close, not bit-identical; zero rows are the same rows
+        a, b = h[k].reshape(P, -1), h0[k].reshape(P, -1)
+        assert np.array_equal((a != 0).any(1), (b != 0).any(1)), k
+        assert (np.abs(a - b) <= 1e-6 + 1e-3 * np.abs(b)).all(), k

@@ -192,6 +192,7 @@ def test_raw_rasterizer_with_no_gaussians(scenes, rast, gpu):
     assert xyz.grad is not None and xyz.grad.shape == (0, 3)
 
 
+@pytest.mark.remembered_cut_only
 @pytest.mark.parametrize("use", [COMBOS[0], COMBOS[6], COMBOS[15]], ids=["1111", "1001", "0000"])
 def test_raw_rasterizer_under_the_list_cut(use, scenes, rast, gpu):
     """The second and third forward of a pose through the raw entry points bin and COLOUR only the early Gaussians (include/gsrast.h:

@@ -9,15 +9,17 @@ os.makedirs("profiles", exist_ok=True)
 for f in os.listdir(src):
     if f.endswith((".txt", ".json", ".csv")) and os.path.getsize(os.path.join(src, f)) > 0:
         shutil.copy(os.path.join(src, f), os.path.join("profiles", f))
-def per_launch(counter):
+def per_launch(counter, kernel):
     p = os.path.join(src, f"{tag}_pmc_{counter}.txt")
     for line in open(p):
-        if "blend_bwd_cull" in line:
+        if kernel in line:
             return float(line.split()[-1])
     return None
-fetch_kb, write_kb = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE")
-if fetch_kb is not None and write_kb is not None:
-    d = {"kernel": "blend_bwd_cull_t_kernel", "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+for kernel, pattern, stem in (("blend_bwd_cull_t_kernel", "blend_bwd_cull", "pmc_blend_bwd"), ("blend_fwd_cull_kernel", "blend_fwd_cull", "pmc_blend_fwd")):
+    fetch_kb, write_kb = per_launch("FETCH_SIZE", pattern), per_launch("WRITE_SIZE", pattern)
+    if fetch_kb is None or write_kb is None:
+        continue
+    d = {"kernel": kernel, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
          "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> doubled "
                        "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as reported (uncalibrated)",
          "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024), "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt, {tag}_pmc_WRITE_SIZE.txt"}
@@ -27,7 +29,7 @@ if fetch_kb is not None and write_kb is not None:
         lines = open(sq).read().splitlines()
         cols = lines[0].split()
         for line in lines[1:]:
-            if "blend_bwd_cull" in line:
+            if pattern in line:
                 vals = line.split()[-(len(cols) - 2):]            # the numeric columns after kernel name and calls
                 named = dict(zip(cols[2:], (float(v) for v in vals)))
                 d["valu_wave_insts_per_launch"] = named.get("SQ_INSTS_VALU")
@@ -35,10 +37,17 @@ if fetch_kb is not None and write_kb is not None:
                 d["lds_wave_insts_per_launch"] = named.get("SQ_INSTS_LDS")
                 d["sq_source"] = f"profiles/{tag}_pmc_SQ.txt"
                 break
+    ks = os.path.join(src, f"{tag}_kernel_stats.txt")
+    if os.path.exists(ks):
+        for line in open(ks):
+            if pattern in line:
+                m = re.findall(r"[-+]?\d*\.\d+|\d+", line)
+                d["kernel_stats_line"] = line.strip()
+                break
     bj = os.path.join(src, f"bench_{tag}_under_rocprof.json")
     try:
         d["gaussians"] = json.loads(open(bj).read().strip().splitlines()[-1])["config"]["gaussians"]
     except Exception:
         pass
-    json.dump(d, open(os.path.join("profiles", f"pmc_blend_bwd{suffix}.json"), "w"), indent=1)
+    json.dump(d, open(os.path.join("profiles", f"{stem}{suffix}.json"), "w"), indent=1)
     print(d)
