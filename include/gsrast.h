@@ -16,7 +16,16 @@
  *   - functions return a status (or num_rendered) instead of throwing; gsrast_last_error() has text;
  *   - the contents of the three state buffers are opaque and differ from the reference's chunks
  *     (typed SoA arrays); gsrast_debug_export() copies them out in the
- *     reference's array layout for parity tests.
+ *     reference's array layout for parity tests;
+ *   - `prefiltered` != 0 is the caller's promise that no Gaussian lies behind the near plane: the reference prints and TRAPS the kernel
+ *     when one does (auxiliary.h:156-160), gsrast_forward returns GSRAST_E_ARG (after waiting for the device: the promise costs a
+ *     synchronisation; SaRO-GS always passes False);
+ *   - arithmetic, all within north_star's 1e-5 bar and checked against the fp64 oracle: exp() is a fixed sequence of exactly rounded fp32
+ *     operations shared with the oracle (options.exp_mode 0; the reference calls exp(), forward.cu:349), so "bit-exact forward" means
+ *     HIP == oracle; the blend backward rebuilds T with v_rcp_f32(1 - alpha) (1 ulp) where the reference divides (backward.cu:503), takes the
+ *     geometric sums about the 8 x 8 pixel block's origin and shifts them to the Gaussian's mean afterwards (csrc/gsrast_blend.h: separable
+ *     moments), and evaluates backward.cu:505-507's accum_rec for the NEXT contributor (same operands); gradients are accumulated with
+ *     float atomics into one 64-byte record per Gaussian (the reference: nine atomics per pixel pair), so their last bits depend on the order.
  * No torch / STL types cross this boundary.
  */
 #ifndef GSRAST_H_INCLUDED
@@ -132,6 +141,11 @@ size_t gsrast_image_bytes(int width, int height);
  * chunks = N records of chunk_stride floats: [3P floats g_r | 3 floats campos_r | padding].  All device pointers. */
 int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
                            float scale, float* dL_dsh /*[P][M][3]*/, void* stream);
+/* Round 5: which Gaussians can have a non-zero gradient row in this view?  flags[i] = 1 if some pixel consumed Gaussian i in the forward
+ * that filled geom_buffer (its blend keeps one bit per Gaussian for the backward, csrc/gsrast_common.h: GeomLayout::untouched), 0 if none
+ * did -- every gradient row of such a Gaussian is exactly zero; all 1 if that forward kept no bits.  The sparse exchange takes its
+ * "rows some rank touched" from here instead of scanning the five gradient arrays (56 B per Gaussian). */
+int gsrast_touched_rows(int P, const char* geom_buffer, unsigned char* flags /*[P]*/, void* stream);
 /* The same recombination for an exchange that moves only the rows some rank touched, and for the raw leaves (round 4):
  *   chunks = N records of chunk_stride floats: [3 * rows floats g_r | 3 floats campos_r | padding], rows <= P;
  *   row_of [P] or NULL: Gaussian i's factor is row row_of[i] of every record, -1 = no rank sent it (its dL/dsh is zero);

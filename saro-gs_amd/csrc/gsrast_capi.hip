@@ -1907,6 +1907,24 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
     return GSRAST_OK;
 }
 
+__global__ void __launch_bounds__(256)
+touched_rows_kernel(int P, const unsigned long long* __restrict__ untouched, const uint32_t* __restrict__ scalars, unsigned char* __restrict__ flags)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    flags[i] = scalars[SC_TOUCH_VALID] != 0u ? (unsigned char)(((untouched[i >> 6] >> (i & 63)) & 1ull) ^ 1ull) : (unsigned char)1;
+}
+int gsrast_touched_rows(int P, const char* geom_buffer, unsigned char* flags, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || (P > 0 && (!geom_buffer || !flags))) return fail(GSRAST_E_ARG, "touched_rows: bad arguments");
+    if (P == 0) return GSRAST_OK;
+    const GeomLayout GL = geom_layout((size_t)P);
+    touched_rows_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, at<unsigned long long>(geom_buffer, GL.untouched), at<uint32_t>(geom_buffer, GL.scalars), flags);
+    GS_LAUNCHED("touched_rows");
+    return GSRAST_OK;
+}
+
 int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
                            float scale, float* dL_dsh, void* stream)
 {

@@ -34,7 +34,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
+    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query", "gsrast_policy_event",
@@ -173,6 +173,8 @@ def lib() -> C.CDLL:
     L.gsrast_loss_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
     L.gsrast_sh_grad_combine.restype = ci
     L.gsrast_sh_grad_combine.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, cf, vp, vp]
+    L.gsrast_touched_rows.restype = ci
+    L.gsrast_touched_rows.argtypes = [ci, vp, vp, vp]
     L.gsrast_sh_grad_combine_rows.restype = ci
     L.gsrast_sh_grad_combine_rows.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_activate_forward.restype = ci
@@ -289,6 +291,19 @@ class GradArena:
         if zero:
             v.zero_()
         return v
+
+
+def _export_touched(ar: "GradArena", P: int, geomBuffer: torch.Tensor, dev: torch.device) -> None:
+    """gsrast_touched_rows into the arena (round 5): one byte per Gaussian, 1 = some pixel of THIS view consumed it -- what the sparse
+    exchange (view_parallel.exchange_gradients(sparse=True)) takes the union over ranks of, instead of scanning the gradient arrays."""
+    t = getattr(ar, "touched", None)
+    if t is None or t.numel() != P or t.device != dev:
+        t = ar.touched = torch.empty(P, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().gsrast_touched_rows(P, _ptr(geomBuffer), t.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_touched_rows")
+    ar.touched_fresh = True
 
 
 _grad_arena: Optional[GradArena] = None
@@ -465,6 +480,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 rc = call(0)
         if rc != 0:
             raise _err(rc, "gsrast_backward")
+        if factors:
+            _export_touched(ar, P, geomBuffer, dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
@@ -601,6 +618,8 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
                 rc = call(0)
         if rc != 0:
             raise _err(rc, "gsrast_backward_raw")
+        if factors:
+            _export_touched(ar, P, geomBuffer, dev)
     if keep["motion_res"] is not None:
         g["motion_res"] = g["xyz"]
     return g

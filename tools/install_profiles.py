@@ -13,7 +13,7 @@ def per_launch(counter, kernel):
     p = os.path.join(src, f"{tag}_pmc_{counter}.txt")
     for line in open(p):
         if kernel in line:
-            return float(line.split()[-1])
+            return float(line.split()[-2])          # (kernel, calls, value, all)
     return None
 for kernel, pattern, stem in (("blend_bwd_cull_t_kernel", "blend_bwd_cull", "pmc_blend_bwd"), ("blend_fwd_cull_kernel", "blend_fwd_cull", "pmc_blend_fwd")):
     fetch_kb, write_kb = per_launch("FETCH_SIZE", pattern), per_launch("WRITE_SIZE", pattern)
@@ -30,7 +30,7 @@ for kernel, pattern, stem in (("blend_bwd_cull_t_kernel", "blend_bwd_cull", "pmc
         cols = lines[0].split()
         for line in lines[1:]:
             if pattern in line:
-                vals = line.split()[-(len(cols) - 2):]            # the numeric columns after kernel name and calls
+                vals = line.split()[-(len(cols) - 2):]            # the numeric columns after kernel name and calls (the last one, `all`, is a count)
                 named = dict(zip(cols[2:], (float(v) for v in vals)))
                 d["valu_wave_insts_per_launch"] = named.get("SQ_INSTS_VALU")
                 d["salu_wave_insts_per_launch"] = named.get("SQ_INSTS_SALU")

@@ -12,7 +12,7 @@ for kv in sys.argv[4:]:
     k, v = kv.split("=")
     rast._C.set_option(k, int(v))
 dev = torch.device("cuda:0")
-wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, V, dev)
+wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, V, dev, poses=V)      # V poses of the ring dealt round-robin, as the headline
 for i in range(N):
     wl.step(None, 1)
 torch.cuda.synchronize()
