@@ -44,6 +44,18 @@ def test_a_pause_belongs_to_the_scene_that_earned_it(ctx):
     assert ev("begin", 3_000_000, Q, 0) == 1            # another scene: void
 
 
+def test_what_was_learned_on_one_scene_is_void_on_another(ctx):
+    ev = ctx.policy_event
+    ev("begin", P, Q, 0)
+    for _ in range(6):
+        ev("pass", Q // 5, Q, 1)
+    assert ev("get", MARGIN) == 16 and ev("get", TAU_REQ) > 40 and ev("get", TAU_FORCE) == 512
+    ev("begin", P + P // 20, Q, 0)                      # the same scene after a densification step: kept
+    assert ev("get", MARGIN) == 16
+    ev("begin", 1_000_000, Q, 0)                        # another scene: a fresh policy
+    assert ev("get", MARGIN) == 6 and ev("get", TAU_REQ) == 10 and ev("get", TAU_FORCE) == 0 and ev("get", SCORE) == 0
+
+
 def test_completion_passes_are_scored_by_size(ctx):
     ev = ctx.policy_event
     ev("begin", P, Q, 0)
