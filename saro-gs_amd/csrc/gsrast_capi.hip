@@ -979,7 +979,11 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // runs, and paused for CUT_PAUSE forwards whenever a cut forward removed fewer than that (a surface-like scene; measured
     // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
     CutPolicy& pol = ctx->pol;          // (the decisions: gsrast_policy.h)
-    pol.begin_forward((uint32_t)P);     // (a pause belongs to the scene that earned it: a context that moves on to a scene of another size starts afresh)
+    if (pol.begin_forward((uint32_t)P)) {     // (what was learned belongs to the scene it was learned on: a context that moves on to a scene of another size starts afresh)
+        if (hints) GS_HIP(hipMemsetAsync(hints, 0, offsetof(HintTable, cam), s));      // (keys, stamps, clock: every slot free again; ordered in front of this call's lookup)
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->pose_seen.clear(); ctx->Qe_hint = 0; ctx->Qe_hint_tau = 0;
+    }
     const bool cut_pays = pol.pays(ctx->last_Q.load(), g_list_cut_always.load() != 0);
     const int cut_cs = cut_cell_shift((size_t)cam.gx, (size_t)cam.gy);
     // Round 4: the cut no longer needs the pose table.  With remembered cut depths (a pose the table knows) the first pass lists what lies

@@ -44,17 +44,21 @@ struct CutPolicy {
     // start of a forward over P Gaussians: what the policy has learned belongs to the scene (size) it learned it on -- a pause, a widened
     // margin, a raised requirement, a switch to predicted cuts earned on one scene are void on another (a context that moves from a 3 M scene
     // to a 1 M one must not render the second with the first's scars: bench.py's sweep, a caller with several models)
-    void begin_forward(uint32_t P)
+    // Returns true when the scene is another one than the last forward's (the caller then also forgets the pose table's entries: cut
+    // depths remembered for a pose of the OLD scene are running maxima and would take eight visits to fade).
+    bool begin_forward(uint32_t P)
     {
         const uint32_t pp = pause_P.load();
         if (pause.load() > 0 && (pp > P ? pp - P : P - pp) > pp / 8) pause = 0;
         const uint32_t sp = scene_P.load();
-        if (sp == 0u) scene_P = P;
-        else if ((sp > P ? sp - P : P - sp) > sp / 8) {
+        if (sp == 0u) { scene_P = P; return false; }
+        if ((sp > P ? sp - P : P - sp) > sp / 8) {
             scene_P = P;
             fb_score = 0; fb_pause = 0; ok_streak = 0; small_streak = 0; margin = MARGIN_MIN; margin_streak = 0;
             tau_req = tau_min.load(); tau_force = 0; tau_streak = 0; pass_rate = 0;
+            return true;
         }
+        return false;
     }
     bool pays(uint32_t last_Q, bool always) const { return always || (last_Q >= MIN_RUNS && pause.load() == 0); }
     void sits_out() { dec_to_zero(pause); }             // a forward without the cut serves one forward of a pause
