@@ -261,6 +261,8 @@ int gsrast_context_query(const gsrast_context* ctx, const char* name);
  *   "size"   (a = early-run hint, b = capacity in column runs, c = 1: an early set is expected) -> column runs the launches over the cut lists are sized for
  *   "grow"   (a = count) -> the capacity requested for it;   "follow" (a = hint, b = this forward's count, c = shift) -> the next hint
  *   "get"    (a = 0 pause, 1 score, 2 margin x 4, 3 tau_req, 4 tau_force, 5 length of the last fallback pause)
+ *   "zrange" (a = first | last << 16 occupied bin of the depth histogram a forward filled with the context's current table) -> the next table's
+ *            shift, | 256 if the current table was a learned one that held every key;   "zget" (a = 0 klo / 256, 1 shift, 2 khi / 256)
  *   "reset"  (a fresh policy: tests);   "tau_min" (a = the predicted cut's requirement and its floor: experiments)
  * ctx NULL = the calling thread's context. */
 int gsrast_policy_event(gsrast_context* ctx, const char* what, int a, int b, int c);

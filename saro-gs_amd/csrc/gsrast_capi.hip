@@ -405,8 +405,7 @@ struct gsrast_context {
     // costs one forward its cut (an address reused for another camera: the snapshot finds no slot, nothing is predicted), never a result.
     std::unordered_map<const void*, uint8_t> pose_seen;
     // equalised depth buckets (gsrast_common.h): the key range the depth histogram's bins cover, learned from the previous forwards
-    std::atomic<uint32_t> zh_klo{ZH_KLO_DEFAULT}; std::atomic<int> zh_shift{ZH_SHIFT_DEFAULT};
-    std::atomic<uint32_t> zh_khi{0};   // ... and its upper end BEFORE the bins' width was rounded up to a power of two (0: nothing learned): the predicted cut's bins span [zh_klo, zh_khi]
+    DepthRange zrange;                 // (gsrast_policy.h) klo / shift: the histogram's bins; khi: the range's un-rounded upper end (the predicted cut's bins span [klo, khi])
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
@@ -728,6 +727,12 @@ int gsrast_policy_event(gsrast_context* c, const char* what, int a, int b, int c
     if (!strcmp(what, "follow")) return (int)follow_hint((uint32_t)a, (uint32_t)b, c3);
     if (!strcmp(what, "reset")) { c->pol.~CutPolicy(); new (&c->pol) CutPolicy(); return 0; }      // (tests: a fresh policy, whatever earlier calls left)
     if (!strcmp(what, "tau_min")) { pol.tau_min = std::max(1, a); pol.tau_req = std::max(1, a); return a; }      // (experiments: the predicted cut's requirement and its floor)
+    if (!strcmp(what, "zrange")) {      // a = first | last << 16 occupied bin of a forward that used the context's current table -> the next table's shift (| 256 if that table had held every key)
+        const uint32_t k = c->zrange.klo.load(); const int sh = c->zrange.shift.load();
+        const bool held = c->zrange.learn((uint32_t)a, k, sh);
+        return c->zrange.shift.load() | (held ? 256 : 0);
+    }
+    if (!strcmp(what, "zget")) return a == 0 ? (int)(c->zrange.klo.load() >> 8) : a == 1 ? c->zrange.shift.load() : (int)(c->zrange.khi.load() >> 8);      // (keys / 256: they do not fit an int)
     if (!strcmp(what, "get")) {
         switch (a) { case 0: return pol.pause.load(); case 1: return pol.fb_score.load(); case 2: return pol.margin.load(); case 3: return pol.tau_req.load();
                      case 4: return pol.tau_force.load(); case 5: return pol.fb_pause.load(); default: return GSRAST_E_ARG; }
@@ -943,7 +948,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // near-pose borrowing (HintTable::cam): the position tolerance is relative to the camera's distance from the scene = the middle of the
     // depth range the context has learned (0: nothing learned yet, the kernel falls back to the distance from the origin)
     float near_scale2 = 0.0f;
-    {   const uint32_t klo = ctx->zh_klo.load(); const int sh = ctx->zh_shift.load();
+    {   const uint32_t klo = ctx->zrange.klo.load(); const int sh = ctx->zrange.shift.load();
         if (!(klo == ZH_KLO_DEFAULT && sh == ZH_SHIFT_DEFAULT)) {
             const uint64_t kmid = (uint64_t)klo + (((uint64_t)ZH_MID << sh) >> 1);
             if (kmid < (uint64_t)ZH_KEY_TOP) { const uint32_t kb = (uint32_t)kmid; float z; memcpy(&z, &kb, sizeof z); if (z > 0.0f && z < 1e18f) near_scale2 = z * z; }
@@ -956,7 +961,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool bucket_sort = runbin && o.depth_sort == 0 && (size_t)P >= BUCKET_SORT_MIN_P && ctx->bucket_skip.load() == 0;
     const uint32_t nbk = depth_buckets_host((size_t)P);
     // equalised depth buckets: the histogram's bins (range hint of this context) and which waves of preprocess_fwd are sampled (512-1024 of them)
-    const uint32_t zh_klo = ctx->zh_klo.load(); const int zh_shift = ctx->zh_shift.load();
+    const uint32_t zh_klo = ctx->zrange.klo.load(); const int zh_shift = ctx->zrange.shift.load();
     uint32_t zh_wave_mask = 0u;
     while ((((size_t)P + 63) / 64) / ((size_t)zh_wave_mask + 1) > 1024) zh_wave_mask = 2u * zh_wave_mask + 1u;
     // Colour half of the per-Gaussian forward (SH -> RGB: most of its bytes) on the context's side stream, forked off the
@@ -1005,7 +1010,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool tau_on = cut && tau_mode && !pose_expected;
     uint32_t* tau_hist = tau_on ? at<uint32_t>(img, IL.tau_hist) : nullptr;
     TauBins tau_bins{0u, 0.0f, 0.0f, (1u << g_tau_sample.load()) - 1u};      // (scale 0: the context has not learned a depth range yet -- no prediction in this call)
-    {   const uint32_t klo = ctx->zh_klo.load(), khi = ctx->zh_khi.load();
+    {   const uint32_t klo = ctx->zrange.klo.load(), khi = ctx->zrange.khi.load();
         if (tau_on && khi > klo + (uint32_t)TAU_BINS) { tau_bins.lo = klo; tau_bins.scale = (float)TAU_BINS / (float)(khi - klo); tau_bins.inv_scale = (float)(khi - klo) / (float)TAU_BINS; } }
     uint32_t* zcut_used = cut ? at<uint32_t>(img, IL.zcut_used) : nullptr;
     // The backward's gradient records (64 B / Gaussian) are zero-filled by the forward: inside the default (culling) blend kernel; by a
@@ -1394,31 +1399,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // equalised depth buckets: the MIDDLE of the next forward's histogram (448-895 bins) covers this one's occupied key range, padded by
     // an eighth on either side (the tails beyond take a view a whole range away); it widens at once and narrows slowly (consecutive
     // forwards render different views).  Returns whether this call's table was a learned one that held every key.
-    auto learn_depth_range = [&](uint32_t zb) -> bool {
-        if (zb == 0xFFFFFFFFu) return true;
-        const uint32_t first = zb & 0xFFFFu, last = zb >> 16;
-        const long long top = ZH_KEY_TOP, bot = ZH_KLO_DEFAULT;
-        long long kmin = std::max(zh_bin_start(first, zh_klo, zh_shift), bot), kmax = std::min(zh_bin_start(last + 1u, zh_klo, zh_shift), top);
-        if (kmax <= kmin) kmax = kmin + 1;
-        const long long span = kmax - kmin;
-        const bool coarse = zh_shift == ZH_SHIFT_DEFAULT && zh_klo == ZH_KLO_DEFAULT;
-        const bool clipped = first == 0u || last >= (uint32_t)ZH_BINS - 1u;          // keys may lie beyond the table's tails
-        const long long pad_lo = first == 0u ? 4 * span : span / 8 + 1, pad_hi = last >= (uint32_t)ZH_BINS - 1u ? 4 * span : span / 8 + 1;
-        long long lo = std::max(kmin - pad_lo, bot), hi = std::min(kmax + pad_hi, top);
-        if (!coarse) {      // (the middle of the previous table)
-            // (the previous range's upper end BEFORE its bins were rounded up to a power of two, if known: measured against the rounded one
-            // the range never narrowed below half the table -- harmless for the depth buckets, which follow the histogram's shape, but
-            // the predicted cut's 32 bins span [klo, khi] and a bin's width is what its prediction gives away)
-            const uint32_t khi_prev = ctx->zh_khi.load();
-            const long long plo = zh_klo, phi = khi_prev > zh_klo ? (long long)khi_prev : (long long)zh_klo + ((long long)ZH_MID << zh_shift);
-            lo = lo < plo ? lo : plo + (lo - plo) / 8;
-            hi = hi > phi ? hi : phi - (phi - hi) / 8;
-        }
-        int sh = 0;
-        while (((hi - lo) >> sh) >= (long long)ZH_MID) sh++;
-        ctx->zh_klo = (uint32_t)lo; ctx->zh_shift = sh; ctx->zh_khi = (uint32_t)hi;
-        return !coarse && !clipped;
-    };
+    auto learn_depth_range = [&](uint32_t zb) -> bool { return ctx->zrange.learn(zb, zh_klo, zh_shift); };      // (gsrast_policy.h: DepthRange)
     bool sort_redone = false;
     if (!bucket_sort && o.depth_sort == 0) dec_to_zero(ctx->bucket_skip);
     if (bucket_sort) {

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <atomic>
+#include "gsrast_common.h"      // (the depth histogram's bin geometry: ZH_*, zh_bin_start)
 
 namespace gsrast {
 
@@ -101,6 +102,40 @@ struct CutPolicy {
         if (++ok_streak >= 64) fb_pause = 0;
         if (++margin_streak >= 128) { margin_streak = 0; const int m = margin.load(); if (m > MARGIN_MIN) margin = m - 1; }
         if (++tau_streak >= 64) { tau_streak = 0; const int r = tau_req.load(), lo = tau_min.load(); if (r > lo) tau_req = std::max(lo, r - 2); }
+    }
+};
+
+// ---- the depth histogram's key range (gsrast_common.h: equalised depth buckets; the predicted cut's bins) ------------------------------
+// The MIDDLE of the next forward's histogram covers this one's occupied key range padded by an eighth on either side (the tails beyond take
+// a view a whole range away); the range widens at once and narrows by an eighth of the gap per forward (consecutive forwards render
+// different views).  khi is the upper end BEFORE the bins' width is rounded up to a power of two: the predicted cut's 32 bins span [klo, khi].
+struct DepthRange {
+    std::atomic<uint32_t> klo{ZH_KLO_DEFAULT}; std::atomic<int> shift{ZH_SHIFT_DEFAULT}; std::atomic<uint32_t> khi{0};
+    bool coarse() const { return shift.load() == ZH_SHIFT_DEFAULT && klo.load() == ZH_KLO_DEFAULT; }      // nothing learned yet: 4 bins per octave over every finite float
+    // zb = first | last << 16 occupied bin of the histogram a forward filled with the table (call_klo, call_shift); 0xFFFFFFFF: no sample.
+    // Returns whether that table was a learned one that held every key (an overflow of the depth buckets is then the scene's doing).
+    bool learn(uint32_t zb, uint32_t call_klo, int call_shift)
+    {
+        if (zb == 0xFFFFFFFFu) return true;
+        const uint32_t first = zb & 0xFFFFu, last = zb >> 16;
+        const long long top = ZH_KEY_TOP, bot = ZH_KLO_DEFAULT;
+        long long kmin = std::max(zh_bin_start(first, call_klo, call_shift), bot), kmax = std::min(zh_bin_start(last + 1u, call_klo, call_shift), top);
+        if (kmax <= kmin) kmax = kmin + 1;
+        const long long span = kmax - kmin;
+        const bool was_coarse = call_shift == ZH_SHIFT_DEFAULT && call_klo == ZH_KLO_DEFAULT;
+        const bool clipped = first == 0u || last >= (uint32_t)ZH_BINS - 1u;          // keys may lie beyond the table's tails
+        const long long pad_lo = first == 0u ? 4 * span : span / 8 + 1, pad_hi = last >= (uint32_t)ZH_BINS - 1u ? 4 * span : span / 8 + 1;
+        long long lo = std::max(kmin - pad_lo, bot), hi = std::min(kmax + pad_hi, top);
+        if (!was_coarse) {      // (against the previous range -- its UN-rounded upper end if known: measured against the rounded one the range never narrowed below half the table)
+            const uint32_t khi_prev = khi.load();
+            const long long plo = call_klo, phi = khi_prev > call_klo ? (long long)khi_prev : (long long)call_klo + ((long long)ZH_MID << call_shift);
+            lo = lo < plo ? lo : plo + (lo - plo) / 8;
+            hi = hi > phi ? hi : phi - (phi - hi) / 8;
+        }
+        int sh = 0;
+        while (((hi - lo) >> sh) >= (long long)ZH_MID) sh++;
+        klo = (uint32_t)lo; shift = sh; khi = (uint32_t)hi;
+        return !was_coarse && !clipped;
     }
 };
 

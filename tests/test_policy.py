@@ -155,3 +155,35 @@ def test_speculative_launch_sizes(ctx):
     assert ev("size", 4_000_000, 5_000_000, 1) == 5_000_000
     with pytest.raises(ValueError):
         ev("no_such_event")
+
+
+def test_depth_range_widens_at_once_and_narrows_slowly(ctx):
+    """gsrast_policy.h: DepthRange -- the key range the depth histogram's middle bins (and the predicted cut's 32 bins) cover."""
+    ev = ctx.policy_event
+    ZH_TAIL, ZH_MID, ZH_BINS = 64, 896, 1024
+    klo0, sh0 = ev("zget", 0), ev("zget", 1)
+    assert sh0 == 21 and ev("zget", 2) == 0              # nothing learned: 4 bins per octave over every finite float, no upper end
+    # a context's first forward (coarse table): the scene occupies bins 78-83 = depths 2.4 ... 6.7 -- not "held" (the table was not a learned one)
+    r = ev("zrange", 78 | (83 << 16))
+    assert not (r & 256)
+    sh1, klo1, khi1 = ev("zget", 1), ev("zget", 0), ev("zget", 2)
+    assert sh1 < sh0 and klo1 > klo0 and khi1 > klo1     # the table now resolves the scene: finer bins, a range around it
+    span1 = khi1 - klo1
+    # the same scene seen through the learned table occupies the middle (an eighth of padding on either side): held, and the range stays put
+    first = ZH_TAIL + ZH_MID // 10
+    last = ZH_TAIL + int(0.9 * ((span1 * 256) >> sh1))       # (zget returns keys / 256)
+    r = ev("zrange", first | (last << 16))
+    assert r & 256
+    # a view whose keys reach the table's last bin: clipped (not held), the range widens AT ONCE, far beyond the old end
+    r = ev("zrange", first | ((ZH_BINS - 1) << 16))
+    assert not (r & 256) and ev("zget", 2) > khi1
+    wide = ev("zget", 2) - ev("zget", 0)
+    # ... and narrows by an eighth of the gap per forward once the views are narrow again
+    prev = wide
+    for _ in range(40):
+        sh = ev("zget", 1)
+        ev("zrange", (ZH_TAIL + 100) | ((ZH_TAIL + 200) << 16))
+        now = ev("zget", 2) - ev("zget", 0)
+        assert now <= prev
+        prev = now
+    assert prev < wide // 4
