@@ -277,7 +277,9 @@ def roofline_of(st, bwd_ms, P, exp2=None, kernel="blend_bwd_cull_t_kernel"):
                           "traffic / traffic_ratio": (src + ": rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 units per MI355X_MICROARCH.md), committed pass, not this run") if src else None,
                           "valu.wave_insts_per_launch": (src + ": SQ_INSTS_VALU per launch, committed pass, not this run") if src else None,
                           "valu.avg_cycles_per_inst": "profiles/r0x_valu_mix.json over profiles/r02_valu_calib.json (measured issue costs)"},
-           "note": "VALU-issue-bound kernel: valu.issue_slot_frac is the binding fraction; frac is the HBM fraction the contract asks for (small by construction)"}
+           "note": "VALU-issue-bound kernel: valu.issue_slot_frac is the binding fraction; frac is the HBM fraction the contract asks for (small by construction)"
+                   + ("; traffic includes what this kernel does beside K4's algorithmic bytes: the zero-fill of the backward's gradient records (64 B per Gaussian, "
+                      "non-temporal stores) and the untouched-bit atomics" if fwd else "")}
     if exp2:
         out["exp_mode_2"] = exp2
     return out
