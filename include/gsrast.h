@@ -155,6 +155,19 @@ int gsrast_touched_rows(int P, const char* geom_buffer, unsigned char* flags /*[
 int gsrast_sh_grad_combine_rows(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride, int rows,
                                 const int* row_of, float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
 
+/* Round 5: the recombination for the rows of the union ONLY.  idx [rows] (int64, ascending, distinct): record row j is Gaussian idx[j]'s
+ * factor.  Rows of the output arrays outside the union are NOT written: the caller keeps them zero between steps (it clears the previous
+ * step's union, a fraction of the array, instead of having all P rows rewritten: 3 M Gaussians, 150 k in the union, 29 MB instead of 576).
+ * M * 3 must be a multiple of 4 and at most 48; dL_dsh 16-byte aligned. */
+int gsrast_sh_grad_combine_union(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride, int rows,
+                                 const long long* idx, float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
+
+/* Round 5: the compaction either side of the sparse exchange.  Rows idx[0..n) (int64, device) of n_arrays (<= 8) row-major float arrays
+ * (arrays[k]: device pointer, widths[k] floats per row; `arrays` and `widths` themselves are HOST arrays) side by side into
+ * packed [n][sum of widths], and back into those rows (other rows are not touched). */
+int gsrast_rows_pack(long long n, const long long* idx, int n_arrays, const float* const* arrays, const int* widths, float* packed, void* stream);
+int gsrast_rows_unpack(long long n, const long long* idx, int n_arrays, float* const* arrays, const int* widths, const float* packed, void* stream);
+
 /* Parity-test helper: copies internal state out in the reference's array layout
  * (GeometryState / BinningState / ImageState members, rasterizer_impl.h:30-65).  Any output
  * pointer may be NULL.  All pointers are device pointers.  keys_sorted is rebuilt as

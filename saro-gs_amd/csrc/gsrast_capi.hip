@@ -1910,6 +1910,28 @@ int gsrast_touched_rows(int P, const char* geom_buffer, unsigned char* flags, vo
     return GSRAST_OK;
 }
 
+static int rows_pack_impl(bool pack, long long n, const long long* idx, int n_arrays, float* const* arrays, const int* widths, float* packed, void* stream)
+{
+    if (n < 0 || n_arrays < 1 || n_arrays > 8 || !arrays || !widths) return fail(GSRAST_E_ARG, "rows_pack: bad arguments");
+    if (n == 0) return GSRAST_OK;
+    RowArrays a{}; a.n = n_arrays;
+    for (int k = 0; k < n_arrays; k++) {
+        if (!arrays[k] || widths[k] < 1) return fail(GSRAST_E_ARG, "rows_pack: NULL array or width < 1");
+        a.ptr[k] = arrays[k]; a.width[k] = widths[k]; a.total += widths[k];
+    }
+    if (!idx || !packed || n * a.total > 0x7FFFFFFFll * 256) return fail(GSRAST_E_ARG, "rows_pack: NULL index / packed array, or too large");
+    const unsigned blocks = (unsigned)((n * a.total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (pack) rows_pack_kernel<true><<<blocks, 256, 0, s>>>(n, idx, a, packed);
+    else rows_pack_kernel<false><<<blocks, 256, 0, s>>>(n, idx, a, packed);
+    GS_LAUNCHED("rows_pack");
+    return GSRAST_OK;
+}
+int gsrast_rows_pack(long long n, const long long* idx, int n_arrays, const float* const* arrays, const int* widths, float* packed, void* stream)
+{ return rows_pack_impl(true, n, idx, n_arrays, const_cast<float* const*>(arrays), widths, packed, stream); }
+int gsrast_rows_unpack(long long n, const long long* idx, int n_arrays, float* const* arrays, const int* widths, const float* packed, void* stream)
+{ return rows_pack_impl(false, n, idx, n_arrays, arrays, widths, const_cast<float*>(packed), stream); }
+
 int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
                            float scale, float* dL_dsh, void* stream)
 {
@@ -1937,6 +1959,24 @@ int gsrast_sh_grad_combine_rows(int P, int D, int M, int N, const float* means3D
     sh_grad_combine_kernel<<<(P + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(P, D, M, N, means3D, chunks, chunk_stride, scale, dL_dsh, rows, row_of,
                                                                                    d_features_dc, d_features_rest);
     GS_LAUNCHED("sh_grad_combine_rows");
+    return GSRAST_OK;
+}
+
+int gsrast_sh_grad_combine_union(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride, int rows,
+                                 const long long* idx, float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || N < 1 || M < 1 || D < 0 || D > 3 || (D + 1) * (D + 1) > M || rows < 0 || rows > P)
+        return fail(GSRAST_E_ARG, "sh_grad_combine_union: bad sizes");
+    if (P == 0 || rows == 0) return GSRAST_OK;
+    if (!means3D || !chunks || !idx || chunk_stride < (size_t)3 * rows + 3) return fail(GSRAST_E_ARG, "sh_grad_combine_union: NULL or short buffer");
+    if (!dL_dsh && !d_features_dc) return fail(GSRAST_E_ARG, "sh_grad_combine_union: no output array");
+    if (d_features_dc && !d_features_rest) return fail(GSRAST_E_ARG, "sh_grad_combine_union: d_features_dc without d_features_rest");
+    if (M * 3 > PP_SH_MAX || ((M * 3) & 3) || ((uintptr_t)dL_dsh & 15))
+        return fail(GSRAST_E_ARG, "sh_grad_combine_union: needs M = 4, 8, 12 or 16 and a 16-byte aligned dL_dsh");
+    sh_grad_combine_union_kernel<<<(rows + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(rows, idx, D, M, N, means3D, chunks, chunk_stride, scale,
+                                                                                          dL_dsh, d_features_dc, d_features_rest);
+    GS_LAUNCHED("sh_grad_combine_union");
     return GSRAST_OK;
 }
 

@@ -34,7 +34,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
+    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_sh_grad_combine_union", "gsrast_rows_pack", "gsrast_rows_unpack", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query", "gsrast_policy_event",
@@ -177,6 +177,11 @@ def lib() -> C.CDLL:
     L.gsrast_touched_rows.argtypes = [ci, vp, vp, vp]
     L.gsrast_sh_grad_combine_rows.restype = ci
     L.gsrast_sh_grad_combine_rows.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, ci, vp, cf, vp, vp, vp, vp]
+    for fn in (L.gsrast_rows_pack, L.gsrast_rows_unpack):
+        fn.restype = ci
+        fn.argtypes = [C.c_longlong, vp, ci, C.POINTER(vp), C.POINTER(ci), vp, vp]
+    L.gsrast_sh_grad_combine_union.restype = ci
+    L.gsrast_sh_grad_combine_union.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_activate_forward.restype = ci
     L.gsrast_activate_forward.argtypes = [ci, ci] + [vp] * 16
     L.gsrast_activate_backward.restype = ci
@@ -626,10 +631,16 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
 
 
 def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Tensor, n_views: int, scale: float,
-                    rows: Optional[int] = None, row_of: Optional[torch.Tensor] = None, chunk_stride: Optional[int] = None):
-    """dL/dsh of `n_views` views from their factors (include/gsrast.h: gsrast_sh_grad_combine / _rows), written into the arena's
-    SH region(s) -- the tensor(s) autograd already handed out as shs.grad, or as features_dc.grad / features_rest.grad for a raw
-    arena.  rows / row_of: the records hold only `rows` factors, Gaussian i's is row row_of[i] (int32 [P], -1 = not sent)."""
+                    rows: Optional[int] = None, row_of: Optional[torch.Tensor] = None, chunk_stride: Optional[int] = None,
+                    idx: Optional[torch.Tensor] = None):
+    """dL/dsh of `n_views` views from their factors (include/gsrast.h: gsrast_sh_grad_combine / _rows / _union), written into the
+    arena's SH region(s) -- the tensor(s) autograd already handed out as shs.grad, or as features_dc.grad / features_rest.grad for a
+    raw arena.  rows / row_of: the records hold only `rows` factors, Gaussian i's is row row_of[i] (int32 [P], -1 = not sent).
+
+    idx (int64 [rows], ascending, distinct; round 5) instead of row_of: record row j is Gaussian idx[j]'s, and ONLY those rows of the
+    SH region are written.  The region is kept zero elsewhere from one step to the next: the rows of the previous union are cleared
+    first (the whole region once after a dense combine or a fresh arena).  Whoever writes into those .grad tensors in a way that makes
+    a zero row non-zero must set arena.sh_rows_known = False."""
     L = lib()
     P, M = arena.P, arena.M
     if getattr(arena, "raw", False):
@@ -639,6 +650,30 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
     if P == 0:
         return whole if whole is not None else (dc, rest)
     dev = means3D.device
+    union = idx is not None and (M * 3) % 4 == 0 and M * 3 <= 48
+    if union:
+        views = [v.view(P, -1) for v in (whole, dc, rest) if v is not None and v.numel()]
+        prev = getattr(arena, "_sh_union", None)
+        if not getattr(arena, "sh_rows_known", False) or prev is None:
+            for v in views:
+                v.zero_()
+        else:
+            for v in views:
+                v.index_fill_(0, prev, 0.0)
+        arena._sh_union, arena.sh_rows_known = idx, True
+        with torch.cuda.device(dev):
+            rc = L.gsrast_sh_grad_combine_union(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
+                                                int(chunk_stride if chunk_stride is not None else arena.chunk), int(idx.numel()),
+                                                idx.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
+                                                torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise _err(rc, "gsrast_sh_grad_combine_union")
+        return whole if whole is not None else (dc, rest)
+    if idx is not None:                  # (an M the union kernel does not take: the row map form)
+        row_of = torch.full((P,), -1, dtype=torch.int32, device=dev)
+        row_of[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=dev)
+        rows = int(idx.numel())
+    arena.sh_rows_known = False
     with torch.cuda.device(dev):
         rc = L.gsrast_sh_grad_combine_rows(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
                                            int(chunk_stride if chunk_stride is not None else arena.chunk), int(P if rows is None else rows),
@@ -647,6 +682,24 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
     if rc != 0:
         raise _err(rc, "gsrast_sh_grad_combine_rows")
     return whole if whole is not None else (dc, rest)
+
+
+def rows_pack(idx: torch.Tensor, arrays, packed: torch.Tensor, unpack: bool = False) -> torch.Tensor:
+    """Rows `idx` (int64) of the [P, w_k] float32 arrays side by side in packed [n, sum w_k] (include/gsrast.h: gsrast_rows_pack), or --
+    unpack=True -- back into those rows.  One launch either way."""
+    n, k = int(idx.numel()), len(arrays)
+    widths = [int(a.shape[1]) for a in arrays]
+    if packed.shape != (n, sum(widths)) or not packed.is_contiguous() or any(not a.is_contiguous() for a in arrays):
+        raise ValueError("rows_pack: packed must be a contiguous [n, sum of widths] array, the arrays contiguous")
+    ptrs = (C.c_void_p * k)(*[a.data_ptr() for a in arrays])
+    wid = (C.c_int * k)(*widths)
+    dev = packed.device
+    with torch.cuda.device(dev):
+        fn = lib().gsrast_rows_unpack if unpack else lib().gsrast_rows_pack
+        rc = fn(n, idx.data_ptr(), k, ptrs, wid, packed.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_rows_pack")
+    return packed
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

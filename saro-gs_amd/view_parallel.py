@@ -175,9 +175,7 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
         segs = arena.dense_segments()
         fac = arena.factor[: 3 * P].view(P, 3)
         # "touched" = any of the row's 14 floats is non-zero (all five arrays are looked at: a sum can cancel to exactly zero in one of
-        # them); the flag and the row map live on the arena, not in fresh [P] tensors every step
-        if getattr(arena, "_row_of", None) is None or arena._row_of.numel() != P:
-            arena._row_of = torch.empty(P, dtype=torch.int32, device=fac.device)
+        # them); the flag lives on the arena, not in a fresh [P] tensor every step
         if getattr(arena, "touched_fresh", False) and arena.touched.numel() == P:
             # round 5: the backward left one byte per Gaussian, "some pixel of this view consumed it" (the forward blend's untouched bits,
             # gsrast_touched_rows): a superset of the rows with a non-zero gradient, for 1 B instead of 56 B read per Gaussian
@@ -193,22 +191,27 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
         dist.all_reduce(touched, op=dist.ReduceOp.MAX)
         idx = torch.nonzero(touched, as_tuple=False).squeeze(1)          # (host synchronisation: every rank learns the same n)
         n = int(idx.numel())
-        comp = torch.cat([sg.index_select(0, idx) for sg in segs], dim=1).contiguous()       # [n, 11]
-        allreduce_mean_inplace(comp.view(-1), batch)
-        o = 0
-        for sg in segs:
-            sg.index_copy_(0, idx, comp[:, o: o + sg.shape[1]])
-            o += sg.shape[1]
         stride = ((3 * n + 3 + 3) // 4) * 4
-        mine = torch.zeros(stride, dtype=torch.float32, device=fac.device)
-        mine[: 3 * n] = fac.index_select(0, idx).reshape(-1)
+        mine = torch.empty(stride, dtype=torch.float32, device=fac.device)
+        if fac.is_cuda:                 # one launch each way (gsrast_rows_pack) instead of an index_select / index_copy_ per array
+            comp = _C.rows_pack(idx, segs, torch.empty((n, sum(sg.shape[1] for sg in segs)), dtype=torch.float32, device=fac.device))
+            allreduce_mean_inplace(comp.view(-1), batch)
+            _C.rows_pack(idx, segs, comp, unpack=True)
+            _C.rows_pack(idx, [fac], mine[: 3 * n].view(n, 3))
+        else:                           # (CPU tensors: the gloo tests of this function)
+            comp = torch.cat([sg.index_select(0, idx) for sg in segs], dim=1).contiguous()       # [n, 11]
+            allreduce_mean_inplace(comp.view(-1), batch)
+            o = 0
+            for sg in segs:
+                sg.index_copy_(0, idx, comp[:, o: o + sg.shape[1]])
+                o += sg.shape[1]
+            mine[: 3 * n] = fac.index_select(0, idx).reshape(-1)
+        mine[3 * n:] = 0.0
         mine[3 * n: 3 * n + 3] = arena.factor[3 * P: 3 * P + 3]
         gathered = torch.empty(n_views * stride, dtype=torch.float32, device=fac.device)
         dist.all_gather_into_tensor(gathered, mine)
-        row_of = arena._row_of                     # (cached on the arena: no fresh [P] tensor per step)
-        row_of.fill_(-1)
-        row_of[idx] = torch.arange(n, dtype=torch.int32, device=fac.device)
-        _C.sh_grad_combine(arena, means3D, gathered, n_views, 1.0 / batch, rows=n, row_of=row_of, chunk_stride=stride)
+        # round 5: the recombination writes the union's rows only (29 MB of 576 at 3 M); rows outside it are kept zero from step to step
+        _C.sh_grad_combine(arena, means3D, gathered, n_views, 1.0 / batch, chunk_stride=stride, idx=idx)
         return {"allreduce": comp.numel() * 4 + P, "allgather": stride * 4, "rows": n}
     allreduce_mean_inplace(arena.dense, batch)
     if multi:

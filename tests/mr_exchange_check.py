@@ -50,6 +50,37 @@ def main():
     wl.sparse = False
     assert 0 < sent["rows"] < P and sent["allreduce"] < P * 44, sent          # (fewer rows than Gaussians: most are never blended)
 
+    # consecutive sparse steps over DIFFERENT views on ONE arena (round 5: the recombination writes the union's rows only and the
+    # exchange clears the previous union's -- a row that leaves the union must read zero again), against the plain all-reduce
+    wa = bench.Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=5, dev=dev, poses=3)
+    wb = bench.Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=5, dev=dev, poses=3)
+    wb.sparse = True
+    arena_a, arena_b = _C.GradArena(P, 16, dev, world=world), _C.GradArena(P, 16, dev, sh_factors=True, world=world)
+    worst_seq, unions = 0.0, []
+    for s in range(4):
+        if s == 3:                      # a dense combine in between voids what is known about the rows: the next sparse step clears all
+            wb.sparse = False
+        _C.set_grad_arena(arena_a)
+        wa.step(arena_a, world)
+        _C.set_grad_arena(arena_b)
+        wb.step(arena_b, world)
+        torch.cuda.synchronize()
+        unions.append(wb.exchanged["rows"])
+        for k in wa.leaves:
+            a, b = wa.leaves[k].grad, wb.leaves[k].grad
+            worst_seq = max(worst_seq, ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item())
+    wb.sparse = True
+    _C.set_grad_arena(arena_a)
+    wa.step(arena_a, world)
+    _C.set_grad_arena(arena_b)
+    wb.step(arena_b, world)
+    torch.cuda.synchronize()
+    for k in wa.leaves:
+        a, b = wa.leaves[k].grad, wb.leaves[k].grad
+        worst_seq = max(worst_seq, ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item())
+    _C.set_grad_arena(None)
+    assert worst_seq <= 1.0 and len(set(unions[:3])) > 1, (worst_seq, unions)     # (the unions differed from step to step)
+
     # the RAW leaves (GaussianRasterizerRaw: SaRO-GS's call pattern, `shs` is cat(features_dc, features_rest), never a leaf)
     L = wl.leaves
     raw = dict(xyz=L["means3D"].detach().clone(), rotation=L["rotations"].detach().clone(), scaling=torch.log(L["scales"].detach()),

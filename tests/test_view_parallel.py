@@ -373,7 +373,11 @@ def _sparse_worker(rank, world, port, out_dir, raw):
     means = torch.from_numpy(sc["means3D"])
     calls = {}
 
-    def combine(ar, means3D, chunks, n_views, scale, rows=None, row_of=None, chunk_stride=None):      # the HIP kernel's arithmetic, in torch
+    def combine(ar, means3D, chunks, n_views, scale, rows=None, row_of=None, chunk_stride=None, idx=None):      # the HIP kernel's arithmetic, in torch
+        if idx is not None:             # (round 5: the union's rows as an index list; rows outside it are left as they are -- zero here)
+            rows = int(idx.numel())
+            row_of = torch.full((ar.P,), -1, dtype=torch.long)
+            row_of[idx] = torch.arange(rows)
         rows = ar.P if rows is None else rows
         stride = ar.chunk if chunk_stride is None else chunk_stride
         row_of = torch.arange(ar.P) if row_of is None else row_of.long()
