@@ -2089,6 +2089,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
             if (rawin) { add(rawg.d_rot_res, 7); add(rawg.d_trbf, 1); add(rawg.d_shs_res, M * 3); add(rawg.d_dc, 3); add(rawg.d_rest, M * 3 - 3); }
             else if (use_sh && !o.sh_grad_factors) add(dL_dsh, M * 3);
             la.n = n;
+            if (g_ablate.load() != 3)      // (3, experiments only: the step without the zero rows -- what a caller with persistent outputs could save)
             {   ProfScope ps(K_LATE_ZERO, side->stream);
                 late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la, at<unsigned long long>(geom, GL.untouched)); }
             hipError_t e = hipGetLastError();

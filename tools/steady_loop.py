@@ -13,6 +13,12 @@ for kv in sys.argv[4:]:
     rast._C.set_option(k, int(v))
 dev = torch.device("cuda:0")
 wl = bench.Workload(rast, scenes, P, 1920, 1080, 3, 0, V, dev, poses=V)      # V poses of the ring dealt round-robin, as the headline
-for i in range(N):
+for i in range(N // 2):
     wl.step(None, 1)
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for i in range(N - N // 2):
+    wl.step(None, 1)
+torch.cuda.synchronize()
+print("steady_loop P=%d poses=%d %s: %.4f ms per step" % (P, V, " ".join(sys.argv[4:]), (time.perf_counter() - t0) * 1e3 / (N - N // 2)))
