@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--exchange", choices=("sparse", "factors", "allreduce"), default="sparse",
-                    help="multi-GPU gradient exchange: 'factors' = all-reduce 11 + all-gather 3 floats/Gaussian, 'sparse' (default) = the "
-                         "same for the rows some rank touched only, 'allreduce' = all-reduce all 59 floats/Gaussian")
+    ap.add_argument("--exchange", choices=("gather", "sparse", "factors", "allreduce"), default="gather",
+                    help="multi-GPU gradient exchange: 'gather' (default) = ONE all-gather of the rows each rank's own view touched (64 B per "
+                         "row), added in rank order; 'factors' = all-reduce 11 + all-gather 3 floats/Gaussian; 'sparse' = the same for the "
+                         "rows some rank touched only; 'allreduce' = all-reduce all 59 floats/Gaussian")
     ap.add_argument("--exp-mode", type=int, default=None, help="0 fixed-sequence (default), 1 ocml, 2 v_exp_f32")
     ap.add_argument("--sweep", type=str, default="100000,300000,1000000,3000000",
                     help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
@@ -1098,7 +1099,7 @@ def main():
         # of all 59 floats.  Both give the batch-mean gradient of set_batch_gradient (saro_gaussian.py:266-276).
         bucket = _C.GradArena(P, 16, dev, sh_factors=(a.exchange != "allreduce"), world=world)
         _C.set_grad_arena(bucket)
-        wl.sparse = a.exchange == "sparse"
+        wl.sparse = "gather" if a.exchange == "gather" else a.exchange == "sparse"
         if a.exchange == "factors":
             import view_parallel
             view_parallel.overlap_factor_exchange(True)     # the all-gather starts between the two phases of the backward
@@ -1185,7 +1186,9 @@ def main():
             # rendered, and the floor for a scene that changes too much between two visits of a pose for the table to help
             "value_cold": no_hint["views_per_s"] if no_hint else None, "ms_per_step_cold": no_hint["ms_per_step"] if no_hint else None,
             "config": {"workload": f"BASELINE configs[4] stress-1080p: {scene_fn}(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
-                                   + ((" + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
+                                   + ((" + RCCL all-gather of the 64-byte gradient rows each rank's view touched (11 dense floats + the 3-float dL/dsh factor), added in rank order"
+                                       if a.exchange == "gather" else
+                                       " + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
                                        + (" -- of the rows some rank touched only" if a.exchange == "sparse" else "")
                                        if a.exchange != "allreduce" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if exchanging else ""),
                        "exchange": a.exchange if exchanging else None,

@@ -168,6 +168,20 @@ int gsrast_sh_grad_combine_union(int P, int D, int M, int N, const float* means3
 int gsrast_rows_pack(long long n, const long long* idx, int n_arrays, const float* const* arrays, const int* widths, float* packed, void* stream);
 int gsrast_rows_unpack(long long n, const long long* idx, int n_arrays, float* const* arrays, const int* widths, const float* packed, void* stream);
 
+/* Round 5: the ALL-GATHER gradient exchange (csrc/gsrast_exchange.h; view_parallel.exchange_gradients(sparse="gather")).  Every rank
+ * sends only the gradient rows its own view touched, 64-byte rows { Gaussian index | 11 dense floats: mean 3, opacity 1, scale 3,
+ * rotation 4 | dL/dsh factor 3 | 0 }, in ONE all-gather of chunks { header row: count, campos x y z | cap rows }, and adds the chunks
+ * into its arrays in rank order.  `dense`: a HOST array of four device pointers, [P][3], [P][1], [P][3], [P][4].
+ *   pack : rows[0] word 0 (the count, zeroed by the caller) counts the touched rows, rows[1 + k] receive them (arrival order), at most cap.
+ *   clear: zeroes, for every row the chunks name, the dense arrays' rows (dense != NULL) and / or the SH arrays' rows (any SH pointer given).
+ *   add  : dense[idx] += scale * row, dL/dsh[idx] += scale * w(dir(means3D[idx] - campos)) (x) factor -- no atomics: indices within a chunk
+ *          are distinct, chunks are added by consecutive launches. */
+int gsrast_grad_rows_pack(int P, const unsigned char* touched /*[P]*/, float* const* dense, const float* factor /*[P][3]*/, uint32_t* rows, uint32_t cap, void* stream);
+int gsrast_grad_rows_clear(const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense /* or NULL */, int M,
+                           float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
+int gsrast_grad_rows_add(const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale,
+                         float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
+
 /* Parity-test helper: copies internal state out in the reference's array layout
  * (GeometryState / BinningState / ImageState members, rasterizer_impl.h:30-65).  Any output
  * pointer may be NULL.  All pointers are device pointers.  keys_sorted is rebuilt as

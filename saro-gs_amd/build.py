@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "diff_gaussian_rasterization_ch3", "libgsrast_hip.so")
 SOURCES = ["gsrast_capi.hip"]
-HEADERS = ["gsrast_common.h", "gsrast_policy.h", "gsrast_preprocess.h", "gsrast_binning.h", "gsrast_blend.h", "gsrast_loss.h", "gsrast_epilogue.h", "gsrast_adam.h", "gsrast_knn.h", "gsrast_hexplane.h",
+HEADERS = ["gsrast_common.h", "gsrast_policy.h", "gsrast_preprocess.h", "gsrast_binning.h", "gsrast_blend.h", "gsrast_loss.h", "gsrast_epilogue.h", "gsrast_adam.h", "gsrast_knn.h", "gsrast_hexplane.h", "gsrast_exchange.h",
            os.path.join("..", "..", "include", "gsrast.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

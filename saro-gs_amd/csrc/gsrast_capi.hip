@@ -21,6 +21,7 @@
 #include "gsrast_adam.h"
 #include "gsrast_knn.h"
 #include "gsrast_hexplane.h"
+#include "gsrast_exchange.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1931,6 +1932,59 @@ int gsrast_rows_pack(long long n, const long long* idx, int n_arrays, const floa
 { return rows_pack_impl(true, n, idx, n_arrays, const_cast<float* const*>(arrays), widths, packed, stream); }
 int gsrast_rows_unpack(long long n, const long long* idx, int n_arrays, float* const* arrays, const int* widths, const float* packed, void* stream)
 { return rows_pack_impl(false, n, idx, n_arrays, arrays, widths, const_cast<float*>(packed), stream); }
+
+// ---- the all-gather gradient exchange (gsrast_exchange.h) ----
+static int grow_arrays(GradRowArrays& a, float* const* dense, int M, float* dL_dsh, float* d_dc, float* d_rest, const char* who, bool need_dense = true)
+{
+    for (int k = 0; k < 4; k++) {
+        if (need_dense && (!dense || !dense[k])) return fail(GSRAST_E_ARG, who);
+        a.dense[k] = dense ? dense[k] : nullptr;
+    }
+    a.sh = dL_dsh; a.dc = d_dc; a.rest = d_rest; a.M = M;
+    if (dL_dsh || d_dc) {
+        if (M < 1 || M * 3 > PP_SH_MAX || ((M * 3) & 3) || ((uintptr_t)dL_dsh & 15) || (d_dc && M > 1 && !d_rest)) return fail(GSRAST_E_ARG, who);
+    }
+    return GSRAST_OK;
+}
+int gsrast_grad_rows_pack(int P, const unsigned char* touched, float* const* dense, const float* factor, uint32_t* rows, uint32_t cap, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || (P > 0 && (!touched || !factor || !rows))) return fail(GSRAST_E_ARG, "grad_rows_pack: bad arguments");
+    if (P == 0) return GSRAST_OK;
+    GradRowArrays a{};
+    if (int rc = grow_arrays(a, dense, 0, nullptr, nullptr, nullptr, "grad_rows_pack: four dense arrays are required")) return rc;
+    grad_rows_pack_kernel<<<(P + GROW_PACK - 1) / GROW_PACK, 256, 0, s>>>(P, touched, a, factor, rows, cap);
+    GS_LAUNCHED("grad_rows_pack");
+    return GSRAST_OK;
+}
+int gsrast_grad_rows_clear(const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense, int M, float* dL_dsh,
+                           float* d_features_dc, float* d_features_rest, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_chunks < 0 || (n_chunks > 0 && cap > 0 && !chunks) || chunk_words < (size_t)(1 + (size_t)cap) * GROW_WORDS) return fail(GSRAST_E_ARG, "grad_rows_clear: bad arguments");
+    if (n_chunks == 0 || cap == 0) return GSRAST_OK;
+    const int what = (dense ? 1 : 0) | ((dL_dsh || d_features_dc) ? 2 : 0);
+    if (!what) return GSRAST_OK;
+    GradRowArrays a{};
+    if (int rc = grow_arrays(a, dense, M, dL_dsh, d_features_dc, d_features_rest, "grad_rows_clear: bad arrays", dense != nullptr)) return rc;
+    const size_t lanes = (size_t)n_chunks * cap * 16;
+    if (lanes > 0x7FFFFFFFull * 256) return fail(GSRAST_E_ARG, "grad_rows_clear: too many rows");
+    grad_rows_clear_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(chunks, n_chunks, chunk_words, cap, a, what);
+    GS_LAUNCHED("grad_rows_clear");
+    return GSRAST_OK;
+}
+int gsrast_grad_rows_add(const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale, float* dL_dsh,
+                         float* d_features_dc, float* d_features_rest, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (cap == 0) return GSRAST_OK;
+    if (!chunk || !means3D || D < 0 || D > 3 || ((dL_dsh || d_features_dc) && (D + 1) * (D + 1) > M)) return fail(GSRAST_E_ARG, "grad_rows_add: bad arguments");
+    GradRowArrays a{};
+    if (int rc = grow_arrays(a, dense, M, dL_dsh, d_features_dc, d_features_rest, "grad_rows_add: bad arrays")) return rc;
+    grad_rows_add_kernel<<<(cap + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(chunk, cap, a, means3D, D, scale);
+    GS_LAUNCHED("grad_rows_add");
+    return GSRAST_OK;
+}
 
 int gsrast_sh_grad_combine(int P, int D, int M, int N, const float* means3D, const float* chunks, size_t chunk_stride,
                            float scale, float* dL_dsh, void* stream)

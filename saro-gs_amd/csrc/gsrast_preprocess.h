@@ -1384,34 +1384,40 @@ late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, c
 // bit-identical to what preprocess_bwd_kernel writes itself (0 + w*g).
 // rows / row_of (gsrast_sh_grad_combine_rows): the records hold `rows` factors, Gaussian i's is row row_of[i] (-1: nobody sent it, its
 // gradient is zero); d_dc / d_rest: the result split into SaRO-GS's two SH leaves (and / or whole into dL_dsh).
+// one view's term of dL/dsh for a Gaussian at `pos`: acc[k][c] += w_k(dir(pos - campos)) * g[c]
+__device__ __forceinline__ void sh_factor_term(float (&acc)[PP_SH_MAX], const float (&pos)[3], int D, float cx, float cy, float cz, float g0, float g1, float g2)
+{
+    const float o0 = pos[0] - cx, o1 = pos[1] - cy, o2 = pos[2] - cz;
+    const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+    const float x = o0 / len, y = o1 / len, z = o2 / len;
+    const float g[3] = { g0, g1, g2 };
+#define ACC(k, w) { const float w_ = (w); acc[(k) * 3 + 0] += w_ * g[0]; acc[(k) * 3 + 1] += w_ * g[1]; acc[(k) * 3 + 2] += w_ * g[2]; }
+    ACC(0, kSH0);
+    if (D > 0) {
+        ACC(1, -kSH1 * y); ACC(2, kSH1 * z); ACC(3, -kSH1 * x);
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            ACC(4, kSH2[0] * xy); ACC(5, kSH2[1] * yz); ACC(6, kSH2[2] * (2.0f * zz - xx - yy));
+            ACC(7, kSH2[3] * xz); ACC(8, kSH2[4] * (xx - yy));
+            if (D > 2) {
+                ACC(9, kSH3[0] * y * (3.0f * xx - yy)); ACC(10, kSH3[1] * xy * z);
+                ACC(11, kSH3[2] * y * (4.0f * zz - xx - yy));
+                ACC(12, kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
+                ACC(13, kSH3[4] * x * (4.0f * zz - xx - yy)); ACC(14, kSH3[5] * z * (xx - yy));
+                ACC(15, kSH3[6] * x * (xx - 3.0f * yy));
+            }
+        }
+    }
+#undef ACC
+}
 // the sum over the N records for one Gaussian at `pos` whose factor is row `row` of each record
 __device__ __forceinline__ void sh_factor_sum(float (&acc)[PP_SH_MAX], const float (&pos)[3], int D, int N, const float* __restrict__ chunks,
                                               size_t stride, int rows, int row)
 {
     for (int r = 0; r < N; r++) {
         const float* ch = chunks + (size_t)r * stride;
-        const float o0 = pos[0] - ch[3 * (size_t)rows], o1 = pos[1] - ch[3 * (size_t)rows + 1], o2 = pos[2] - ch[3 * (size_t)rows + 2];
-        const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
-        const float x = o0 / len, y = o1 / len, z = o2 / len;
-        const float g[3] = { ch[3 * (size_t)row], ch[3 * (size_t)row + 1], ch[3 * (size_t)row + 2] };
-#define ACC(k, w) { const float w_ = (w); acc[(k) * 3 + 0] += w_ * g[0]; acc[(k) * 3 + 1] += w_ * g[1]; acc[(k) * 3 + 2] += w_ * g[2]; }
-        ACC(0, kSH0);
-        if (D > 0) {
-            ACC(1, -kSH1 * y); ACC(2, kSH1 * z); ACC(3, -kSH1 * x);
-            if (D > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                ACC(4, kSH2[0] * xy); ACC(5, kSH2[1] * yz); ACC(6, kSH2[2] * (2.0f * zz - xx - yy));
-                ACC(7, kSH2[3] * xz); ACC(8, kSH2[4] * (xx - yy));
-                if (D > 2) {
-                    ACC(9, kSH3[0] * y * (3.0f * xx - yy)); ACC(10, kSH3[1] * xy * z);
-                    ACC(11, kSH3[2] * y * (4.0f * zz - xx - yy));
-                    ACC(12, kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
-                    ACC(13, kSH3[4] * x * (4.0f * zz - xx - yy)); ACC(14, kSH3[5] * z * (xx - yy));
-                    ACC(15, kSH3[6] * x * (xx - 3.0f * yy));
-                }
-            }
-        }
-#undef ACC
+        sh_factor_term(acc, pos, D, ch[3 * (size_t)rows], ch[3 * (size_t)rows + 1], ch[3 * (size_t)rows + 2],
+                       ch[3 * (size_t)row], ch[3 * (size_t)row + 1], ch[3 * (size_t)row + 2]);
     }
 }
 

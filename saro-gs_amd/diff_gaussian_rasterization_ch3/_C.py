@@ -34,7 +34,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_sh_grad_combine_union", "gsrast_rows_pack", "gsrast_rows_unpack", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
+    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_sh_grad_combine_union", "gsrast_rows_pack", "gsrast_rows_unpack", "gsrast_grad_rows_pack", "gsrast_grad_rows_clear", "gsrast_grad_rows_add", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query", "gsrast_policy_event",
@@ -180,6 +180,12 @@ def lib() -> C.CDLL:
     for fn in (L.gsrast_rows_pack, L.gsrast_rows_unpack):
         fn.restype = ci
         fn.argtypes = [C.c_longlong, vp, ci, C.POINTER(vp), C.POINTER(ci), vp, vp]
+    L.gsrast_grad_rows_pack.restype = ci
+    L.gsrast_grad_rows_pack.argtypes = [ci, vp, C.POINTER(vp), vp, vp, C.c_uint32, vp]
+    L.gsrast_grad_rows_clear.restype = ci
+    L.gsrast_grad_rows_clear.argtypes = [vp, ci, C.c_size_t, C.c_uint32, C.POINTER(vp), ci, vp, vp, vp, vp]
+    L.gsrast_grad_rows_add.restype = ci
+    L.gsrast_grad_rows_add.argtypes = [vp, C.c_uint32, C.POINTER(vp), ci, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_sh_grad_combine_union.restype = ci
     L.gsrast_sh_grad_combine_union.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_activate_forward.restype = ci
@@ -313,6 +319,7 @@ def _export_touched(ar: "GradArena", P: int, geomBuffer: torch.Tensor, dev: torc
 
 _grad_arena: Optional[GradArena] = None
 _factor_ready_hook = None
+_touched_ready_hook = None
 
 
 def set_grad_arena(arena: Optional[GradArena]) -> None:
@@ -326,6 +333,13 @@ def set_factor_ready_hook(fn) -> None:
     view_parallel starts the asynchronous all-gather of the factors there, so that it runs beside the second phase."""
     global _factor_ready_hook
     _factor_ready_hook = fn
+
+
+def set_touched_ready_hook(fn) -> None:
+    """fn(arena) is called INSIDE the backward of a factor-mode arena BEFORE any of its kernels is enqueued, right after arena.touched
+    (one byte per Gaussian: some pixel of this view consumed it) has been written on the current stream."""
+    global _touched_ready_hook
+    _touched_ready_hook = fn
 
 
 class _Arena:
@@ -476,6 +490,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), sh_out, dL_dscales.data_ptr(),
                     dL_drotations.data_ptr(), stream)
 
+            if factors:
+                # which rows this view can touch is known since the forward's blend (its untouched bits): exported BEFORE the backward
+                # is enqueued, so that a caller's hook can start on it -- the all-gather exchange agrees on its row capacity beside
+                # the backward instead of waiting for it (view_parallel._touched_hook)
+                _export_touched(ar, P, geomBuffer, dev)
+                if _touched_ready_hook is not None:
+                    _touched_ready_hook(ar)
             if factors and _factor_ready_hook is not None:
                 rc = call(1)                     # blend backward + the factors
                 if rc == 0:
@@ -485,8 +506,6 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 rc = call(0)
         if rc != 0:
             raise _err(rc, "gsrast_backward")
-        if factors:
-            _export_touched(ar, P, geomBuffer, dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
@@ -614,6 +633,13 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
                     float(tan_fovx), float(tan_fovy), _ptr(radii_c), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
                     _ptr(dL_dout_color), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream)
 
+            if factors:
+                # which rows this view can touch is known since the forward's blend (its untouched bits): exported BEFORE the backward
+                # is enqueued, so that a caller's hook can start on it -- the all-gather exchange agrees on its row capacity beside
+                # the backward instead of waiting for it (view_parallel._touched_hook)
+                _export_touched(ar, P, geomBuffer, dev)
+                if _touched_ready_hook is not None:
+                    _touched_ready_hook(ar)
             if factors and _factor_ready_hook is not None:
                 rc = call(1)                     # blend backward + the factors
                 if rc == 0:
@@ -623,8 +649,6 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
                 rc = call(0)
         if rc != 0:
             raise _err(rc, "gsrast_backward_raw")
-        if factors:
-            _export_touched(ar, P, geomBuffer, dev)
     if keep["motion_res"] is not None:
         g["motion_res"] = g["xyz"]
     return g
@@ -654,6 +678,7 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
     if union:
         views = [v.view(P, -1) for v in (whole, dc, rest) if v is not None and v.numel()]
         prev = getattr(arena, "_sh_union", None)
+        arena._rows_prev = None                      # (the all-gather exchange keeps its own record of the rows it wrote)
         if not getattr(arena, "sh_rows_known", False) or prev is None:
             for v in views:
                 v.zero_()
@@ -700,6 +725,58 @@ def rows_pack(idx: torch.Tensor, arrays, packed: torch.Tensor, unpack: bool = Fa
     if rc != 0:
         raise _err(rc, "gsrast_rows_pack")
     return packed
+
+
+# ---- the all-gather gradient exchange (include/gsrast.h: gsrast_grad_rows_*; csrc/gsrast_exchange.h) -----------------------------------
+GRAD_ROW_WORDS = 16
+
+
+def _arena_sh_arrays(arena: "GradArena"):
+    P, M = arena.P, arena.M
+    if getattr(arena, "raw", False):
+        return None, arena.take("features_dc", (P, 1, 3), False), (arena.take("features_rest", (P, M - 1, 3), False) if M > 1 else None)
+    return arena.take("sh", (P, M, 3), False), None, None
+
+
+def _dense_ptrs(arena: "GradArena"):
+    segs = arena.dense_segments()
+    if [int(sg.shape[1]) for sg in segs] != [3, 1, 3, 4]:
+        raise ValueError("the gradient rows hold mean 3 | opacity 1 | scale 3 | rotation 4: the arena's dense segments differ")
+    return (C.c_void_p * 4)(*[sg.data_ptr() for sg in segs])
+
+
+def grad_rows_pack(arena: "GradArena", touched: torch.Tensor, rows: torch.Tensor) -> None:
+    """This rank's touched gradient rows into rows[1:] (int32 [1 + cap, 16]; rows[0, 0], zeroed by the caller, counts them)."""
+    dev = rows.device
+    with torch.cuda.device(dev):
+        rc = lib().gsrast_grad_rows_pack(arena.P, touched.data_ptr(), _dense_ptrs(arena), arena.factor.data_ptr(), rows.data_ptr(),
+                                         int(rows.shape[0]) - 1, torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_grad_rows_pack")
+
+
+def grad_rows_clear(arena: "GradArena", chunks: torch.Tensor, dense: bool, sh: bool) -> None:
+    """Zero the rows the chunks (int32 [n, 1 + cap, 16]) name: of the dense arrays and / or of the SH region(s)."""
+    n, cap = int(chunks.shape[0]), int(chunks.shape[1]) - 1
+    whole, dc, rest = _arena_sh_arrays(arena) if sh else (None, None, None)
+    dev = chunks.device
+    with torch.cuda.device(dev):
+        rc = lib().gsrast_grad_rows_clear(chunks.data_ptr(), n, (1 + cap) * GRAD_ROW_WORDS, cap, _dense_ptrs(arena) if dense else None, arena.M,
+                                          _ptr(whole), _ptr(dc), _ptr(rest), torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_grad_rows_clear")
+
+
+def grad_rows_add(arena: "GradArena", chunk: torch.Tensor, means3D: torch.Tensor, scale: float) -> None:
+    """One rank's chunk (int32 [1 + cap, 16]) added into the arena: the dense rows and, recombined from the factor, dL/dsh."""
+    whole, dc, rest = _arena_sh_arrays(arena)
+    dev = chunk.device
+    with torch.cuda.device(dev):
+        rc = lib().gsrast_grad_rows_add(chunk.data_ptr(), int(chunk.shape[0]) - 1, _dense_ptrs(arena), int(arena.last_degree), arena.M,
+                                        means3D.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise _err(rc, "gsrast_grad_rows_add")
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

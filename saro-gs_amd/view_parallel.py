@@ -135,7 +135,7 @@ def allreduce_mean_inplace(flat: torch.Tensor, batch: int) -> None:
     flat.mul_(1.0 / batch)
 
 
-def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = False) -> Dict[str, int]:
+def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse=False) -> Dict[str, int]:
     """Cross-rank mean of one view-per-rank backward whose leaf gradients live in a GradArena built with
     sh_factors=True (diff_gaussian_rasterization_ch3/_C.py; raw=True for GaussianRasterizerRaw's six leaves -- SaRO-GS's own call
     pattern, where `shs` is never a leaf).  Same result as all-reducing all 59 floats per Gaussian (up to fp32 summation order),
@@ -155,6 +155,8 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
     compacted [n, 11] all-reduce and a compacted [n, 3] all-gather; rows outside the union are zero on every rank and stay so.
     One host synchronisation per step (the union's size), beside the one every forward already has.
 
+    sparse="gather" (round 5): every rank sends only the rows its OWN view touched, in one all-gather -- see _exchange_gather.
+
     Returns the bytes this rank handed to the collectives: {"allreduce", "allgather", "rows"}."""
     from diff_gaussian_rasterization_ch3 import _C
     if not getattr(arena, "sh_factors", False):
@@ -171,23 +173,12 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
         warnings.warn("exchange_gradients(sparse=True) with overlap_factor_exchange() in force: the dense factor gather has already "
                       "been started inside the backward, the exchange falls back to the dense form; switch the overlap off "
                       "(overlap_factor_exchange(False)) to send only the touched rows", RuntimeWarning, stacklevel=2)
+    if sparse == "gather" and multi and pending is None and P > 0:
+        return _exchange_gather(arena, means3D, batch, n_views)
     if sparse and multi and pending is None and P > 0:
         segs = arena.dense_segments()
         fac = arena.factor[: 3 * P].view(P, 3)
-        # "touched" = any of the row's 14 floats is non-zero (all five arrays are looked at: a sum can cancel to exactly zero in one of
-        # them); the flag lives on the arena, not in a fresh [P] tensor every step
-        if getattr(arena, "touched_fresh", False) and arena.touched.numel() == P:
-            # round 5: the backward left one byte per Gaussian, "some pixel of this view consumed it" (the forward blend's untouched bits,
-            # gsrast_touched_rows): a superset of the rows with a non-zero gradient, for 1 B instead of 56 B read per Gaussian
-            touched = arena.touched
-            arena.touched_fresh = False
-        else:
-            touched = getattr(arena, "_touched", None)
-            if touched is None or touched.numel() != P:
-                touched = arena._touched = torch.empty(P, dtype=torch.uint8, device=fac.device)
-            torch.any(fac != 0, dim=1, out=touched.view(torch.bool))
-            for sg in segs:
-                touched |= (sg != 0).any(dim=1).view(torch.uint8)
+        touched = _touched_flags(arena, segs, fac)
         dist.all_reduce(touched, op=dist.ReduceOp.MAX)
         idx = torch.nonzero(touched, as_tuple=False).squeeze(1)          # (host synchronisation: every rank learns the same n)
         n = int(idx.numel())
@@ -225,6 +216,96 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse: bool = 
         chunks = arena.factor
     _C.sh_grad_combine(arena, means3D, chunks, n_views, 1.0 / batch)
     return {"allreduce": arena.dense.numel() * 4 if multi else 0, "allgather": arena.chunk * 4 if multi else 0, "rows": P}
+
+
+def _touched_flags(arena, segs, fac) -> torch.Tensor:
+    """uint8 [P]: 1 = this rank's gradient row of the Gaussian may be non-zero."""
+    P = arena.P
+    if getattr(arena, "touched_fresh", False) and arena.touched.numel() == P:
+        # round 5: the backward left one byte per Gaussian, "some pixel of this view consumed it" (the forward blend's untouched bits,
+        # gsrast_touched_rows): a superset of the rows with a non-zero gradient, for 1 B instead of 56 B read per Gaussian
+        arena.touched_fresh = False
+        return arena.touched
+    # any of the row's 14 floats is non-zero (all five arrays are looked at: a sum can cancel to exactly zero in one of them); the flag
+    # lives on the arena, not in a fresh [P] tensor every step
+    touched = getattr(arena, "_touched", None)
+    if touched is None or touched.numel() != P:
+        touched = arena._touched = torch.empty(P, dtype=torch.uint8, device=fac.device)
+    torch.any(fac != 0, dim=1, out=touched.view(torch.bool))
+    for sg in segs:
+        touched |= (sg != 0).any(dim=1).view(torch.uint8)
+    return touched
+
+
+def _touched_hook(arena) -> None:
+    """Inside the backward of an arena that exchanges by all-gather, before its kernels are enqueued: the ranks take the MAX of their
+    touched-row counts on a side stream and the result travels to pinned host memory, all of it beside the backward -- the exchange
+    then sizes its buffers without waiting for the device (the step's host synchronisation moves off the critical path)."""
+    if not getattr(arena, "_gather_armed", False) or not collectives_active() or not arena.touched.is_cuda:
+        return
+    dev = arena.touched.device
+    side = getattr(arena, "_cap_stream", None)
+    if side is None:
+        side = arena._cap_stream = torch.cuda.Stream(device=dev)
+        arena._cap_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        cnt = arena.touched.sum(dtype=torch.int32).view(1)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        arena._cap_host.copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    arena._cap_event = ev
+
+
+def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> Dict[str, int]:
+    """exchange_gradients(sparse="gather") (round 5; csrc/gsrast_exchange.h): every rank sends the rows ITS view touched -- 64 bytes each:
+    index, the 11 dense floats, the 3 floats of the dL/dsh factor -- in ONE all-gather of chunks [header | cap rows], cap = the largest
+    count of the step (a 4-byte MAX all-reduce, the step's one host synchronisation), and adds the chunks into its arrays in RANK order:
+    no atomics, the same sums in the same order on every rank.  The views of a batch touch mostly different Gaussians, so the union-sized
+    buffers of sparse=True carry mostly zeros: 3 M Gaussians, 8 ranks, ~150 k rows per view: 67 MB received per rank instead of ~200."""
+    from diff_gaussian_rasterization_ch3 import _C
+    P = arena.P
+    dev = arena.flat.device
+    segs = arena.dense_segments()
+    fac = arena.factor[: 3 * P].view(P, 3)
+    touched = _touched_flags(arena, segs, fac)
+    send = getattr(arena, "_rows_send", None)
+    if send is None or send.shape[0] != P + 1 or send.device != dev:
+        # (sized for every row: 64 B per Gaussian of address space, of which a step touches the header and its own rows)
+        send = arena._rows_send = torch.empty((P + 1, _C.GRAD_ROW_WORDS), dtype=torch.int32, device=dev)
+    send[0].zero_()
+    send[0, 1:4] = arena.factor[3 * P: 3 * P + 3].view(torch.int32)
+    _C.grad_rows_pack(arena, touched, send)
+    ev = getattr(arena, "_cap_event", None)
+    if ev is not None:
+        # the ranks agreed on the capacity BESIDE the backward (_touched_hook): the host has had the number for a millisecond
+        ev.synchronize()
+        cap, arena._cap_event = int(arena._cap_host[0]), None
+    else:
+        cmax = send[0, :1].clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        cap = int(cmax.item())                                         # (host synchronisation: every rank learns the same cap)
+    if not getattr(arena, "_gather_armed", False):                     # from the next backward on: the capacity is agreed on early
+        arena._gather_armed = True
+        _C.set_touched_ready_hook(_touched_hook)
+    mine = send[: 1 + cap]
+    gathered = torch.empty((n_views, 1 + cap, _C.GRAD_ROW_WORDS), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1))
+    # the SH region is kept zero outside the rows the previous step wrote (the backward does not write it in factor mode); the dense
+    # arrays hold this rank's own gradient: its rows go to zero and come back with everybody's, in rank order
+    prev = getattr(arena, "_rows_prev", None)
+    if getattr(arena, "sh_rows_known", False) and prev is not None:
+        _C.grad_rows_clear(arena, prev, dense=False, sh=True)
+    else:
+        for v in _C._arena_sh_arrays(arena):
+            if v is not None:
+                v.zero_()
+    _C.grad_rows_clear(arena, mine.unsqueeze(0), dense=True, sh=False)
+    for r in range(n_views):
+        _C.grad_rows_add(arena, gathered[r], means3D, 1.0 / batch)
+    arena._rows_prev, arena._sh_union, arena.sh_rows_known = gathered, None, True
+    return {"allreduce": 4, "allgather": (1 + cap) * _C.GRAD_ROW_WORDS * 4, "rows": cap}
 
 
 def overlap_factor_exchange(enable: bool = True) -> None:

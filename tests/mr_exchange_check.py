@@ -52,14 +52,15 @@ def main():
 
     # consecutive sparse steps over DIFFERENT views on ONE arena (round 5: the recombination writes the union's rows only and the
     # exchange clears the previous union's -- a row that leaves the union must read zero again), against the plain all-reduce
+    # ... and the all-gather exchange (sparse="gather"), alternating with the other forms on the same arena: each form keeps its own record
+    # of the SH rows it wrote, a change of form clears everything once
     wa = bench.Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=5, dev=dev, poses=3)
     wb = bench.Workload(rast, scenes, P, W, H, deg, view_k=rank, n_views=5, dev=dev, poses=3)
-    wb.sparse = True
     arena_a, arena_b = _C.GradArena(P, 16, dev, world=world), _C.GradArena(P, 16, dev, sh_factors=True, world=world)
     worst_seq, unions = 0.0, []
-    for s in range(4):
-        if s == 3:                      # a dense combine in between voids what is known about the rows: the next sparse step clears all
-            wb.sparse = False
+    forms = [True, True, True, False, True, "gather", "gather", "gather", True, "gather", False, "gather"]
+    for form in forms:                  # (False = the dense combine: it voids what is known about the rows, the next sparse step clears all)
+        wb.sparse = form
         _C.set_grad_arena(arena_a)
         wa.step(arena_a, world)
         _C.set_grad_arena(arena_b)
@@ -68,18 +69,12 @@ def main():
         unions.append(wb.exchanged["rows"])
         for k in wa.leaves:
             a, b = wa.leaves[k].grad, wb.leaves[k].grad
-            worst_seq = max(worst_seq, ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item())
-    wb.sparse = True
-    _C.set_grad_arena(arena_a)
-    wa.step(arena_a, world)
-    _C.set_grad_arena(arena_b)
-    wb.step(arena_b, world)
-    torch.cuda.synchronize()
-    for k in wa.leaves:
-        a, b = wa.leaves[k].grad, wb.leaves[k].grad
-        worst_seq = max(worst_seq, ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item())
+            err = ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item()
+            assert err <= 1.0, (form, len(unions), k, err)
+            worst_seq = max(worst_seq, err)
     _C.set_grad_arena(None)
     assert worst_seq <= 1.0 and len(set(unions[:3])) > 1, (worst_seq, unions)     # (the unions differed from step to step)
+    res["factors_gather"] = {k: v.grad.detach().clone() for k, v in wb.leaves.items()}      # (the last step: must be the same on every rank, bit for bit)
 
     # the RAW leaves (GaussianRasterizerRaw: SaRO-GS's call pattern, `shs` is cat(features_dc, features_rest), never a leaf)
     L = wl.leaves
@@ -90,7 +85,7 @@ def main():
     raster_raw = rast.GaussianRasterizerRaw(wl.rs)
     m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
     res_raw = {}
-    for mode in ("allreduce", "factors", "factors_sparse"):
+    for mode in ("allreduce", "factors", "factors_sparse", "factors_gather"):
         arena = _C.GradArena(P, 16, dev, sh_factors=(mode != "allreduce"), world=world, raw=True)
         _C.set_grad_arena(arena)
         for v in list(raw.values()) + [m2]:
@@ -101,14 +96,14 @@ def main():
         if mode == "allreduce":
             vp.allreduce_mean_inplace(arena.flat, world)
         else:
-            vp.exchange_gradients(arena, raw["xyz"].detach(), world, sparse=(mode == "factors_sparse"))
+            vp.exchange_gradients(arena, raw["xyz"].detach(), world, sparse=("gather" if mode == "factors_gather" else mode == "factors_sparse"))
         torch.cuda.synchronize()
         assert all(v.grad.data_ptr() >= arena.flat.data_ptr() and v.grad.data_ptr() < arena.flat.data_ptr() + arena.flat.numel() * 4 for v in raw.values()), "the raw leaves' gradients must be views of the bucket"
         res_raw[mode] = {k: v.grad.detach().clone() for k, v in raw.items()}
         _C.set_grad_arena(None)
     worst = 0.0
     for k in res_raw["allreduce"]:
-        for other_mode in ("factors", "factors_sparse"):
+        for other_mode in ("factors", "factors_sparse", "factors_gather"):
             a, b = res_raw["allreduce"][k], res_raw[other_mode][k]
             worst = max(worst, ((a - b).abs() / (1e-6 + 1e-4 * a.abs())).max().item())
         assert res_raw["allreduce"][k].abs().max().item() > 0, k
@@ -121,6 +116,10 @@ def main():
     # every rank must hold the same averaged gradient
     flat = torch.cat([v.reshape(-1) for v in list(res["factors"].values()) + list(res["factors_overlapped"].values()) + list(res["factors_sparse"].values())
                       + list(res_raw["factors"].values()) + list(res_raw["factors_sparse"].values())])
+    exact = torch.cat([v.reshape(-1) for v in list(res["factors_gather"].values()) + list(res_raw["factors_gather"].values())])
+    exact_other = exact.clone()
+    torch.distributed.broadcast(exact_other, src=0)
+    assert torch.equal(exact, exact_other), "the all-gather exchange adds the chunks in rank order: every rank must hold the same bits"
     other = flat.clone()
     torch.distributed.broadcast(other, src=0)
     same = bool(((flat - other).abs() <= 1e-7 + 1e-5 * other.abs()).all())

@@ -67,7 +67,7 @@ def test_distributed_step_with_two_views_in_flight_on_the_real_chain(ranks):
     assert len(reports) == ranks and all(ok == "True" for _, ok in reports), out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("exchange", ["sparse", "factors", "allreduce"])
+@pytest.mark.parametrize("exchange", ["gather", "sparse", "factors", "allreduce"])
 def test_bench_two_ranks(exchange):
     out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "100000", "--exchange", exchange,
                      "--sweep", "", "--no-cpu-baseline"])

@@ -50,7 +50,7 @@ def test_distributed_step_through_rccl_one_rank():
     assert reports == [("0", "True")], out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("exchange", ["sparse", "factors", "allreduce"])
+@pytest.mark.parametrize("exchange", ["gather", "sparse", "factors", "allreduce"])
 def test_bench_one_gpu_through_the_nccl_code_path(exchange):
     out = _run(["bench.py", "--gpus", "1", "--force-collectives", "--steps", "3", "--warmup", "1", "--gaussians", "100000", "--exchange", exchange])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]

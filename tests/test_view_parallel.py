@@ -418,6 +418,113 @@ def _sparse_worker(rank, world, port, out_dir, raw):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, out_dir, raw):
+    """exchange_gradients(sparse="gather") with the three row kernels (csrc/gsrast_exchange.h) restated in torch."""
+    for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import scenes
+    import view_parallel as vp
+    from diff_gaussian_rasterization_ch3 import _C
+    from oracle import oracle as orc
+    vp.init_from_env("gloo")
+    P, W, H, deg, M = 600, 64, 48, 3, 16
+    sc = scenes.synth(P, 13)
+    arena = _C.GradArena(P, M, torch.device("cpu"), sh_factors=True, world=world, raw=raw)
+    names = ("xyz", "opacity_logit", "scaling", "rotation") if raw else ("means3D", "opacity", "scales", "rotations")
+    means = torch.from_numpy(sc["means3D"])
+    counts = {"clear_dense": 0, "clear_sh": 0, "add": 0}
+
+    def sh_views(ar):
+        if getattr(ar, "raw", False):
+            return [ar.take("features_dc", (ar.P, 3), False), ar.take("features_rest", (ar.P, 45), False)]
+        return [ar.take("sh", (ar.P, 48), False)]
+
+    def rows_of(chunk):
+        n = int(chunk[0, 0])
+        return chunk[1: 1 + n]
+
+    def pack(ar, touched, rows):
+        idx = torch.nonzero(touched).squeeze(1)
+        n = idx.numel()
+        body = torch.cat([idx.to(torch.int32).view(-1, 1), torch.cat(ar.dense_segments(), 1)[idx].contiguous().view(torch.int32),
+                          ar.factor[: 3 * ar.P].view(ar.P, 3)[idx].contiguous().view(torch.int32), torch.zeros((n, 1), dtype=torch.int32)], 1)
+        rows[1: 1 + n] = body
+        rows[0, 0] += n
+
+    def clear(ar, chunks, dense, sh):
+        counts["clear_dense" if dense else "clear_sh"] += 1
+        for ch in chunks:
+            idx = rows_of(ch)[:, 0].long()
+            for v in (ar.dense_segments() if dense else []) + (sh_views(ar) if sh else []):
+                v[idx] = 0.0
+
+    def add(ar, chunk, means3D, scale):
+        counts["add"] += 1
+        r = rows_of(chunk)
+        idx = r[:, 0].long()
+        o = 1
+        for sg in ar.dense_segments():
+            sg[idx] += scale * r[:, o: o + sg.shape[1]].contiguous().view(torch.float32)
+            o += sg.shape[1]
+        g = r[:, 12:15].contiguous().view(torch.float32)
+        d = means3D[idx] - chunk[0, 1:4].contiguous().view(torch.float32)
+        d = d / d.norm(dim=1, keepdim=True)
+        term = (_sh_weights(d, ar.last_degree)[:, :, None] * g[:, None, :] * scale).reshape(-1, 48)
+        vs = sh_views(ar)
+        if len(vs) == 1:
+            vs[0][idx] += term
+        else:
+            vs[0][idx] += term[:, :3]
+            vs[1][idx] += term[:, 3:]
+
+    _C.grad_rows_pack, _C.grad_rows_clear, _C.grad_rows_add = pack, clear, add
+    ok, report = True, []
+    for step in range(3):               # three steps with different views: a row that leaves the union must read zero again
+        cam = scenes.camera((rank + 3 * step) % 11, 11, W, H)
+        o = orc.render(sc, cam, scenes.upstream_grad(H, W, 5 + step) * (H * W))
+        for n, k in zip(names, ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")):
+            arena.take(n, (P, arena.widths[n]), False).copy_(torch.from_numpy(o[k].astype(np.float32)).reshape(P, -1))
+        fac = torch.from_numpy((o["dL_dcolors"] * (1 - o["clamped"].astype(np.float32)) * (o["radii"] > 0)[:, None]).astype(np.float32))
+        arena.factor[: 3 * P] = fac.reshape(-1)
+        arena.factor[3 * P: 3 * P + 3] = torch.from_numpy(np.asarray(cam["campos"], np.float32))
+        arena.last_degree = deg
+        sent = vp.exchange_gradients(arena, means, world, sparse="gather")
+        full = torch.cat([torch.from_numpy(o[k].astype(np.float32)).reshape(-1) for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
+        dist.all_reduce(full)
+        full /= world
+        if raw:
+            sh = torch.cat([arena.take("features_dc", (P, 1, 3), False), arena.take("features_rest", (P, 15, 3), False)], dim=1)
+        else:
+            sh = arena.take("sh", (P, 16, 3), False)
+        got = torch.cat([arena.take(n, (P, arena.widths[n]), False).reshape(-1) for n in names] + [sh.reshape(-1)])
+        err = float(((got - full).abs() / (1e-6 + 1e-4 * full.abs())).max())
+        same = got.clone()
+        dist.broadcast(same, src=0)
+        mine = int((torch.from_numpy(o["radii"]) > 0).sum())
+        ok = ok and err <= 1.0 and torch.equal(same, got) and 0 < sent["rows"] <= P and sent["allgather"] == (1 + sent["rows"]) * 64 and sent["allreduce"] == 4 \
+            and sent["rows"] >= 1 and mine >= 1
+        report.append(f"step {step} err {err:.3f} rows {sent['rows']} same {torch.equal(same, got)}")
+    ok = ok and counts["add"] == 3 * world and counts["clear_dense"] == 3 and counts["clear_sh"] == 2      # (the first step zeroes the SH region whole)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(f"{ok} {report} {counts}")
+    vp.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("raw", [False, True], ids=["rasterizer_leaves", "raw_leaves"])
+@pytest.mark.parametrize("world", [2, 8], ids=["two_ranks", "cfg4_eight_ranks"])
+def test_all_gather_exchange_equals_the_literal_batch_mean_bit_identical_on_every_rank(tmp_path, world, raw):
+    """exchange_gradients(sparse="gather") on CPU over gloo: ONE all-gather of the 64-byte rows each rank's own view touched (cap from a
+    4-byte MAX all-reduce), the chunks added in rank order -- the reference's batch mean (scene/saro_gaussian.py:266-276) within
+    tolerance, the SAME BITS on every rank, over three steps whose views differ (rows that leave the union read zero again)."""
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path), raw), nprocs=world, join=True)
+    reports = [open(tmp_path / f"ok{r}").read() for r in range(world)]
+    assert all(r.startswith("True") for r in reports), reports
+
+
 @pytest.mark.parametrize("raw", [False, True], ids=["rasterizer_leaves", "raw_leaves"])
 @pytest.mark.parametrize("world", [2, 8], ids=["two_ranks", "cfg4_eight_ranks"])
 def test_sparse_factor_exchange_equals_the_literal_batch_mean(tmp_path, world, raw):

@@ -41,6 +41,7 @@ def fbx(sparse):
     vp.exchange_gradients(arena, wl.leaves["means3D"].detach(), 1, sparse=sparse)
 print("... + exchange dense factors     %.3f ms" % timeit(lambda: fbx(False)))
 print("... + exchange sparse            %.3f ms" % timeit(lambda: fbx(True)))
+print("... + exchange gather            %.3f ms" % timeit(lambda: fbx("gather")))
 # pieces of the sparse exchange
 fb(); torch.cuda.synchronize()
 segs = arena.dense_segments(); fac = arena.factor[: 3 * P].view(P, 3)
@@ -70,4 +71,22 @@ def rowof():
 piece("row_of", rowof)
 piece("sh_grad_combine (rows)", lambda: _C.sh_grad_combine(arena, wl.leaves["means3D"].detach(), gathered, 1, 1.0, rows=n, row_of=row_of, chunk_stride=stride))
 piece("sh_grad_combine (union: clear + write)", lambda: _C.sh_grad_combine(arena, wl.leaves["means3D"].detach(), gathered, 1, 1.0, chunk_stride=stride, idx=idx))
+# pieces of the all-gather exchange
+fb(); torch.cuda.synchronize()
+send = torch.empty((P + 1, 16), dtype=torch.int32, device=dev)
+def hdr():
+    send[0].zero_(); send[0, 1:4] = arena.factor[3 * P: 3 * P + 3].view(torch.int32)
+piece("gather: header", hdr)
+def pk():
+    send[0].zero_(); _C.grad_rows_pack(arena, touched, send)
+piece("gather: header zero + pack", pk)
+cap = int(send[0, 0].item())
+piece("gather: clone + all_reduce MAX (4 B)", lambda: dist.all_reduce(send[0, :1].clone(), op=dist.ReduceOp.MAX))
+piece("gather: .item()", lambda: int(send[0, 0].item()))
+mine = send[: 1 + cap]
+g2 = torch.empty((1, 1 + cap, 16), dtype=torch.int32, device=dev)
+piece("gather: all_gather_into_tensor cap=%d" % cap, lambda: dist.all_gather_into_tensor(g2.view(-1), mine.reshape(-1)))
+piece("gather: clear sh rows (previous chunks)", lambda: _C.grad_rows_clear(arena, g2, dense=False, sh=True))
+piece("gather: clear my dense rows", lambda: _C.grad_rows_clear(arena, mine.unsqueeze(0), dense=True, sh=False))
+piece("gather: add one chunk", lambda: _C.grad_rows_add(arena, g2[0], wl.leaves["means3D"].detach(), 1.0))
 dist.destroy_process_group()
