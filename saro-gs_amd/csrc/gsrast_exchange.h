@@ -1,14 +1,15 @@
 // gsrast_exchange.h -- the kernels of the ALL-GATHER gradient exchange (view_parallel.exchange_gradients(sparse="gather"), round 5).
 //
-// One view per rank: a rank's gradient rows are exactly zero for every Gaussian its view did not blend (~95 % of a 3 M scene), and the
-// views of a batch touch mostly DIFFERENT Gaussians -- the union over 8 views is close to the sum.  So instead of reducing arrays the size
-// of the union (all-reduce 11 floats + all-gather 3 floats per union row, each rank sending mostly zeros), every rank sends ITS OWN touched
-// rows and nothing else, in ONE all-gather:
+// One view per rank: a rank's gradient rows are exactly zero for every Gaussian its view did not blend (~95 % of a 3 M scene).  Instead of
+// reducing arrays the size of the UNION of the views' rows (sparse=True: MAX all-reduce of P flag bytes, all-reduce of 11 floats and
+// all-gather of 3 floats per union row, every rank sending zeros for the union rows it did not touch), every rank sends ITS OWN touched rows
+// and nothing else, in ONE all-gather:
 //     row = 16 words = 64 bytes: { Gaussian index | 11 dense gradient floats (mean 3, opacity 1, scale 3, rotation 4) | dL/dsh factor 3 | 0 }
 //     a rank's chunk = header row { count, campos.x, campos.y, campos.z, 0... } + cap rows (cap = the largest count of the step)
 // and every rank adds the W chunks into its own arrays IN RANK ORDER (one launch per chunk, no atomics: the indices inside a chunk are
 // distinct), so all ranks compute bit-identical means.  xGMI is point-to-point: what a replica must receive in any scheme is the other
-// ranks' non-zero rows, 7 x ~150 k x 64 B = 67 MB at 3 M / 8 ranks; the union-sized all-reduce + all-gather moved ~200 MB.
+// ranks' non-zero rows -- 3 M Gaussians, 8 ranks, 0.12-0.16 M rows per view (their union 0.43 M: the bench's ring of views overlaps):
+// 7 x 0.15 M x 64 B = 67 MB per rank and step in one collective; the union form moves 75 MB in three, the dense factor form 483 MB.
 #pragma once
 #include "gsrast_preprocess.h"
 
