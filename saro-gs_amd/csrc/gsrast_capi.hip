@@ -45,7 +45,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_late_fill_min_p{750000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */,
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_sparse_grec{1} /* 1: a forward that keeps those bits zeroes only the consumed Gaussians' gradient records (A/B switch) */, g_late_fill_min_p{750000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */,
                  g_tau_sample{1} /* the predicted cut's opacity mass comes from one wave in 2^this of preprocess_fwd */, g_tau_cut{1} /* 1: a pose without (trustworthy) remembered cut depths gets PREDICTED ones from this call's own opacity mass (gsrast_common.h) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points
@@ -751,6 +751,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "chain_gate")) { g_chain_gate = value ? 1 : 0; return 0; }               // 0: the completion pass's launches on the caller's stream (round 3)
     if (!strcmp(name, "touch_bits")) { g_touch_bits = value ? 1 : 0; return 0; }               // 0: only the list cut's late bits serve the backward (round 4)
     if (!strcmp(name, "late_fill_min_p")) { g_late_fill_min_p = value < 0 ? 0 : value; return 0; }
+    if (!strcmp(name, "sparse_grec")) { g_sparse_grec = value != 0; return 0; }
     if (!strcmp(name, "near_pose")) { g_near_pose = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }                 // 0: only the pose's own slot (round 3)
     if (!strcmp(name, "tau_sample")) { g_tau_sample = value < 0 ? 0 : (value > 6 ? 6 : value); return 0; }
     if (!strcmp(name, "tau_cut")) { g_tau_cut = value ? 1 : 0; return 0; }                    // 0: only poses with remembered cut depths are cut (round 4's behaviour)
@@ -791,6 +792,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "chain_gate")) return g_chain_gate.load();
     if (!strcmp(name, "touch_bits")) return g_touch_bits.load();
     if (!strcmp(name, "late_fill_min_p")) return g_late_fill_min_p.load();
+    if (!strcmp(name, "sparse_grec")) return g_sparse_grec.load();
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
     if (!strcmp(name, "tau_sample")) return g_tau_sample.load();
     if (!strcmp(name, "tau_cut")) return g_tau_cut.load();
@@ -1019,6 +1021,16 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool zero_in_blend = o.cull != 0 && o.fwd_pixels_per_lane == 0 && (size_t)P * 4 <= 0xFFFFFFFFull;
     // ... and it keeps the "no pixel consumed this Gaussian" bits for the backward (GeomLayout::untouched), unless no backward will follow
     unsigned long long* untouched = (o.cull != 0 && o.fwd_pixels_per_lane == 0 && !o.forward_only && g_touch_bits.load() != 0) ? at<unsigned long long>(geom, GL.untouched) : nullptr;
+    // ... and then only the records of the Gaussians somebody consumed are zeroed, by a kernel of their own behind the last blend (gsrast_preprocess.h:
+    // grec_zero_touched_kernel) instead of all P records from inside the blend
+    const bool zero_touched = untouched != nullptr && zero_in_blend && g_sparse_grec.load() != 0;
+    auto finish_records = [&]() -> int {
+        if (!zero_touched) return GSRAST_OK;
+        ProfScope ps(K_BLEND_FWD, s);
+        grec_zero_touched_kernel<<<std::min((P + 255) / 256, 2048), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
+        GS_LAUNCHED("grec_zero_touched");
+        return GSRAST_OK;
+    };
     bool color_launched = false;
     // Every exit after the fork must order the caller's stream behind the side stream: the colour kernel and the zero-fill write
     // into the geometry buffer, which the caller is free to release (on `s`) as soon as this function has returned -- an error
@@ -1309,7 +1321,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         ba.bg = background; ba.oc = out_color; ba.od = out_depth; ba.fT = fT; ba.nc = nc; ba.tm = tm;
         const int ppl = pick_ppl(T, false, o);
         const bool cull = o.cull != 0 && o.fwd_pixels_per_lane == 0;   // a forced pixels-per-lane selects the un-culled template
-        if (zero_in_blend && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
+        if (zero_in_blend && !zero_touched && !o.forward_only && mode != 2) { ba.zero4 = at<float4>(geom, GL.grec); ba.n_zero4 = (uint32_t)((size_t)P * 4); }
         if (fwd_lists_built) { ba.hints = hints; ba.hint_sel = hint_sel; }      // (the slot is only claimed on the work-bucket path)
         ba.cut_margin_x4 = (uint32_t)pol.margin.load();
         ba.untouched = untouched;
@@ -1503,6 +1515,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             }
             if (rc != GSRAST_OK) return rc;
         }
+        { int rc = finish_records(); if (rc != GSRAST_OK) return rc; }
         if (prefilter_word) { int rc = prefilter_verdict(prefilter_word, s); if (rc != GSRAST_OK) return rc; }
         return (int)R;
     }
@@ -1560,6 +1573,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         }
     }
     { int rc = launch_blend(plist, runbin && R > 0 && Q > 0); if (rc != GSRAST_OK) return rc; }
+    { int rc = finish_records(); if (rc != GSRAST_OK) return rc; }
     if (prefilter_word) { int rc = prefilter_verdict(prefilter_word, s); if (rc != GSRAST_OK) return rc; }
     return (int)R;
 }
@@ -2095,7 +2109,8 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // (the forward leaves them zero: a caller that knows this is the first backward on this state says so and saves the fill)
     float* grec = at<float>(geom, GL.grec);
     const bool do_blend = o.backward_phase != 2, do_geom = o.backward_phase != 1;
-    if (do_blend && !o.grads_zeroed) GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
+    // (a forward that was told no backward would follow has not zeroed the records)
+    if (do_blend && (!o.grads_zeroed || o.forward_only)) GS_HIP(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
     // What the per-Gaussian backward needs of the SH coefficients -- d(colour)/d(view direction), 36 B instead of 12*M -- depends on
     // nothing the blend backward produces: evaluated on the side stream of the calling thread's context WHILE the VALU-bound blend
     // backward runs, joined in front of preprocess_bwd (or at the end of phase 1 of a two-phase backward).
@@ -2186,7 +2201,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         GS_LAUNCHED("blend_bwd");
     }
     if (do_blend && use_sh && o.sh_grad_factors) {      // dL_dsh is [P][3] in this mode: the factor, final after the blend backward
-        sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh);
+        sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh, at<uint32_t>(geom, GL.scalars), at<unsigned long long>(geom, GL.untouched));
         GS_LAUNCHED("sh_factor");
     }
     if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
@@ -2200,7 +2215,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         const int factors = (use_sh && o.sh_grad_factors) ? 1 : 0;
 #define GS_PB_ARGS P, D, M, means3D, radii, raw, rawg, sh_in, at<unsigned char>(geom, GL.clamped), at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), \
                    at<float>(geom, GL.shdC), sc_in, ro_in, cov, cam, reinterpret_cast<const float4*>(grec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,  \
-                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars), (late_fill ? at<unsigned long long>(geom, GL.untouched) : nullptr)
+                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars), at<unsigned long long>(geom, GL.untouched)
         const bool skip = !o.dense_backward;        // Gaussians with an all-zero gradient record are not read
         if (late_fill) {       // (late_fill implies skip) grouped: 1024 Gaussians per workgroup, the ones late_rows_zero_kernel does not write compacted
             const int gg = (P + PB_GROUP - 1) / PB_GROUP;

@@ -173,6 +173,8 @@ constexpr int HINT_SEL = 16;
 // write the key while the kernel's other lookup blocks read the table): scalars[HINT_PUB] = 1 "publish", [+1, +2] the pose's key,
 // [+3 .. +8] its camera (position, viewing direction)
 constexpr int HINT_PUB = 32;
+constexpr int SC_GREC_SPARSE = 46;    // scalars: 1 = only the gradient records of the Gaussians whose untouched bit is CLEAR were zeroed (grec_zero_touched_kernel): every
+                                      // other record holds whatever the buffer held -- its readers take it for zero (record_is_stale)
 constexpr int SC_TOUCH_VALID = 45;    // scalars: 1 = this forward's blend kept GeomLayout::untouched (the backward trusts the bits)
 constexpr int SC_PREFILTER = 44;      // scalars: set by preprocess_fwd when a Gaussian is culled although the caller passed prefiltered = 1
 __host__ __device__ inline uint16_t* hint_work(HintTable* h, uint32_t) { return reinterpret_cast<uint16_t*>(h + 1); }

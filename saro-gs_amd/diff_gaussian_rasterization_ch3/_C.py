@@ -342,6 +342,9 @@ def set_touched_ready_hook(fn) -> None:
     _touched_ready_hook = fn
 
 
+POISON_STATE_BUFFERS = bool(int(os.environ.get("GSRAST_POISON_STATE", "0")))      # tests: every state buffer is handed out filled with 0xFF bytes (NaN as floats, all-ones as bits / indices)
+
+
 class _Arena:
     """The three resizable state buffers of the reference (rasterize_points.cu:27-33, :71-78):
     each allocation callback creates one uint8 tensor that is later saved for backward."""
@@ -355,6 +358,8 @@ class _Arena:
         def alloc(_ctx, nbytes):
             try:
                 buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                if POISON_STATE_BUFFERS:
+                    buf.fill_(255)
             except Exception:  # out of memory -> NULL -> GSRAST_E_ALLOC
                 return None
             self.buffers[slot] = buf

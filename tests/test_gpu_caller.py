@@ -94,7 +94,7 @@ class _Buffers:
     def _make(self, k):
         def alloc(_ctx, nbytes):
             self.calls[k] += 1
-            self.held[k] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.dev)
+            self.held[k] = torch.full((int(nbytes) + 256,), 255, dtype=torch.uint8, device=self.dev)      # (NaN / all-ones: the library must not depend on what a buffer held)
             p = self.held[k].data_ptr()
             return (p + 255) & ~255
         return alloc

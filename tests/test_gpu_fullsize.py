@@ -657,3 +657,47 @@ def test_predicted_cut_at_full_size_without_the_pose_table(scenes, rast, gpu):
     finally:
         _C.set_option("no_list_cut", 0)
         _C.set_option("no_order_hint", 0)
+
+
+def test_stale_gradient_records_at_full_size(scenes, rast, gpu):
+    """BASELINE cfg5 (3 M Gaussians @ 1080p), the library's own defaults (list cut, untouched bits, grouped per-Gaussian backward, only the
+    consumed Gaussians' gradient records zeroed): a step whose state buffers were handed out full of 0xFF bytes gives the same gradients as
+    a step with the records zeroed whole -- finite everywhere, the same rows zero -- directly and through the dL/dsh factor path
+    (sh_factor_kernel + gsrast_sh_grad_combine read the records too)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import view_parallel as vp
+    _C = rast._C
+    P, W, H = 3_000_000, 1920, 1080
+    wl = bench.Workload(rast, scenes, P, W, H, 3, view_k=1, n_views=8, dev=gpu)
+    for _ in range(3):
+        wl.step(None, 1)            # (the context learns its launch sizes and the pose's cut depths)
+    ref = None
+    for arena_mode in (False, True):
+        arena = _C.GradArena(P, 16, gpu, sh_factors=True, world=1) if arena_mode else None
+        _C.set_grad_arena(arena)
+        try:
+            got = {}
+            for sparse in (0, 1):
+                _C.set_option("sparse_grec", sparse)
+                _C.POISON_STATE_BUFFERS = bool(sparse)
+                wl.step(arena, 1)
+                if arena_mode:
+                    vp.exchange_gradients(arena, wl.leaves["means3D"].detach(), 1)
+                torch.cuda.synchronize()
+                got[sparse] = {k: v.grad.detach().clone() for k, v in wl.leaves.items()}
+                assert _C.context_query("last_late") > P // 4
+        finally:
+            _C.POISON_STATE_BUFFERS = False
+            _C.set_option("sparse_grec", 1)
+            _C.set_grad_arena(None)
+        for k in got[1]:
+            a, b = got[1][k].reshape(P, -1), got[0][k].reshape(P, -1)
+            assert bool(torch.isfinite(a).all()), (arena_mode, k)
+            assert torch.equal((a != 0).any(1), (b != 0).any(1)), (arena_mode, k)
+            assert bool(((a - b).abs() <= 1e-6 + 1e-3 * b.abs()).all()), (arena_mode, k)      # (float-atomic order differs between two backwards)
+            if ref is not None:
+                assert bool(((a - ref[k].reshape(P, -1)).abs() <= 1e-6 + 1e-3 * a.abs()).all()), k
+        ref = got[1] if ref is None else ref

@@ -1464,3 +1464,40 @@ def test_untouched_rows_are_zero_rows(P, W, H, deg, orc, scenes, rast, gpu):
         a, b = h[k].reshape(P, -1), h0[k].reshape(P, -1)
         assert np.array_equal((a != 0).any(1), (b != 0).any(1)), k
         assert (np.abs(a - b) <= 1e-6 + 1e-3 * np.abs(b)).all(), k
+
+
+@pytest.mark.parametrize("late_fill", [True, False], ids=["grouped_backward", "per_gaussian_backward"])
+@pytest.mark.parametrize("P,W,H,deg", [(20000, 256, 192, 3), (5000, 97, 83, 1)])
+def test_stale_gradient_records_are_never_read(P, W, H, deg, late_fill, orc, scenes, rast, gpu):
+    """Round 5: a forward that keeps untouched bits zeroes only the gradient records of the Gaussians some pixel consumed
+    (grec_zero_touched_kernel); every other record holds whatever the buffer held before.  The state buffers are handed out filled with 0xFF
+    bytes (NaN as floats): every gradient is finite, at the oracle bar, and the rows of untouched Gaussians are exactly zero -- through the
+    grouped and the per-Gaussian form of the backward, and with the records zeroed whole (option sparse_grec = 0) for comparison."""
+    _C = rast._C
+    sc = scenes.synth(P, 830, sh_degree=deg, scale_mul=1.2)
+    cam = scenes.camera(1, 5, W, H)
+    g = scenes.upstream_grad(H, W, 831) * (H * W)
+    o32 = orc.render(sc, cam, g)
+    o64 = orc.render(sc, cam, g, f64=True)
+    names = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"]
+    _C.set_option("late_fill_min_p", 0 if late_fill else 1 << 30)
+    _C.POISON_STATE_BUFFERS = True
+    try:
+        assert _C.get_option("sparse_grec") == 1
+        h = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+        _C.set_option("sparse_grec", 0)
+        try:
+            h0 = run_hip(rast, sc, cam, gpu, dL_dcolor=g, tile_clip=1)
+        finally:
+            _C.set_option("sparse_grec", 1)
+    finally:
+        _C.POISON_STATE_BUFFERS = False
+        _C.set_option("late_fill_min_p", 750000)
+    assert np.array_equal(bits(h["out_color"]), bits(o32["out_color"]))
+    for k in names:
+        assert np.isfinite(h[k]).all(), k
+    _check_grads(o64, o32, h, names)
+    for k in names:
+        a, b = h[k].reshape(P, -1), h0[k].reshape(P, -1)
+        assert np.array_equal((a != 0).any(1), (b != 0).any(1)), k
+        assert (np.abs(a - b) <= 1e-6 + 1e-3 * np.abs(b)).all(), k
