@@ -334,6 +334,10 @@ int gsrast_backward_ex(const gsrast_options* options,
  * the nearest eighth of the Gaussians first (measured slower: default 0);  "list_cut_always" 1 = the cut also where it does not pay;
  * "near_pose" r (default 3; 0 = off): a camera pose the context's table does not know takes the launch order and the cut depths of a
  * NEAR pose's slot (a camera path's previous frame), the cut depths widened over (2 r + 1)^2 tiles -- verified like any cut.
+ * Round 5 (process-wide A/B switches, default 1): "tau_cut" = cut depths PREDICTED from the call's own opacity mass for a pose without remembered
+ * ones;  "touch_bits" = the forward blend keeps one "no pixel consumed it" bit per Gaussian for the backward;  "sparse_grec" = such a forward
+ * zeroes only the consumed Gaussians' gradient records instead of all P (the backward takes every other record for zero);
+ * "late_fill_min_p" (default 750000): scenes of at least that many Gaussians write the untouched Gaussians' zero rows beside the blend backward.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
  * last forward call of the CALLING THREAD's context, "redo_count" (= gsrast_context_query(NULL, name)). */
 int gsrast_set_option(const char* name, int value);

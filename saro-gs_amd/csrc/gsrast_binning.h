@@ -467,6 +467,12 @@ constexpr int BK_MAX_BUCKETS = 8192;
 constexpr int BK_ITEMS = 8, BK_ITEMS_WIDE = 16;
 constexpr uint32_t BK_ROUND = 1280u * 256u * BK_ITEMS, BK_ROUND_WIDE = 768u * 256u * BK_ITEMS_WIDE;      // elements of one round (256 CUs)
 __host__ __device__ inline int depth_scatter_items(size_t n) { return n > BK_ROUND && n <= BK_ROUND_WIDE ? BK_ITEMS_WIDE : BK_ITEMS; }
+#ifdef GSRAST_SCATTER_TIMING
+__device__ unsigned long long g_scat[16];
+#define SCAT_T(k) do { if (threadIdx.x == 0) { const long long now_ = wall_clock64(); atomicAdd(&g_scat[k], (unsigned long long)(now_ - scat_t)); scat_t = now_; } } while (0)
+#else
+#define SCAT_T(k) do { } while (0)
+#endif
 template <int BK_ITEMS_T>
 __global__ void __launch_bounds__(256)
 depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles,
@@ -509,6 +515,10 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     __shared__ uint32_t s_late;
     const unsigned lane = lane_id();
     const uint32_t xcd = blockIdx.x & (BK_XCD - 1);
+#ifdef GSRAST_SCATTER_TIMING
+    long long scat_t = wall_clock64();
+    if (threadIdx.x == 0) { atomicAdd(&g_scat[15], 1ull); atomicMin(&g_scat[14], (unsigned long long)scat_t); }
+#endif
     if (threadIdx.x == 0) { s_late = 0u; s_fl[0] = 0xFFFFu; s_fl[1] = 0u; }
     for (uint32_t k = threadIdx.x; k < nb / 2u; k += 256) cnt[k] = 0u;
     // (the keys are requested first: their round trip passes under the construction of the bucket map)
@@ -532,6 +542,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         // keeps a positive width); the total stays far below 2^24, exact in the floats below.
         s_C[4 * threadIdx.x] = hv.x; s_C[4 * threadIdx.x + 1] = hv.y; s_C[4 * threadIdx.x + 2] = hv.z; s_C[4 * threadIdx.x + 3] = hv.w;
         __syncthreads();
+        SCAT_T(0);      // histogram loaded
         uint32_t h0 = 16u * hv.x, h1 = 16u * hv.y, h2 = 16u * hv.z, h3 = 16u * hv.w;
         if (4u * threadIdx.x >= (uint32_t)ZH_TAIL && 4u * threadIdx.x < (uint32_t)(ZH_TAIL + ZH_MID)) {
             static_assert(ZH_TAIL % 4 == 0 && ZH_MID % 4 == 0, "a lane's four bins lie on one side of the tails' boundaries");
@@ -592,7 +603,9 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             }
         }
     }
+    SCAT_T(1);          // scan done, cut cells requested
     __syncthreads();
+    SCAT_T(2);          // cut cells in LDS
     const float scale = (float)nb / (float)s_C[ZH_BINS];
     if (blockIdx.x == 0 && threadIdx.x == 0) *zbins_out = s_fl[0] == 0xFFFFu ? 0xFFFFFFFFu : (s_fl[0] | (s_fl[1] << 16));
     uint32_t kB = ZCUT_NONE;
@@ -636,7 +649,9 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         rc[r] = make_uint2(0u, 0u); tl[r] = 0u;
         if (i < n) { rc[r] = rect[i]; tl[r] = tiles[i]; }
     }
+    SCAT_T(3);          // ranks + rect loads issued
     __syncthreads();
+    SCAT_T(4);
     // one returning global atomic per non-empty bucket of this workgroup, sixteen in flight per lane (issued back to back: a loop
     // that stores each result before it asks for the next waits a full memory round trip per bucket)
     uint32_t* gc = gcount + (size_t)xcd * nb;
@@ -659,7 +674,9 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             if (!(threadIdx.x & 1u) && k < nb) cnt[k >> 1] = mine | (other << 16);
         }
     }
+    SCAT_T(5);          // global atomics (thread 0's share)
     __syncthreads();
+    SCAT_T(6);
     uint32_t nlate = 0;
 #pragma unroll
     for (int r = 0; r < BK_ITEMS_T; r++) {
@@ -701,6 +718,10 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
         __syncthreads();
         if (threadIdx.x == 0 && s_late) atomicAdd(n_late_out, s_late);
     }
+    SCAT_T(7);          // late test + slab stores
+#ifdef GSRAST_SCATTER_TIMING
+    if (threadIdx.x == 0) atomicMax(&g_scat[13], (unsigned long long)wall_clock64());
+#endif
     {   // the map's inverse at the bucket boundaries, a few per workgroup: the key where the running sum reaches b * total / nb
         const uint32_t per = (nb + gridDim.x) / gridDim.x;      // ceil((nb + 1) / gridDim.x)
         const uint32_t b = blockIdx.x * per + threadIdx.x;

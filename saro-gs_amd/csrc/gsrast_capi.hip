@@ -1027,7 +1027,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     auto finish_records = [&]() -> int {
         if (!zero_touched) return GSRAST_OK;
         ProfScope ps(K_BLEND_FWD, s);
-        grec_zero_touched_kernel<<<std::min((P + 255) / 256, 2048), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
+        grec_zero_touched_kernel<<<(unsigned)(((size_t)P + 64 * 256 - 1) / (64 * 256)), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
         GS_LAUNCHED("grec_zero_touched");
         return GSRAST_OK;
     };
@@ -2357,6 +2357,14 @@ int gsrast_loss_backward(int C, int H, int W, const float* img, const float* gt,
 
 } // extern "C"
 
+#ifdef GSRAST_SCATTER_TIMING
+extern "C" int gsrast_debug_scatter_timing(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gsrast::g_scat), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; z[14] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(gsrast::g_scat), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #if defined(GSRAST_DEBUG_COUNTERS) || defined(GSRAST_DEBUG_TIMING)
 extern "C" int gsrast_debug_counters(unsigned long long* out, int reset)
 {

@@ -982,11 +982,19 @@ __global__ void __launch_bounds__(256)
 grec_zero_touched_kernel(int P, const unsigned long long* __restrict__ untouched, float4* __restrict__ grec, uint32_t* __restrict__ scalars)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) scalars[SC_GREC_SPARSE] = 1u;
+    // a wave takes 64 words at once (one coalesced load: a loop of dependent wave-uniform loads took 10 us at 3 M), then walks them: lane l
+    // owns Gaussian 64 w + l of every word w
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t nw = ((uint32_t)P + 63u) / 64u;
-    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4u) {
-        const unsigned long long m = ~untouched[w];                 // (wave-uniform load)
-        const uint32_t i = w * 64u + lane;
+    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    if (w0 >= nw) return;
+    const unsigned long long mine = w0 + lane < nw ? ~untouched[w0 + lane] : 0ull;
+    unsigned long long any = __ballot(mine != 0ull);
+    while (any) {
+        const int k = __builtin_ctzll(any);
+        any &= any - 1ull;
+        const unsigned long long m = __shfl(mine, k, 64);
+        const uint32_t i = (w0 + (uint32_t)k) * 64u + lane;
         if (((m >> lane) & 1ull) && i < (uint32_t)P) {
             float4* r = grec + 4 * (size_t)i;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
