@@ -538,7 +538,7 @@ def eval_fps_row(rast, scenes, dev, P, W, H, deg):
             if opt_name:
                 _C.set_option(opt_name, 0)
     # a camera PATH: 60 frames 1.5 degrees apart, every pose rendered exactly once (a test trajectory / a video: what test.py does with a
-    # scene's test cameras) -- the table never holds the pose, but with option near_pose (default) it holds the previous frame's
+    # scene's test cameras) -- the table never holds the pose (predicted cut depths serve it); with option near_pose = 3 it borrows the previous frame's remembered ones
     VP, NF = 240, 60
 
     def path(first, opts):
@@ -564,8 +564,8 @@ def eval_fps_row(rast, scenes, dev, P, W, H, deg):
             return {"fps": round(1.0 / float(np.mean(ds)), 1), "ms_per_view": round(float(np.mean(ds)) * 1e3, 4), "frames_timed": len(ds), "frames_under_the_list_cut": cut}
         finally:
             for k_ in opts:
-                _C.set_option(k_, 3 if k_ == "near_pose" else 0)
-    out["camera_path_every_pose_new"] = {"pose_table_off": path(30, {"no_order_hint": 1}), "own_slot_only": path(100, {"near_pose": 0}), "near_pose_borrowing": path(170, {}),
+                _C.set_option(k_, 0)
+    out["camera_path_every_pose_new"] = {"pose_table_off": path(30, {"no_order_hint": 1}), "own_slot_only": path(100, {}), "near_pose_borrowing": path(170, {"near_pose": 3}),
                                          "note": "60 frames 1.5 degrees apart on the orbit, each pose rendered once, the first 10 discarded; same timing protocol"}
     out["note"] = "forward only, torch.no_grad(), synchronised wall clock per call (test.py:155-168 protocol), P = %d at %dx%d; first_pass = views 12-20 of pass 1 (poses never seen before)" % (P, W, H)
     return out

@@ -332,8 +332,9 @@ int gsrast_backward_ex(const gsrast_options* options,
  * second stream and the caller's stream is released by the cut forward's blend itself (hipStreamWaitValue32 on a word of the
  * context's own), 0 = its predicated launches on the caller's stream;  "layer_cut" 1 = a pose without remembered cut depths lists
  * the nearest eighth of the Gaussians first (measured slower: default 0);  "list_cut_always" 1 = the cut also where it does not pay;
- * "near_pose" r (default 3; 0 = off): a camera pose the context's table does not know takes the launch order and the cut depths of a
- * NEAR pose's slot (a camera path's previous frame), the cut depths widened over (2 r + 1)^2 tiles -- verified like any cut.
+ * "near_pose" r (default 0 = off; 3 in round 4): a camera pose the context's table does not know takes the launch order and the cut depths of a
+ * NEAR pose's slot (a camera path's previous frame), the cut depths widened over (2 r + 1)^2 tiles -- verified like any cut.  Off since such a
+ * pose gets predicted cut depths ("tau_cut"), which measured faster along a camera path.
  * Round 5 (process-wide A/B switches, default 1): "tau_cut" = cut depths PREDICTED from the call's own opacity mass for a pose without remembered
  * ones;  "touch_bits" = the forward blend keeps one "no pixel consumed it" bit per Gaussian for the backward;  "sparse_grec" = such a forward
  * zeroes only the consumed Gaussians' gradient records instead of all P (the backward takes every other record for zero);

@@ -45,7 +45,7 @@ using namespace gsrast;
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_sparse_grec{1} /* 1: a forward that keeps those bits zeroes only the consumed Gaussians' gradient records (A/B switch) */, g_late_fill_min_p{750000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{3} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */,
+std::atomic<int> g_profile{0}, g_debug_sync{0}, g_ablate{0}, g_debug_state{0}, g_list_cut_always{0}, g_chain_gate{1} /* 1: the completion pass of the list cut runs on its own stream behind a gate (ChainGate); 0: inline, eleven predicated launches on the caller's stream */, g_touch_bits{1} /* 1: the forward blend keeps GeomLayout::untouched for the backward (A/B switch) */, g_sparse_grec{1} /* 1: a forward that keeps those bits zeroes only the consumed Gaussians' gradient records (A/B switch) */, g_late_fill_min_p{750000} /* scenes of at least this many Gaussians write their zero rows beside the blend backward */, g_near_pose{0} /* r > 0: a pose the table does not know borrows a near pose's launch order and cut depths (HintTable::cam), widened over (2 r + 1)^2 tiles.  Default 3 in round 4; 0 since round 5: such a pose gets PREDICTED cut depths, which serve a camera path better (3 M, 50 new poses 1.5 degrees apart, forward only: 0.786 ms per view against 0.887 with borrowing, which left 11 of the 50 frames without a cut) */, g_layer_cut{0} /* 1: a pose without remembered cut depths lists a depth LAYER first (measured slower, see DESIGN.md: off) */,
                  g_tau_sample{1} /* the predicted cut's opacity mass comes from one wave in 2^this of preprocess_fwd */, g_tau_cut{1} /* 1: a pose without (trustworthy) remembered cut depths gets PREDICTED ones from this call's own opacity mass (gsrast_common.h) */;      // process-wide diagnostics (not per-call behaviour)
 
 // Per-call behaviour lives in a gsrast_options value: the *_ex entry points take one, the reference-shaped entry points

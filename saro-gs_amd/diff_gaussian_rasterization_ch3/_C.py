@@ -307,6 +307,10 @@ class GradArena:
 def _export_touched(ar: "GradArena", P: int, geomBuffer: torch.Tensor, dev: torch.device) -> None:
     """gsrast_touched_rows into the arena (round 5): one byte per Gaussian, 1 = some pixel of THIS view consumed it -- what the sparse
     exchange (view_parallel.exchange_gradients(sparse=True)) takes the union over ranks of, instead of scanning the gradient arrays."""
+    pending = getattr(ar, "touched_reader_event", None)      # somebody still reads the previous step's flags on another stream
+    if pending is not None:
+        pending.synchronize()
+        ar.touched_reader_event = None
     t = getattr(ar, "touched", None)
     if t is None or t.numel() != P or t.device != dev:
         t = ar.touched = torch.empty(P, dtype=torch.uint8, device=dev)

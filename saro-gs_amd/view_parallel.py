@@ -255,7 +255,7 @@ def _touched_hook(arena) -> None:
         arena._cap_host.copy_(cnt, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(side)
-    arena._cap_event = ev
+    arena._cap_event = arena.touched_reader_event = ev      # (_C._export_touched waits for it before it overwrites the flags: a step that never exchanged)
 
 
 def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> Dict[str, int]:
@@ -282,7 +282,7 @@ def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> 
     if ev is not None:
         # the ranks agreed on the capacity BESIDE the backward (_touched_hook): the host has had the number for a millisecond
         ev.synchronize()
-        cap, arena._cap_event = int(arena._cap_host[0]), None
+        cap, arena._cap_event, arena.touched_reader_event = int(arena._cap_host[0]), None, None
     else:
         cmax = send[0, :1].clone()
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)

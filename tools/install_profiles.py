@@ -21,7 +21,8 @@ for kernel, pattern, stem in (("blend_bwd_cull_t_kernel", "blend_bwd_cull", "pmc
         continue
     d = {"kernel": kernel, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
          "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> doubled "
-                       "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as reported (uncalibrated)",
+                       "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported, in KB (calibrated in round 5 on late_rows_zero_kernel's "
+                       "streaming fill of the same pass: 692 MB reported, 707 MB by arithmetic)",
          "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024), "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt, {tag}_pmc_WRITE_SIZE.txt"}
     # SQ counters of the same kernel (separate --pmc pass): VALU instructions issued per launch
     sq = os.path.join(src, f"{tag}_pmc_SQ.txt")
