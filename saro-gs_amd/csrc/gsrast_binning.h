@@ -776,7 +776,9 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
                          const unsigned long long* __restrict__ keep_bits = nullptr,
                          // round 5: the sampled depth histogram lives in the CONTEXT and is zeroed HERE for the context's next forward (every
                          // workgroup of the scatter in front of this kernel has read it): no memset launch in front of preprocess_fwd
-                         uint32_t* __restrict__ zero_words = nullptr, uint32_t n_zero_words = 0)
+                         uint32_t* __restrict__ zero_words = nullptr, uint32_t n_zero_words = 0,
+                         // ... and so does the predicted cut's opacity-mass table when it is the context's (tau_cut_kernel, in front of this kernel, has read it)
+                         uint4* __restrict__ zero_quads = nullptr, uint32_t n_zero_quads = 0)
 {
     __shared__ unsigned long long s_grp[BK_WAVES][BK_CAP];      // composites grouped by sub-interval (arrival order inside)
     __shared__ uint16_t s_aux[BK_WAVES][BK_CAP];                // arrival ranks, later the widths in sorted order (their running sum goes through s_grp, free by then: 26 KB of LDS = six workgroups per CU)
@@ -784,6 +786,7 @@ depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restr
     __shared__ uint32_t s_cnt[BK_WAVES][BK_SUB + 1];
     if (pred && *pred == 0u) return;
     if (zero_words) for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
+    if (zero_quads) for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_quads; k += gridDim.x * blockDim.x) zero_quads[k] = make_uint4(0u, 0u, 0u, 0u);
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * BK_WAVES + wave;
     if (b >= nb) return;

@@ -413,6 +413,8 @@ struct gsrast_context {
     std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
     ChainGate gate[32];               // per device: the completion pass's own stream and release words (created on first use)
+    uint32_t* tau_dev[32] = {}; size_t tau_dev_words[32] = {}; bool tau_dev_dirty[32] = {};      // per device: the predicted cut's opacity-mass table [TAU_COPIES][T][TAU_BINS] (ImgLayout::tau_hist's twin), kept ZERO between
+                                                                                                   // forwards: filled by preprocess_fwd, read by tau_cut_kernel, zeroed again by the bucket sort behind it -- no memset launch per forward
     uint32_t* zhist_dev[32] = {};     // per device: the sampled depth histogram of the bucket depth sort [ZH_COPIES][ZH_BINS] -- filled by preprocess_fwd, read by the
                                       // scatter, zeroed again by the bucket sort behind it (no memset launch per forward).  Two forwards of one context in flight on two
                                       // streams mix their samples: the bucket map stays monotone whatever the histogram holds (gsrast_common.h), only the balance suffers
@@ -666,6 +668,7 @@ void gsrast_context_destroy(gsrast_context* c)
         if (g.words) (void)hipFree(g.words);
     }
     for (uint32_t* z : c->zhist_dev) if (z) (void)hipFree(z);
+    for (uint32_t* z : c->tau_dev) if (z) (void)hipFree(z);
     for (SideStream& x : c->side) {
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
@@ -1099,6 +1102,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // list cut: the device says at once whether the pose has a slot in the table (RB_FOUND); the launches over the cut lists of a pose
     // that has none -- everything is early -- are sized for all column runs, not for the early runs of recent forwards (a launch
     // that turned out too small cost a first-seen pose a whole second forward: 1.35 instead of 1.05 ms forward-only at 3 M)
+    int tau_ctx_device = -1;             // >= 0: tau_hist is the context's table on that device (gsrast_context::tau_dev)
     uint32_t* zhist_call = nullptr; bool zhist_ctx = false;      // the depth histogram this call fills and reads: the context's (zeroed by the bucket sort) or the call's own
     Readback* rb_pre = nullptr; uint32_t* pre_alias = nullptr; uint32_t pre_seq = 0;
     if (cut) rb_pre = read_flag_prepare(&pre_alias, &pre_seq);
@@ -1129,7 +1133,26 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             }
         }
         zhist_call = zr;
-        if (tau_hist) GS_HIP(hipMemsetAsync(tau_hist, 0, (size_t)TAU_COPIES * T * TAU_BINS * sizeof(uint32_t), s));
+        if (tau_hist) {
+            // the context's table where the bucket sort will zero it again behind tau_cut_kernel; else the call's own and a memset
+            const size_t words = (size_t)TAU_COPIES * T * TAU_BINS;
+            int device = 0;
+            if (bucket_sort && zhist_ctx && !g_debug_state.load() /* (diagnostics read the table back from the image buffer: tools/tau_debug.py) */ && (words & 3) == 0 && words / 4 <= 0xFFFFFFFFull && hipGetDevice(&device) == hipSuccess && device >= 0 && device < 32) {
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                if (ctx->tau_dev_words[device] < words) {
+                    if (ctx->tau_dev[device]) { (void)hipFree(ctx->tau_dev[device]); ctx->tau_dev[device] = nullptr; ctx->tau_dev_words[device] = 0; }
+                    uint32_t* z = nullptr;
+                    if (hipMalloc((void**)&z, words * sizeof(uint32_t)) == hipSuccess) { ctx->tau_dev[device] = z; ctx->tau_dev_words[device] = words; ctx->tau_dev_dirty[device] = true; }
+                }
+                if (ctx->tau_dev[device]) {
+                    tau_hist = ctx->tau_dev[device]; tau_ctx_device = device;
+                    // (a fresh table, or a forward that filled it and never reached its bucket sort: zeroed here)
+                    if (ctx->tau_dev_dirty[device]) GS_HIP(hipMemsetAsync(tau_hist, 0, ctx->tau_dev_words[device] * sizeof(uint32_t), s));
+                    ctx->tau_dev_dirty[device] = true;
+                }
+            }
+            if (tau_ctx_device < 0) GS_HIP(hipMemsetAsync(tau_hist, 0, words * sizeof(uint32_t), s));
+        }
         const int nzero = bucket_sort ? (int)nbk * BK_XCD : 0;
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
@@ -1170,13 +1193,16 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)
                 // list cut: only the bucket's EARLY Gaussians are sorted (into the early set); the late ones count into bk_info's totals
+                uint4* const tau_zero = tau_ctx_device >= 0 ? reinterpret_cast<uint4*>(tau_hist) : nullptr;
+                const uint32_t tau_zero_n = tau_ctx_device >= 0 ? (uint32_t)((size_t)TAU_COPIES * T * TAU_BINS / 4) : 0u;
                 if (cut) depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e),
                                                                                                             at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), at<uint4>(geom, GL.bk_info),
-                                                                                                            nullptr, nullptr, zhist_ctx ? zhist_call : nullptr, ZH_COPIES * ZH_BINS);
+                                                                                                            nullptr, nullptr, zhist_ctx ? zhist_call : nullptr, ZH_COPIES * ZH_BINS, tau_zero, tau_zero_n);
                 else depth_bucket_sort_kernel<<<(nbk + BK_WAVES - 1) / BK_WAVES, 64 * BK_WAVES, 0, s>>>(slab, gcount, nbk, at<uint32_t>(geom, GL.bk_key), at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl),
                                                                                                         at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base),
-                                                                                                        nullptr, nullptr, nullptr, zhist_ctx ? zhist_call : nullptr, ZH_COPIES * ZH_BINS);
-                GS_LAUNCHED("depth_bucket_sort"); }
+                                                                                                        nullptr, nullptr, nullptr, zhist_ctx ? zhist_call : nullptr, ZH_COPIES * ZH_BINS, tau_zero, tau_zero_n);
+                GS_LAUNCHED("depth_bucket_sort");
+                if (tau_zero) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->tau_dev_dirty[tau_ctx_device] = false; } }
             totals_pending = true;      // by the run emission's last workgroup, or by launch_bucket_totals() if the host needs them first
             return GSRAST_OK;
         } else {

@@ -217,7 +217,10 @@ static inline int cut_cell_shift(size_t gx, size_t gy)      // 1, 2, 3, or 0 = n
 // eighth, gsrast_capi.hip: learn_depth_range) -- the depth histogram's own bins are powers of two of key steps and cover up to twice
 // that range, too coarse here: a tile's cut lands on a bin's FAR edge, so a bin's width is what the prediction gives away.  The last
 // bin also takes everything behind hi and has no far edge (no cut there).
-constexpr int TAU_BINS = 32, TAU_COPIES = 4;      // (copies: workgroup b adds into copy b mod 4)
+#ifndef GSRAST_TAU_BINS
+#define GSRAST_TAU_BINS 32
+#endif
+constexpr int TAU_BINS = GSRAST_TAU_BINS, TAU_COPIES = 4;      // (copies: workgroup b adds into copy b mod 4)
 struct TauBins { uint32_t lo; float scale /* bins per key step */; float inv_scale; uint32_t wave_mask /* wave w of preprocess_fwd adds its Gaussians iff (hash(w) & mask) == 0, each (mask + 1) times its mass */; };
 __host__ __device__ inline uint32_t tau_bin_of(uint32_t key, const TauBins& tb)
 {

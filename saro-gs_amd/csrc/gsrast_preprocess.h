@@ -993,7 +993,9 @@ grec_zero_touched_kernel(int P, const unsigned long long* __restrict__ untouched
     while (any) {
         const int k = __builtin_ctzll(any);
         any &= any - 1ull;
-        const unsigned long long m = __shfl(mine, k, 64);
+        // (k is wave-uniform: two v_readlane, not two ds_bpermute round trips per word -- 62 dependent ones per wave made this kernel 12 us)
+        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), k) << 32) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, k);
         const uint32_t i = (w0 + (uint32_t)k) * 64u + lane;
         if (((m >> lane) & 1ull) && i < (uint32_t)P) {
             float4* r = grec + 4 * (size_t)i;

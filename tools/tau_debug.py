@@ -54,6 +54,7 @@ if not verbose:
     pk = _C.profile_read(); _C.set_option("profile", 0)
     print("   stages (ms):", {k: round(v[0] / max(v[1], 1), 3) for k, v in pk.items() if v[1]})
     sys.exit(0)
+_C.set_option("debug_state", 1)      # (the mass table in the call's own image buffer, not the context's self-zeroing one)
 for i in range(10):
     k = i % 2
     cam = scenes.camera(k, 8, W, H)
