@@ -1030,7 +1030,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     auto finish_records = [&]() -> int {
         if (!zero_touched) return GSRAST_OK;
         ProfScope ps(K_BLEND_FWD, s);
-        grec_zero_touched_kernel<<<(unsigned)(((size_t)P + 64 * 256 - 1) / (64 * 256)), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
+        grec_zero_touched_kernel<<<(unsigned)(((size_t)P + 64 * GZ_WORDS * 4 - 1) / (64 * GZ_WORDS * 4)), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
         GS_LAUNCHED("grec_zero_touched");
         return GSRAST_OK;
     };

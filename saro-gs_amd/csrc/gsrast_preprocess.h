@@ -978,29 +978,29 @@ __device__ __forceinline__ bool record_is_stale(const uint32_t* __restrict__ sca
 {
     return scalars && untouched && scalars[SC_GREC_SPARSE] != 0u && ((untouched[i >> 6] >> (i & 63)) & 1ull) != 0ull;
 }
+constexpr int GZ_WORDS = 16;          // words of bits per wave (64 per wave: 12 us at 3 M -- too few waves, 62 serial steps each; 16: see DESIGN_LOG)
 __global__ void __launch_bounds__(256)
 grec_zero_touched_kernel(int P, const unsigned long long* __restrict__ untouched, float4* __restrict__ grec, uint32_t* __restrict__ scalars)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) scalars[SC_GREC_SPARSE] = 1u;
-    // a wave takes 64 words at once (one coalesced load: a loop of dependent wave-uniform loads took 10 us at 3 M), then walks them: lane l
-    // owns Gaussian 64 w + l of every word w
+    // a wave takes GZ_WORDS words at once (one coalesced load), then walks them: lane l owns Gaussian 64 w + l of every word w
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t nw = ((uint32_t)P + 63u) / 64u;
-    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)GZ_WORDS;
     if (w0 >= nw) return;
-    const unsigned long long mine = w0 + lane < nw ? ~untouched[w0 + lane] : 0ull;
+    const unsigned long long mine = (lane < (unsigned)GZ_WORDS && w0 + lane < nw) ? ~untouched[w0 + lane] : 0ull;
     unsigned long long any = __ballot(mine != 0ull);
     while (any) {
         const int k = __builtin_ctzll(any);
         any &= any - 1ull;
-        // (k is wave-uniform: two v_readlane, not two ds_bpermute round trips per word -- 62 dependent ones per wave made this kernel 12 us)
+        // (k is wave-uniform: two v_readlane, not two ds_bpermute round trips per word)
         const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), k) << 32) |
                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, k);
         const uint32_t i = (w0 + (uint32_t)k) * 64u + lane;
         if (((m >> lane) & 1ull) && i < (uint32_t)P) {
             float4* r = grec + 4 * (size_t)i;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            r[0] = z; r[1] = z; r[2] = z; r[3] = z;
+            r[0] = z; r[1] = z; r[2] = z; r[3] = z;      // (the kernel is bound by these scattered 16-byte store transactions: 4.5 us without them, 6.7 with one per record, 10.2 with four)
         }
     }
 }
