@@ -330,7 +330,8 @@ int gsrast_backward_ex(const gsrast_options* options,
  * group of eight staged instances (blend_bwd_cull_t_kernel), 0 = nine wave reductions per surviving (wave, instance) pair.
  * "chain_gate" (process-wide A/B switch) 1 (default) = the list cut's completion pass (no_list_cut above) is enqueued on the context's
  * second stream and the caller's stream is released by the cut forward's blend itself (hipStreamWaitValue32 on a word of the
- * context's own), 0 = its predicated launches on the caller's stream;  "layer_cut" 1 = a pose without remembered cut depths lists
+ * context's own), 0 = its predicated launches on the caller's stream (also chosen by itself when the process runs under a counter-collecting
+ * profiler -- ROCPROF_COUNTERS / ROCPROF_COUNTER_GROUPS in the environment: such a profiler serialises kernels, a stream that waits for another deadlocks);  "layer_cut" 1 = a pose without remembered cut depths lists
  * the nearest eighth of the Gaussians first (measured slower: default 0);  "list_cut_always" 1 = the cut also where it does not pay;
  * "near_pose" r (default 0 = off; 3 in round 4): a camera pose the context's table does not know takes the launch order and the cut depths of a
  * NEAR pose's slot (a camera path's previous frame), the cut depths widened over (2 r + 1)^2 tiles -- verified like any cut.  Off since such a

@@ -388,6 +388,14 @@ struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, joi
 // if the chain of n - GATE_RING / 2 has completed (hipEventQuery, no wait) -- otherwise that call runs its completion pass inline on the
 // caller's stream, the round-3 form, which needs no slot.  So at most GATE_RING / 2 chains are ever pending and no slot is rewritten
 // under a chain (the gate stream has the lowest priority and nothing else bounded its backlog).
+// A profiler that collects hardware counters SERIALISES the device's kernels: the caller's stream would sit in its wait while the chain that
+// releases it cannot start (round 5: every rocprofv3 --pmc pass of bench.py hung until its timeout).  rocprofv3 announces counter collection
+// in the environment of the process it launches; the completion pass then runs inline on the caller's stream, as with option chain_gate = 0.
+static bool counter_collection_env()
+{
+    static const bool on = getenv("ROCPROF_COUNTERS") != nullptr || getenv("ROCPROF_COUNTER_GROUPS") != nullptr || getenv("GSRAST_SERIALIZED_KERNELS") != nullptr;
+    return on;
+}
 constexpr uint32_t GATE_RING = 64;
 struct ChainGate { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; uint32_t* words = nullptr /* [64] done | [64] pred */; uint32_t seq = 0; bool failed = false;
                    hipEvent_t tail[GATE_RING] = {}; uint32_t tail_seq[GATE_RING] = {} /* sequence number whose chain the slot's event follows; 0 = none */; uint32_t inline_calls = 0 /* forwards that found the ring's older half still pending (diagnostic) */; };
@@ -1352,7 +1360,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         ba.cut_margin_x4 = (uint32_t)pol.margin.load();
         ba.untouched = untouched;
         if (mode == 1) { ba.zcut_used = zcut_used; ba.cut_scalars = scalars; ba.tile_flags = at<unsigned char>(img, IL.tile_flags); }
-        if (mode == 1 && cull && g_chain_gate.load() != 0 && (gate = chain_gate_of(ctx)) != nullptr) {
+        if (mode == 1 && cull && g_chain_gate.load() != 0 && !counter_collection_env() && (gate = chain_gate_of(ctx)) != nullptr) {
             {   std::lock_guard<std::mutex> lk(ctx->mu);
                 uint32_t n = gate->seq + 1u; if (n == 0u) n = 1u;
                 // the slot of n was last used by n - GATE_RING; it is free once the chain of n - GATE_RING / 2 (enqueued later on the same
