@@ -217,6 +217,9 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     float pxa = inside ? pxf : FAR;
     uint64_t alive = __ballot(inside);
     uint64_t m_above = alive;                     // lanes whose T is still above 0.5 (median-depth test below)
+#if defined(GSRAST_DEBUG_COUNTERS) && !defined(GSRAST_DEBUG_TIMING)
+    uint32_t dbg_h[2] = { 0u, 0u }, dbg_q[4] = { 0u, 0u, 0u, 0u };
+#endif
 
     // (Measured and dropped, round 3: software-pipelined staging as in the backward -- the next batch's records requested behind the
     // barrier that opens a batch.  -0.3 ... -1.2 % per step at 3 M / 1 M / shell: most tiles saturate inside their first batch and
@@ -286,6 +289,11 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
                 // that no mask lets through.
                 const uint64_t m_in = __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(power >= b.w);
                 GS_COUNT(0, 1);
+#if defined(GSRAST_DEBUG_COUNTERS) && !defined(GSRAST_DEBUG_TIMING)
+                // (what packing two / four instances into one wave could save: iterations in which each half / quarter of the block has a lane in range)
+                dbg_h[0] += (m_in & 0xFFFFFFFFull) ? 1u : 0u; dbg_h[1] += (m_in >> 32) ? 1u : 0u;
+                dbg_q[0] += (m_in & 0xFFFFull) ? 1u : 0u; dbg_q[1] += ((m_in >> 16) & 0xFFFFull) ? 1u : 0u; dbg_q[2] += ((m_in >> 32) & 0xFFFFull) ? 1u : 0u; dbg_q[3] += (m_in >> 48) ? 1u : 0u;
+#endif
                 if (m_in == 0ull) continue;
                 float alpha = b.y * gs_exp<EXPMODE, true>(power);          // b.w >= -80: the bounded exp is exact here
                 alpha = alpha < 0.99f ? alpha : 0.99f;
@@ -322,6 +330,12 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
         }
         if (cut_here) break;                                // uniform
     }
+#if defined(GSRAST_DEBUG_COUNTERS) && !defined(GSRAST_DEBUG_TIMING)
+    if (lane == 0) {
+        atomicAdd(&g_dbg[10], (unsigned long long)max(dbg_h[0], dbg_h[1]));
+        atomicAdd(&g_dbg[12], (unsigned long long)max(max(dbg_q[0], dbg_q[1]), max(dbg_q[2], dbg_q[3])));
+    }
+#endif
     if (inside) {
         const size_t pid = (size_t)W * py + px;
         const size_t plane = (size_t)W * H;

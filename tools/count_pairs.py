@@ -25,7 +25,9 @@ try:
     print("RAW", v)
     print("fwd: survivor iterations %d, with a lane in range %d, with a contribution %d, contributing lanes %d (%.1f / iteration)" % (v[0], v[1], v[3], v[2], v[2] / max(v[1], 1)))
     print("bwd: survivor iterations %d, with a contribution %d, contributing lanes %d (%.1f / contributing iteration), lanes still in reach (pos < last) %.1f / iteration" % (v[4], v[5], v[6], v[6] / max(v[5], 1), v[7] / max(v[4], 1)))
-    if v[10]:
+    if v[10] and not os.environ.get("TIMING"):
+        print("fwd, if one wave carried TWO instances (one per 8 x 4 half): %d iterations (%.2f of today's), FOUR (one per 8 x 2 quarter): %d (%.2f)" % (v[10], v[10] / max(v[0], 1), v[12], v[12] / max(v[0], 1)))
+    elif v[10]:
         print("bwd blend: longest workgroup %.1f us (list prefix walked: %d entries), launch first start -> last end %.1f us" % (v[10] / 100.0, v[13], (v[12] - v[11]) / 100.0))
     if v[8]:
         print("bwd transposed phases %d, live instances in them %d (%.2f of 8); phases with ONE live instance %d (%.1f %%), with TWO %d (%.1f %%)" % (v[8], v[9], v[9] / v[8], v[14], 100.0 * v[14] / v[8], v[15], 100.0 * v[15] / v[8]))
