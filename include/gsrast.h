@@ -339,6 +339,7 @@ int gsrast_backward_ex(const gsrast_options* options,
  * Round 5 (process-wide A/B switches, default 1): "tau_cut" = cut depths PREDICTED from the call's own opacity mass for a pose without remembered
  * ones;  "touch_bits" = the forward blend keeps one "no pixel consumed it" bit per Gaussian for the backward;  "sparse_grec" = such a forward
  * zeroes only the consumed Gaussians' gradient records instead of all P (the backward takes every other record for zero);
+ * "word_fork" = the side stream is forked by the next kernel's own start (a stored word, hipStreamWaitValue32) instead of an event where a kernel can do that;
  * "late_fill_min_p" (default 750000): scenes of at least that many Gaussians write the untouched Gaussians' zero rows beside the blend backward.
  * Read-only through gsrast_get_option: "last_instances" (num_rendered) and "last_runs" (column runs) of the
  * last forward call of the CALLING THREAD's context, "redo_count" (= gsrast_context_query(NULL, name)). */

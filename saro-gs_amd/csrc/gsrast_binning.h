@@ -1118,8 +1118,11 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                         const unsigned char* __restrict__ need2 = nullptr, int gx_tiles = 0, uint32_t* __restrict__ pass2_counts = nullptr,
                         // binrec == null (list cut: preprocess_fwd did not write the 32-byte binning records): the same numbers from the blend's
                         // records and the rectangles -- three gathers instead of two, for the few Gaussians that are listed
-                        const float4* __restrict__ rec0 = nullptr, const float4* __restrict__ rec1 = nullptr, const uint2* __restrict__ rect = nullptr)
+                        const float4* __restrict__ rec0 = nullptr, const float4* __restrict__ rec1 = nullptr, const uint2* __restrict__ rect = nullptr,
+                        // word fork (gsrast_capi.hip: WORD FORKS): "this kernel has started", for the side stream's colour kernel
+                        uint32_t* __restrict__ fork_word = nullptr, uint32_t fork_seq = 0)
 {
+    if (fork_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fork_word, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (pred && *pred == 0u) return;
     if (redo_bucket_cnt && blockIdx.x == nbuckets) {
         for (int i = threadIdx.x; i < n_redo_cnt; i += blockDim.x) redo_bucket_cnt[i] = 0u;

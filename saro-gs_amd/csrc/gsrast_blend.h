@@ -1015,9 +1015,11 @@ blend_bwd_cull_t_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                         const uint32_t* __restrict__ tile_max, const float* __restrict__ dL_dpix,
                         float* __restrict__ grec /*[P][GREC]: per-Gaussian gradient records, zero on entry*/,
-                        const uint32_t* __restrict__ bucket_cnt, const uint16_t* __restrict__ bucket_list)
+                        const uint32_t* __restrict__ bucket_cnt, const uint16_t* __restrict__ bucket_list,
+                        uint32_t* __restrict__ fork_word /* or null: "this kernel has started" for a stream that waits for it (gsrast_capi.hip: WORD FORKS) */, uint32_t fork_seq)
 {
 #pragma clang fp contract(fast)
+    if (fork_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fork_word, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     constexpr int NT = 256, BATCH = 64, NW = 4;
     constexpr int GB = 8;            // instances per group
     // (Round 5, measured and dropped: the pair's derivative FRONT TO BACK --  dC/dalpha_i . g = T_i (c_i . g) - R_i / (1 - alpha_i), R_i = what

@@ -27,6 +27,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
+#include <map>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -375,7 +377,14 @@ int read_u32(const uint32_t* dev, hipStream_t s, uint32_t* out, int nwords = 1)
 // These hints (and the counts of the last call) belong to a gsrast_context: one per caller that renders a sequence of similar
 // views.  The reference-shaped entry points use a context private to the calling host thread.
 } // namespace
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
+// WORD FORKS (round 5).  Forking work onto the side stream with an event costs the CALLER's stream ~7 us (tools/fork_probe.hip: A; record, other stream
+// waits + kernel; B = +7.5 us against A; B -- the record is a barrier packet between A and B).  Where the caller's next kernel can say "I have
+// started" itself -- thread 0 of its first workgroup stores a sequence number into a word of the context's -- the side stream waits for that word
+// with hipStreamWaitValue32 instead (+0.0 us in the probe): everything in front of that kernel on the caller's stream has completed, which is all
+// the event said.  The wait is enqueued AFTER the kernel that releases it (submission order, as for the completion pass's gate), one word and one
+// counter per caller stream (two streams sharing a context must not release each other's waits).
+struct ForkWord { uint32_t* word = nullptr; uint32_t seq = 0; };
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; bool can_wait = false; std::map<hipStream_t, ForkWord> words; };
 // The list cut's completion pass OFF the critical path (round 4).  Its eleven predicated launches used to sit between the forward blend and
 // whatever the caller enqueues next: 55-80 us of dependent-launch latency in the steady state, where every one of them returns at once.
 // Now the blend's LAST workgroup (gsrast_blend.h, GateArgs) copies the blend's verdict into a word of the context's own (`pred`: the chain's predicate; the
@@ -453,8 +462,31 @@ SideStream* side_stream_of(gsrast_context* ctx)
             x = SideStream{};
             return nullptr;
         }
+        int can = 0;
+        x.can_wait = hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can != 0;
     }
     return &x;
+}
+std::atomic<int> g_word_fork{1};          // 1: word forks where a kernel can signal its own start (A/B switch)
+// the caller stream's fork word and the next sequence number to signal, or {nullptr, 0}: fork with the event
+static ForkWord fork_word_next(gsrast_context* ctx, SideStream* side, hipStream_t caller)
+{
+    if (!side || !side->can_wait || !g_word_fork.load() || counter_collection_env()) return ForkWord{};
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ForkWord& w = side->words[caller];
+    if (!w.word) {
+        if (side->words.size() > 64) { side->words.erase(caller); return ForkWord{}; }      // (a caller that creates streams without end: events for it)
+        uint32_t* p = nullptr;
+        if (hipMalloc((void**)&p, 64) != hipSuccess) { side->words.erase(caller); return ForkWord{}; }
+        if (hipMemset(p, 0, 64) != hipSuccess) { (void)hipFree(p); side->words.erase(caller); return ForkWord{}; }
+        w.word = p; w.seq = 0;
+    }
+    if (w.seq >= 0xFFFFFFF0u) {      // (the comparison is >=: start over before the counter wraps -- nothing may still be waiting on the old values)
+        if (hipStreamSynchronize(side->stream) != hipSuccess || hipStreamSynchronize(caller) != hipSuccess || hipMemset(w.word, 0, 64) != hipSuccess) return ForkWord{};
+        w.seq = 0;
+    }
+    w.seq++;
+    return w;
 }
 ChainGate* chain_gate_of(gsrast_context* ctx)
 {
@@ -605,6 +637,7 @@ struct BlendArgs {
     GateArgs gate{};                                             // forward, list cut's first pass: the completion pass's gate (ChainGate)
     uint32_t cut_margin_x4 = 6;                                  // forward: the next cut depth's margin (gsrast_context::cut_margin)
     unsigned long long* untouched = nullptr;                     // forward (culling kernel): GeomLayout::untouched
+    uint32_t* fork_word = nullptr; uint32_t fork_seq = 0;        // backward (transposed kernel): the word fork's signal (SideStream)
 };
 template <int MODE, int PPL>
 void launch_fwd(uint32_t grid, hipStream_t s, const BlendArgs& a)
@@ -634,7 +667,7 @@ void dispatch_bwd_cull(int ppl, uint32_t grid, hipStream_t s, const BlendArgs& a
 {
     if (ppl == 1 && g_bwd_transposed.load()) {
         blend_bwd_cull_t_kernel<MODE><<<grid, 256, 0, s>>>(a.ranges, a.plist, a.order, a.W, a.H, a.gx, a.T, a.r0, a.r1, a.r2, a.bg, a.fT, a.nc, a.tm, a.dpix, a.grec,
-                                                           a.from_buckets ? a.bcnt : nullptr, a.blist);
+                                                           a.from_buckets ? a.bcnt : nullptr, a.blist, a.fork_word, a.fork_seq);
         return;
     }
     if (ppl == 4) launch_bwd_cull<MODE, 4>(grid, s, a); else if (ppl == 2) launch_bwd_cull<MODE, 2>(grid, s, a); else launch_bwd_cull<MODE, 1>(grid, s, a);
@@ -682,6 +715,7 @@ void gsrast_context_destroy(gsrast_context* c)
         if (x.fork) (void)hipEventDestroy(x.fork);
         if (x.join) (void)hipEventDestroy(x.join);
         if (x.join2) (void)hipEventDestroy(x.join2);
+        for (auto& kv : x.words) if (kv.second.word) (void)hipFree(kv.second.word);
     }
     delete c;
 }
@@ -763,6 +797,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "touch_bits")) { g_touch_bits = value ? 1 : 0; return 0; }               // 0: only the list cut's late bits serve the backward (round 4)
     if (!strcmp(name, "late_fill_min_p")) { g_late_fill_min_p = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "sparse_grec")) { g_sparse_grec = value != 0; return 0; }
+    if (!strcmp(name, "word_fork")) { g_word_fork = value != 0; return 0; }
     if (!strcmp(name, "near_pose")) { g_near_pose = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }                 // 0: only the pose's own slot (round 3)
     if (!strcmp(name, "tau_sample")) { g_tau_sample = value < 0 ? 0 : (value > 6 ? 6 : value); return 0; }
     if (!strcmp(name, "tau_cut")) { g_tau_cut = value ? 1 : 0; return 0; }                    // 0: only poses with remembered cut depths are cut (round 4's behaviour)
@@ -804,6 +839,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "touch_bits")) return g_touch_bits.load();
     if (!strcmp(name, "late_fill_min_p")) return g_late_fill_min_p.load();
     if (!strcmp(name, "sparse_grec")) return g_sparse_grec.load();
+    if (!strcmp(name, "word_fork")) return g_word_fork.load();
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
     if (!strcmp(name, "tau_sample")) return g_tau_sample.load();
     if (!strcmp(name, "tau_cut")) return g_tau_cut.load();
@@ -1089,9 +1125,13 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // List cut: a Gaussian the bucket scatter found late is in no list -- its colour is not evaluated (3 M cube: 87 % of them).
     // Not under the diagnostic option debug_state (gsrast_debug_export shows every Gaussian's colour).
     bool cut_colors = cut && zero_in_blend && !g_debug_state.load();       // (switched off below for a pose the table does not know: everything is early)
-    auto launch_color = [&]() -> int {
+    // WORD FORK (see SideStream): with the run emission about to be launched, the colour kernels are not forked with an event here but
+    // enqueued behind that launch, waiting for the word the emission kernel stores when it starts (color_fork: pending until then)
+    ForkWord color_fork{};
+    auto launch_color = [&](bool emit_follows = false) -> int {
         if (color_launched) return GSRAST_OK;
         color_launched = true;
+        if (side && emit_follows) { color_fork = fork_word_next(ctx, side, s); if (color_fork.word) return GSRAST_OK; }
         if (side) {
             GS_HIP(hipEventRecord(side->fork, s));             // the inputs (and the buffers just handed out) are ordered on s
             GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
@@ -1104,6 +1144,22 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 GS_HIP(hipMemsetAsync(at<float>(geom, GL.grec), 0, (size_t)P * GREC * sizeof(float), side->stream));
                 GS_HIP(hipEventRecord(side->join2, side->stream));
             }
+        }
+        return GSRAST_OK;
+    };
+    // the pending word fork's side-stream half: `signalled` = the kernel that stores the word has been launched on s; otherwise s stores it itself
+    auto flush_color_fork = [&](bool signalled) -> int {
+        if (!color_fork.word) return GSRAST_OK;
+        const ForkWord fw = color_fork;
+        color_fork = ForkWord{};
+        if (!signalled) GS_HIP(hipStreamWriteValue32(s, fw.word, fw.seq, 0));
+        GS_HIP(hipStreamWaitValue32(side->stream, fw.word, fw.seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        cs = side->stream;
+        { int rc = color_kernels(cs, cut_colors, nullptr); if (rc != GSRAST_OK) return rc; }
+        GS_HIP(hipEventRecord(side->join, side->stream));
+        if (!zero_in_blend) {
+            GS_HIP(hipMemsetAsync(at<float>(geom, GL.grec), 0, (size_t)P * GREC * sizeof(float), side->stream));
+            GS_HIP(hipEventRecord(side->join2, side->stream));
         }
         return GSRAST_OK;
     };
@@ -1252,7 +1308,6 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         ctx->pose_seen[viewmatrix] = pose_known ? 1 : 0;
     }
     if (!pose_known && layer_mode == 0 && !tau_on) cut_colors = false;
-    { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }
     // Everything that does not depend on num_rendered is enqueued / prepared before the host waits.
     uint2* ranges = at<uint2>(img, IL.ranges);
     // reference rasterizer_impl.cu:311 (the run-compressed path writes every tile's range itself, empty ones included)
@@ -1274,6 +1329,8 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         if (!bin) cap = capQ = 0;
     }
     auto t1 = std::chrono::steady_clock::now();
+    // the colour kernels, beside the binning (with the speculative run emission next on s: forked by that kernel's own start, no event)
+    { int rc = launch_color(runbin && bin != nullptr && o.speculative != 0 && bucketed && totals_pending); if (rc != GSRAST_OK) return rc; }
 
     // ---- the rest of the forward as two re-launchable pieces ----
     // run-compressed binning; nQ / capR are either exact counts (counts_dev == nullptr) or capacities with the real
@@ -1293,10 +1350,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         const uint32_t* Q_dev = counts_dev ? counts_dev + 1 : nullptr;
         const int xbits = tile_bits((size_t)cam.gx);
         {   ProfScope ps(K_EMIT, s);
+            const ForkWord fw = mode != 2 ? color_fork : ForkWord{};      // (pending word fork of the colour kernels: this launch signals it)
             if (bucketed && mode == 1)
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order_e), at<uint32_t>(geom, GL.bk_wincl_e), binrec_p, W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info_e), at<uint32_t>(geom, GL.bk_base_e), nbk, scalars,
-                                                            flag_alias, flag_seq, at<uint4>(geom, GL.bk_info), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect);
+                                                            flag_alias, flag_seq, at<uint4>(geom, GL.bk_info), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect,
+                                                            fw.word, fw.seq);
             else if (bucketed && mode == 2) {
                 // COMPLETION pass: only the CANDIDATES -- the Gaussians, early or late, whose rectangle touches a tile flagged by the
                 // blend -- are sorted (the buckets' non-early arrays are free) and listed, and only into flagged tiles
@@ -1316,11 +1375,14 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 }
                 emit_column_runs_kernel<<<nbk + 1, 256, 0, s>>>(P, at<uint32_t>(geom, GL.bk_order), at<uint32_t>(geom, GL.bk_wincl), binrec_p, W, H,
                                                             o.tile_clip, capQ_, rkA, rvA, at<uint4>(geom, GL.bk_info), at<uint32_t>(geom, GL.bk_base), nbk, scalars,
-                                                            flag_alias, flag_seq, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect);
+                                                            flag_alias, flag_seq, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect,
+                                                            fw.word, fw.seq);
             } else
                 emit_column_runs_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, order, woffsets, binrec_p, W, H,
                                                                        o.tile_clip, capQ_, rkA, rvA, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, rec0, rec1, rect);
-            GS_LAUNCHED("emit_column_runs"); }
+            GS_LAUNCHED("emit_column_runs");
+            // (signalled only by the two bucketed launches above that were handed the word)
+            if (fw.word) { int rc = flush_color_fork(bucketed); if (rc != GSRAST_OK) return rc; } }
         if (bucketed && mode != 2) totals_pending = false;
         if (after_emit) { int rc = after_emit(); if (rc != GSRAST_OK) return rc; }
         const uint32_t nblk = (nQ + RUNS_PER_BLOCK - 1) / RUNS_PER_BLOCK;
@@ -1345,6 +1407,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     ChainGate* gate = nullptr; uint32_t gseq = 0, *gdone = nullptr, *gpred = nullptr;
     auto launch_blend = [&](const uint32_t* plist, bool fwd_lists_built, int mode = 0 /* list cut: as launch_run_binning */) -> int {
         { int rc = launch_color(); if (rc != GSRAST_OK) return rc; }  // the other binning scheme / nothing to bin: not forked yet
+        { int rc = flush_color_fork(false); if (rc != GSRAST_OK) return rc; }      // (a word fork no emission picked up: s releases it itself)
         if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); if (zero_in_blend) side_guard.joined = true; }       // the colours (rec2) are the blend's input
         ProfScope ps(K_BLEND_FWD, s);
         uint32_t grid = ((T + 7) / 8) * 8;
@@ -1556,6 +1619,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     if (speculative && !sort_redone) ctx->redo_count++;
     if (cut) GS_HIP(hipMemsetAsync(scalars + SC_N_LATE, 0, sizeof(uint32_t), s));      // (the backward must not take a late Gaussian's rows for zero: below it is listed)
     if (cut_colors && color_launched) {     // everything from here on lists ALL Gaussians: the colours the list cut left out are evaluated now
+        { int rc = flush_color_fork(false); if (rc != GSRAST_OK) return rc; }
         if (side) GS_HIP(hipStreamWaitEvent(s, side->join, 0));
         int rc = color_kernels(s, false, nullptr);
         if (rc != GSRAST_OK) return rc;
@@ -2179,10 +2243,14 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // backward; preprocess_bwd then neither reads nor writes them.  Both kernels check on the device that the forward's cut was in force
     // and held.  Only where it pays for the two events (large scenes), with the sparse per-Gaussian backward, in a one-phase call.
     bool late_fill = false;
+    ForkWord late_fork{};
+    std::function<int()> launch_late_fill;
     if (do_blend && do_geom && R > 0 && !o.dense_backward && o.side_stream && (P >= g_late_fill_min_p.load() || g_list_cut_always.load() != 0)) {
         if (!side) {
             side = side_stream_of(thread_context());
-            if (side) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); }
+            // word fork: the blend backward below signals its own start, the side stream waits for that -- when it is the transposed kernel
+            if (side && o.cull != 0 && o.lpt && pick_ppl(T, true, o) == 1 && g_bwd_transposed.load() && g_ablate.load() == 0) late_fork = fork_word_next(thread_context(), side, s);
+            if (side && !late_fork.word) { GS_HIP(hipEventRecord(side->fork, s)); GS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0)); }
         }
         if (side) {
             LateRowsArgs la{}; int n = 0;
@@ -2192,12 +2260,17 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
             if (rawin) { add(rawg.d_rot_res, 7); add(rawg.d_trbf, 1); add(rawg.d_shs_res, M * 3); add(rawg.d_dc, 3); add(rawg.d_rest, M * 3 - 3); }
             else if (use_sh && !o.sh_grad_factors) add(dL_dsh, M * 3);
             la.n = n;
-            if (g_ablate.load() != 3)      // (3, experiments only: the step without the zero rows -- what a caller with persistent outputs could save)
-            {   ProfScope ps(K_LATE_ZERO, side->stream);
-                late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la, at<unsigned long long>(geom, GL.untouched)); }
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
-            GS_HIP(hipEventRecord(side->join, side->stream));
+            launch_late_fill = [=]() -> int {
+                if (late_fork.word) GS_HIP(hipStreamWaitValue32(side->stream, late_fork.word, late_fork.seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                if (g_ablate.load() != 3)      // (3, experiments only: the step without the zero rows -- what a caller with persistent outputs could save)
+                {   ProfScope ps(K_LATE_ZERO, side->stream);
+                    late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la, at<unsigned long long>(geom, GL.untouched)); }
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
+                GS_HIP(hipEventRecord(side->join, side->stream));
+                return GSRAST_OK;
+            };
+            if (!late_fork.word) { int rc = launch_late_fill(); if (rc != GSRAST_OK) return rc; }       // (word fork: behind the blend backward's launch, below)
             late_fill = true;
         }
     }
@@ -2211,6 +2284,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         ba.ranges = ranges; ba.plist = plist; ba.W = W; ba.H = H; ba.gx = cam.gx; ba.T = T; ba.r0 = rec0; ba.r1 = rec1; ba.r2 = rec2;
         ba.bg = background; ba.fT = const_cast<float*>(fT); ba.nc = const_cast<uint32_t*>(nc); ba.tm = const_cast<uint32_t*>(tm);
         ba.dpix = dL_dpix; ba.grec = grec;
+        ba.fork_word = late_fork.word; ba.fork_seq = late_fork.seq;
         const int ppl = pick_ppl(T, true, o);
         const bool cull = o.cull != 0;
         if (cull && o.lpt) {
@@ -2233,7 +2307,10 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         default: if (cull) dispatch_bwd_cull<2>(ppl, grid, s, ba); else dispatch_bwd<2>(ppl, grid, s, ba); break;
         }
         GS_LAUNCHED("blend_bwd");
+        // (belt and braces: should anything but the signalling kernel have been launched, the caller's stream releases the side stream itself)
+        if (late_fork.word && !(g_ablate.load() == 0 && cull && ppl == 1 && g_bwd_transposed.load())) GS_HIP(hipStreamWriteValue32(s, late_fork.word, late_fork.seq, 0));
     }
+    if (late_fork.word) { int rc = launch_late_fill(); if (rc != GSRAST_OK) return rc; }      // (its wait was released by the kernel just launched, or will be)
     if (do_blend && use_sh && o.sh_grad_factors) {      // dL_dsh is [P][3] in this mode: the factor, final after the blend backward
         sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh, at<uint32_t>(geom, GL.scalars), at<unsigned long long>(geom, GL.untouched));
         GS_LAUNCHED("sh_factor");
