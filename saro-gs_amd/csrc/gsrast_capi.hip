@@ -2216,6 +2216,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // (preprocess_color_kernel), so this kernel only runs for a state whose forward was told that no backward would follow
     // (options.forward_only, passed to both calls by a caller that changed its mind).
     SideStream* side = nullptr;
+    bool side_has_derivs = false;       // the side stream computes something the per-Gaussian backward reads (a forward_only state's direction derivatives)
     struct BwdSideGuard {       // an error exit below must not leave side-stream work running on the caller's arrays
         SideStream*& side; bool joined = false;
         ~BwdSideGuard() { if (side && !joined) (void)hipStreamSynchronize(side->stream); }
@@ -2237,7 +2238,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "sh_dir_derivs", e);
         }
-        if (side) GS_HIP(hipEventRecord(side->join, side->stream));
+        if (side) { GS_HIP(hipEventRecord(side->join, side->stream)); side_has_derivs = true; }
     }
     // List cut (gsrast_common.h): the zero rows of the Gaussians the forward left out are written on the side stream, beside the blend
     // backward; preprocess_bwd then neither reads nor writes them.  Both kernels check on the device that the forward's cut was in force
@@ -2315,7 +2316,11 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh, at<uint32_t>(geom, GL.scalars), at<unsigned long long>(geom, GL.untouched));
         GS_LAUNCHED("sh_factor");
     }
-    if (side) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
+    // The zero rows and the per-Gaussian backward write DISJOINT rows (untouched / touched Gaussians, by the same bits): when they are all the side
+    // stream carries, it is joined BEHIND the per-Gaussian backward -- that kernel neither waits for the last zero row nor pays the join's latency
+    // in front of it (the table-off step showed it waiting 18 us for a fill that had started later than the blend backward)
+    const bool join_late = side && late_fill && !side_has_derivs && do_geom && g_ablate.load() != 5 /* (5, experiments only: the join in front, as before) */;
+    if (side && !join_late) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
     if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);
         const float* cov = cov3D_precomp ? cov3D_precomp : at<float>(geom, GL.cov3D);
@@ -2337,6 +2342,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
 #undef GS_PB_ARGS
         GS_LAUNCHED("preprocess_bwd");
     }
+    if (join_late) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
     return GSRAST_OK;
 }
 
