@@ -27,6 +27,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <functional>
 #include <map>
 #include <cstdio>
@@ -428,6 +429,7 @@ struct gsrast_context {
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
     std::atomic<int> bucket_backoff{0}, bucket_clean{0};   // length of the last such pause (doubles per overflow), bucket-sorted forwards without one since
+    bool counted_streams = false;     // this context is one of g_stream_contexts (it owns a side stream)
     SideStream side[32];              // per device: the stream the colour kernel runs on beside the sort (created on first use)
     ChainGate gate[32];               // per device: the completion pass's own stream and release words (created on first use)
     uint32_t* tau_dev[32] = {}; size_t tau_dev_words[32] = {}; bool tau_dev_dirty[32] = {};      // per device: the predicted cut's opacity-mass table [TAU_COPIES][T][TAU_BINS] (ImgLayout::tau_hist's twin), kept ZERO between
@@ -442,6 +444,20 @@ struct gsrast_context {
 namespace {
 // The context's side stream on the current device (created on first use, lowest priority: its bandwidth-heavy kernels should fill
 // the gaps the critical path leaves, not compete with it for compute units).  nullptr if it cannot be had.
+// Word forks and the late join of the backward are used only while the library's calls do not OVERLAP in time and at most two contexts own
+// streams (PyTorch's usual shape: the forward on the caller's thread, the backward on the autograd engine's thread, one after the other).  With
+// one submitter at a time every wait is submitted behind everything that can release it, whatever hardware queues the streams share.  Threads
+// that submit concurrently interleave; tests/test_gpu_gate.py's soak (two threads, two contexts, completion passes for real) hung once with both
+// features on -- once two calls have been seen inside the library at the same time, or a third context has created its streams, the library
+// falls back to events and the join in front for good: the configuration that test has always passed.
+static std::atomic<int> g_calls_inside{0}, g_stream_contexts{0};
+static std::atomic<bool> g_concurrent_callers{false};
+struct CallScope { CallScope() { if (g_calls_inside.fetch_add(1) > 0) g_concurrent_callers = true; } ~CallScope() { g_calls_inside.fetch_sub(1); } };
+static bool single_host_thread()
+{
+    static const bool forced = getenv("GSRAST_FORCE_WORD_FORK") != nullptr;      // (experiments only: reproduces the hang the rule avoids)
+    return forced || (!g_concurrent_callers.load(std::memory_order_relaxed) && g_stream_contexts.load(std::memory_order_relaxed) <= 2);
+}
 SideStream* side_stream_of(gsrast_context* ctx)
 {
     int device = 0;
@@ -464,6 +480,7 @@ SideStream* side_stream_of(gsrast_context* ctx)
         }
         int can = 0;
         x.can_wait = hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can != 0;
+        if (!ctx->counted_streams) { ctx->counted_streams = true; g_stream_contexts++; }
     }
     return &x;
 }
@@ -471,7 +488,7 @@ std::atomic<int> g_word_fork{1};          // 1: word forks where a kernel can si
 // the caller stream's fork word and the next sequence number to signal, or {nullptr, 0}: fork with the event
 static ForkWord fork_word_next(gsrast_context* ctx, SideStream* side, hipStream_t caller)
 {
-    if (!side || !side->can_wait || !g_word_fork.load() || counter_collection_env()) return ForkWord{};
+    if (!side || !side->can_wait || !g_word_fork.load() || counter_collection_env() || !single_host_thread()) return ForkWord{};
     std::lock_guard<std::mutex> lk(ctx->mu);
     ForkWord& w = side->words[caller];
     if (!w.word) {
@@ -710,6 +727,7 @@ void gsrast_context_destroy(gsrast_context* c)
     }
     for (uint32_t* z : c->zhist_dev) if (z) (void)hipFree(z);
     for (uint32_t* z : c->tau_dev) if (z) (void)hipFree(z);
+    if (c->counted_streams) g_stream_contexts--;
     for (SideStream& x : c->side) {
         if (x.stream) { (void)hipStreamSynchronize(x.stream); (void)hipStreamDestroy(x.stream); }
         if (x.fork) (void)hipEventDestroy(x.fork);
@@ -946,6 +964,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                       const gsrast_raw_inputs* rawin)
 {
     RoctxRange range_fwd(rawin ? "gsrast_forward_raw" : "gsrast_forward");
+    CallScope call_scope;
     RawArgs raw{};
     if (rawin) {
         raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
@@ -2170,6 +2189,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
                        const gsrast_raw_inputs* rawin, const gsrast_raw_grads* rawout)
 {
     RoctxRange range_bwd(rawin ? "gsrast_backward_raw" : "gsrast_backward");
+    CallScope call_scope;
     RawArgs raw{}; RawGrads rawg{};
     if (rawin) {
         raw.motion_res = rawin->motion_res; raw.rot_res = rawin->rot_res; raw.trbf = rawin->trbf; raw.opacity_logit = rawin->opacity_logit;
@@ -2319,7 +2339,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // The zero rows and the per-Gaussian backward write DISJOINT rows (untouched / touched Gaussians, by the same bits): when they are all the side
     // stream carries, it is joined BEHIND the per-Gaussian backward -- that kernel neither waits for the last zero row nor pays the join's latency
     // in front of it (the table-off step showed it waiting 18 us for a fill that had started later than the blend backward)
-    const bool join_late = side && late_fill && !side_has_derivs && do_geom && g_ablate.load() != 5 /* (5, experiments only: the join in front, as before) */;
+    const bool join_late = side && late_fill && !side_has_derivs && do_geom && single_host_thread() && g_ablate.load() != 5 /* (5, experiments only: the join in front, as before) */;
     if (side && !join_late) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
     if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);

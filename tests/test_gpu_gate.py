@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.remembered_cut_only          # (with predicted cut depths the first wide failure switches the context to them, and they hold: the gate would idle)
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(300)          # (it takes 5 s; a hang here once cost the round 50 GPU-minutes)
 def test_gate_soak_two_threads_two_contexts(scenes, rast, gpu):
     _C = rast._C
     P, W, H, N = 1_000_000, 1920, 1080, 400
@@ -75,7 +75,7 @@ def test_gate_soak_two_threads_two_contexts(scenes, rast, gpu):
         for th in threads:
             th.start()
         for th in threads:
-            th.join(timeout=600)
+            th.join(timeout=120)
         assert not any(th.is_alive() for th in threads), "a worker is stuck: the gate (or its inline fallback) hangs"
         wall = time.perf_counter() - t0
     finally:
