@@ -444,11 +444,12 @@ struct gsrast_context {
 namespace {
 // The context's side stream on the current device (created on first use, lowest priority: its bandwidth-heavy kernels should fill
 // the gaps the critical path leaves, not compete with it for compute units).  nullptr if it cannot be had.
-// Word forks and the late join of the backward are used only while the library's calls do not OVERLAP in time and at most two contexts own
-// streams (PyTorch's usual shape: the forward on the caller's thread, the backward on the autograd engine's thread, one after the other).  With
+// Word forks and the late join of the backward are used only while the library's calls do not OVERLAP in time and at most four contexts own
+// streams (PyTorch's usual shape: the forward on the caller's thread, the backward on the autograd engine's thread, one after the other; two more
+// for a caller that keeps two views in flight from one thread).  With
 // one submitter at a time every wait is submitted behind everything that can release it, whatever hardware queues the streams share.  Threads
 // that submit concurrently interleave; tests/test_gpu_gate.py's soak (two threads, two contexts, completion passes for real) hung once with both
-// features on -- once two calls have been seen inside the library at the same time, or a third context has created its streams, the library
+// features on -- once two calls have been seen inside the library at the same time, or a fifth context has created its streams, the library
 // falls back to events and the join in front for good: the configuration that test has always passed.
 static std::atomic<int> g_calls_inside{0}, g_stream_contexts{0};
 static std::atomic<bool> g_concurrent_callers{false};
@@ -456,7 +457,7 @@ struct CallScope { CallScope() { if (g_calls_inside.fetch_add(1) > 0) g_concurre
 static bool single_host_thread()
 {
     static const bool forced = getenv("GSRAST_FORCE_WORD_FORK") != nullptr;      // (experiments only: reproduces the hang the rule avoids)
-    return forced || (!g_concurrent_callers.load(std::memory_order_relaxed) && g_stream_contexts.load(std::memory_order_relaxed) <= 2);
+    return forced || (!g_concurrent_callers.load(std::memory_order_relaxed) && g_stream_contexts.load(std::memory_order_relaxed) <= 4);
 }
 SideStream* side_stream_of(gsrast_context* ctx)
 {
