@@ -173,6 +173,8 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse=False) -
         warnings.warn("exchange_gradients(sparse=True) with overlap_factor_exchange() in force: the dense factor gather has already "
                       "been started inside the backward, the exchange falls back to the dense form; switch the overlap off "
                       "(overlap_factor_exchange(False)) to send only the touched rows", RuntimeWarning, stacklevel=2)
+    if sparse == "gather" and (arena.M * 3) % 4 != 0:
+        sparse = True                   # (the row kernels move SH rows in 16-byte pieces: M = 4, 8, 12, 16; other M take the union form)
     if sparse == "gather" and multi and pending is None and P > 0:
         return _exchange_gather(arena, means3D, batch, n_views)
     if sparse and multi and pending is None and P > 0:
