@@ -444,20 +444,21 @@ struct gsrast_context {
 namespace {
 // The context's side stream on the current device (created on first use, lowest priority: its bandwidth-heavy kernels should fill
 // the gaps the critical path leaves, not compete with it for compute units).  nullptr if it cannot be had.
-// Word forks and the late join of the backward are used only while the library's calls do not OVERLAP in time and at most four contexts own
-// streams (PyTorch's usual shape: the forward on the caller's thread, the backward on the autograd engine's thread, one after the other; two more
-// for a caller that keeps two views in flight from one thread).  With
-// one submitter at a time every wait is submitted behind everything that can release it, whatever hardware queues the streams share.  Threads
-// that submit concurrently interleave; tests/test_gpu_gate.py's soak (two threads, two contexts, completion passes for real) hung once with both
-// features on -- once two calls have been seen inside the library at the same time, or a fifth context has created its streams, the library
-// falls back to events and the join in front for good: the configuration that test has always passed.
+// Word forks are used only while the library's calls do not OVERLAP in time and at most two contexts own streams (PyTorch's usual shape: the
+// forward on the caller's thread, the backward on the autograd engine's thread, one after the other).  tests/test_gpu_gate.py's soak -- two threads
+// submitting concurrently, completion passes for real -- hung in 3 of 28 runs with word forks forced on (tools/soak_stress.sh; both threads stuck in
+// the forward's read-back, the device making no progress) and in 0 of 20 without them; the backward's late join alone: 0 of 14.  Every wait is
+// still submitted behind its releaser, so this is not a dependency cycle; what grows with concurrent submitters is the number of queues sitting in
+// a value wait at the same time (two gate waits + up to three side-stream waits there), and a queue that polls a word seems to keep its place
+// on the command processor -- with enough of them the queue that holds a releaser is not scheduled.  One submitter at a time keeps it at two.
+// Once two calls have been seen inside the library at the same time, or a third context has created its streams, the library forks with events for good.
 static std::atomic<int> g_calls_inside{0}, g_stream_contexts{0};
 static std::atomic<bool> g_concurrent_callers{false};
 struct CallScope { CallScope() { if (g_calls_inside.fetch_add(1) > 0) g_concurrent_callers = true; } ~CallScope() { g_calls_inside.fetch_sub(1); } };
 static bool single_host_thread()
 {
-    static const bool forced = getenv("GSRAST_FORCE_WORD_FORK") != nullptr;      // (experiments only: reproduces the hang the rule avoids)
-    return forced || (!g_concurrent_callers.load(std::memory_order_relaxed) && g_stream_contexts.load(std::memory_order_relaxed) <= 4);
+    static const bool forced = getenv("GSRAST_FORCE_WORD_FORK") != nullptr;      // (experiments only: switches the rule off -- to reproduce the hang it avoids)
+    return forced || (!g_concurrent_callers.load(std::memory_order_relaxed) && g_stream_contexts.load(std::memory_order_relaxed) <= 2);
 }
 SideStream* side_stream_of(gsrast_context* ctx)
 {
@@ -2340,7 +2341,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     // The zero rows and the per-Gaussian backward write DISJOINT rows (untouched / touched Gaussians, by the same bits): when they are all the side
     // stream carries, it is joined BEHIND the per-Gaussian backward -- that kernel neither waits for the last zero row nor pays the join's latency
     // in front of it (the table-off step showed it waiting 18 us for a fill that had started later than the blend backward)
-    const bool join_late = side && late_fill && !side_has_derivs && do_geom && single_host_thread() && g_ablate.load() != 5 /* (5, experiments only: the join in front, as before) */;
+    const bool join_late = side && late_fill && !side_has_derivs && do_geom && g_ablate.load() != 5 /* (5, experiments only: the join in front, as before) */;
     if (side && !join_late) { GS_HIP(hipStreamWaitEvent(s, side->join, 0)); side_guard.joined = true; }
     if (do_geom) {
         ProfScope ps(K_PREPROCESS_BWD, s);
