@@ -860,6 +860,8 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "late_fill_min_p")) return g_late_fill_min_p.load();
     if (!strcmp(name, "sparse_grec")) return g_sparse_grec.load();
     if (!strcmp(name, "word_fork")) return g_word_fork.load();
+    if (!strcmp(name, "stream_contexts")) return g_stream_contexts.load();          // (diagnostics: the rule of the word forks)
+    if (!strcmp(name, "concurrent_callers")) return g_concurrent_callers.load() ? 1 : 0;
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
     if (!strcmp(name, "tau_sample")) return g_tau_sample.load();
     if (!strcmp(name, "tau_cut")) return g_tau_cut.load();

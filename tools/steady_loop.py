@@ -21,4 +21,5 @@ t0 = time.perf_counter()
 for i in range(N - N // 2):
     wl.step(None, 1)
 torch.cuda.synchronize()
-print("steady_loop P=%d poses=%d %s: %.4f ms per step" % (P, V, " ".join(sys.argv[4:]), (time.perf_counter() - t0) * 1e3 / (N - N // 2)))
+print("steady_loop P=%d poses=%d %s: %.4f ms per step (contexts with streams %d, overlapping calls seen %d)" % (P, V, " ".join(sys.argv[4:]), (time.perf_counter() - t0) * 1e3 / (N - N // 2),
+      rast._C.get_option("stream_contexts"), rast._C.get_option("concurrent_callers")))
