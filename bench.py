@@ -353,6 +353,7 @@ def stage_table(_C, wl, st, P, deg, H):
         "late_rows_zero": late_n * (12 * C + 12 + 4 + 12 + 12 + 16) if late_n else 0,   # dL/dsh, dL/dmean2D, dL/dopacity, dL/dmean3D, dL/dscale, dL/drot rows of zeros
         "sh_dir_derivs": Pv * (12 * C + 12 + 36) + P * 4,       # side stream, beside the blend backward: SH + mean in, 36 B out
         "cut_redo": 0,                                          # list cut: the predicated second binning + blend (ten launches that return at once)
+        "grec_zero_touched": Pe * 64 + P // 8,                  # behind the last blend: a bit per Gaussian in, one 64-byte record per consumed Gaussian out (at most the early ones)
     }
     per_kernel = {}
     for name, nbytes in alg.items():

@@ -90,12 +90,13 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 // ---- per-kernel device timing (option "profile") -------------------------------------------
 enum KernelId { K_PREPROCESS_FWD, K_SORT_DEPTH, K_SCAN_TILES, K_EMIT, K_SORT_TILE, K_RANGES, K_BLEND_FWD,
-                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_CUT_REDO, K_LATE_ZERO, K_COUNT };
+                K_BLEND_BWD, K_PREPROCESS_BWD, K_MARK_VISIBLE, K_LOSS_FWD, K_LOSS_BWD, K_COLOR, K_SH_DERIVS, K_CUT_REDO, K_LATE_ZERO, K_GREC_ZERO, K_COUNT };
 const char* const kKernelNames[K_COUNT] = { "preprocess_fwd", "sort_depth", "scan_tiles", "emit_instances",
                                             "sort_tile", "tile_ranges", "blend_fwd", "blend_bwd",
                                             "preprocess_bwd", "mark_visible", "loss_fwd", "loss_bwd", "preprocess_color", "sh_dir_derivs",
                                             "cut_redo" /* list cut: the predicated second binning + blend behind the forward blend, as ONE stage */,
-                                            "late_rows_zero" /* list cut: the late Gaussians' zero rows, on the side stream beside the blend backward */ };
+                                            "late_rows_zero" /* list cut: the late Gaussians' zero rows, on the side stream beside the blend backward */,
+                                            "grec_zero_touched" /* the consumed Gaussians' gradient records zeroed behind the forward's last blend */ };
 thread_local int t_prof_off = 0;      // > 0: the stages below are part of an enclosing one (cut_redo) and not recorded on their own
 struct Pending { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -1096,7 +1097,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool zero_touched = untouched != nullptr && zero_in_blend && g_sparse_grec.load() != 0;
     auto finish_records = [&]() -> int {
         if (!zero_touched) return GSRAST_OK;
-        ProfScope ps(K_BLEND_FWD, s);
+        ProfScope ps(K_GREC_ZERO, s);
         grec_zero_touched_kernel<<<(unsigned)(((size_t)P + 64 * GZ_WORDS * 4 - 1) / (64 * GZ_WORDS * 4)), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
         GS_LAUNCHED("grec_zero_touched");
         return GSRAST_OK;
