@@ -152,3 +152,4 @@ def test_python_context_handle(scenes, rast, gpu):
     with pytest.raises(RuntimeError):
         c1.query("last_instances")
     assert all(torch.equal(x, y) for x, y in zip(render(rs_a), want_a))  # the thread's own context is untouched
+
