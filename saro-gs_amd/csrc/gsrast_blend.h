@@ -152,7 +152,7 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
                       // their full lists (the launch with `pred`); every other tile is final after this launch
                       unsigned char* __restrict__ tile_flags = nullptr,
                       uint32_t cut_margin_x4 = GSRAST_CUT_MARGIN_X4 /* round 5: the context's margin (6 = 1.5 x; it widens while completion passes are reported) */,
-                      unsigned long long* __restrict__ untouched = nullptr /* GeomLayout::untouched: bit i cleared = some pixel consumed Gaussian i */)
+                      unsigned char* __restrict__ untouched = nullptr /* GeomLayout::untouched: byte i cleared = some pixel consumed Gaussian i */)
 {
     constexpr uint32_t FB = 256;                  // instances staged per batch (64 / 128 / 256 measured equal)
     if (pred && *pred == 0u) return;
@@ -240,7 +240,7 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     uint32_t g_prev = 0xFFFFFFFFu, base_prev = 0u;
     for (uint32_t base = 0; base < n; base += FB) {
         if (__syncthreads_and(alive == 0ull)) break;
-        if (untouched && g_prev != 0xFFFFFFFFu) atomicAnd(&untouched[g_prev >> 6], ~(1ull << (g_prev & 63u)));
+        if (untouched && g_prev != 0xFFFFFFFFu) untouched[g_prev] = 0;      // (a plain store: every writer writes the same zero)
         g_prev = 0xFFFFFFFFu; base_prev = base;
         const uint32_t i = base + t;
         bool safe = false;
@@ -358,7 +358,7 @@ blend_fwd_cull_body(const uint2* __restrict__ ranges, const uint32_t* __restrict
     // 3 M), every other Gaussian's output rows are zeros that late_rows_zero_kernel writes beside the blend backward and the per-Gaussian
     // backward skips -- for ANY forward, not only one that ran under a remembered cut.  (Batches in front of the last one are cleared whole, a
     // tile the completion pass blends again clears a few bits too many: harmless, a cleared bit only means "look at the record".)
-    if (untouched && g_prev != 0xFFFFFFFFu && base_prev + t < s_max) atomicAnd(&untouched[g_prev >> 6], ~(1ull << (g_prev & 63u)));
+    if (untouched && g_prev != 0xFFFFFFFFu && base_prev + t < s_max) untouched[g_prev] = 0;
     if (t == 0) {
         tile_max[tile] = s_max;
         // list cut: the speculation failed for this tile if it had a cut and some pixel would have looked further
@@ -430,7 +430,7 @@ blend_fwd_cull_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       uint32_t* __restrict__ bucket_cnt, uint16_t* __restrict__ bucket_list, int order_from_buckets,
                       float4* __restrict__ zero4, uint32_t n_zero4, HintTable* __restrict__ hints, const uint32_t* __restrict__ hint_sel,
                       const uint32_t* __restrict__ zcut_used, uint32_t* __restrict__ cut_scalars, const uint32_t* __restrict__ pred,
-                      unsigned char* __restrict__ tile_flags, GateArgs gate, uint32_t cut_margin_x4, unsigned long long* __restrict__ untouched)
+                      unsigned char* __restrict__ tile_flags, GateArgs gate, uint32_t cut_margin_x4, unsigned char* __restrict__ untouched)
 {
     blend_fwd_cull_body<EXPMODE>(ranges, point_list, order, W, H, gx, ntiles, rec0, rec1, rec2, bg, out_color, out_depth, final_T, n_contrib, tile_max,
                                  bucket_cnt, bucket_list, order_from_buckets, zero4, n_zero4, hints, hint_sel, zcut_used, cut_scalars, pred, tile_flags, cut_margin_x4, untouched);

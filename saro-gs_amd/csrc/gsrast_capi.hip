@@ -656,7 +656,7 @@ struct BlendArgs {
     unsigned char* tile_flags = nullptr;                         // forward: tiles the completion pass lists and blends again
     GateArgs gate{};                                             // forward, list cut's first pass: the completion pass's gate (ChainGate)
     uint32_t cut_margin_x4 = 6;                                  // forward: the next cut depth's margin (gsrast_context::cut_margin)
-    unsigned long long* untouched = nullptr;                     // forward (culling kernel): GeomLayout::untouched
+    unsigned char* untouched = nullptr;                          // forward (culling kernel): GeomLayout::untouched
     uint32_t* fork_word = nullptr; uint32_t fork_seq = 0;        // backward (transposed kernel): the word fork's signal (SideStream)
 };
 template <int MODE, int PPL>
@@ -1091,14 +1091,14 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // memset behind the colour kernel (side stream) / by the colour kernel itself (no side stream) when another blend kernel runs.
     const bool zero_in_blend = o.cull != 0 && o.fwd_pixels_per_lane == 0 && (size_t)P * 4 <= 0xFFFFFFFFull;
     // ... and it keeps the "no pixel consumed this Gaussian" bits for the backward (GeomLayout::untouched), unless no backward will follow
-    unsigned long long* untouched = (o.cull != 0 && o.fwd_pixels_per_lane == 0 && !o.forward_only && g_touch_bits.load() != 0) ? at<unsigned long long>(geom, GL.untouched) : nullptr;
+    unsigned char* untouched = (o.cull != 0 && o.fwd_pixels_per_lane == 0 && !o.forward_only && g_touch_bits.load() != 0) ? at<unsigned char>(geom, GL.untouched) : nullptr;
     // ... and then only the records of the Gaussians somebody consumed are zeroed, by a kernel of their own behind the last blend (gsrast_preprocess.h:
     // grec_zero_touched_kernel) instead of all P records from inside the blend
     const bool zero_touched = untouched != nullptr && zero_in_blend && g_sparse_grec.load() != 0;
     auto finish_records = [&]() -> int {
         if (!zero_touched) return GSRAST_OK;
         ProfScope ps(K_GREC_ZERO, s);
-        grec_zero_touched_kernel<<<(unsigned)(((size_t)P + 64 * GZ_WORDS * 4 - 1) / (64 * GZ_WORDS * 4)), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
+        grec_zero_touched_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
         GS_LAUNCHED("grec_zero_touched");
         return GSRAST_OK;
     };
@@ -2030,11 +2030,11 @@ int gsrast_hexplane_backward(int N, int D, int C, int F, int n_planes, const gsr
 }
 
 __global__ void __launch_bounds__(256)
-touched_rows_kernel(int P, const unsigned long long* __restrict__ untouched, const uint32_t* __restrict__ scalars, unsigned char* __restrict__ flags)
+touched_rows_kernel(int P, const unsigned char* __restrict__ untouched, const uint32_t* __restrict__ scalars, unsigned char* __restrict__ flags)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    flags[i] = scalars[SC_TOUCH_VALID] != 0u ? (unsigned char)(((untouched[i >> 6] >> (i & 63)) & 1ull) ^ 1ull) : (unsigned char)1;
+    flags[i] = scalars[SC_TOUCH_VALID] != 0u ? (unsigned char)(untouched[i] ? 0 : 1) : (unsigned char)1;
 }
 int gsrast_touched_rows(int P, const char* geom_buffer, unsigned char* flags, void* stream)
 {
@@ -2042,7 +2042,7 @@ int gsrast_touched_rows(int P, const char* geom_buffer, unsigned char* flags, vo
     if (P < 0 || (P > 0 && (!geom_buffer || !flags))) return fail(GSRAST_E_ARG, "touched_rows: bad arguments");
     if (P == 0) return GSRAST_OK;
     const GeomLayout GL = geom_layout((size_t)P);
-    touched_rows_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, at<unsigned long long>(geom_buffer, GL.untouched), at<uint32_t>(geom_buffer, GL.scalars), flags);
+    touched_rows_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, at<unsigned char>(geom_buffer, GL.untouched), at<uint32_t>(geom_buffer, GL.scalars), flags);
     GS_LAUNCHED("touched_rows");
     return GSRAST_OK;
 }
@@ -2290,7 +2290,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
                 if (late_fork.word) GS_HIP(hipStreamWaitValue32(side->stream, late_fork.word, late_fork.seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                 if (g_ablate.load() != 3)      // (3, experiments only: the step without the zero rows -- what a caller with persistent outputs could save)
                 {   ProfScope ps(K_LATE_ZERO, side->stream);
-                    late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la, at<unsigned long long>(geom, GL.untouched)); }
+                    late_rows_zero_kernel<<<GSRAST_LATE_FILL_WGS, 256, 0, side->stream>>>(P, at<unsigned long long>(geom, GL.color_skip), at<uint32_t>(geom, GL.scalars), la, at<unsigned char>(geom, GL.untouched)); }
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) return fail(GSRAST_E_DEVICE, "late_rows_zero", e);
                 GS_HIP(hipEventRecord(side->join, side->stream));
@@ -2338,7 +2338,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
     }
     if (late_fork.word) { int rc = launch_late_fill(); if (rc != GSRAST_OK) return rc; }      // (its wait was released by the kernel just launched, or will be)
     if (do_blend && use_sh && o.sh_grad_factors) {      // dL_dsh is [P][3] in this mode: the factor, final after the blend backward
-        sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh, at<uint32_t>(geom, GL.scalars), at<unsigned long long>(geom, GL.untouched));
+        sh_factor_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, radii, at<unsigned char>(geom, GL.clamped), reinterpret_cast<const float4*>(grec), dL_dsh, at<uint32_t>(geom, GL.scalars), at<unsigned char>(geom, GL.untouched));
         GS_LAUNCHED("sh_factor");
     }
     // The zero rows and the per-Gaussian backward write DISJOINT rows (untouched / touched Gaussians, by the same bits): when they are all the side
@@ -2356,7 +2356,7 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         const int factors = (use_sh && o.sh_grad_factors) ? 1 : 0;
 #define GS_PB_ARGS P, D, M, means3D, radii, raw, rawg, sh_in, at<unsigned char>(geom, GL.clamped), at<float4>(geom, GL.shdA), at<float4>(geom, GL.shdB), \
                    at<float>(geom, GL.shdC), sc_in, ro_in, cov, cam, reinterpret_cast<const float4*>(grec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,  \
-                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars), at<unsigned long long>(geom, GL.untouched)
+                   dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, factors, (late_fill ? at<unsigned long long>(geom, GL.color_skip) : nullptr), at<uint32_t>(geom, GL.scalars), at<unsigned char>(geom, GL.untouched)
         const bool skip = !o.dense_backward;        // Gaussians with an all-zero gradient record are not read
         if (late_fill) {       // (late_fill implies skip) grouped: 1024 Gaussians per workgroup, the ones late_rows_zero_kernel does not write compacted
             const int gg = (P + PB_GROUP - 1) / PB_GROUP;

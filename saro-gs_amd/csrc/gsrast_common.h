@@ -52,7 +52,7 @@ struct GeomLayout {
         color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */,
         cand_bits /* u64[ceil(P / 64)]: bit i = Gaussian i touches a tile the completion pass lists again */,
         skip2 /* u64[ceil(P / 64)]: bit i = the completion pass need NOT evaluate Gaussian i's colour (it is not a late candidate) */,
-        untouched /* u64[ceil(P / 64)]: bit i = NO pixel consumed Gaussian i (round 5, stateless: set by preprocess_fwd, cleared by the forward
+        untouched /* u8[P]: byte i != 0 = NO pixel consumed Gaussian i (bytes, not bits: the blend clears them with plain stores -- 2.4 M bit-clearing atomics per 3 M forward cost it 9 us) (round 5, stateless: set by preprocess_fwd, cleared by the forward
                      blend for the list prefix each tile consumed): the backward's rows of such a Gaussian are zero -- written beside the
                      blend backward, skipped by the per-Gaussian backward, whatever the pose table knows */, total;
 };
@@ -300,7 +300,7 @@ static inline GeomLayout geom_layout(size_t P)
     L.color_skip = take(((Pp + 63) / 64) * 8 + 256);
     L.cand_bits = take(((Pp + 63) / 64) * 8 + 256);
     L.skip2 = take(((Pp + 63) / 64) * 8 + 256);
-    L.untouched = take(((Pp + 63) / 64) * 8 + 256);
+    L.untouched = take(Pp + 256);            // (one BYTE per Gaussian: the blend marks with plain stores)
     L.total = o + 256;
     return L;
 }

@@ -684,7 +684,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
                       int borrow = 0 /* r > 0: a pose the table does not know takes the estimates and cut depths of a near pose's slot (HintTable::cam), the cut depths widened over (2 r + 1)^2 tiles */,
                       float near_scale2 = 0.0f /* (camera-to-scene distance)^2 the near-pose tolerance is relative to; 0: the camera's distance from the origin */,
                       uint32_t* __restrict__ prefilter_violation = nullptr /* or a word that is set when a Gaussian is culled although the caller said `prefiltered` (auxiliary.h:156-160) */,
-                      unsigned long long* __restrict__ untouched = nullptr /* or GeomLayout::untouched: every bit set here, cleared by the forward blend */,
+                      unsigned char* __restrict__ untouched = nullptr /* or GeomLayout::untouched: every byte set here, cleared by the forward blend */,
                       uint32_t* __restrict__ tau_hist = nullptr /* or ImgLayout::tau_hist [TAU_COPIES][ntiles_img][TAU_BINS] (zeroed by a memset): the predicted cut's opacity mass */,
                       TauBins tau_bins = TauBins{0u, 0.0f, 0.0f, 0u})
 {
@@ -772,7 +772,7 @@ preprocess_fwd_kernel(int P, const float* __restrict__ means3D, const float* __r
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (untouched && i < P && (i & 63) == 0) untouched[i >> 6] = ~0ull;      // (one word per wave; the blend clears what it consumes)
+    if (untouched && i < P) untouched[i] = 1;      // (the blend clears what it consumes)
     // Every per-Gaussian input is requested up front: loads issued where they are first used (inside the visibility / area
     // branches) put three more memory round trips into a latency-bound kernel.  Clamped index: lanes past P load a valid
     // element and never use it.
@@ -974,34 +974,21 @@ __device__ __forceinline__ void sh_backward(int deg, const float pos[3], const f
 // more (192 MB of stores per 3 M forward, from inside the forward blend: the step 1.19 -> 1.11 ms without them).  Only the Gaussians some pixel
 // consumed can receive a gradient: grec_zero_touched_kernel, behind the forward's last blend, zeroes THEIR records (0.15 M of 3 M) and raises
 // scalars[SC_GREC_SPARSE]; every reader of a record asks record_is_stale() first and takes a stale record for the zero it stands for.
-__device__ __forceinline__ bool record_is_stale(const uint32_t* __restrict__ scalars, const unsigned long long* __restrict__ untouched, int i)
+__device__ __forceinline__ bool record_is_stale(const uint32_t* __restrict__ scalars, const unsigned char* __restrict__ untouched, int i)
 {
-    return scalars && untouched && scalars[SC_GREC_SPARSE] != 0u && ((untouched[i >> 6] >> (i & 63)) & 1ull) != 0ull;
+    return scalars && untouched && scalars[SC_GREC_SPARSE] != 0u && untouched[i] != 0;
 }
-constexpr int GZ_WORDS = 16;          // words of bits per wave (64 per wave: 12 us at 3 M -- too few waves, 62 serial steps each; 16: see DESIGN_LOG)
 __global__ void __launch_bounds__(256)
-grec_zero_touched_kernel(int P, const unsigned long long* __restrict__ untouched, float4* __restrict__ grec, uint32_t* __restrict__ scalars)
+grec_zero_touched_kernel(int P, const unsigned char* __restrict__ untouched, float4* __restrict__ grec, uint32_t* __restrict__ scalars)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) scalars[SC_GREC_SPARSE] = 1u;
-    // a wave takes GZ_WORDS words at once (one coalesced load), then walks them: lane l owns Gaussian 64 w + l of every word w
-    const unsigned lane = threadIdx.x & 63u;
-    const uint32_t nw = ((uint32_t)P + 63u) / 64u;
-    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)GZ_WORDS;
-    if (w0 >= nw) return;
-    const unsigned long long mine = (lane < (unsigned)GZ_WORDS && w0 + lane < nw) ? ~untouched[w0 + lane] : 0ull;
-    unsigned long long any = __ballot(mine != 0ull);
-    while (any) {
-        const int k = __builtin_ctzll(any);
-        any &= any - 1ull;
-        // (k is wave-uniform: two v_readlane, not two ds_bpermute round trips per word)
-        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), k) << 32) |
-                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, k);
-        const uint32_t i = (w0 + (uint32_t)k) * 64u + lane;
-        if (((m >> lane) & 1ull) && i < (uint32_t)P) {
-            float4* r = grec + 4 * (size_t)i;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            r[0] = z; r[1] = z; r[2] = z; r[3] = z;      // (the kernel is bound by these scattered 16-byte store transactions: 4.5 us without them, 6.7 with one per record, 10.2 with four)
-        }
+    // one lane per Gaussian (a coalesced byte each); the kernel is bound by the scattered 16-byte store transactions of the ~5 % that were consumed
+    // (3 M: 4.5 us without the stores, 6.7 with one per record, 10 with four)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P && untouched[i] == 0) {
+        float4* r = grec + 4 * (size_t)i;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        r[0] = z; r[1] = z; r[2] = z; r[3] = z;
     }
 }
 
@@ -1010,7 +997,7 @@ grec_zero_touched_kernel(int P, const unsigned long long* __restrict__ untouched
 // caller can start exchanging the factors WHILE the per-Gaussian backward (below) is still running (backward_phase).
 __global__ void __launch_bounds__(256)
 sh_factor_kernel(int P, const int* __restrict__ radii, const unsigned char* __restrict__ clamped, const float4* __restrict__ grec,
-                 float* __restrict__ g_out /* [P][3] */, const uint32_t* __restrict__ scalars, const unsigned long long* __restrict__ untouched)
+                 float* __restrict__ g_out /* [P][3] */, const uint32_t* __restrict__ scalars, const unsigned char* __restrict__ untouched)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -1096,7 +1083,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       // Round 5: `untouched` (GeomLayout::untouched, kept by the forward blend whenever scalars[SC_TOUCH_VALID] says so) takes
                       // the bits' place -- "no pixel consumed this Gaussian", a superset of "culled or late" that needs no pose table
                       const unsigned long long* __restrict__ late_bits = nullptr, const uint32_t* __restrict__ cut_scalars = nullptr,
-                      const unsigned long long* __restrict__ untouched = nullptr)
+                      const unsigned char* __restrict__ untouched = nullptr)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     __shared__ uint32_t s_list[GROUPED ? PB_GROUP : 1];
@@ -1105,8 +1092,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     const bool staged = shs && M * 3 <= PP_SH_MAX;
     float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
     const bool touch_ok = GROUPED && untouched && cut_scalars[SC_TOUCH_VALID] != 0u;  // (uniform)
-    if (touch_ok) late_bits = untouched;
-    const bool late_rows = GROUPED && late_bits && (touch_ok || cut_scalars[SC_N_LATE] != 0u);      // (uniform; the completion pass has taken the Gaussians it listed after all out of the cut's bits)
+    const bool late_rows = GROUPED && (touch_ok || (late_bits && cut_scalars[SC_N_LATE] != 0u));      // (uniform; the completion pass has taken the Gaussians it listed after all out of the cut's bits)
     const int gbase = blockIdx.x * (GROUPED ? PB_GROUP : PP_THREADS);
     int nround = 1;
     uint32_t total = 0;
@@ -1116,7 +1102,12 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (late_rows) {
             const uint32_t b0 = (uint32_t)gbase + threadIdx.x * (uint32_t)PER;
             uint32_t fl = 0xFFFFFFFFu;
-            if (b0 < (uint32_t)P) {
+            if (b0 < (uint32_t)P && touch_ok) {      // the blend's marks: a byte per Gaussian (the array is padded past P)
+                fl = 0u;
+                if (PER == 4) { const uint32_t w = *reinterpret_cast<const uint32_t*>(untouched + b0); for (int k = 0; k < 4; k++) fl |= ((w >> (8 * k)) & 0xFFu) ? 1u << k : 0u; }
+                else for (int k = 0; k < PER; k++) fl |= untouched[b0 + k] ? 1u << k : 0u;
+                for (int k = 0; k < PER; k++) if (b0 + k >= (uint32_t)P) fl |= 1u << k;
+            } else if (b0 < (uint32_t)P) {
                 const unsigned char* bytes = reinterpret_cast<const unsigned char*>(late_bits) + (b0 >> 3);
                 fl = PER == 4 ? ((uint32_t)bytes[0] >> (b0 & 4u)) & 0xFu : PER == 8 ? (uint32_t)bytes[0] : PER == 16 ? (uint32_t)*reinterpret_cast<const unsigned short*>(bytes) : *reinterpret_cast<const uint32_t*>(bytes);
                 for (int k = 0; k < PER; k++) if (b0 + k >= (uint32_t)P) fl |= 1u << k;      // (the array is padded: the word may reach past P)
@@ -1385,15 +1376,15 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 struct LateRowsArgs { float* ptr[12]; int rowlen[12]; int n; };
 __global__ void __launch_bounds__(256)
 late_rows_zero_kernel(int P, const unsigned long long* __restrict__ late_bits, const uint32_t* __restrict__ cut_scalars, LateRowsArgs a,
-                      const unsigned long long* __restrict__ untouched)
+                      const unsigned char* __restrict__ untouched)
 {
-    if (untouched && cut_scalars[SC_TOUCH_VALID] != 0u) late_bits = untouched;      // the same verdict as preprocess_bwd_kernel's
-    else if (cut_scalars[SC_N_LATE] == 0u) return;
+    const bool marks = untouched && cut_scalars[SC_TOUCH_VALID] != 0u;      // the same verdict as preprocess_bwd_kernel's: the blend's byte marks, or the cut's bits
+    if (!marks && cut_scalars[SC_N_LATE] == 0u) return;
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t nw = ((uint32_t)P + 63u) / 64u;
     for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4u) {
-        unsigned long long m = late_bits[w];
         const uint32_t base = w * 64u, left = (uint32_t)P - base;
+        unsigned long long m = marks ? __ballot(base + lane < (uint32_t)P && untouched[base + lane] != 0) : late_bits[w];
         if (left < 64u) m &= (1ull << left) - 1ull;              // (rows past P do not exist)
         if (m == 0ull) continue;
         for (int k = 0; k < a.n; k++) {
