@@ -1098,7 +1098,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     auto finish_records = [&]() -> int {
         if (!zero_touched) return GSRAST_OK;
         ProfScope ps(K_GREC_ZERO, s);
-        grec_zero_touched_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
+        grec_zero_touched_kernel<<<(unsigned)(((size_t)P + 256 * GZ_PER - 1) / (256 * GZ_PER)), 256, 0, s>>>(P, untouched, at<float4>(geom, GL.grec), scalars);
         GS_LAUNCHED("grec_zero_touched");
         return GSRAST_OK;
     };
