@@ -405,19 +405,23 @@ radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ 
 // one depth) raises a flag the host reads back with the instance counts; the
 // forward then repeats the sort with the radix passes and the context uses those for its next calls (gsrast_forward).
 // PREDICTED CUT (gsrast_common.h): every tile's cut depth from this call's own opacity mass.  One workgroup = a 16 x 16 block of tiles of which
-// the inner 14 x 14 are written (the ring around them only feeds the 3 x 3 maxima), one lane per tile: TAU_COPIES x TAU_BINS / 4 = 32
+// the inner ones are written (the ring around them only feeds the 3 x 3 maxima), one lane per tile: TAU_COPIES x TAU_BINS / 4 = 32
 // sixteen-byte loads, a running sum, the first bin whose far edge lies behind tau_req of mean alpha mass.
-constexpr int TAU_TILE = 14;
-__global__ void __launch_bounds__(256)
+#ifndef GSRAST_TAU_BLK
+#define GSRAST_TAU_BLK 16
+#endif
+constexpr int TAU_BLK = GSRAST_TAU_BLK;      // tiles per workgroup side (16: 45 workgroups at 1080p; 8 -- 240 one-wave workgroups -- measured equal, 1.160 ms per cold step either way)
+constexpr int TAU_TILE = TAU_BLK - 2;
+__global__ void __launch_bounds__(TAU_BLK * TAU_BLK)
 tau_cut_kernel(const uint32_t* __restrict__ tau_hist /* [TAU_COPIES][ntiles][TAU_BINS] */, uint32_t ntiles, int gx, int gy,
                TauBins tau_bins, uint32_t tau_req_x256 /* tau_req in the table's unit: pixels^2 of alpha mass per tile = 256 x the mean */,
                const uint32_t* __restrict__ hint_sel /* or null (no pose table): [1] = 1: the pose has remembered cut depths */, int force /* 1: predicted cuts also for a pose the table knows */,
                uint32_t* __restrict__ zcut_used /* [ntiles] out */, int coarse_range /* 1: the depth histogram has no learned range (a context's first forward): no prediction */)
 {
-    __shared__ int s_bin[16][16];
+    __shared__ int s_bin[TAU_BLK][TAU_BLK];
     const bool known = hint_sel && hint_sel[1] != 0u;      // (1: the pose's own slot, 2: a near pose's, widened -- both tighter than a prediction)
     if (known && !force) return;                                   // (uniform) the remembered cut depths are already in zcut_used
-    const int lx = (int)(threadIdx.x & 15u), ly = (int)(threadIdx.x >> 4);
+    const int lx = (int)(threadIdx.x % (unsigned)TAU_BLK), ly = (int)(threadIdx.x / (unsigned)TAU_BLK);
     const int tx = (int)blockIdx.x * TAU_TILE - 1 + lx, ty = (int)blockIdx.y * TAU_TILE - 1 + ly;
     int cb = -1;                                                    // -1: not a tile of the image (ignored by its neighbours)
     if (tx >= 0 && ty >= 0 && tx < gx && ty < gy) {
@@ -442,7 +446,7 @@ tau_cut_kernel(const uint32_t* __restrict__ tau_hist /* [TAU_COPIES][ntiles][TAU
     }
     s_bin[ly][lx] = cb;
     __syncthreads();
-    if (cb < 0 || lx == 0 || ly == 0 || lx == 15 || ly == 15) return;
+    if (cb < 0 || lx == 0 || ly == 0 || lx == TAU_BLK - 1 || ly == TAU_BLK - 1) return;
     int m = cb;
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++)

@@ -1255,7 +1255,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
         GS_LAUNCHED("preprocess_fwd");
         if (tau_hist) {       // the predicted cut depths of a pose without remembered ones (a no-op for a pose the table knows, unless forced)
             const dim3 tg((unsigned)((cam.gx + TAU_TILE - 1) / TAU_TILE), (unsigned)((cam.gy + TAU_TILE - 1) / TAU_TILE));
-            tau_cut_kernel<<<tg, 256, 0, s>>>(tau_hist, T, cam.gx, cam.gy, tau_bins, (uint32_t)pol.tau_req.load() * 256u, hints ? hint_sel : nullptr, tau_forced,
+            tau_cut_kernel<<<tg, TAU_BLK * TAU_BLK, 0, s>>>(tau_hist, T, cam.gx, cam.gy, tau_bins, (uint32_t)pol.tau_req.load() * 256u, hints ? hint_sel : nullptr, tau_forced,
                                               zcut_used, tau_bins.scale > 0.0f ? 0 : 1);
             GS_LAUNCHED("tau_cut");
         }
