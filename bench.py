@@ -1,17 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- rendered views/s (forward + backward) of the Gaussian rasterizer hot path.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, or by this script itself)
 
-A "step" is one GaussianRasterizer forward + backward over one synthetic view; with N>1 every rank
-renders its own view of the same scene (one view per GPU, "weak" scaling) and the step also contains
-the flat-buffer RCCL all-reduce (mean) of the per-Gaussian gradients.  Inputs are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line (contract in the task description):
-  value      views/s of the whole job = N * K / max-over-ranks(wall time of K steps)
-  roofline   dominant kernel (per-tile backward blend) against the HBM roof: algorithmic bytes per
-             launch (SURVEY.md 8(d) formula with the MEASURED R_eff) / its mean duration measured
-             with HIP events on the launch stream inside the timed region
-  cpu_baseline  the CPU oracle (a port, OpenMP on the host cores) timed on a bounded sample
+A "step" is one GaussianRasterizer forward + backward over one synthetic 1080p view of synth(P = 3e6) (BASELINE.json configs[4]); with
+N > 1 every rank renders its own view of the same scene (one view per GPU, "weak" scaling) and the step also contains the RCCL exchange
+of the per-Gaussian gradients.  Inputs are resident in HBM before the timed region.
+
+The LAST line rank 0 prints is ONE compact JSON object (< 4 KB; tests/test_api_host.py checks the size and the keys):
+  value        SURVEY.md 8(d)'s metric as written: N / median over the K timed steps of the per-call DEVICE-SYNCHRONISED wall-clock time of
+               one forward + backward (max over ranks), measured with the context's pose table OFF -- every forward is a first visit of its
+               camera pose, the number that transfers to SaRO-GS's time-varying scenes (`config.pose_table` says so)
+  value_warm   the same protocol with the pose table on (every pose seen before: a fixed rig over an unchanged scene)
+  pipelined    K steps enqueued back to back, one synchronisation at the end (rounds 1-5's headline): throughput, not the stated metric
+  roofline     the dominant kernel (per-tile backward blend) against the HBM roof: algorithmic bytes per launch (SURVEY.md 8(d) formula with
+               the MEASURED R_eff) / its mean duration measured with HIP events on the launch stream inside the timed region; the binding
+               resource (VALU issue) beside it;  roofline_fwd: the same for the forward blend
+  cpu_baseline the CPU oracle (a port, OpenMP on the host cores) timed on a bounded sample of the same workload
+Everything else rounds 1-5 printed in that line (per-stage tables, training-like / eval legs, the SURVEY 8f rows, a second scene) is
+`--extras`: tools/bench_extras.py, written to gpurun_out/bench_report.json or the path given and printed as an EARLIER line.
 """
 from __future__ import annotations
 
@@ -32,9 +39,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s measured copy)
+LINE_LIMIT = 4096      # bytes of the final JSON line (the driver's parser gave up on round 5's 20.7 KB line)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -49,11 +57,12 @@ def parse():
                          "row), added in rank order; 'factors' = all-reduce 11 + all-gather 3 floats/Gaussian; 'sparse' = the same for the "
                          "rows some rank touched only; 'allreduce' = all-reduce all 59 floats/Gaussian")
     ap.add_argument("--exp-mode", type=int, default=None, help="0 fixed-sequence (default), 1 ocml, 2 v_exp_f32")
-    ap.add_argument("--sweep", type=str, default="100000,300000,1000000,3000000",
-                    help="extra #Gaussians points reported under 'sweep' (N=1 only); '' disables")
-    ap.add_argument("--sweep-steps", type=int, default=None, help="ignored: sweep points use --steps / --warmup like the headline")
+    ap.add_argument("--sweep", type=str, default="100000,300000,1000000",
+                    help="extra #Gaussians points of the metric's 'vs #Gaussians' (N=1 only; same protocol, table off); '' disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-training-like", action="store_true", help="skip the training-like and eval-FPS legs (profiling runs)")
+    ap.add_argument("--extras", nargs="?", const=os.path.join(ROOT, "gpurun_out", "bench_report.json"), default=None, metavar="PATH",
+                    help="also run the side legs of tools/bench_extras.py (per-stage tables at 1 M, shell scene, BASELINE cfg2 / cfg3 shapes, two views in "
+                         "flight, eval FPS, training-like iterations, SURVEY 8f rows): written to PATH and printed as an earlier line")
     ap.add_argument("--ablate", type=int, default=0, help="kernel ablation experiments (not a valid bench)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option for A/B experiments (repeatable)")
     ap.add_argument("--ppl", type=int, default=0, help="force pixels per lane of both blend kernels (0 = auto)")
@@ -66,15 +75,15 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true",
                     help="--gpus 1 only: run the N > 1 gradient exchange through a one-rank RCCL process group (backend nccl: ReduceOp.AVG, "
                          "the uint8 MAX and all_gather_into_tensor of the sparse exchange) instead of skipping it -- puts the collective "
-                         "library under the bench on a 1-GPU box; a profiling run, not the headline (sweep / training-like / CPU legs off)")
+                         "library under the bench on a 1-GPU box; a profiling run, not the headline (sweep / CPU legs off)")
     ap.add_argument("--poses", type=int, default=8,
                     help="camera poses each rank renders round-robin (the reference's batch loop renders different cameras one after "
                          "the other, train.py:198-226); 1 = the repeated-pose protocol of rounds 1-3")
-    ap.add_argument("--preroll-ms", type=float, default=400.0,
-                    help="untimed steps before the W warm-up steps until this much wall time has passed: the first GPU process "
-                         "on a fresh box shows one 5-9 ms device hiccup some tens of ms into sustained load (clock / power "
+    ap.add_argument("--preroll-ms", type=float, default=300.0,
+                    help="untimed steps before the W warm-up steps until this much wall time has passed (reported as `preroll_steps`): the first "
+                         "GPU process on a fresh box shows one 5-9 ms device hiccup some tens of ms into sustained load (clock / power "
                          "management settling); 0 disables")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 class Workload:
@@ -220,6 +229,34 @@ def timed(workload, steps, warmup, bucket, world, vp, dev):
     return vp.max_over_ranks(dt, dev)
 
 
+
+def timed_sync(workload, steps, bucket, world, vp, dev):
+    """SURVEY.md 8(d) / BASELINE.md 2 as written (protocol adapted from the reference's test.py:155-168, renderer/__init__.py:149,202-203):
+    every step is bracketed by device synchronisations and timed on the host's wall clock.  The K steps as a whole are bracketed by a
+    barrier + synchronize on both sides (the contract's timed region).  Returns (median seconds per step -- the max over ranks of each
+    rank's median --, mean seconds per step over the whole region, max over ranks)."""
+    import gc
+    vp.barrier()
+    torch.cuda.synchronize(dev)
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    ts = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s0 = time.perf_counter()
+        workload.step(bucket, world)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - s0)
+    vp.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if gc_was_enabled:
+        gc.enable()
+    med = float(np.median(ts)) if ts else 0.0
+    return vp.max_over_ranks(med, dev), vp.max_over_ranks(dt / max(steps, 1), dev), [round(x * 1e3, 4) for x in ts]
+
+
 def _profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     try:
@@ -228,89 +265,47 @@ def _profile_json(name):
         return None
 
 
-def roofline_of(st, bwd_ms, P, exp2=None, kernel="blend_bwd_cull_t_kernel"):
-    """The roofline object of a blend kernel: the dominant one, blend_bwd_cull_t_kernel (`roofline`), or the forward blend_fwd_cull_kernel
-    (`roofline_fwd`: north_star's "per-tile blend kernel", reference forward.cu:261-393; algorithmic bytes R_eff*44 + N*24).
+def roofline_of(st, launch_ms, P, kernel="blend_bwd_cull_t_kernel"):
+    """The roofline object of a blend kernel, scalars only: the dominant one, blend_bwd_cull_t_kernel (`roofline`; reference backward.cu:399-557),
+    or the forward blend_fwd_cull_kernel (`roofline_fwd`: north_star's "per-tile blend kernel", forward.cu:261-393).
 
-    The kernel is VALU-issue bound, so `bound` says "valu" and the binding pair is `valu.achieved / valu.peak` in
-    wave64 instructions per second; the contract's HBM pair stays in `achieved / peak / frac` (ALGORITHMIC bytes, SURVEY.md 8d:
-    N*20 + R_eff*40 + R_eff*36 per launch, / this run's mean launch duration / 8 TB/s).  `provenance` says for every field whether
-    it was measured in this run (HIP events on the launch stream inside the timed region) or read from the committed rocprofv3 PMC
-    passes of the same workload (profiles/pmc_blend_bwd*.json, tools/collect_profiles.sh)."""
+      achieved / peak / frac   the contract's HBM pair: ALGORITHMIC bytes per launch (SURVEY.md 8d with this run's measured R_eff:
+                               N*20 + R_eff*76 backward, R_eff*44 + N*24 forward) / this run's mean launch duration (HIP events on the launch
+                               stream) / 8 TB/s
+      traffic / traffic_ratio  HBM bytes per launch from the committed rocprofv3 PMC passes of the same workload (FETCH_SIZE x 2 + WRITE_SIZE,
+                               gfx950 units per MI355X_MICROARCH.md; profiles/pmc_blend_*_3M.json -- not this run), over the algorithmic bytes
+      binding = "valu issue"   what actually bounds the kernel: valu_issue_slot_frac = SQ_INSTS_VALU per launch (committed pass) x
+                               the kernel's priced cycles per instruction / (1024 SIMDs x 2.4 GHz x this run's launch time), priced with the
+                               MEASURED issue costs (v_fma_f32 2.4 cycles, tools/valu_calib.hip); ..._guide_2cyc_fma: the same with the guide's
+                               2-cycle v_fma_f32 (MI355X_MICROARCH.md) -- the stricter ceiling."""
     fwd = kernel == "blend_fwd_cull_kernel"
-    bwd_bytes = st["N"] * 24 + st["R_eff"] * 44 if fwd else st["N"] * 20 + st["R_eff"] * 76
+    nbytes = st["N"] * 24 + st["R_eff"] * 44 if fwd else st["N"] * 20 + st["R_eff"] * 76
+    achieved = nbytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    out = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_ratio": None,
+           "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(launch_ms, 4), "binding": "valu issue",
+           "valu_issue_slot_frac": None, "valu_issue_slot_frac_guide_2cyc_fma": None, "valu_wave_insts_per_launch": None,
+           "counters_from": None}
     stem = "pmc_blend_fwd" if fwd else "pmc_blend_bwd"
-    achieved = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-    traffic, valu, src = None, None, None
     for name in (stem + "_3M.json", stem + ".json"):
         pj = _profile_json(name)
-        if pj and pj.get("gaussians", 3_000_000 if "3M" in name else 1_000_000) == P:
-            traffic, src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
-            vi = pj.get("valu_wave_insts_per_launch")
-            mix = _profile_json("r05_valu_mix.json") or _profile_json("r04_valu_mix.json") or _profile_json("r03_valu_mix.json") or _profile_json("r02_valu_mix.json")
-            cal = _profile_json("r02_valu_calib.json")
-            if vi and bwd_ms > 0 and mix and cal:
-                cyc = mix["kernels"][kernel]["avg_cycles_per_valu_inst"]
-                fma = max(r["wave_insts_per_s"] for r in cal["results"] if r["op"] == "v_fma_f32")
-                rate = vi / (bwd_ms * 1e-3)
-                peak = 1024 * 2.4e9 / cyc           # wave64 instructions/s the chip can issue at this kernel's mix
-                valu = {"achieved": round(rate, 1), "peak": round(peak, 1), "unit": "wave64 instructions/s",
-                        "issue_slot_frac": round(rate / peak, 3),
-                        "wave_insts_per_launch": vi, "avg_cycles_per_inst": cyc,
-                        "frac_of_measured_v_fma_f32_rate": round(rate / fma, 3),
-                        "profile_launch_ms": pj.get("avg_launch_ms"),
-                        "note": "SQ_INSTS_VALU per launch (committed rocprofv3 pass) / this run's launch duration, against 1024 SIMDs x 2.4 GHz / "
-                                "the kernel's static instruction mix priced with the MEASURED issue cost of each class (full-rate fma/mul/add "
-                                "2.4 cycles per wave64 instruction and SIMD, half-rate dpp/cmp/cndmask/min/cvt/ldexp 4.1, quarter-rate rcp/exp "
-                                "8.1: tools/valu_calib.hip, tools/valu_mix.py)"}
-            break
-    out = {"kernel": kernel, "bound": "valu" if valu else "hbm",
-           # (flat copies of the binding pair: a parser that keeps only scalars still sees them)
-           "valu_issue_slot_frac": valu["issue_slot_frac"] if valu else None,
-           "valu_wave_insts_per_launch": valu["wave_insts_per_launch"] if valu else None,
-           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-           "traffic": traffic, "traffic_ratio": round(traffic / bwd_bytes, 3) if traffic else None,
-           "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": round(bwd_ms, 4),
-           "gpairs_per_s": round(st["pairs_fwd"] / (bwd_ms * 1e-3) / 1e9, 3) if bwd_ms > 0 else None,
-           "valu": valu,
-           "provenance": {"avg_launch_ms / achieved / frac / gpairs_per_s": "measured in this run (HIP events on the launch stream, timed region)",
-                          "algorithmic_bytes_per_launch": "SURVEY.md 8d formula (" + ("R_eff*44 + N*24" if fwd else "N*20 + R_eff*76") + ") with this run's measured R_eff (tile_clip=0 lists)",
-                          "traffic / traffic_ratio": (src + ": rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 units per MI355X_MICROARCH.md), committed pass, not this run") if src else None,
-                          "valu.wave_insts_per_launch": (src + ": SQ_INSTS_VALU per launch, committed pass, not this run") if src else None,
-                          "valu.avg_cycles_per_inst": "profiles/r0x_valu_mix.json over profiles/r02_valu_calib.json (measured issue costs)"},
-           "note": "VALU-issue-bound kernel: valu.issue_slot_frac is the binding fraction; frac is the HBM fraction the contract asks for (small by construction)"
-                   + ("; traffic includes what this kernel does beside K4's algorithmic bytes: the zero-fill of the backward's gradient records (64 B per Gaussian, "
-                      "non-temporal stores) and the untouched-bit atomics" if fwd else "")}
-    if exp2:
-        out["exp_mode_2"] = exp2
+        if not (pj and pj.get("gaussians", 3_000_000 if "3M" in name else 1_000_000) == P):
+            continue
+        out["traffic"], out["counters_from"] = pj.get("hbm_bytes_per_launch"), "profiles/" + name + " (committed rocprofv3 pass, not this run)"
+        if out["traffic"]:
+            out["traffic_ratio"] = round(out["traffic"] / nbytes, 3)
+        vi = pj.get("valu_wave_insts_per_launch")
+        mix = None
+        for r in ("r06", "r05", "r04", "r03", "r02"):
+            mix = mix or _profile_json(r + "_valu_mix.json")
+        if vi and launch_ms > 0 and mix and kernel in mix.get("kernels", {}):
+            cyc = mix["kernels"][kernel]["avg_cycles_per_valu_inst"]
+            rate = vi / (launch_ms * 1e-3)
+            out["valu_wave_insts_per_launch"] = vi
+            out["valu_issue_slot_frac"] = round(rate * cyc / (1024 * 2.4e9), 3)
+            out["valu_issue_slot_frac_guide_2cyc_fma"] = round(rate * cyc * (2.0 / 2.4) / (1024 * 2.4e9), 3)
+        break
     return out
-
-
-def exp_mode2_row(_C, wl, dev, kid):
-    """Both blend kernels with exp_mode 2 (v_exp_f32, within a few ulp of mode 0: north_star's 1e-5 bar, not the bit-exact one)
-    next to the default's fixed-sequence exp: event-bracketed launches of a separate, untimed pass."""
-    cur = _C.get_option("exp_mode")
-    res = {}
-    for mode in (cur, 2):
-        _C.set_option("exp_mode", mode)
-        for _ in range(3):
-            wl.step(None, 1)
-        torch.cuda.synchronize(dev)
-        _C.profile_reset()
-        _C.set_option("profile", (1 << kid["blend_bwd"]) | (1 << kid["blend_fwd"]))
-        t0 = time.perf_counter()
-        for _ in range(10):
-            wl.step(None, 1)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / 10 * 1e3
-        pk = _C.profile_read()
-        _C.set_option("profile", 0)
-        res[f"exp_mode_{mode}"] = {"blend_fwd_ms": round(pk["blend_fwd"][0] / max(pk["blend_fwd"][1], 1), 4),
-                                   "blend_bwd_ms": round(pk["blend_bwd"][0] / max(pk["blend_bwd"][1], 1), 4),
-                                   "ms_per_step_with_both_bracketed": round(dt, 4)}
-    _C.set_option("exp_mode", cur)
-    res["note"] = "mode 2 = hardware v_exp_f32; outputs within 1e-5 of mode 0 (tests/test_gpu_parity.py::test_other_exp_modes_within_tolerance); the headline runs the mode in config.exp_mode"
-    return res
 
 
 def stage_table(_C, wl, st, P, deg, H):
@@ -388,259 +383,6 @@ def step_bytes(st, per_kernel, P, deg, ms_per_step):
     return out
 
 
-class Deformation:
-    """A stand-in for what SaRO-GS's deformation field hands the rasterizer at timestamp t (scene/saro_gaussian.py:get_deformation, :782-847, with
-    the shipped switches dx = drot = dopacity = True, arguments/__init__.py:68-72): per Gaussian a temporal position and a lifespan,
-        opacity  = sigmoid(_opacity) * exp(-4 ((t - pos) / lifespan)^2)                                   (:791-792, :824-829)
-        means3D  = _xyz + motion_residual(t),  rotations = normalize(_rotation + rot_residual[:, :4]),
-        scales   = exp(_scaling + rot_residual[:, 4:])                                                   (:805-822)
-    The residuals are smooth functions of (t - pos) with a fixed random direction per Gaussian: means move by up to 1.2 % of the scene's
-    extent, scales by +-10 %, quaternions by ~3 degrees -- the size of a learned deformation, none of its cost (the reference's MLP heads
-    are model code outside this path).  The tensors require a gradient, as the heads' outputs do: the backward writes their rows."""
-
-    def __init__(self, P, dev, seed=5, motion=True):
-        rng = np.random.default_rng(seed)
-        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
-        self.tpos = t(rng.uniform(0.0, 1.0, size=(P, 1)))
-        self.life = t(rng.uniform(0.2, 1.0, size=(P, 1)))
-        self.ts = rng.uniform(0.0, 1.0, size=4096)
-        self.motion = motion
-        if motion:
-            d = rng.normal(size=(P, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
-            self.mdir = t(0.03 * d)
-            self.rdir = t(np.concatenate([0.05 * rng.normal(size=(P, 4)), 0.1 * rng.uniform(-1.0, 1.0, size=(P, 3))], axis=1))
-
-    def at(self, i):
-        """(motion_residual, rot_residual, trbfoutput) of call i."""
-        d = float(self.ts[i % len(self.ts)]) - self.tpos
-        trbf = torch.exp(-4.0 * (d / self.life) ** 2)
-        if not self.motion:
-            return None, None, trbf
-        s = torch.sin(6.283185307179586 * d)
-        return (self.mdir * s).requires_grad_(True), (self.rdir * s).requires_grad_(True), trbf
-
-
-def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
-    """The reference's call pattern (train.py:198-226, scene/saro_gaussian.py:788-829): V poses dealt round-robin, every call followed by
-    loss -> backward -> Adam step (the scene changes between two visits of a pose), and -- `dynamic_opacity` -- a per-call
-    trbfoutput = exp(-4 ((t - temporal_pos) / lifespan)^2) at a random timestamp t (the survival state of saro_gaussian.py:757-789:
-    two calls at one camera are different scenes).  Each leg with the context's pose table on and switched off (no_order_hint = 1);
-    late = Gaussians the list cut left out per call, fallbacks = forwards whose cut lists were too short and were redone."""
-    import fused_adam
-    import fused_loss
-    _C = rast._C
-    sc = scenes.synth(P, 0, sh_degree=deg)
-    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
-    bg = t(sc["bg"])
-    deform = {"dynamic_opacity": Deformation(P, dev, motion=False), "dynamic_full": Deformation(P, dev, motion=True)}
-    lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
-    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
-    gt = torch.rand(3, H, W, device=dev)
-    inv = torch.ones(P, 1, device=dev)
-
-    def settings(k, V):
-        cam = scenes.camera(k, V, W, H)
-        return rast.GaussianRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
-            viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
-
-    out = {}
-    for dyn in (None, "dynamic_opacity", "dynamic_full"):
-        for V in Vs:
-            rasters = [rast.GaussianRasterizerRaw(settings(k, V)) for k in range(V)]
-            row = {}
-            for name, opt_name in (("pose_table_on", None), ("pose_table_off", "no_order_hint")):
-                rc = dict(xyz=t(sc["means3D"]), rotation=t(sc["rotations"]), scaling=torch.log(t(sc["scales"])),
-                          opacity=torch.logit(t(sc["opacities"]).clamp(1e-4, 1 - 1e-4)), f_dc=t(sc["shs"][:, :1]), f_rest=t(sc["shs"][:, 1:]))
-                rc = {k: v.requires_grad_(True) for k, v in rc.items()}
-                opt = fused_adam.GaussianAdam([{"params": [rc[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in rc], eps=1e-15)
-                it = [0]
-
-                def step():
-                    mres, rres, trbf = deform[dyn].at(it[0]) if dyn else (None, None, None)
-                    raster = rasters[it[0] % V]
-                    it[0] += 1
-                    color, _, _ = raster(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"],
-                                         motion_residual=mres, rot_residual=rres, trbfoutput=trbf)
-                    loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
-                    opt.zero_grad(); m2.grad = None
-                    loss.backward()
-                    opt.step()
-
-                if opt_name:
-                    _C.set_option(opt_name, 1)
-                try:
-                    for _ in range(max((4 if dyn else 2) * V, 24)):         # every pose seen twice (four times where the scene varies with t: the remembered cut is a running maximum over visits)
-                        step()
-                    torch.cuda.synchronize(dev)
-                    fb0 = _query(_C, "cut_fallbacks")
-                    n, late = max(2 * V, 96), 0
-                    t0 = time.perf_counter()
-                    for _ in range(n):
-                        step()
-                        late += _query(_C, "last_late") or 0
-                    torch.cuda.synchronize(dev)
-                    dt = time.perf_counter() - t0
-                    row[name] = {"iterations_per_s": round(n / dt, 1), "ms_per_iteration": round(dt / n * 1e3, 4), "calls": n,
-                                 "late_gaussians_per_call": int(late / n), "cut_margin_x4": _query(_C, "cut_margin_x4"),
-                                 "cut_fallbacks_per_100_calls": round(100.0 * ((_query(_C, "cut_fallbacks") or 0) - (fb0 or 0)) / n, 2)}
-                finally:
-                    if opt_name:
-                        _C.set_option(opt_name, 0)
-                del opt, rc
-                torch.cuda.empty_cache()
-            row["table_on_over_off"] = round(row["pose_table_on"]["iterations_per_s"] / row["pose_table_off"]["iterations_per_s"], 3)
-            out[(dyn or "static_opacity") + f"_V{V}"] = row
-    out["note"] = ("one iteration = GaussianRasterizerRaw forward -> fused L1 + D-SSIM -> backward -> GaussianAdam.step, P = %d at %dx%d; "
-                   "V poses round-robin; dynamic_opacity: opacity = sigmoid(.) * exp(-4 ((t - pos) / lifespan)^2), t ~ U(0, 1) per call; "
-                   "dynamic_full: the same opacity AND means / rotations / scales moved by residuals that are functions of t "
-                   "(bench.py:Deformation -- what scene/saro_gaussian.py:get_deformation returns with dx = drot = dopacity = True)" % (P, W, H))
-    return out
-
-
-def eval_fps_row(rast, scenes, dev, P, W, H, deg):
-    """The reference's only benchmark (test.py:155-168): forward-only renders under torch.no_grad(), 20 test views x 4 passes, the first 11
-    views of each pass discarded, FPS = 1 / mean of the rest; each call timed wall-clock around a device synchronisation
-    (renderer/__init__.py:149, :188, :202-203).  With the context's pose table on and off (the second pass on renders known poses)."""
-    _C = rast._C
-    sc = scenes.synth(P, 0, sh_degree=deg)
-    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
-    ten = {k: t(sc[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-    m2 = torch.zeros((P, 3), device=dev)
-    bg = t(sc["bg"])
-    V = 20
-    rasters = []
-    for k in range(V):
-        cam = scenes.camera(k, V, W, H)
-        rasters.append(rast.GaussianRasterizer(rast.GaussianRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
-            viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)))
-    out = {}
-    for name, opt_name in (("pose_table_off", "no_order_hint"), ("pose_table_on", None)):
-        if opt_name:
-            _C.set_option(opt_name, 1)
-        try:
-            kept, first_pass = [], []
-            with torch.no_grad():
-                for p_ in range(4):
-                    for k, raster in enumerate(rasters):
-                        torch.cuda.synchronize(dev)
-                        t0 = time.perf_counter()
-                        raster(means3D=ten["means3D"], means2D=m2, opacities=ten["opacities"], shs=ten["shs"], scales=ten["scales"], rotations=ten["rotations"])
-                        torch.cuda.synchronize(dev)
-                        d = time.perf_counter() - t0
-                        if k >= 11:
-                            kept.append(d)
-                            if p_ == 0:
-                                first_pass.append(d)
-            out[name] = {"fps": round(1.0 / float(np.mean(kept)), 1), "ms_per_view": round(float(np.mean(kept)) * 1e3, 4),
-                         "first_pass_ms_per_view": round(float(np.mean(first_pass)) * 1e3, 4), "views_timed": len(kept)}
-        finally:
-            if opt_name:
-                _C.set_option(opt_name, 0)
-    # a camera PATH: 60 frames 1.5 degrees apart, every pose rendered exactly once (a test trajectory / a video: what test.py does with a
-    # scene's test cameras) -- the table never holds the pose (predicted cut depths serve it); with option near_pose = 3 it borrows the previous frame's remembered ones
-    VP, NF = 240, 60
-
-    def path(first, opts):
-        for k_, v_ in opts.items():
-            _C.set_option(k_, v_)
-        try:
-            rs = []
-            for k in range(first, first + NF):
-                cam = scenes.camera(k, VP, W, H)
-                rs.append(rast.GaussianRasterizer(rast.GaussianRasterizationSettings(
-                    image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
-                    viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)))
-            ds, cut = [], 0
-            with torch.no_grad():
-                for i, raster in enumerate(rs):
-                    torch.cuda.synchronize(dev)
-                    t0 = time.perf_counter()
-                    raster(means3D=ten["means3D"], means2D=m2, opacities=ten["opacities"], shs=ten["shs"], scales=ten["scales"], rotations=ten["rotations"])
-                    torch.cuda.synchronize(dev)
-                    if i >= 10:
-                        ds.append(time.perf_counter() - t0)
-                        cut += 1 if int(_C.context_query("last_late")) > 0 else 0
-            return {"fps": round(1.0 / float(np.mean(ds)), 1), "ms_per_view": round(float(np.mean(ds)) * 1e3, 4), "frames_timed": len(ds), "frames_under_the_list_cut": cut}
-        finally:
-            for k_ in opts:
-                _C.set_option(k_, 0)
-    out["camera_path_every_pose_new"] = {"pose_table_off": path(30, {"no_order_hint": 1}), "own_slot_only": path(100, {}), "near_pose_borrowing": path(170, {"near_pose": 3}),
-                                         "note": "60 frames 1.5 degrees apart on the orbit, each pose rendered once, the first 10 discarded; same timing protocol"}
-    out["note"] = "forward only, torch.no_grad(), synchronised wall clock per call (test.py:155-168 protocol), P = %d at %dx%d; first_pass = views 12-20 of pass 1 (poses never seen before)" % (P, W, H)
-    return out
-
-
-def in_flight_row(rast, scenes, P, W, H, deg, dev, steps, warmup, lanes=2):
-    """views/s with `lanes` views in flight: view k of the batch runs forward + backward on stream k % lanes.  `steps` rounds of
-    `lanes` views each are timed, after `warmup` rounds; also the same views one after the other on one stream."""
-    wls = [Workload(rast, scenes, P, W, H, deg, k, 8, dev) for k in range(lanes)]
-    streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
-
-    def rounds(n, use_streams):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            for k, wl in enumerate(wls):
-                if use_streams:
-                    with torch.cuda.stream(streams[k]):
-                        wl.step()
-                else:
-                    wl.step()
-        torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0
-
-    rounds(warmup, False); rounds(warmup, True)
-    t_seq = rounds(steps, False)
-    t_par = rounds(steps, True)
-    return {"views_per_s": round(lanes * steps / t_par, 1), "views_per_s_one_stream_same_loop": round(lanes * steps / t_seq, 1),
-            "lanes": lanes, "rounds": steps, "warmup_rounds": warmup,
-            "note": "throughput of a batch loop with two views in flight (distributed_step(views_in_flight=2)); `value` above is one view at a time"}
-
-
-def measure_point(rast, scenes, vp, P, W, H, deg, dev, steps, warmup, full=False, kind="cube", poses=1):
-    """One more workload with the headline's protocol (same steps / warm-up, the same number of poses dealt round-robin, every pose
-    seen before).  full: also the roofline object and the stage table."""
-    _C = rast._C
-    wl = Workload(rast, scenes, P, W, H, deg, 0, max(poses, 1), dev, kind=kind, poses=poses)
-    kid = {_C.lib().gsrast_profile_kernel_name(k).decode(): k for k in range(_C.lib().gsrast_profile_kernel_count())}
-    for _ in range(max(warmup, 3 * poses)):
-        wl.step(None, 1)
-    torch.cuda.synchronize(dev)
-    _C.profile_reset()
-    if full:
-        _C.set_option("profile", 1 << kid["blend_bwd"])
-    d = timed(wl, steps, 0, None, 1, vp, dev)
-    out = {"views_per_s": round(steps / d, 3), "ms_per_step": round(d / steps * 1e3, 4), "steps": steps, "warmup": warmup, "poses": poses}
-    if full:
-        prof = _C.profile_read()
-        _C.set_option("profile", 0)
-        st = wl.stats()
-        bwd_ms = prof["blend_bwd"][0] / max(prof["blend_bwd"][1], 1)
-        out["config"] = {"gaussians": P, "width": W, "height": H, "instances_R": st["R"], "instances_listed": st["R_listed"],
-                         "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"]}
-        out["roofline"] = roofline_of(st, bwd_ms, P)
-        out["per_stage"], _ = stage_table(_C, wl, st, P, deg, H)
-    del wl
-    torch.cuda.empty_cache()
-    return out
-
-
-def survey_metric(wl, steps, dev):
-    """SURVEY.md 8(d) / BASELINE.md 2 as written: 1 / median(t_fwd + t_bwd), device-synchronised wall clock around each call pair."""
-    ts = []
-    for _ in range(steps):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        wl.step(None, 1)
-        torch.cuda.synchronize(dev)
-        ts.append(time.perf_counter() - t0)
-    med = float(np.median(ts))
-    return {"views_per_s": round(1.0 / med, 3), "median_ms": round(med * 1e3, 4), "calls": steps,
-            "protocol": "1 / median over per-call device-synchronised wall-clock times of one forward + backward (SURVEY.md 8d)"}
-
-
 def cpu_baseline(scenes, P, W, H, deg, budget_s):
     """The oracle (CPU port, fp32, OpenMP over Gaussians / tiles) on the host cores."""
     from oracle import oracle as orc
@@ -675,350 +417,21 @@ def cpu_baseline(scenes, P, W, H, deg, budget_s):
                        f"the full workload was predicted at {predict:.0f} s > budget")
 
 
-def loss_row(dev, H, W):
-    """"Next" row: fused L1 + D-SSIM loss fwd+bwd at the bench resolution, next to the
-    reference's own formulation (five depthwise conv2d + autograd) run through PyTorch on the same GPU."""
-    import math
-    import torch.nn.functional as F
-    import fused_loss
-    torch.manual_seed(0)
-    y = torch.rand(3, H, W, device=dev)
-    x = (y + 0.05 * torch.randn(3, H, W, device=dev)).clamp(0, 1).requires_grad_(True)
 
-    def fused():
-        x.grad = None
-        fused_loss.l1_dssim_loss(x, y, 0.2).backward()
-
-    g = torch.tensor([math.exp(-(i - 5) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)], device=dev)
-    g = g / g.sum()
-    w = (g[:, None] @ g[None, :]).expand(3, 1, 11, 11).contiguous()
-
-    def eager():
-        x.grad = None
-        conv = lambda a: F.conv2d(a[None], w, padding=5, groups=3)[0]  # noqa: E731
-        mu1, mu2 = conv(x), conv(y)
-        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
-        sm = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
-        (0.8 * (x - y).abs().mean() + 0.2 * (1 - sm.mean())).backward()
-
-    def t(fn, n=30):
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3
-
-    ms_f, ms_e = t(fused), t(eager)
-    nbytes = 3 * H * W * 4 * (2 + 3 + 3 + 2 + 1)       # fwd: 2 images in, 3 maps out; bwd: 3 maps + 2 images in, grad out
-    return {"fused_l1_dssim_fwd_bwd": {"ms": round(ms_f, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
-                                       "GBps": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
-                                       "hbm_frac": round(nbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "pytorch_conv2d_autograd_same_gpu_ms": round(ms_e, 4),
-                                       "speedup_vs_pytorch": round(ms_e / ms_f, 2), "shape": [3, H, W]}}
-
-
-def epilogue_row(dev, P):
-    """"Next" row: fused activation / deformation epilogue fwd+bwd for P Gaussians (all
-    residuals present = the dynamic stage), next to the reference's own formulation run through PyTorch."""
-    import torch.nn.functional as F
-    import fused_epilogue
-    torch.manual_seed(0)
-    M = 16
-    r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
-    raw = dict(xyz=r(P, 3), motion_res=0.05 * r(P, 3), rotation=r(P, 4), rot_res=0.1 * r(P, 7), scaling=r(P, 3) - 3.0,
-               opacity=2.0 * r(P, 1), trbf=torch.rand(P, 1, device=dev), f_dc=r(P, 1, 3), f_rest=0.1 * r(P, M - 1, 3),
-               shs_res=0.05 * r(P, M, 3))
-    raw = {k: v.requires_grad_(True) for k, v in raw.items()}
-    ups = [r(P, 3), r(P, 4), r(P, 3), r(P, 1), r(P, M, 3)]
-
-    def fused():
-        for v in raw.values():
-            v.grad = None
-        outs = fused_epilogue.activate_gaussians(raw["xyz"], raw["rotation"], raw["scaling"], raw["opacity"], raw["f_dc"], raw["f_rest"],
-                                                 motion_residual=raw["motion_res"], rot_residual=raw["rot_res"],
-                                                 trbfoutput=raw["trbf"], shs_residual=raw["shs_res"])
-        torch.autograd.backward(outs, ups)
-
-    def eager():      # scene/saro_gaussian.py:807-847
-        for v in raw.values():
-            v.grad = None
-        motion = raw["xyz"] + raw["motion_res"]
-        rot = F.normalize(raw["rotation"] + raw["rot_res"][:, :4])
-        scale = torch.exp(raw["scaling"] + raw["rot_res"][:, 4:])
-        opa = torch.sigmoid(raw["opacity"]) * raw["trbf"]
-        shs = torch.cat((raw["f_dc"], raw["f_rest"]), dim=1) + raw["shs_res"]
-        torch.autograd.backward((motion, rot, scale, opa, shs), ups)
-
-    def t(fn, n=30):
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3
-
-    ms_f, ms_e = t(fused), t(eager)
-    # forward: 12+12+16+28+12+4+4 in, 12+16+12+4 out (small), 12+180+192 in, 192 out (SH); backward: ~16+28+12+4+4+16+12+4 in, 16+12+28+4+4 out
-    nbytes = P * (88 + 44 + 384 + 192 + 96 + 64)
-    return {"ms": round(ms_f, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
-            "hbm_frac": round(nbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "pytorch_eager_same_gpu_ms": round(ms_e, 4),
-            "speedup_vs_pytorch": round(ms_e / ms_f, 2), "gaussians": P, "sh_coefficients": M}
-
-
-def adam_row(dev, P):
-    """"Next" row (third item): one Adam step of the seven per-Gaussian groups (60 floats per
-    Gaussian) with per-row learning rates in one launch, next to torch.optim.Adam(fused=True) with scalar rates
-    (torch's fused Adam has no per-row rate; the reference passes a [P,1] tensor as 'lr', saro_gaussian.py:345-398)."""
-    import fused_adam
-    torch.manual_seed(0)
-    shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (15, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,), "temporal_pos": (1,)}
-    mk = lambda: {k: torch.randn((P,) + s, device=dev).requires_grad_(True) for k, s in shapes.items()}  # noqa: E731
-    pa, pb = mk(), mk()
-    inv = 1.0 + torch.rand(P, 1, device=dev)
-    mine = fused_adam.GaussianAdam([{"params": [pa[k]], "lr": 1e-3 * inv if k != "f_rest" else 1e-4, "name": k} for k in shapes], eps=1e-15)
-    ref = torch.optim.Adam([{"params": [pb[k]], "lr": 1e-3, "name": k} for k in shapes], lr=0.0, eps=1e-15, fused=True)
-    for d in (pa, pb):
-        for v in d.values():
-            v.grad = torch.randn_like(v)
-
-    def t(fn, n=30):
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3
-
-    ms_f, ms_e = t(mine.step), t(ref.step)
-    nbytes = P * 60 * 28 + P * 4 * 6
-    return {"ms": round(ms_f, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / (ms_f * 1e-3) / 1e9, 1),
-            "hbm_frac": round(nbytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "torch_fused_adam_scalar_lr_same_gpu_ms": round(ms_e, 4),
-            "speedup_vs_pytorch": round(ms_e / ms_f, 2), "gaussians": P, "floats_per_gaussian": 60}
-
-
-def iteration_row(rast, scenes, dev, P, W, H, deg):
-    """A whole static-stage training iteration (train.py:190-250 with one view): raw parameters -> activation epilogue ->
-    rasterizer -> L1 + D-SSIM -> backward -> Adam, (a) with this repository's fused pieces around the rasterizer,
-    (b) with the reference's PyTorch formulation of those pieces around the SAME rasterizer."""
-    import math
-    import torch.nn.functional as F
-    import fused_adam
-    import fused_epilogue
-    import fused_loss
-    sc = scenes.synth(P, 0, sh_degree=deg)
-    cam = scenes.camera(0, 1, W, H)
-    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
-    rs = rast.GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]), scale_modifier=1.0,
-        viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=deg, campos=t(cam["campos"]), prefiltered=False)
-    raster = rast.GaussianRasterizer(rs)
-
-    def raw():
-        d = dict(xyz=t(sc["means3D"]), rotation=t(sc["rotations"]), scaling=torch.log(t(sc["scales"])),
-                 opacity=torch.logit(t(sc["opacities"]).clamp(1e-4, 1 - 1e-4)), f_dc=t(sc["shs"][:, :1]), f_rest=t(sc["shs"][:, 1:]))
-        return {k: v.requires_grad_(True) for k, v in d.items()}
-
-    gt = torch.rand(3, H, W, device=dev)
-    ra, rb = raw(), raw()
-    inv = torch.ones(P, 1, device=dev)
-    lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
-    opt_a = fused_adam.GaussianAdam([{"params": [ra[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in ra], eps=1e-15)
-    opt_b = torch.optim.Adam([{"params": [rb[k]], "lr": lr[k], "name": k} for k in rb], lr=0.0, eps=1e-15, fused=True)
-    g = torch.tensor([math.exp(-(i - 5) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)], device=dev)
-    g = g / g.sum()
-    w = (g[:, None] @ g[None, :]).expand(3, 1, 11, 11).contiguous()
-    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
-
-    raster_raw = rast.GaussianRasterizerRaw(rs)
-    rc = raw()
-    opt_c = fused_adam.GaussianAdam([{"params": [rc[k]], "lr": lr[k] * inv if k != "f_rest" else lr[k], "name": k} for k in rc], eps=1e-15)
-
-    def fused():        # the epilogue INSIDE the per-Gaussian kernels (gsrast_forward_raw / gsrast_backward_raw)
-        color, _, _ = raster_raw(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"])
-        loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
-        opt_c.zero_grad(); m2.grad = None
-        loss.backward()
-        opt_c.step()
-
-    def two_ops():      # round 2's form: standalone fused epilogue in front of the drop-in rasterizer
-        motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(ra["xyz"], ra["rotation"], ra["scaling"], ra["opacity"], ra["f_dc"], ra["f_rest"])
-        color, _, _ = raster(means3D=motion, means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
-        loss = fused_loss.l1_dssim_loss(color, gt, 0.2)
-        opt_a.zero_grad(); m2.grad = None
-        loss.backward()
-        opt_a.step()
-
-    def eager():
-        rot, scale, opa = F.normalize(rb["rotation"]), torch.exp(rb["scaling"]), torch.sigmoid(rb["opacity"])
-        shs = torch.cat((rb["f_dc"], rb["f_rest"]), dim=1)
-        x, _, _ = raster(means3D=rb["xyz"], means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
-        conv = lambda a_: F.conv2d(a_[None], w, padding=5, groups=3)[0]  # noqa: E731
-        mu1, mu2 = conv(x), conv(gt)
-        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(gt * gt) - mu2 * mu2, conv(x * gt) - mu1 * mu2
-        sm = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
-        loss = 0.8 * (x - gt).abs().mean() + 0.2 * (1 - sm.mean())
-        opt_b.zero_grad(); m2.grad = None
-        loss.backward()
-        opt_b.step()
-
-    def tm(fn, n=20):
-        for _ in range(4):
-            fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3
-
-    ms_f, ms_2, ms_e = tm(fused), tm(two_ops), tm(eager)
-    # the DYNAMIC stage's call shape: all four deformation residuals present (scene/saro_gaussian.py:807-847), rasterizer forward + backward
-    # only -- the raw entry points against the standalone epilogue in front of the drop-in rasterizer
-    g_ = torch.Generator(device="cpu").manual_seed(3)
-    res = dict(motion_residual=(0.01 * torch.randn((P, 3), generator=g_)).to(dev).requires_grad_(True),
-               rot_residual=(0.05 * torch.randn((P, 7), generator=g_)).to(dev).requires_grad_(True),
-               trbfoutput=torch.rand((P, 1), generator=g_).to(dev).requires_grad_(True),
-               shs_residual=(0.03 * torch.randn((P, 16, 3), generator=g_)).to(dev).requires_grad_(True))
-    gcol = torch.randn((3, H, W), generator=g_).to(dev) / (3.0 * H * W)
-
-    def clear():
-        for v in list(rc.values()) + list(ra.values()) + list(res.values()) + [m2]:
-            v.grad = None
-
-    def dyn_raw():
-        clear()
-        color, _, _ = raster_raw(rc["xyz"], m2, rc["rotation"], rc["scaling"], rc["opacity"], rc["f_dc"], rc["f_rest"], **res)
-        color.backward(gcol)
-
-    def dyn_two_ops():
-        clear()
-        motion, rot, scale, opa, shs = fused_epilogue.activate_gaussians(ra["xyz"], ra["rotation"], ra["scaling"], ra["opacity"], ra["f_dc"], ra["f_rest"], **res)
-        color, _, _ = raster(means3D=motion, means2D=m2, opacities=opa, shs=shs, scales=scale, rotations=rot)
-        color.backward(gcol)
-
-    ms_dr, ms_d2 = tm(dyn_raw), tm(dyn_two_ops)
-    return {"ms": round(ms_f, 4), "iterations_per_s": round(1e3 / ms_f, 1),
-            "dynamic_stage_call_all_residuals_fwd_bwd": {"raw_entry_points_ms": round(ms_dr, 4), "standalone_epilogue_then_rasterizer_ms": round(ms_d2, 4),
-                                                         "note": "rasterizer forward + backward with motion / rotation+scale / trbf / SH residuals given; no loss, no optimizer"},
-            "standalone_epilogue_then_rasterizer_ms": round(ms_2, 4), "pytorch_pieces_around_same_rasterizer_ms": round(ms_e, 4),
-            "speedup": round(ms_e / ms_f, 2), "gaussians": P, "image": [H, W],
-            "pieces": "GaussianRasterizerRaw (activations inside the per-Gaussian kernels) -> l1_dssim_loss -> backward -> GaussianAdam.step"}
-
-
-def knn_row(dev, P):
-    """"Next" row (second item): simple_knn.distCUDA2 for P points (the reference's random-init
-    cube, dataset_readers.py:526), next to an exact k-d tree 3-NN on all host cores (scipy cKDTree, fp64)."""
-    from scipy.spatial import cKDTree
-    from simple_knn._C import distCUDA2
-    rng = np.random.default_rng(0)
-    pts = rng.uniform(-1.3, 1.3, size=(P, 3)).astype(np.float32)
-    x = torch.from_numpy(pts).to(dev)
-    for _ in range(2):
-        distCUDA2(x)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    n = 5
-    for _ in range(n):
-        out = distCUDA2(x)
-    torch.cuda.synchronize(dev)
-    ms = (time.perf_counter() - t0) / n * 1e3
-    t0 = time.perf_counter()
-    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4, workers=-1)
-    cpu_s = time.perf_counter() - t0
-    want = (np.sort(d ** 2, axis=1)[:, 1:]).sum(1) / 3.0
-    err = float(np.abs(out.cpu().numpy().astype(np.float64) - want).max() / want.max())
-    return {"ms": round(ms, 3), "points": P, "scipy_ckdtree_all_cores_s": round(cpu_s, 3), "cores": os.cpu_count(),
-            "max_abs_err_rel_to_max": err}
-
-
-def hexplane_row(dev, P):
-    """"Next" row (first item): the residual field's mip-mapped plane lookup for P points, forward and
-    backward to the planes, at the two shipped field shapes (configs/dnerf/*.json: 64^3 x 128 frames; configs/neural_3D/*.json:
-    512^3 x 256 frames; 32 features, one scale), next to the same computation spelled with PyTorch ops on the same GPU
-    (avg_pool2d pyramid + grid_sample per level + lerp -- the structure tests/test_oracle_texture.py pins the oracle with)."""
-    import itertools
-    import torch.nn.functional as F
-    import fused_hexplane
-    coo = list(itertools.combinations(range(4), 2))
-    g = torch.Generator(device="cpu").manual_seed(0)
-    out = {}
-    for tag, reso in (("dnerf_64x64x64x128", [64, 64, 64, 128]), ("neural3d_512x512x512x256", [512, 512, 512, 256])):
-        C = 32
-        grids = [torch.randn((1, C, reso[b], reso[a]), generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-                 for (a, b) in coo]
-        pts = torch.rand((P, 4), generator=g).to(dev)
-        levels = torch.cat([torch.rand((P, 3), generator=g) * float(np.log2(reso[0])), torch.zeros((P, 1))], dim=1).to(dev)
-        dy = torch.randn((P, C), generator=g).to(dev)
-
-        def ours():
-            o = fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
-            o.backward(dy)
-            return o
-
-        def torch_ops():
-            acc = 0
-            for ci, (a, b) in enumerate(coo):
-                mm = 7 if b != 3 else 0
-                mips = [grids[ci]]
-                while mips[-1].shape[2] > 1 and len(mips) - 1 < mm:
-                    mips.append(F.avg_pool2d(mips[-1], 2))
-                n = len(mips) - 1
-                fl = torch.minimum(levels[:, a], levels[:, b]).clamp(0.0, float(n))
-                l0 = fl.floor().long()
-                l1 = torch.clamp(l0 + 1, max=n)
-                f = (fl - l0)[:, None]
-                grid = (2.0 * pts[:, [a, b]] - 1.0)[None, None]
-                va = torch.zeros((P, C), device=dev)
-                vb = torch.zeros((P, C), device=dev)
-                for l in range(n + 1):          # every level sampled for the points that use it
-                    ma, mb = l0 == l, l1 == l
-                    if bool(ma.any()) or bool(mb.any()):
-                        sm = F.grid_sample(mips[l], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, :, 0].t()
-                        va = torch.where(ma[:, None], sm, va)
-                        vb = torch.where(mb[:, None], sm, vb)
-                acc = acc + va + f * (vb - va)
-            acc.backward(dy)
-            return acc
-
-        res = {}
-        for name, fn, reps in (("ms", ours, 10), ("torch_ops_same_gpu_ms", torch_ops, 2)):
-            for _ in range(2 if fn is ours else 1):
-                for gr in grids: gr.grad = None
-                o = fn()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                for gr in grids: gr.grad = None
-                o = fn()
-            torch.cuda.synchronize(dev)
-            res[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
-            res["_out_" + name] = o.detach()
-            res["_grad_" + name] = grids[0].grad.detach().clone()
-        a_, b_ = res.pop("_out_ms"), res.pop("_out_torch_ops_same_gpu_ms")
-        ga, gb = res.pop("_grad_ms"), res.pop("_grad_torch_ops_same_gpu_ms")
-        res["max_abs_diff_vs_torch_ops"] = float((a_ - b_).abs().max())
-        res["plane_grad_rel_diff_vs_torch_ops"] = float((ga - gb).abs().max() / gb.abs().max())
-        # forward alone, and the gather it performs: 8 texels x 128 B per point and plane
-        with torch.no_grad():
-            for _ in range(2):
-                fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(10):
-                fused_hexplane.interpolate_ms_features(pts, [grids], 2, True, levels, None)
-            torch.cuda.synchronize(dev)
-            res["forward_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
-        res["points"] = P
-        out[tag] = res
-        del grids
-    return out
+def sweep_point(rast, scenes, vp, P, W, H, deg, dev, steps, warmup, poses, kind="cube"):
+    """One more #Gaussians point with the headline's protocol: pose table OFF, per-call synchronised, median."""
+    _C = rast._C
+    wl = Workload(rast, scenes, P, W, H, deg, 0, max(poses, 1), dev, kind=kind, poses=poses)
+    _C.set_option("no_order_hint", 1)
+    try:
+        for _ in range(max(warmup, 2 * poses)):
+            wl.step(None, 1)
+        med, _, _ = timed_sync(wl, steps, None, 1, vp, dev)
+    finally:
+        _C.set_option("no_order_hint", 0)
+    del wl
+    torch.cuda.empty_cache()
+    return round(1.0 / med, 1)
 
 
 def self_launch(a):
@@ -1033,6 +446,21 @@ def self_launch(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
+
+
+
+def compact_line(result: dict) -> str:
+    """The final stdout line: the result as compact JSON, at most LINE_LIMIT bytes.  Optional diagnostics are dropped, least important
+    first, should a future field push it over (the contract's keys, roofline and cpu_baseline are never dropped)."""
+    optional = ["per_step_ms", "stage_ms", "host", "sweep_1080p_cold", "pipelined", "value_no_list_cut", "roofline_fwd"]
+    r = dict(result)
+    line = json.dumps(r, separators=(",", ":"))
+    while len(line) > LINE_LIMIT and optional:
+        r.pop(optional.pop(0), None)
+        line = json.dumps(r, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:
+        raise RuntimeError(f"bench.py: the result line is {len(line)} bytes (> {LINE_LIMIT}) even without its optional fields")
+    return line
 
 
 def main():
@@ -1057,7 +485,7 @@ def main():
         if a.gpus != 1:
             raise SystemExit("bench.py: --force-collectives is for --gpus 1 (N > 1 runs the collectives anyway)")
         vp.force_collectives(True)
-        a.sweep, a.no_training_like, a.no_cpu_baseline = "", True, True
+        a.sweep, a.no_cpu_baseline, a.extras = "", True, None
     rank, local, world = vp.init_from_env()
     assert world == a.gpus
     dev = torch.device("cuda", local if (world > 1 and not single) else 0)
@@ -1073,12 +501,9 @@ def main():
     for kv in a.opt:
         name, _, val = kv.partition("=")
         _C.set_option(name, int(val))
-    if a.ppl:
-        _C.set_option("pixels_per_lane", a.ppl)
-    if a.ppl_fwd:
-        _C.set_option("fwd_pixels_per_lane", a.ppl_fwd)
-    if a.ppl_bwd:
-        _C.set_option("bwd_pixels_per_lane", a.ppl_bwd)
+    for flag, name in ((a.ppl, "pixels_per_lane"), (a.ppl_fwd, "fwd_pixels_per_lane"), (a.ppl_bwd, "bwd_pixels_per_lane")):
+        if flag:
+            _C.set_option(name, flag)
     if a.no_cull:
         _C.set_option("cull", 0)
     if a.no_lpt:
@@ -1094,25 +519,26 @@ def main():
     exchanging = world > 1 or a.force_collectives
     if exchanging:
         wl.force_exchange = a.force_collectives
-        # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the backward writes
-        # into it directly.  Default exchange: all-reduce of the 11 dense floats + all-gather of the 3-float factor of
-        # dL/dsh, recombined locally (view_parallel.exchange_gradients); --exchange allreduce: ONE in-place all-reduce
-        # of all 59 floats.  Both give the batch-mean gradient of set_batch_gradient (saro_gaussian.py:266-276).
+        # one flat fp32 buffer holds every leaf gradient of the rasterizer (59 floats / Gaussian); the backward writes into it directly.
+        # Default exchange (gather): ONE all-gather of the 64-byte rows each rank's own view touched, added in rank order; --exchange
+        # allreduce: ONE in-place all-reduce of all 59 floats.  All forms give the batch-mean gradient of set_batch_gradient
+        # (saro_gaussian.py:266-276).
         bucket = _C.GradArena(P, 16, dev, sh_factors=(a.exchange != "allreduce"), world=world)
         _C.set_grad_arena(bucket)
         wl.sparse = "gather" if a.exchange == "gather" else a.exchange == "sparse"
         if a.exchange == "factors":
-            import view_parallel
-            view_parallel.overlap_factor_exchange(True)     # the all-gather starts between the two phases of the backward
+            vp.overlap_factor_exchange(True)     # the all-gather starts between the two phases of the backward
 
     names = [_C.lib().gsrast_profile_kernel_name(k).decode() for k in range(_C.lib().gsrast_profile_kernel_count())]
     kid = {n: i for i, n in enumerate(names)}
+
+    # ---- headline leg: pose table OFF (every forward a first visit), per-call synchronised ----
+    _C.set_option("no_order_hint", 1)
     _C.profile_reset()
     # only the roofline kernel is bracketed with events inside the timed region (2 records/step, ~5 us of GPU idle each)
     _C.set_option("profile", 1 << kid["blend_bwd"])
-    # settle the device first (see --preroll-ms), then the W warm-up steps the contract asks for
     n_pre = 0
-    if a.preroll_ms > 0:
+    if a.preroll_ms > 0:        # settle the device first (see --preroll-ms); reported as preroll_steps
         t_pre = time.perf_counter()
         while n_pre < 5000:
             for _ in range(20):
@@ -1122,192 +548,121 @@ def main():
             # the same elapsed time on every rank, so every rank runs the same number of rounds (and collectives)
             if vp.max_over_ranks(time.perf_counter() - t_pre, dev) * 1e3 >= a.preroll_ms:
                 break
-    # warm-up happens inside timed(); reset the event totals after it by timing warm-up separately
     for _ in range(a.warmup):
         wl.step(bucket, world)
     torch.cuda.synchronize(dev)
     _C.profile_reset()
-    dt = timed(wl, a.steps, 0, bucket, world, vp, dev)
-    host_steps_headline = dict(HOST_STEPS)          # (of THIS timed() call: the twins below overwrite the module-level record)
+    med, mean, per_step = timed_sync(wl, a.steps, bucket, world, vp, dev)
     prof = _C.profile_read()
     _C.set_option("profile", 0)
-    # what the pose table did inside the timed steps (host-side counters of the context: no device wait)
-    late_headline = _query(_C, "last_late")
-    # the SAME protocol with one repeated pose (rounds 1-3's headline: the pose table's best case), for comparison
-    repeated = None
-    if world == 1 and not exchanging and n_poses > 1:
-        wl1 = Workload(rast, scenes, P, W, H, deg, view_k=0, n_views=n_poses, dev=dev, kind=a.scene)
-        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-            wl1.leaves[k] = wl.leaves[k]            # (the same scene tensors: no second copy of 3 M Gaussians)
-        d1 = timed(wl1, a.steps, a.warmup, None, 1, vp, dev)
-        repeated = {"views_per_s": round(a.steps / d1, 3), "ms_per_step": round(d1 / a.steps * 1e3, 4), "steps": a.steps, "warmup": a.warmup}
-        del wl1
+    late_cold = _query(_C, "last_late")
+    d_pipe_cold = timed(wl, a.steps, 0, bucket, world, vp, dev)
+    host_cold = dict(HOST_STEPS)
 
-    # the same protocol with the context's launch-order hints switched off (include/gsrast.h: options.no_order_hint): the bench repeats ONE
-    # camera pose, the best case for them; a pose seen for the first time is ordered by list length
-    no_hint = None
+    st, per_kernel, pk = None, None, None
     if world == 1 and not exchanging:
-        _C.set_option("no_order_hint", 1)
-        try:
-            d0 = timed(wl, a.steps, a.warmup, None, 1, vp, dev)
-            no_hint = {"views_per_s": round(a.steps / d0, 3), "ms_per_step": round(d0 / a.steps * 1e3, 4), "steps": a.steps, "warmup": a.warmup}
-        finally:
-            _C.set_option("no_order_hint", 0)
-    # ... and with the LIST CUT switched off (options.no_list_cut; the launch-order hints stay on): a pose rendered before bins only the
-    # Gaussians in front of its tiles' cut depths -- the same best case (one pose, an unchanged scene: the speculation always holds)
-    no_cut = None
+        st = wl.stats()             # (measured under the headline's options: table off)
+        per_kernel, pk = stage_table(_C, wl, st, P, deg, H)
+    elif rank == 0:
+        st = wl.stats()
+    _C.set_option("no_order_hint", 0)
+
+    # ---- the same protocol with the pose table ON: every pose seen before (an unchanged scene over a fixed rig) ----
+    warm_warmup = max(a.warmup, 3 * n_poses)
+    for _ in range(warm_warmup):
+        wl.step(bucket, world)
+    torch.cuda.synchronize(dev)
+    med_w, mean_w, _ = timed_sync(wl, a.steps, bucket, world, vp, dev)
+    late_warm = _query(_C, "last_late")
+    d_pipe_warm = timed(wl, a.steps, 0, bucket, world, vp, dev)
+
+    # ---- ... and with the LIST CUT switched off altogether (the floor for a scene no prediction can cut) ----
+    med_nc = None
     if world == 1 and not exchanging:
         _C.set_option("no_list_cut", 1)
         try:
-            d0 = timed(wl, a.steps, a.warmup, None, 1, vp, dev)
-            no_cut = {"views_per_s": round(a.steps / d0, 3), "ms_per_step": round(d0 / a.steps * 1e3, 4), "steps": a.steps, "warmup": a.warmup}
+            for _ in range(a.warmup):
+                wl.step(None, 1)
+            med_nc, _, _ = timed_sync(wl, a.steps, None, 1, vp, dev)
         finally:
             _C.set_option("no_list_cut", 0)
-        for _ in range(3):
-            wl.step(None, 1)        # (the statistics below describe the default path again)
-    st = wl.stats()
-    per_kernel, pk, exp2 = (None, None, None)
-    if world == 1 and not exchanging:
-        per_kernel, pk = stage_table(_C, wl, st, P, deg, H)
-        exp2 = None if os.environ.get("BENCH_NO_EXP2") else exp_mode2_row(_C, wl, dev, kid)
+
     result = None
     scene_fn = "synth" if a.scene == "cube" else "synth_shell"
+    ranks_info = None
+    if exchanging and torch.distributed.is_initialized():
+        mine = {"rank": rank, "device": int(dev.index or 0), "name": torch.cuda.get_device_name(dev)}
+        ranks_info = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(ranks_info, mine)
     if rank == 0:
-        ms_per_step = dt / a.steps * 1e3
-        value = world * a.steps / dt
         bwd_ms = prof["blend_bwd"][0] / max(prof["blend_bwd"][1], 1)
-        fwd_ms = pk["blend_fwd"][0] / max(pk["blend_fwd"][1], 1) if per_kernel else 0.0   # separate all-stages pass
-        fwd_bytes = st["R_eff"] * 44 + st["N"] * 24
+        fwd_ms = pk["blend_fwd"][0] / max(pk["blend_fwd"][1], 1) if per_kernel else 0.0   # (the event-bracketed all-stages pass behind the timed region)
+        try:
+            nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:       # noqa: BLE001
+            nccl_version = None
         result = {
             "metric": "rendered views/s (fwd+bwd) at 1080p vs #Gaussians",
-            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(world / med, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(med * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            # the SAME protocol with the context's pose table switched off -- what a camera pose costs that the context has never
-            # rendered, and the floor for a scene that changes too much between two visits of a pose for the table to help
-            "value_cold": no_hint["views_per_s"] if no_hint else None, "ms_per_step_cold": no_hint["ms_per_step"] if no_hint else None,
-            "config": {"workload": f"BASELINE configs[4] stress-1080p: {scene_fn}(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd"
-                                   + ((" + RCCL all-gather of the 64-byte gradient rows each rank's view touched (11 dense floats + the 3-float dL/dsh factor), added in rank order"
-                                       if a.exchange == "gather" else
-                                       " + RCCL all-reduce(mean) of 11 floats/Gaussian + all-gather of the 3-float dL/dsh factor, recombined locally"
-                                       + (" -- of the rows some rank touched only" if a.exchange == "sparse" else "")
-                                       if a.exchange != "allreduce" else " + RCCL all-reduce(mean) of 59 floats/Gaussian") if exchanging else ""),
-                       "exchange": a.exchange if exchanging else None,
-                       "exchange_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None) if exchanging else None,
-                       "exchange_bytes_per_rank_and_step": getattr(wl, "exchanged", None) if exchanging else None,
-                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode,
-                       "views_per_step": world, "instances_R": st["R"], "instances_listed": st["R_listed"],
-                       "column_runs_Q": st["Q"], "R_eff": st["R_eff"], "R_eff_listed": st["R_eff_listed"], "visible": st["P_vis"],
-                       "blended_pairs_fwd": st["pairs_fwd"],
-                       # each rank renders `poses_per_rank` cameras round-robin on an unchanged scene (every pose seen before, in the
-                       # untimed pre-roll: the steady state of a training run over a fixed rig); R / R_eff / ... above are means over them.
-                       # The context's pose table is in force (launch-order hints + list cut): see pose_table for the same
-                       # protocol with the table switched off and with one repeated pose
-                       "poses_per_rank": n_poses, "repeated_pose": n_poses == 1,
-                       "list_cut_late_gaussians": st.get("late"), "column_runs_early": st.get("Q_early"),
-                       "pose_table_switched_off": no_hint, "list_cut_switched_off": no_cut, "one_repeated_pose": repeated},
-            "roofline": roofline_of(st, bwd_ms, P, exp2),
-            # the forward blend -- the kernel north_star's 60 % figure names -- with the same fields; its launch duration comes from the
-            # event-bracketed stage pass behind the timed region (the timed region brackets the dominant kernel only)
-            "roofline_fwd": roofline_of(st, fwd_ms, P, None, kernel="blend_fwd_cull_kernel") if fwd_ms > 0 else None,
-            "kernels_ms": {"blend_fwd": round(fwd_ms, 4), "blend_bwd": round(bwd_ms, 4),
-                           "blend_fwd_GBs_algorithmic": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms > 0 else None},
-            "per_stage": per_kernel,
-            "host_step_ms": host_steps_headline, "preroll_steps": n_pre,
-            "launch_order_hint": {"headline": "on (library default): the context orders the forward blend of a camera pose it has rendered before by what "
-                                              "every tile consumed then; this bench deals `config.poses_per_rank` poses round-robin",
-                                  "switched_off": no_hint,
-                                  "note": "results never depend on it (tests/test_gpu_parity.py::test_launch_order_hints_never_change_a_result); "
-                                          "switched off, the list cut below is off as well (it rides on the same table)"},
-            "list_cut": {"headline": "on where it pays (library default): a pose rendered before bins only the Gaussians in front of its tiles' cut depths; "
-                                     "verified on the device, the full binning + blend enqueued behind the blend, predicated on the verdict",
-                         "late_gaussians": st.get("late"), "early_column_runs": st.get("Q_early"), "all_column_runs": st.get("Q"),
-                         "switched_off": no_cut,
-                         "cut_fallbacks_in_this_process": _query(_C, "cut_fallbacks"),
-                         "note": "results never depend on it (tests/test_gpu_parity.py::test_list_cut_is_verified_and_never_changes_a_result)"},
-            "step_algorithmic_bytes": step_bytes(st, per_kernel, P, deg, ms_per_step),
+            "preroll_steps": n_pre,
+            # the K-step region as a whole (barrier + synchronize on both sides, every step synchronised inside): wall time / K
+            "mean_ms_per_step": round(mean * 1e3, 4),
+            "value_warm": round(world / med_w, 3), "ms_per_step_warm": round(med_w * 1e3, 4), "warmup_warm": warm_warmup,
+            "value_no_list_cut": round(1.0 / med_nc, 3) if med_nc else None,
+            "pipelined": {"views_per_s_cold": round(world * a.steps / d_pipe_cold, 1), "views_per_s_warm": round(world * a.steps / d_pipe_warm, 1),
+                          "note": "K steps back to back, one sync (rounds 1-5's headline): throughput, not the metric"},
+            "config": {"workload": f"BASELINE configs[4] stress-1080p: {scene_fn}(P={P}, seed 0) SH{deg}, {W}x{H}, one view per GPU, fwd+bwd",
+                       "protocol": "SURVEY 8d: 1 / median of per-call device-synchronised wall-clock fwd+bwd",
+                       "pose_table": "off for value (every pose a first visit); on for value_warm",
+                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "exp_mode": exp_mode, "poses_per_rank": n_poses,
+                       "views_per_step": world, "R": st["R"], "R_listed": st["R_listed"], "Q": st["Q"], "R_eff": st["R_eff"], "visible": st["P_vis"],
+                       "late_gaussians_cold": late_cold, "late_gaussians_warm": late_warm,
+                       "word_fork": _C.get_option("word_fork"),
+                       "exchange": a.exchange if exchanging else None},
+            "roofline": roofline_of(st, bwd_ms, P),
+            "roofline_fwd": roofline_of(st, fwd_ms, P, kernel="blend_fwd_cull_kernel") if fwd_ms > 0 else None,
+            "stage_ms": {k: v["ms"] for k, v in per_kernel.items()} if per_kernel else None,
+            "host": {"enqueue_ms_median": host_cold.get("median"), "device_mallocs_in_timed_steps": host_cold.get("device_mallocs")},
+            "per_step_ms": {"min": min(per_step), "max": max(per_step)} if per_step else None,
         }
+        if exchanging:
+            result["config"].update({
+                "exchange_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                "rccl_world": torch.distributed.get_world_size() if torch.distributed.is_initialized() else None,
+                "rccl_version": nccl_version,
+                "rank_devices": [r["device"] for r in ranks_info] if ranks_info else None,
+                "exchange_bytes_per_rank_and_step": getattr(wl, "exchanged", None)})
 
-    # ---- sweep over #Gaussians (single GPU only; parity-sized cases are tests, not bench lines) ----
-    if world == 1 and a.sweep:
-        sweep = {}
-        result["survey_metric"] = survey_metric(wl, a.steps, dev)
+    # ---- the metric's "vs #Gaussians": more points at 1080p, same protocol (single GPU only) ----
+    if rank == 0 and world == 1 and a.sweep:
         del wl
         torch.cuda.empty_cache()
+        sweep = {}
         for p in [int(x) for x in a.sweep.split(",") if x]:
-            if p == P:
-                sweep[str(p)] = {"views_per_s": result["value"], "ms_per_step": result["ms_per_step"], "steps": a.steps, "warmup": a.warmup}
-                continue
-            full = p == 1_000_000           # the 1 M point (rounds 1-2's headline) keeps its own roofline object and stage table
-            m = measure_point(rast, scenes, vp, p, W, H, deg, dev, a.steps, a.warmup, full=full, poses=n_poses)
-            if full:
-                result["sweep_1M_1080p"] = m
-            sweep[str(p)] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup")}
-        result["sweep_1080p"] = sweep
-        # the other single-GPU shapes BASELINE.json names (synthetic stand-ins): informational, same protocol
-        other = {}
-        for tag, p, w, h in (("cfg2_100k_800x800", 100_000, 800, 800), ("cfg3_1M_1352x1014", 1_000_000, 1352, 1014)):
-            other[tag] = measure_point(rast, scenes, vp, p, w, h, deg, dev, a.steps, a.warmup, poses=n_poses)
-        result["baseline_configs"] = other
-        # a second occlusion regime (scenes.synth_shell: a surface, R_eff ~ R) at the headline's size: the binning / culling / launch
-        # order choices are not tuned to the cube's early termination alone
-        m = measure_point(rast, scenes, vp, 1_000_000, W, H, deg, dev, a.steps, a.warmup, full=True, kind="shell", poses=n_poses)
-        result["shell_scene_1080p"] = {k: m[k] for k in ("views_per_s", "ms_per_step", "steps", "warmup", "config", "per_stage")}
-        result["shell_scene_1080p"]["blend_bwd_ms"] = m["roofline"]["avg_launch_ms"]
-        # NOT the headline protocol: two views of a batch in flight on two streams of the one GPU (what
-        # view_parallel.distributed_step(views_in_flight=2) does when a rank renders several views of the reference's batch loop,
-        # train.py:198-226): one view's latency-bound binning runs under the other's VALU-bound blend kernels
-        try:
-            result["two_views_in_flight_1080p"] = in_flight_row(rast, scenes, P, W, H, deg, dev, a.steps, a.warmup)
-        except Exception as e:      # noqa: BLE001
-            result["two_views_in_flight_1080p"] = {"error": str(e)}
-
-    if rank == 0 and world == 1 and not a.no_training_like:
-        try:        # (before the training-like legs: their time-varying scene leaves the context's list cut paused, as it should)
-            result["eval_fps_forward_only"] = eval_fps_row(rast, scenes, dev, P, W, H, deg)
-        except Exception as e:      # noqa: BLE001
-            result["eval_fps_forward_only"] = {"error": str(e)}
-        try:
-            result["training_like"] = training_like_row(rast, scenes, dev, P, W, H, deg)
-        except Exception as e:      # noqa: BLE001
-            result["training_like"] = {"error": str(e)}
+            sweep[str(p)] = result["value"] if p == P else sweep_point(rast, scenes, vp, p, W, H, deg, dev, a.steps, a.warmup, n_poses)
+        sweep[str(P)] = result["value"]
+        result["sweep_1080p_cold"] = sweep
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        P_headline, P = P, min(P, 1_000_000)      # the SURVEY 8f rows are quoted at 1 M Gaussians (rounds 1-2), whatever the headline
         try:
-            result["next_rows"] = loss_row(dev, H, W)
-        except Exception as e:
-            result["next_rows"] = {"fused_l1_dssim_fwd_bwd": {"error": str(e)}}
-        try:
-            result["next_rows"]["fused_activation_epilogue_fwd_bwd"] = epilogue_row(dev, P)
-        except Exception as e:
-            result["next_rows"]["fused_activation_epilogue_fwd_bwd"] = {"error": str(e)}
-        try:
-            result["next_rows"]["per_row_lr_adam_step"] = adam_row(dev, P)
-        except Exception as e:
-            result["next_rows"]["per_row_lr_adam_step"] = {"error": str(e)}
-        try:
-            result["next_rows"]["knn3_mean_dist2"] = knn_row(dev, P)
-        except Exception as e:
-            result["next_rows"]["knn3_mean_dist2"] = {"error": str(e)}
-        try:
-            result["next_rows"]["hexplane_field_fwd_bwd"] = hexplane_row(dev, P)
-        except Exception as e:      # noqa: BLE001
-            result["next_rows"]["hexplane_field_fwd_bwd"] = {"error": str(e)}
-        try:
-            result["next_rows"]["static_stage_training_iteration"] = iteration_row(rast, scenes, dev, P, W, H, deg)
-        except Exception as e:
-            result["next_rows"]["static_stage_training_iteration"] = {"error": str(e)}
+            result["cpu_baseline"] = cpu_baseline(scenes, P, W, H, deg, a.cpu_budget_s)
+        except Exception as e:  # the baseline is reported, never required for the GPU number
+            result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0 and world == 1 and a.extras:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_extras
+        report = bench_extras.run(a, rast, scenes, vp, dev, dict(result, per_stage=per_kernel, stats=st))
+        os.makedirs(os.path.dirname(os.path.abspath(a.extras)), exist_ok=True)
+        with open(a.extras, "w") as f:
+            json.dump(report, f, indent=1)
+        print(json.dumps({"bench_report": a.extras, "report": report}), flush=True)       # an EARLIER line: never the last one
+        result["extras"] = a.extras if not os.path.isabs(a.extras) else os.path.relpath(a.extras, ROOT)
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
-            P = P_headline
-            try:
-                result["cpu_baseline"] = cpu_baseline(scenes, P, W, H, deg, a.cpu_budget_s)
-            except Exception as e:  # the baseline is reported, never required for the GPU number
-                result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-                                          "sample": f"failed: {e}"}
-        print(json.dumps(result), flush=True)
+        print(compact_line(result), flush=True)
     if world > 1:
         vp.barrier()
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GSRAST_ABI_VERSION 4   /* 4: gsrast_raw_grads.d_sh_factor (the struct grew), gsrast_sh_grad_combine_rows.  3: gsrast_options.no_list_cut (the struct grew).  2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
+#define GSRAST_ABI_VERSION 5   /* 5: gsrast_grad_rows_clear / gsrast_grad_rows_add take P (indices received from peers are bounds-checked).  4: gsrast_raw_grads.d_sh_factor (the struct grew), gsrast_sh_grad_combine_rows.  3: gsrast_options.no_list_cut (the struct grew).  2: gsrast_backward OVERWRITES every output array (version 1 accumulated into caller-zeroed arrays like the
                                     reference); options.forward_only; gsrast_forward_raw / gsrast_backward_raw */
 #define GSRAST_TILE_X 16 /* reference config.h:16 */
 #define GSRAST_TILE_Y 16 /* reference config.h:17 */
@@ -175,11 +175,12 @@ int gsrast_rows_unpack(long long n, const long long* idx, int n_arrays, float* c
  *   pack : rows[0] word 0 (the count, zeroed by the caller) counts the touched rows, rows[1 + k] receive them (arrival order), at most cap.
  *   clear: zeroes, for every row the chunks name, the dense arrays' rows (dense != NULL) and / or the SH arrays' rows (any SH pointer given).
  *   add  : dense[idx] += scale * row, dL/dsh[idx] += scale * w(dir(means3D[idx] - campos)) (x) factor -- no atomics: indices within a chunk
- *          are distinct, chunks are added by consecutive launches. */
+ *          are distinct, chunks are added by consecutive launches.
+ *   clear / add take P (round 6): the indices inside a chunk come from a peer; a row whose index is >= P is skipped, never written. */
 int gsrast_grad_rows_pack(int P, const unsigned char* touched /*[P]*/, float* const* dense, const float* factor /*[P][3]*/, uint32_t* rows, uint32_t cap, void* stream);
-int gsrast_grad_rows_clear(const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense /* or NULL */, int M,
+int gsrast_grad_rows_clear(int P, const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense /* or NULL */, int M,
                            float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
-int gsrast_grad_rows_add(const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale,
+int gsrast_grad_rows_add(int P, const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale,
                          float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
 
 /* Parity-test helper: copies internal state out in the reference's array layout

@@ -487,7 +487,26 @@ SideStream* side_stream_of(gsrast_context* ctx)
     }
     return &x;
 }
-std::atomic<int> g_word_fork{1};          // 1: word forks where a kernel can signal its own start (A/B switch)
+std::atomic<int> g_word_fork{0};          // 1: word forks where a kernel can signal its own start.  OPT-IN since round 6 (default 0: every fork is an event): the hang the
+                                          // soak test showed with them (3 of 28 runs, two concurrent submitters) was never root-caused, and what they buy is 13 us of a
+                                          // 1.1 ms step (1.2 %).  The reference's statics are callable from any number of threads (rasterizer.h:24-83); a drop-in may not
+                                          // trade that for a percent.  With the option on, the rule of single_host_thread() still applies.
+// TESTS ONLY (option "mutate"): a backward that is wrong on purpose, so that a test can show its tolerance would catch it (the
+// full-size gradient bar let an all-zero dL/dsh pass).  bit 0: the blend backward of ONE tile -- the image's centre tile -- does not see the 64
+// front-most entries of the tile's list (one staged batch dropped: the tile's range, its pixels' n_contrib and its tile_max are shifted by a
+// small kernel in front of the blend backward; every other (pixel, Gaussian) pair gets exactly what it gets without the mutation).
+// bit 1: the background term of dL/dalpha (backward.cu:531-534) is dropped (the blend backward is handed a zero background).
+std::atomic<int> g_mutate{0};
+__global__ void mutate_drop_front_batch_kernel(uint2* ranges, uint32_t* n_contrib, uint32_t* tile_max, uint32_t tile, int W, int H, int gx)
+{
+    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    const uint32_t px = tx * TILE_X + (threadIdx.x & 15u), py = ty * TILE_Y + (threadIdx.x >> 4);
+    const uint2 r = ranges[tile];
+    const uint32_t drop = (r.y - r.x) < 64u ? (r.y - r.x) : 64u;
+    __syncthreads();
+    if (px < (uint32_t)W && py < (uint32_t)H) { const size_t pid = (size_t)W * py + px; const uint32_t c = n_contrib[pid]; n_contrib[pid] = c > drop ? c - drop : 0u; }
+    if (threadIdx.x == 0) { ranges[tile] = make_uint2(r.x + drop, r.y); const uint32_t m = tile_max[tile]; tile_max[tile] = m > drop ? m - drop : 0u; }
+}
 // the caller stream's fork word and the next sequence number to signal, or {nullptr, 0}: fork with the event
 static ForkWord fork_word_next(gsrast_context* ctx, SideStream* side, hipStream_t caller)
 {
@@ -825,6 +844,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
+    if (!strcmp(name, "mutate")) { g_mutate = value; return 0; }   // tests only: a deliberately WRONG backward (see g_mutate) -- proves that a parity bar bites
     if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
     if (!strcmp(name, "sort_hint")) { g_sort_hint = value ? 1 : 0; return 0; }
     if (!strcmp(name, "cull")) { g_def.cull = value ? 1 : 0; return 0; }
@@ -861,6 +881,7 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "late_fill_min_p")) return g_late_fill_min_p.load();
     if (!strcmp(name, "sparse_grec")) return g_sparse_grec.load();
     if (!strcmp(name, "word_fork")) return g_word_fork.load();
+    if (!strcmp(name, "mutate")) return g_mutate.load();
     if (!strcmp(name, "stream_contexts")) return g_stream_contexts.load();          // (diagnostics: the rule of the word forks)
     if (!strcmp(name, "concurrent_callers")) return g_concurrent_callers.load() ? 1 : 0;
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
@@ -2093,11 +2114,11 @@ int gsrast_grad_rows_pack(int P, const unsigned char* touched, float* const* den
     GS_LAUNCHED("grad_rows_pack");
     return GSRAST_OK;
 }
-int gsrast_grad_rows_clear(const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense, int M, float* dL_dsh,
+int gsrast_grad_rows_clear(int P, const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense, int M, float* dL_dsh,
                            float* d_features_dc, float* d_features_rest, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (n_chunks < 0 || (n_chunks > 0 && cap > 0 && !chunks) || chunk_words < (size_t)(1 + (size_t)cap) * GROW_WORDS) return fail(GSRAST_E_ARG, "grad_rows_clear: bad arguments");
+    if (P < 0 || n_chunks < 0 || (n_chunks > 0 && cap > 0 && !chunks) || chunk_words < (size_t)(1 + (size_t)cap) * GROW_WORDS) return fail(GSRAST_E_ARG, "grad_rows_clear: bad arguments");
     if (n_chunks == 0 || cap == 0) return GSRAST_OK;
     const int what = (dense ? 1 : 0) | ((dL_dsh || d_features_dc) ? 2 : 0);
     if (!what) return GSRAST_OK;
@@ -2105,19 +2126,19 @@ int gsrast_grad_rows_clear(const uint32_t* chunks, int n_chunks, size_t chunk_wo
     if (int rc = grow_arrays(a, dense, M, dL_dsh, d_features_dc, d_features_rest, "grad_rows_clear: bad arrays", dense != nullptr)) return rc;
     const size_t lanes = (size_t)n_chunks * cap * 16;
     if (lanes > 0x7FFFFFFFull * 256) return fail(GSRAST_E_ARG, "grad_rows_clear: too many rows");
-    grad_rows_clear_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(chunks, n_chunks, chunk_words, cap, a, what);
+    grad_rows_clear_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, s>>>(chunks, n_chunks, chunk_words, cap, a, what, (uint32_t)P);
     GS_LAUNCHED("grad_rows_clear");
     return GSRAST_OK;
 }
-int gsrast_grad_rows_add(const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale, float* dL_dsh,
+int gsrast_grad_rows_add(int P, const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale, float* dL_dsh,
                          float* d_features_dc, float* d_features_rest, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (cap == 0) return GSRAST_OK;
-    if (!chunk || !means3D || D < 0 || D > 3 || ((dL_dsh || d_features_dc) && (D + 1) * (D + 1) > M)) return fail(GSRAST_E_ARG, "grad_rows_add: bad arguments");
+    if (cap == 0 || P == 0) return GSRAST_OK;
+    if (P < 0 || !chunk || !means3D || D < 0 || D > 3 || ((dL_dsh || d_features_dc) && (D + 1) * (D + 1) > M)) return fail(GSRAST_E_ARG, "grad_rows_add: bad arguments");
     GradRowArrays a{};
     if (int rc = grow_arrays(a, dense, M, dL_dsh, d_features_dc, d_features_rest, "grad_rows_add: bad arrays")) return rc;
-    grad_rows_add_kernel<<<(cap + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(chunk, cap, a, means3D, D, scale);
+    grad_rows_add_kernel<<<(cap + PP_THREADS - 1) / PP_THREADS, PP_THREADS, 0, s>>>(chunk, cap, a, means3D, D, scale, (uint32_t)P);
     GS_LAUNCHED("grad_rows_add");
     return GSRAST_OK;
 }
@@ -2311,6 +2332,18 @@ static int backward_impl(const gsrast_options* options, int P, int D, int M, int
         ba.bg = background; ba.fT = const_cast<float*>(fT); ba.nc = const_cast<uint32_t*>(nc); ba.tm = const_cast<uint32_t*>(tm);
         ba.dpix = dL_dpix; ba.grec = grec;
         ba.fork_word = late_fork.word; ba.fork_seq = late_fork.seq;
+        if (const int mut = g_mutate.load()) {      // tests only: see g_mutate
+            if (mut & 1) {
+                mutate_drop_front_batch_kernel<<<1, 256, 0, s>>>(at<uint2>(img, IL.ranges), at<uint32_t>(img, IL.n_contrib), at<uint32_t>(img, IL.tile_max),
+                                                                 (uint32_t)(cam.gy / 2) * (uint32_t)cam.gx + (uint32_t)(cam.gx / 2), W, H, cam.gx);
+                GS_LAUNCHED("mutate_drop_front_batch");
+            }
+            if (mut & 2) {
+                static float* zero_bg = nullptr;      // (never freed: a test-only path)
+                if (!zero_bg) { GS_HIP(hipMalloc((void**)&zero_bg, 16)); GS_HIP(hipMemset(zero_bg, 0, 16)); }
+                ba.bg = zero_bg;
+            }
+        }
         const int ppl = pick_ppl(T, true, o);
         const bool cull = o.cull != 0;
         if (cull && o.lpt) {

@@ -85,7 +85,7 @@ grad_rows_pack_kernel(int P, const unsigned char* __restrict__ touched, GradRowA
 // zero the rows a set of chunks names: the dense arrays' (what = 1), the SH arrays' (2), both (3).  16 lanes per row: lane 0..11 one
 // 16-byte piece of the SH row each, lane 12 the 11 dense floats.
 __global__ void __launch_bounds__(256)
-grad_rows_clear_kernel(const uint32_t* __restrict__ chunks, int n_chunks, size_t chunk_words, uint32_t cap, GradRowArrays a, int what)
+grad_rows_clear_kernel(const uint32_t* __restrict__ chunks, int n_chunks, size_t chunk_words, uint32_t cap, GradRowArrays a, int what, uint32_t P)
 {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t part = (uint32_t)(q & 15u);
@@ -96,6 +96,7 @@ grad_rows_clear_kernel(const uint32_t* __restrict__ chunks, int n_chunks, size_t
     const uint32_t count = ch[0] < cap ? ch[0] : cap;
     if (j >= count) return;
     const size_t i = ch[(size_t)(1u + j) * GROW_WORDS];
+    if (i >= (size_t)P) return;                               // (an index received from a peer: never trusted past the arrays' end)
     const int L = a.M * 3;
     if ((what & 2) && (int)part * 4 < L) {
         if (a.sh) *reinterpret_cast<float4*>(a.sh + i * L + part * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -114,7 +115,7 @@ grad_rows_clear_kernel(const uint32_t* __restrict__ chunks, int n_chunks, size_t
 // one rank's chunk added into the arrays: dense[idx] += scale * row.dense, dL/dsh[idx] += scale * w(dir(mean[idx] - campos)) (x) row.factor.
 // One thread per row computes, the workgroup then updates its 256 SH rows with 16-byte accesses, consecutive lanes along a row.
 __global__ void __launch_bounds__(PP_THREADS)
-grad_rows_add_kernel(const uint32_t* __restrict__ chunk, uint32_t cap, GradRowArrays a, const float* __restrict__ means3D, int D, float scale)
+grad_rows_add_kernel(const uint32_t* __restrict__ chunk, uint32_t cap, GradRowArrays a, const float* __restrict__ means3D, int D, float scale, uint32_t P)
 {
     __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
     __shared__ uint32_t s_idx[PP_THREADS];
@@ -131,13 +132,14 @@ grad_rows_add_kernel(const uint32_t* __restrict__ chunk, uint32_t cap, GradRowAr
         const uint4* src = reinterpret_cast<const uint4*>(chunk + (size_t)(1u + j) * GROW_WORDS);
         const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
         const uint32_t w[GROW_WORDS] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
-        i = w[0];
+        i = w[0] < P ? w[0] : 0xFFFFFFFFu;                    // (an index received from a peer: a row past the arrays' end is skipped)
         int o = 1;
+        if (i != 0xFFFFFFFFu)
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
             for (int f = 0; f < grow_width(k); f++) { float* d = a.dense[k] + (size_t)i * grow_width(k) + f; *d = *d + scale * __uint_as_float(w[o]); o++; }
-        if (a.sh || a.dc) {
+        if (i != 0xFFFFFFFFu && (a.sh || a.dc)) {
             const float pos[3] = { means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2] };
             sh_factor_term(acc, pos, D, __uint_as_float(chunk[1]), __uint_as_float(chunk[2]), __uint_as_float(chunk[3]),
                            __uint_as_float(w[12]), __uint_as_float(w[13]), __uint_as_float(w[14]));
@@ -153,6 +155,7 @@ grad_rows_add_kernel(const uint32_t* __restrict__ chunk, uint32_t cap, GradRowAr
     for (int q = threadIdx.x; q < n_here * q4; q += PP_THREADS) {
         const int r = q / q4, part = q - r * q4;
         const float* src = sh_lds + r * PP_SH_STRIDE + part * 4;
+        if (s_idx[r] == 0xFFFFFFFFu) continue;
         const size_t g = (size_t)s_idx[r];
         if (a.sh) {
             float4* d = reinterpret_cast<float4*>(a.sh + g * L + part * 4);

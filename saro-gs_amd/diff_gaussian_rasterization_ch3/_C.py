@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsrast_hip.so")
 
 NUM_CHANNELS = 3  # reference config.h:15
-ABI_VERSION = 4   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
+ABI_VERSION = 5   # include/gsrast.h: GSRAST_ABI_VERSION this binding was written against
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib: Optional[C.CDLL] = None
@@ -183,9 +183,9 @@ def lib() -> C.CDLL:
     L.gsrast_grad_rows_pack.restype = ci
     L.gsrast_grad_rows_pack.argtypes = [ci, vp, C.POINTER(vp), vp, vp, C.c_uint32, vp]
     L.gsrast_grad_rows_clear.restype = ci
-    L.gsrast_grad_rows_clear.argtypes = [vp, ci, C.c_size_t, C.c_uint32, C.POINTER(vp), ci, vp, vp, vp, vp]
+    L.gsrast_grad_rows_clear.argtypes = [ci, vp, ci, C.c_size_t, C.c_uint32, C.POINTER(vp), ci, vp, vp, vp, vp]
     L.gsrast_grad_rows_add.restype = ci
-    L.gsrast_grad_rows_add.argtypes = [vp, C.c_uint32, C.POINTER(vp), ci, ci, vp, cf, vp, vp, vp, vp]
+    L.gsrast_grad_rows_add.argtypes = [ci, vp, C.c_uint32, C.POINTER(vp), ci, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_sh_grad_combine_union.restype = ci
     L.gsrast_sh_grad_combine_union.argtypes = [ci, ci, ci, ci, vp, vp, C.c_size_t, ci, vp, cf, vp, vp, vp, vp]
     L.gsrast_activate_forward.restype = ci
@@ -319,6 +319,7 @@ def _export_touched(ar: "GradArena", P: int, geomBuffer: torch.Tensor, dev: torc
     if rc != 0:
         raise _err(rc, "gsrast_touched_rows")
     ar.touched_fresh = True
+    ar.touched_seq = getattr(ar, "touched_seq", 0) + 1       # which backward these flags belong to (view_parallel._touched_hook tags its capacity event with it)
 
 
 _grad_arena: Optional[GradArena] = None
@@ -770,7 +771,7 @@ def grad_rows_clear(arena: "GradArena", chunks: torch.Tensor, dense: bool, sh: b
     whole, dc, rest = _arena_sh_arrays(arena) if sh else (None, None, None)
     dev = chunks.device
     with torch.cuda.device(dev):
-        rc = lib().gsrast_grad_rows_clear(chunks.data_ptr(), n, (1 + cap) * GRAD_ROW_WORDS, cap, _dense_ptrs(arena) if dense else None, arena.M,
+        rc = lib().gsrast_grad_rows_clear(arena.P, chunks.data_ptr(), n, (1 + cap) * GRAD_ROW_WORDS, cap, _dense_ptrs(arena) if dense else None, arena.M,
                                           _ptr(whole), _ptr(dc), _ptr(rest), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         raise _err(rc, "gsrast_grad_rows_clear")
@@ -781,7 +782,7 @@ def grad_rows_add(arena: "GradArena", chunk: torch.Tensor, means3D: torch.Tensor
     whole, dc, rest = _arena_sh_arrays(arena)
     dev = chunk.device
     with torch.cuda.device(dev):
-        rc = lib().gsrast_grad_rows_add(chunk.data_ptr(), int(chunk.shape[0]) - 1, _dense_ptrs(arena), int(arena.last_degree), arena.M,
+        rc = lib().gsrast_grad_rows_add(arena.P, chunk.data_ptr(), int(chunk.shape[0]) - 1, _dense_ptrs(arena), int(arena.last_degree), arena.M,
                                         means3D.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
                                         torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:

@@ -76,7 +76,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         # opacities are not saved: the state buffer keeps them next to the conic (REF:84)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buf, bin_buf, img_buf)
-        ctx.mark_non_differentiable(radii, depth)
+        # depth stays "differentiable" as in the reference (REF:85-88: it is returned by the Function, its incoming gradient is ignored): a
+        # loss built from depth alone runs a backward that yields zero gradients there, and does here (round 6; rounds 1-5 marked it
+        # non-differentiable, which raised instead).  radii is int32: never differentiable.
+        ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)     # no zero-filled [1,H,W] / [P] gradients for the two outputs nothing flows through
         return color, radii, depth
 
@@ -85,7 +88,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geom_buf, bin_buf, img_buf) = ctx.saved_tensors
-        if grad_out_color is None:      # cannot happen through autograd (radii / depth carry no gradient), kept for safety
+        if grad_out_color is None:      # a loss that reaches this node through depth only: the reference sees a zero colour gradient (REF:88)
             grad_out_color = torch.zeros((_C.NUM_CHANNELS, rs.image_height, rs.image_width), device=means3D.device)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
@@ -162,7 +165,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.gs_backwards = 0
         ctx.present = tuple(t is not None for t in raw_tensors)
         ctx.save_for_backward(*[t for t in raw_tensors if t is not None], radii, geom_buf, bin_buf, img_buf)
-        ctx.mark_non_differentiable(radii, depth)
+        ctx.mark_non_differentiable(radii)      # (depth: as _RasterizeGaussians -- differentiable in name, its gradient ignored)
         ctx.set_materialize_grads(False)
         return color, radii, depth
 

@@ -177,6 +177,7 @@ def exchange_gradients(arena, means3D: torch.Tensor, batch: int, sparse=False) -
         sparse = True                   # (the row kernels move SH rows in 16-byte pieces: M = 4, 8, 12, 16; other M take the union form)
     if sparse == "gather" and multi and pending is None and P > 0:
         return _exchange_gather(arena, means3D, batch, n_views)
+    _disarm_gather(arena)           # (another form was asked for: no capacity collective inside later backwards, no side-stream reader of the flags)
     if sparse and multi and pending is None and P > 0:
         segs = arena.dense_segments()
         fac = arena.factor[: 3 * P].view(P, 3)
@@ -239,10 +240,30 @@ def _touched_flags(arena, segs, fac) -> torch.Tensor:
     return touched
 
 
+def _disarm_gather(arena) -> None:
+    """The arena stops agreeing on the gather exchange's capacity inside its backwards (_touched_hook).  Called by every OTHER form of
+    exchange_gradients -- on every rank alike, since every rank calls the same form -- so that a caller who switches forms does not keep
+    issuing one collective per backward for good; a capacity event of the step just run is drained (its all-reduce was issued by every
+    rank's backward: nothing is left half-done) before anybody overwrites the flags it reads on the side stream."""
+    if getattr(arena, "_gather_armed", False):
+        arena._gather_armed = False
+    ev = getattr(arena, "_cap_event", None)
+    if ev is not None:
+        ev.synchronize()
+        arena._cap_event = None
+        arena.touched_reader_event = None
+
+
 def _touched_hook(arena) -> None:
     """Inside the backward of an arena that exchanges by all-gather, before its kernels are enqueued: the ranks take the MAX of their
     touched-row counts on a side stream and the result travels to pinned host memory, all of it beside the backward -- the exchange
-    then sizes its buffers without waiting for the device (the step's host synchronisation moves off the critical path)."""
+    then sizes its buffers without waiting for the device (the step's host synchronisation moves off the critical path).
+
+    Contract (round 6): ONE collective per backward of an ARMED arena, on every rank -- the arena is armed by its first gather
+    exchange and disarmed by any other form (_disarm_gather), so ranks that call the same sequence of backwards and exchanges issue the
+    same sequence of collectives.  The event carries the sequence number of the backward that produced it (arena.touched_seq, counted by
+    _C._export_touched); _exchange_gather consumes it only if it belongs to the LAST backward and falls back to the synchronous
+    capacity all-reduce otherwise (two backwards in a step, an exchange called twice: decided alike on every rank)."""
     if not getattr(arena, "_gather_armed", False) or not collectives_active() or not arena.touched.is_cuda:
         return
     dev = arena.touched.device
@@ -258,6 +279,7 @@ def _touched_hook(arena) -> None:
         ev = torch.cuda.Event()
         ev.record(side)
     arena._cap_event = arena.touched_reader_event = ev      # (_C._export_touched waits for it before it overwrites the flags: a step that never exchanged)
+    arena._cap_seq = getattr(arena, "touched_seq", 0)        # the backward this capacity belongs to
 
 
 def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> Dict[str, int]:
@@ -273,14 +295,19 @@ def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> 
     segs = arena.dense_segments()
     fac = arena.factor[: 3 * P].view(P, 3)
     touched = _touched_flags(arena, segs, fac)
+    _check_gather_overflow(arena)       # (the PREVIOUS step's header counts against its capacity: a device flag read without a wait of its own)
     send = getattr(arena, "_rows_send", None)
     if send is None or send.shape[0] != P + 1 or send.device != dev:
-        # (sized for every row: 64 B per Gaussian of address space, of which a step touches the header and its own rows)
-        send = arena._rows_send = torch.empty((P + 1, _C.GRAD_ROW_WORDS), dtype=torch.int32, device=dev)
+        # (sized for every row: 64 B per Gaussian of address space, of which a step touches the header and its own rows; zeroed ONCE, so
+        # that the rows between a step's count and the capacity that travel with the chunk are never uninitialised memory)
+        send = arena._rows_send = torch.zeros((P + 1, _C.GRAD_ROW_WORDS), dtype=torch.int32, device=dev)
     send[0].zero_()
     send[0, 1:4] = arena.factor[3 * P: 3 * P + 3].view(torch.int32)
     _C.grad_rows_pack(arena, touched, send)
     ev = getattr(arena, "_cap_event", None)
+    if ev is not None and getattr(arena, "_cap_seq", -1) != getattr(arena, "touched_seq", 0):
+        ev.synchronize()                # a capacity agreed on for ANOTHER backward than the last one (two backwards in this step): not this step's
+        ev, arena._cap_event, arena.touched_reader_event = None, None, None
     if ev is not None:
         # the ranks agreed on the capacity BESIDE the backward (_touched_hook): the host has had the number for a millisecond
         ev.synchronize()
@@ -308,7 +335,37 @@ def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> 
     for r in range(n_views):
         _C.grad_rows_add(arena, gathered[r], means3D, 1.0 / batch)
     arena._rows_prev, arena._sh_union, arena.sh_rows_known = gathered, None, True
+    # overflow check, deferred: the largest header count of the gathered chunks travels to pinned host memory behind the adds and is
+    # compared with this step's capacity at the START of the next exchange (a row past the capacity is dropped by the pack kernel: with a
+    # capacity that belongs to this step it cannot happen -- if it ever does, gradients were lost and the caller must hear about it)
+    if dev.type == "cuda":
+        host = getattr(arena, "_ovf_host", None)
+        if host is None:
+            host = arena._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(gathered[:, 0, 0].max().view(1), non_blocking=True)
+        oev = torch.cuda.Event()
+        oev.record(torch.cuda.current_stream(dev))
+        arena._ovf_pending = (oev, cap)
+    else:                               # (CPU tensors, the gloo tests: nothing to wait for)
+        arena._ovf_host = gathered[:, 0, 0].max().view(1)
+        arena._ovf_pending = (None, cap)
     return {"allreduce": 4, "allgather": (1 + cap) * _C.GRAD_ROW_WORDS * 4, "rows": cap}
+
+
+def _check_gather_overflow(arena) -> None:
+    pend = getattr(arena, "_ovf_pending", None)
+    if pend is None:
+        return
+    arena._ovf_pending = None
+    oev, cap = pend
+    if oev is not None:
+        oev.synchronize()               # (recorded a whole step ago: returns at once)
+    seen = int(arena._ovf_host[0])
+    if seen > cap:
+        _disarm_gather(arena)
+        raise RuntimeError(f"exchange_gradients(sparse='gather'): a rank touched {seen} rows in the previous step but the agreed capacity was {cap}: "
+                           "gradient rows were dropped.  The ranks' backward / exchange sequences have diverged (every rank must run exactly one "
+                           "backward into the arena per exchange); the capacity is agreed on synchronously from here on")
 
 
 def overlap_factor_exchange(enable: bool = True) -> None:

@@ -17,6 +17,21 @@ for p in (ROOT, PKG):
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+ATOL, RTOL = 1e-5, 1e-4
+
+
+def grad_tol(ref):
+    """The gradient bar of every -m gpu test (round 6): north_star's "within 1e-5 abs" made SCALE-FREE,
+        |hip - fp64 truth| <= 1e-5 * max|ref| + 1e-4 * |ref|      per tensor.
+    The letter of the bar (1e-5 absolute) has no teeth where the gradients themselves are of that size: the bench's upstream gradient
+    N(0,1)/(3HW) gives max|dL/dsh| ~ 2e-5 at 100 k Gaussians, smaller still at 3 M -- an all-zero tensor passed.  With the absolute term
+    tied to the tensor's own largest entry the bar means the same thing at every size and for every upstream gradient: five digits of the
+    largest entry, four of every entry.  tests/test_gpu_fullsize.py::test_the_gradient_bar_bites shows it turns red for a backward that drops
+    ONE staged batch of ONE tile."""
+    ref = np.abs(np.asarray(ref, dtype=np.float64))
+    return ATOL * float(ref.max(initial=0.0)) + RTOL * ref
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "remembered_cut_only: the test pins the bookkeeping of the list cut's REMEMBERED cut depths (late counts, "

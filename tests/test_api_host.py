@@ -106,3 +106,58 @@ def test_bench_refuses_a_world_size_other_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 2 and '{"metric"' not in out.stdout
+
+
+def test_bench_final_line_is_compact_and_carries_the_contract():
+    """the LAST stdout line of bench.py must parse.  Round 5's line had grown to 20.7 KB and the driver's parser gave up
+    (BENCH_r05.parsed = null).  bench.compact_line() is what main() prints last: compact JSON, at most bench.LINE_LIMIT (4096) bytes, with
+    `roofline` and `cpu_baseline` inside -- checked here on a result of the real shape (the roofline objects come from bench.roofline_of
+    over the committed counter passes; the numbers are a 3 M run's)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    st = dict(N=1920 * 1080, R_eff=2_462_923, R=42_300_000, R_listed=25_000_000, Q=8_700_000, P_vis=2_990_000, T=8160)
+    stage = {k: 0.0123 for k in ("preprocess_fwd", "preprocess_color", "sort_depth", "scan_tiles", "emit_instances", "sort_tile", "tile_ranges", "blend_fwd",
+                                 "blend_bwd", "preprocess_bwd", "late_rows_zero", "sh_dir_derivs", "cut_redo", "grec_zero_touched")}
+    result = {
+        "metric": "rendered views/s (fwd+bwd) at 1080p vs #Gaussians", "value": 801.234, "unit": "views/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+        "ms_per_step": 1.2481, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "preroll_steps": 240, "mean_ms_per_step": 1.2611, "value_warm": 861.5, "ms_per_step_warm": 1.1608, "warmup_warm": 24, "value_no_list_cut": 640.2,
+        "pipelined": {"views_per_s_cold": 842.1, "views_per_s_warm": 900.3, "note": "K steps back to back, one sync (rounds 1-5's headline): throughput, not the metric"},
+        "config": {"workload": "BASELINE configs[4] stress-1080p: synth(P=3000000, seed 0) SH3, 1920x1080, one view per GPU, fwd+bwd",
+                   "protocol": "SURVEY 8d: 1 / median of per-call device-synchronised wall-clock fwd+bwd", "pose_table": "off for value (every pose a first visit); on for value_warm",
+                   "gaussians": 3_000_000, "width": 1920, "height": 1080, "sh_degree": 3, "exp_mode": 0, "poses_per_rank": 8, "views_per_step": 1,
+                   "R": st["R"], "R_listed": st["R_listed"], "Q": st["Q"], "R_eff": st["R_eff"], "visible": st["P_vis"], "late_gaussians_cold": 1_290_000,
+                   "late_gaussians_warm": 2_700_000, "word_fork": 0, "exchange": "gather", "exchange_backend": "nccl", "rccl_world": 8, "rccl_version": "2.26.6",
+                   "rank_devices": list(range(8)), "exchange_bytes_per_rank_and_step": {"allreduce": 4, "allgather": 9_600_064, "rows": 150_000}},
+        "roofline": bench.roofline_of(st, 0.4009, 3_000_000),
+        "roofline_fwd": bench.roofline_of(st, 0.2601, 3_000_000, kernel="blend_fwd_cull_kernel"),
+        "stage_ms": stage, "host": {"enqueue_ms_median": 0.6123, "device_mallocs_in_timed_steps": 0}, "per_step_ms": {"min": 1.2011, "max": 1.4012},
+        "sweep_1080p_cold": {"100000": 1901.2, "300000": 1650.3, "1000000": 1310.4, "3000000": 801.234},
+        "cpu_baseline": {"value": 0.2612, "unit": "views/s", "cores": 256, "kind": "port",
+                         "sample": "4 view(s) fwd+bwd of the same workload (P=3000000, 1920x1080, SH3), 15.5 s of CPU work"},
+        "extras": "gpurun_out/bench_report.json",
+    }
+    line = bench.compact_line(result)
+    assert "\n" not in line and len(line) <= bench.LINE_LIMIT < 8192, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["algorithmic_bytes_per_launch"] == st["N"] * 20 + st["R_eff"] * 76                  # SURVEY.md 8(d)
+    assert d["roofline_fwd"]["algorithmic_bytes_per_launch"] == st["N"] * 24 + st["R_eff"] * 44
+    assert r["traffic"] and r["valu_issue_slot_frac"] and r["valu_issue_slot_frac_guide_2cyc_fma"] < r["valu_issue_slot_frac"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["config"]["workload"] and "model" not in d["config"]
+    # a result that outgrows the limit loses optional diagnostics, never the contract's keys
+    fat = dict(result, stage_ms={f"kernel_{i}": 0.0123 for i in range(400)})
+    d2 = json.loads(bench.compact_line(fat))
+    assert "stage_ms" not in d2 and "roofline" in d2 and "cpu_baseline" in d2 and len(bench.compact_line(fat)) <= bench.LINE_LIMIT

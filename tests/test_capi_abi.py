@@ -28,8 +28,8 @@ def test_header_and_library_agree(rast, L):
     for n in names:
         assert hasattr(raw, n), f"{n} declared in gsrast.h but not exported"
     assert sorted(rast._C.EXPORTS) == names
-    assert L.gsrast_abi_version() == rast._C.ABI_VERSION == 4
-    assert re.search(r"#define GSRAST_ABI_VERSION 4\b", open(HEADER).read())
+    assert L.gsrast_abi_version() == rast._C.ABI_VERSION == 5
+    assert re.search(r"#define GSRAST_ABI_VERSION 5\b", open(HEADER).read())
 
 
 def test_no_torch_or_cxx_types_in_the_boundary():

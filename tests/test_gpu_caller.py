@@ -12,7 +12,7 @@ import torch
 from gpu_harness import bits
 
 pytestmark = pytest.mark.gpu
-ATOL, RTOL = 1e-5, 1e-4
+from conftest import grad_tol
 
 
 def _oracle_inputs(pc, cam):
@@ -48,14 +48,15 @@ def test_train_render_caller_matches_the_oracle(orc, scenes, rast, gpu):
     # train.py:212 -- torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1), the densification statistic
     got = torch.norm(vsp.grad[:, :2], dim=-1).cpu().numpy().astype(np.float64)
     want = np.linalg.norm(o64["dL_dmeans2D"][:, :2], axis=1)
-    assert (np.abs(got - want) <= ATOL + RTOL * want).all()
+    assert (np.abs(got - want) <= grad_tol(want)).all()
     assert float(vsp.grad[:, 2].abs().max()) == 0.0
     # gradients reached the RAW leaves through torch's activations
     for name in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
         gr = getattr(pc, name).grad
         assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().max()) > 0, name
-    np.testing.assert_allclose(pc._xyz.grad.cpu().numpy(), o64["dL_dmeans3D"], rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(pc._features_rest.grad.cpu().numpy(), o64["dL_dsh"][:, 1:], rtol=RTOL, atol=ATOL)
+    for got_t, ref in ((pc._xyz.grad, o64["dL_dmeans3D"]), (pc._features_rest.grad, o64["dL_dsh"][:, 1:])):
+        err = np.abs(got_t.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref)
+        assert (err <= grad_tol(ref)).all(), float(err.max())
 
 
 def test_test_render_caller_with_depth_and_segment_pass(orc, scenes, rast, gpu):
@@ -152,7 +153,7 @@ def test_reference_shaped_entry_points_through_raw_ctypes(orc, scenes, rast, gpu
         got = g[name].cpu().numpy().astype(np.float64)
         ref = o64[key].reshape(got.shape)
         err = np.abs(got - ref)
-        assert (err <= ATOL + RTOL * np.abs(ref)).all(), (name, float(err.max()))
+        assert (err <= grad_tol(ref)).all(), (name, float(err.max()))
     assert float(g["conic"][:, 2].abs().max()) == 0.0               # .z of dL_dconic is never written by the reference (backward.cu:549-551)
     assert float(g["cov3D"].abs().max()) > 0
     # markVisible (rasterizer.h:27-32)
@@ -161,3 +162,38 @@ def test_reference_shaped_entry_points_through_raw_ctypes(orc, scenes, rast, gpu
     assert rc == 0
     torch.cuda.synchronize()
     assert np.array_equal(present.cpu().numpy().astype(bool), orc.mark_visible(sc["means3D"], cam["viewmatrix"], cam["projmatrix"]))
+
+
+def test_a_loss_built_from_depth_alone_is_a_silent_no_op_as_in_the_reference(scenes, rast, gpu):
+    """The reference returns depth from its autograd Function without marking it non-differentiable and ignores the gradient that comes
+    back for it (diff_gaussian_rasterization_ch3/__init__.py:85-88): `depth.sum().backward()` runs and leaves ZERO gradients.  Rounds 1-5
+    raised there (mark_non_differentiable(depth)); a drop-in may not."""
+    from conftest import settings_from
+    P, W, H = 2000, 96, 64
+    sc = scenes.synth(P, 77)
+    cam = scenes.camera(0, 3, W, H)
+    rs = settings_from(rast, cam, sc, gpu)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
+    leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    color, radii, depth = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+                                                      scales=leaves["scales"], rotations=leaves["rotations"])
+    assert depth.requires_grad and not radii.requires_grad
+    depth.sum().backward()
+    for k, v in leaves.items():
+        assert v.grad is not None and float(v.grad.abs().max()) == 0.0, k
+    assert float(m2.grad.abs().max()) == 0.0
+    # depth + colour: the colour's gradient is what arrives, the depth's is dropped
+    for v in list(leaves.values()) + [m2]:
+        v.grad = None
+    color, radii, depth = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+                                                      scales=leaves["scales"], rotations=leaves["rotations"])
+    (color.sum() + 5.0 * depth.sum()).backward()
+    both = {k: v.grad.clone() for k, v in leaves.items()}
+    for v in list(leaves.values()) + [m2]:
+        v.grad = None
+    color, radii, depth = rast.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+                                                      scales=leaves["scales"], rotations=leaves["rotations"])
+    color.sum().backward()
+    for k, v in leaves.items():
+        assert float(v.grad.abs().max()) > 0 and torch.allclose(both[k], v.grad, rtol=1e-4, atol=1e-6 * float(v.grad.abs().max())), k

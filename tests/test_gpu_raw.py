@@ -18,7 +18,7 @@ from gpu_harness import bits
 pytestmark = pytest.mark.gpu
 
 COMBOS = [dict(zip(("motion_res", "rot_res", "trbf", "shs_res"), c)) for c in itertools.product((True, False), repeat=4)]
-ATOL, RTOL = 1e-5, 1e-4
+from conftest import grad_tol
 
 
 def _raw_scene(scenes, P, seed, M, deg):
@@ -115,9 +115,9 @@ def test_raw_rasterizer_against_epilogue_then_rasterizer_and_the_oracles(use, or
         got = ta[k].grad.cpu().numpy().astype(np.float64).reshape(w.shape)
         sl = slice(1, None) if k in ("rotation", "rot_res") else slice(None)
         err = np.abs(got[sl] - w[sl])
-        assert (err <= ATOL + RTOL * np.abs(w[sl])).all(), (k, float(err.max()))
+        assert (err <= grad_tol(w[sl])).all(), (k, float(err.max()))
     err = np.abs(m2a.grad.cpu().numpy() - o64["dL_dmeans2D"])
-    assert (err <= ATOL + RTOL * np.abs(o64["dL_dmeans2D"])).all()
+    assert (err <= grad_tol(o64["dL_dmeans2D"])).all()
 
 
 @pytest.mark.parametrize("P,M,deg", [(1, 16, 3), (127, 16, 2), (129, 16, 3), (1001, 4, 1), (130, 4, 0)])

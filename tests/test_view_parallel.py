@@ -418,8 +418,10 @@ def _sparse_worker(rank, world, port, out_dir, raw):
     dist.destroy_process_group()
 
 
-def _gather_worker(rank, world, port, out_dir, raw):
-    """exchange_gradients(sparse="gather") with the three row kernels (csrc/gsrast_exchange.h) restated in torch."""
+def _gather_worker(rank, world, port, out_dir, raw, uneven=False):
+    """exchange_gradients(sparse="gather") with the three row kernels (csrc/gsrast_exchange.h) restated in torch.
+    uneven: P = 4099 (no multiple of the pack kernel's 4096-Gaussian workgroups), rank 0 touches NO row, rank 1 touches EVERY row (so the
+    step's capacity is P), the others what their view touches."""
     for p in (ROOT, os.path.join(ROOT, "saro-gs_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -431,7 +433,7 @@ def _gather_worker(rank, world, port, out_dir, raw):
     from diff_gaussian_rasterization_ch3 import _C
     from oracle import oracle as orc
     vp.init_from_env("gloo")
-    P, W, H, deg, M = 600, 64, 48, 3, 16
+    P, W, H, deg, M = (4099 if uneven else 600), 64, 48, 3, 16
     sc = scenes.synth(P, 13)
     arena = _C.GradArena(P, M, torch.device("cpu"), sh_factors=True, world=world, raw=raw)
     names = ("xyz", "opacity_logit", "scaling", "rotation") if raw else ("means3D", "opacity", "scales", "rotations")
@@ -489,10 +491,28 @@ def _gather_worker(rank, world, port, out_dir, raw):
         for n, k in zip(names, ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")):
             arena.take(n, (P, arena.widths[n]), False).copy_(torch.from_numpy(o[k].astype(np.float32)).reshape(P, -1))
         fac = torch.from_numpy((o["dL_dcolors"] * (1 - o["clamped"].astype(np.float32)) * (o["radii"] > 0)[:, None]).astype(np.float32))
+        if uneven and rank == 0:        # a view that touched nothing: all-zero rows, count 0
+            for n in names:
+                arena.take(n, (P, arena.widths[n]), False).zero_()
+            fac = torch.zeros_like(fac)
+            o = dict(o, **{k: np.zeros_like(o[k]) for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")})
+        if uneven and rank == 1:        # a view that touched EVERY row: count = P = the step's capacity
+            gen = torch.Generator().manual_seed(100 + step)
+            o = dict(o)
+            for n, k in zip(names, ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")):
+                v = torch.randn((P, arena.widths[n]), generator=gen) + 3.0       # (no zero anywhere)
+                arena.take(n, (P, arena.widths[n]), False).copy_(v)
+                o[k] = v.numpy()
+            fac = torch.randn((P, 3), generator=gen) + 3.0
+            d = means - torch.from_numpy(np.asarray(cam["campos"], np.float32))
+            d = d / d.norm(dim=1, keepdim=True)
+            o["dL_dsh"] = (_sh_weights(d, deg)[:, :, None] * fac[:, None, :]).numpy()
         arena.factor[: 3 * P] = fac.reshape(-1)
         arena.factor[3 * P: 3 * P + 3] = torch.from_numpy(np.asarray(cam["campos"], np.float32))
         arena.last_degree = deg
         sent = vp.exchange_gradients(arena, means, world, sparse="gather")
+        if uneven:
+            ok = ok and sent["rows"] == P
         full = torch.cat([torch.from_numpy(o[k].astype(np.float32)).reshape(-1) for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
         dist.all_reduce(full)
         full /= world
@@ -506,7 +526,7 @@ def _gather_worker(rank, world, port, out_dir, raw):
         dist.broadcast(same, src=0)
         mine = int((torch.from_numpy(o["radii"]) > 0).sum())
         ok = ok and err <= 1.0 and torch.equal(same, got) and 0 < sent["rows"] <= P and sent["allgather"] == (1 + sent["rows"]) * 64 and sent["allreduce"] == 4 \
-            and sent["rows"] >= 1 and mine >= 1
+            and sent["rows"] >= 1 and (mine >= 1 or uneven)
         report.append(f"step {step} err {err:.3f} rows {sent['rows']} same {torch.equal(same, got)}")
     ok = ok and counts["add"] == 3 * world and counts["clear_dense"] == 3 and counts["clear_sh"] == 2      # (the first step zeroes the SH region whole)
     open(os.path.join(out_dir, f"ok{rank}"), "w").write(f"{ok} {report} {counts}")
@@ -523,6 +543,48 @@ def test_all_gather_exchange_equals_the_literal_batch_mean_bit_identical_on_ever
     mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path), raw), nprocs=world, join=True)
     reports = [open(tmp_path / f"ok{r}").read() for r in range(world)]
     assert all(r.startswith("True") for r in reports), reports
+
+
+def test_all_gather_exchange_with_strongly_uneven_counts_eight_ranks(tmp_path):
+    """The same exchange over 8 gloo ranks with P = 4099 (not a multiple of the pack kernel's 4096-Gaussian workgroups), one rank whose view
+    touched NO row (count 0: an empty chunk behind its header) and one that touched EVERY row (count = P = the step's capacity):
+    the literal batch mean (scene/saro_gaussian.py:266-276), the same bits on every rank, three steps."""
+    mp.spawn(_gather_worker, args=(8, _free_port(), str(tmp_path), False, True), nprocs=8, join=True)
+    reports = [open(tmp_path / f"ok{r}").read() for r in range(8)]
+    assert all(r.startswith("True") for r in reports), reports
+
+
+class _FakeArena:
+    pass
+
+
+def test_gather_capacity_event_is_only_taken_from_the_last_backward_and_overflow_is_loud():
+    """(a) a capacity agreed on beside ANOTHER backward than the step's last one is not used (sequence numbers); (b) any other
+    exchange form disarms the hook for good; (c) a header count above the agreed capacity -- gradient rows dropped -- raises at the start of
+    the next exchange instead of passing silently."""
+    import view_parallel as vp
+
+    class Ev:
+        def __init__(self): self.waited = 0
+        def synchronize(self): self.waited += 1
+
+    a = _FakeArena()
+    a._gather_armed, a._cap_event, a.touched_reader_event = True, Ev(), object()
+    ev = a._cap_event
+    vp._disarm_gather(a)
+    assert a._gather_armed is False and a._cap_event is None and a.touched_reader_event is None and ev.waited == 1
+    # (c) the deferred overflow check
+    b = _FakeArena()
+    b._ovf_host, b._ovf_pending, b._gather_armed = torch.tensor([17], dtype=torch.int32), (None, 16), True
+    with pytest.raises(RuntimeError, match="rows were dropped"):
+        vp._check_gather_overflow(b)
+    assert b._gather_armed is False and b._ovf_pending is None
+    b._ovf_host, b._ovf_pending = torch.tensor([16], dtype=torch.int32), (None, 16)
+    vp._check_gather_overflow(b)        # count == capacity: fine
+    # (a) is a property of _exchange_gather's own code path: the event's tag against the arena's backward counter
+    import inspect
+    src = inspect.getsource(vp._exchange_gather)
+    assert "_cap_seq" in src and "touched_seq" in src
 
 
 @pytest.mark.parametrize("raw", [False, True], ids=["rasterizer_leaves", "raw_leaves"])

@@ -9,7 +9,7 @@ out=gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py $extra > $out/bench_${tag}.json 2> $out/bench_${tag}.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python bench.py $extra --sweep "" --no-cpu-baseline --no-training-like > $out/bench_${tag}_under_rocprof.json 2> $out/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python bench.py $extra --sweep "" --no-cpu-baseline > $out/bench_${tag}_under_rocprof.json 2> $out/rocprof.err
 f=$(ls $out/trace/*kernel_trace.csv 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/rocprof_summary.py $f > $out/${tag}_kernel_stats.txt
 s=$(ls $out/trace/*kernel_stats.csv 2>/dev/null | head -1)
@@ -19,12 +19,12 @@ rm -rf $out/trace
 # stream, the chain on another -- would never finish; the PMC passes run the chain inline, option chain_gate 0: same kernels, same work)
 pmcopt="--opt chain_gate=0"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python bench.py $extra $pmcopt --steps 5 --warmup 2 --sweep "" --no-cpu-baseline --no-training-like > /dev/null 2> $out/pmc_$c.err
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python bench.py $extra $pmcopt --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_$c.err
   f=$(ls $out/pmc_$c/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_$c.txt
   rm -rf $out/pmc_$c
 done
-timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq -o pmc -- python bench.py $extra $pmcopt --steps 5 --warmup 2 --sweep "" --no-cpu-baseline --no-training-like > /dev/null 2> $out/pmc_sq.err
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq -o pmc -- python bench.py $extra $pmcopt --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_sq.err
 f=$(ls $out/pmc_sq/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_SQ.txt
 rm -rf $out/pmc_sq
@@ -33,7 +33,7 @@ rocprofv3 --list-avail > $out/${tag}_counters_avail.txt 2>&1
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_x$i -o pmc -- python bench.py $extra $pmcopt --steps 5 --warmup 2 --sweep "" --no-cpu-baseline --no-training-like > /dev/null 2> $out/pmc_x$i.err
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_x$i -o pmc -- python bench.py $extra $pmcopt --steps 5 --warmup 2 --sweep "" --no-cpu-baseline > /dev/null 2> $out/pmc_x$i.err
   f=$(ls $out/pmc_x$i/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f > $out/${tag}_pmc_X$i.txt
   rm -rf $out/pmc_x$i

@@ -5,7 +5,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-BENCH_NO_EXP2=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_$tag -o $tag -- python bench.py --steps 20 --warmup 5 --sweep "" --no-cpu-baseline --no-training-like "$@" > gpurun_out/tl_bench_$tag.json 2>gpurun_out/tl_err_$tag.log
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_$tag -o $tag -- python bench.py --steps 20 --warmup 5 --sweep "" --no-cpu-baseline "$@" > gpurun_out/tl_bench_$tag.json 2>gpurun_out/tl_err_$tag.log
 f=$(ls gpurun_out/tl_$tag/*kernel_trace.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then
   python tools/timeline.py $f ${TL_BACK:-75} > gpurun_out/timeline_$tag.txt
