@@ -426,6 +426,7 @@ struct gsrast_context {
     std::unordered_map<const void*, uint8_t> pose_seen;
     // equalised depth buckets (gsrast_common.h): the key range the depth histogram's bins cover, learned from the previous forwards
     DepthRange zrange;                 // (gsrast_policy.h) klo / shift: the histogram's bins; khi: the range's un-rounded upper end (the predicted cut's bins span [klo, khi])
+    std::atomic<uint32_t> last_prologue_ns{0};   // host time of the last forward from entry to the launch of its first kernel (diagnostic: tools/sync_probe.py)
     std::atomic<int> redo_count{0};   // forwards whose speculative launch did not fit and was repeated with exact sizes
     std::atomic<int> depth_short{0};  // the last forward's depth keys spanned < 2^24: the next one enqueues three sort passes, not four
     std::atomic<int> bucket_skip{0};  // > 0: a recent forward's bucket depth sort overflowed a bucket; that many forwards go straight to the radix sort
@@ -765,6 +766,7 @@ int gsrast_context_query(const gsrast_context* c, const char* name)
     if (!c) c = thread_context();
     if (!strcmp(name, "last_instances")) return (int)c->last_R.load();   // num_rendered / column runs of the context's last forward call
     if (!strcmp(name, "last_runs")) return (int)c->last_Q.load();
+    if (!strcmp(name, "last_prologue_ns")) return (int)c->last_prologue_ns.load();
     if (!strcmp(name, "redo_count")) return c->redo_count.load();
     if (!strcmp(name, "bucket_skip")) return c->bucket_skip.load();
     if (!strcmp(name, "last_late")) return (int)c->last_late.load();
@@ -989,6 +991,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                       float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, void* stream,
                       const gsrast_raw_inputs* rawin)
 {
+    const auto t_entry = std::chrono::steady_clock::now();
     RoctxRange range_fwd(rawin ? "gsrast_forward_raw" : "gsrast_forward");
     CallScope call_scope;
     RawArgs raw{};
@@ -1274,6 +1277,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
                 tiles, rect, binrec_p, kA, bucket_sort ? nullptr : vA, clip, at<uint32_t>(img, IL.bucket_cnt), zr, zh_klo, zh_shift, zh_wave_mask, at<uint32_t>(geom, GL.bk_count), nzero, hints, hint_sel,
                 zcut_used, T, scalars, host_found, pre_seq, g_near_pose.load(), near_scale2, prefilter_word, untouched, tau_hist, tau_bins);
         GS_LAUNCHED("preprocess_fwd");
+        ctx->last_prologue_ns = (uint32_t)std::min<long long>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(), 0xFFFFFFFFll);
         if (tau_hist) {       // the predicted cut depths of a pose without remembered ones (a no-op for a pose the table knows, unless forced)
             const dim3 tg((unsigned)((cam.gx + TAU_TILE - 1) / TAU_TILE), (unsigned)((cam.gy + TAU_TILE - 1) / TAU_TILE));
             tau_cut_kernel<<<tg, TAU_BLK * TAU_BLK, 0, s>>>(tau_hist, T, cam.gx, cam.gy, tau_bins, (uint32_t)pol.tau_req.load() * 256u, hints ? hint_sel : nullptr, tau_forced,

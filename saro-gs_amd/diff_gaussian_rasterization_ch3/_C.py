@@ -71,15 +71,27 @@ def current_options() -> dict:
     return dict(_thread_options())
 
 
+_options_cache: dict = {}
+
+
 def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None, grads_zeroed: bool = False,
                     backward_phase: int = 0, forward_only: bool = False) -> OptionsStruct:
-    o = OptionsStruct()
-    for k, v in (_thread_options() if options is None else options).items():
-        setattr(o, k, int(v))
-    o.forward_only = int(bool(forward_only) or bool(o.forward_only))
-    o.sh_grad_factors = int(bool(sh_grad_factors))
-    o.grads_zeroed = int(bool(grads_zeroed))
-    o.backward_phase = int(backward_phase)
+    """The gsrast_options value of one call.  The library copies it at entry, so one struct per distinct combination is built once and
+    reused (round 6: fourteen setattr on a fresh ctypes Structure were ~8 us of every call's host time in front of the first launch)."""
+    src = _thread_options() if options is None else options
+    key = (tuple(src.items()), bool(sh_grad_factors), bool(grads_zeroed), int(backward_phase), bool(forward_only))
+    o = _options_cache.get(key)
+    if o is None:
+        o = OptionsStruct()
+        for k, v in src.items():
+            setattr(o, k, int(v))
+        o.forward_only = int(bool(forward_only) or bool(o.forward_only))
+        o.sh_grad_factors = int(bool(sh_grad_factors))
+        o.grads_zeroed = int(bool(grads_zeroed))
+        o.backward_phase = int(backward_phase)
+        if len(_options_cache) > 256:
+            _options_cache.clear()
+        _options_cache[key] = o
     return o
 
 
@@ -226,6 +238,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _dev_f32(t: torch.Tensor, name: str, device: torch.device) -> torch.Tensor:
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():      # (the usual case: nothing to do)
+        return t
     if t.numel() == 0:
         return t
     if t.device != device:
@@ -314,7 +328,7 @@ def _export_touched(ar: "GradArena", P: int, geomBuffer: torch.Tensor, dev: torc
     t = getattr(ar, "touched", None)
     if t is None or t.numel() != P or t.device != dev:
         t = ar.touched = torch.empty(P, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib().gsrast_touched_rows(P, _ptr(geomBuffer), t.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         raise _err(rc, "gsrast_touched_rows")
@@ -350,6 +364,27 @@ def set_touched_ready_hook(fn) -> None:
 POISON_STATE_BUFFERS = bool(int(os.environ.get("GSRAST_POISON_STATE", "0")))      # tests: every state buffer is handed out filled with 0xFF bytes (NaN as floats, all-ones as bits / indices)
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` without its cost when `dev` already is the current device (the usual case: two runtime calls and a
+    Python context manager's bookkeeping per entry point, in front of the first launch)."""
+    __slots__ = ("dev", "inner")
+
+    def __init__(self, dev: torch.device):
+        self.dev, self.inner = dev, None
+
+    def __enter__(self):
+        idx = self.dev.index
+        if idx is not None and idx != torch.cuda.current_device():
+            self.inner = torch.cuda.device(self.dev)
+            self.inner.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.inner is not None:
+            return self.inner.__exit__(*exc)
+        return False
+
+
 class _Arena:
     """The three resizable state buffers of the reference (rasterize_points.cu:27-33, :71-78):
     each allocation callback creates one uint8 tensor that is later saved for backward."""
@@ -358,6 +393,19 @@ class _Arena:
         self.device = device
         self.buffers: List[Optional[torch.Tensor]] = [None, None, None]
         self.callbacks = [_ALLOC_FN(self._make(i)) for i in range(3)]  # keep references alive
+
+    @staticmethod
+    def acquire(device: torch.device) -> "_Arena":
+        """An arena of the calling thread's pool (round 6): building three ctypes callbacks per forward cost ~20 us of host time in front of
+        the first launch; a pooled arena keeps its callbacks and only ever holds buffers between acquire() and close()."""
+        pool = getattr(_tls, "arena_pool", None)
+        if pool is None:
+            pool = _tls.arena_pool = []
+        if pool:
+            a = pool.pop()
+            a.device = device
+            return a
+        return _Arena(device)
 
     def _make(self, slot: int):
         def alloc(_ctx, nbytes):
@@ -380,8 +428,12 @@ class _Arena:
         a reference cycle: without this the three state buffers (hundreds of MB) stay alive until Python's CYCLIC
         collector happens to run, the caching allocator sees them freed at irregular times and occasionally has to
         hipMalloc fresh blocks in the middle of a training loop (a ~250 ms stall)."""
-        self.callbacks = None
-        self.buffers = [None, None, None]
+        self.buffers = [None, None, None]       # (the callbacks stay: the arena goes back to its thread's pool, holding nothing)
+        pool = getattr(_tls, "arena_pool", None)
+        if pool is not None and len(pool) < 8:
+            pool.append(self)
+        else:
+            self.callbacks = None
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
@@ -406,9 +458,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
     out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    arena = _Arena(dev)
+    arena = _Arena.acquire(dev)
     try:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             rendered = L.gsrast_forward_ex(
                 _current_context(), C.byref(_options_struct(forward_only=forward_only)),       # context: the innermost `with Context()` of the calling thread, else the thread's own
@@ -484,7 +536,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dscales = out("scales", (P, 3), not use_sr)
     dL_drotations = out("rotations", (P, 4), not use_sr)
     if P != 0:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             sh_out = ar.factor.data_ptr() if factors else _ptr(dL_dsh)
             radii_c = radii.contiguous()
@@ -562,9 +614,9 @@ def rasterize_gaussians_raw(background, raw: dict, scale_modifier, viewmatrix, p
     out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
     out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    arena = _Arena(dev)
+    arena = _Arena.acquire(dev)
     try:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rendered = L.gsrast_forward_raw(
                 _current_context(), C.byref(_options_struct(forward_only=forward_only)),
                 arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
@@ -635,7 +687,7 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
                         d_sh_factor=p_fac)
     if P != 0:
         radii_c = radii.contiguous()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             def call(phase):
                 return L.gsrast_backward_raw(
                     C.byref(_options_struct(options=options, grads_zeroed=first_backward, backward_phase=phase)), P, int(degree), M, int(R),
@@ -696,7 +748,7 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
             for v in views:
                 v.index_fill_(0, prev, 0.0)
         arena._sh_union, arena.sh_rows_known = idx, True
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = L.gsrast_sh_grad_combine_union(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
                                                 int(chunk_stride if chunk_stride is not None else arena.chunk), int(idx.numel()),
                                                 idx.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
@@ -709,7 +761,7 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
         row_of[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=dev)
         rows = int(idx.numel())
     arena.sh_rows_known = False
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.gsrast_sh_grad_combine_rows(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
                                            int(chunk_stride if chunk_stride is not None else arena.chunk), int(P if rows is None else rows),
                                            None if row_of is None else row_of.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
@@ -729,7 +781,7 @@ def rows_pack(idx: torch.Tensor, arrays, packed: torch.Tensor, unpack: bool = Fa
     ptrs = (C.c_void_p * k)(*[a.data_ptr() for a in arrays])
     wid = (C.c_int * k)(*widths)
     dev = packed.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         fn = lib().gsrast_rows_unpack if unpack else lib().gsrast_rows_pack
         rc = fn(n, idx.data_ptr(), k, ptrs, wid, packed.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
@@ -758,7 +810,7 @@ def _dense_ptrs(arena: "GradArena"):
 def grad_rows_pack(arena: "GradArena", touched: torch.Tensor, rows: torch.Tensor) -> None:
     """This rank's touched gradient rows into rows[1:] (int32 [1 + cap, 16]; rows[0, 0], zeroed by the caller, counts them)."""
     dev = rows.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib().gsrast_grad_rows_pack(arena.P, touched.data_ptr(), _dense_ptrs(arena), arena.factor.data_ptr(), rows.data_ptr(),
                                          int(rows.shape[0]) - 1, torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
@@ -770,7 +822,7 @@ def grad_rows_clear(arena: "GradArena", chunks: torch.Tensor, dense: bool, sh: b
     n, cap = int(chunks.shape[0]), int(chunks.shape[1]) - 1
     whole, dc, rest = _arena_sh_arrays(arena) if sh else (None, None, None)
     dev = chunks.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib().gsrast_grad_rows_clear(arena.P, chunks.data_ptr(), n, (1 + cap) * GRAD_ROW_WORDS, cap, _dense_ptrs(arena) if dense else None, arena.M,
                                           _ptr(whole), _ptr(dc), _ptr(rest), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
@@ -781,7 +833,7 @@ def grad_rows_add(arena: "GradArena", chunk: torch.Tensor, means3D: torch.Tensor
     """One rank's chunk (int32 [1 + cap, 16]) added into the arena: the dense rows and, recombined from the factor, dL/dsh."""
     whole, dc, rest = _arena_sh_arrays(arena)
     dev = chunk.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib().gsrast_grad_rows_add(arena.P, chunk.data_ptr(), int(chunk.shape[0]) - 1, _dense_ptrs(arena), int(arena.last_degree), arena.M,
                                         means3D.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
                                         torch.cuda.current_stream(dev).cuda_stream)
@@ -797,7 +849,7 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
     if P != 0:
         means3D, viewmatrix, projmatrix = (_dev_f32(t, n, dev) for t, n in
                                            ((means3D, "means3D"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix")))
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = lib().gsrast_mark_visible(P, means3D.data_ptr(), viewmatrix.data_ptr(), projmatrix.data_ptr(),
                                            present.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
@@ -950,7 +1002,7 @@ def debug_export(P: int, R: int, W: int, H: int, geomBuffer, binningBuffer, imag
     keep_cov = int(lib().gsrast_get_option(b"debug_state")) != 0
     if not keep_cov:
         del out["cov3D"]
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib().gsrast_debug_export(
             P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), out["depths"].data_ptr(),
             out["means2D"].data_ptr(), out["cov3D"].data_ptr() if keep_cov else None, out["conic_opacity"].data_ptr(),

@@ -80,13 +80,15 @@ def test_state_arena_is_freed_by_refcounting_not_by_the_cyclic_gc():
     from diff_gaussian_rasterization_ch3 import _C
     gc.disable()
     try:
-        arena = _C._Arena(torch.device("cpu"))
+        arena = _C._Arena.acquire(torch.device("cpu"))
         ptr = arena.callbacks[1](None, 1024)                 # what libgsrast does: ask for 1 KiB of binning state
         assert ptr and arena.tensor(1).numel() == 1024
-        buf_ref, arena_ref = weakref.ref(arena.tensor(1)), weakref.ref(arena)
+        buf_ref = weakref.ref(arena.tensor(1))
         arena.close()
-        del arena
-        assert arena_ref() is None and buf_ref() is None     # gone without gc.collect()
+        assert buf_ref() is None                             # the buffer is gone without gc.collect() ...
+        again = _C._Arena.acquire(torch.device("cpu"))
+        assert again is arena and again.buffers == [None, None, None] and again.callbacks is not None   # ... and the arena, holding nothing, serves the next call (round 6)
+        again.close()
     finally:
         gc.enable()
 

@@ -8,6 +8,8 @@ Bars (BASELINE.json north_star):
   * gradients: |hip - f64 truth| <= 1e-5 abs (+1e-4 relative for the few large entries); the f64
     truth replays the fp32 control flow, so the comparison has no threshold-flip outliers.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -62,17 +64,23 @@ def _check_forward_exact(o, h, clipped=False):
 
 
 def _check_grads(o64, o32, h, names, strict=False, conditioning=False):
-    """Every gradient tensor within conftest.grad_tol of the fp64 truth: 1e-5 * max|ref| + 1e-4 * |ref| -- the same bar whatever the
-    upstream gradient's scale (`strict` is kept for the call sites' sake: rounds 1-5 used an ABSOLUTE 1e-5 there, which at the bench's
-    N(0,1)/(3HW) upstream gradient was 40 % of the largest entry of dL/dsh)."""
+    """Every gradient tensor within conftest.grad_tol of the fp64 truth: max(1e-5 * max|ref| + 1e-4 * |ref|, 4 x the fp32 oracle's own
+    worst error on the tensor) -- the same bar whatever the upstream gradient's scale (`strict` / `conditioning` are kept for the call
+    sites' sake: rounds 1-5 used an ABSOLUTE 1e-5 with `strict`, which at the bench's N(0,1)/(3HW) upstream gradient was 40 % of the
+    largest entry of dL/dsh, and applied the fp32 floor only to needle-shaped scenes)."""
     from conftest import grad_tol
     for k in names:
         ref = o64[k].astype(np.float64)
         got = h[k].astype(np.float64).reshape(ref.shape)
         err = np.abs(got - ref)
-        tol = grad_tol(ref)
-        if conditioning:     # ill-conditioned inputs (needle-shaped Gaussians): fp32 itself is the limit -- allow 4x the
-            tol = np.maximum(tol, 4.0 * np.abs(o32[k].astype(np.float64) - ref).max())   # fp32 oracle's own worst error
+        tol = grad_tol(ref, o32[k])      # (incl. the fp32 floor: 4x the fp32 oracle's own worst error on this tensor -- see conftest.grad_tol)
+        if os.environ.get("GSRAST_GRAD_REPORT"):      # development: print how far both fp32 evaluations are from the bar instead of asserting
+            e32 = np.abs(o32[k].astype(np.float64) - ref)
+            w = np.unravel_index(np.argmax(err / np.maximum(tol, 1e-300)), err.shape)
+            print(f"GRAD_REPORT {k}: max|ref| {np.abs(ref).max():.3e}  hip worst err/tol {float((err / np.maximum(tol, 1e-300)).max()):.2f} ({int((err > tol).sum())} over; at {w}: ref {ref[w]:.3e} err {err[w]:.3e}, "
+                  f"oracle32 err there {e32[w]:.3e})  oracle32 worst err/tol {float((e32 / np.maximum(tol, 1e-300)).max()):.2f} ({int((e32 > tol).sum())} over)  "
+                  f"max err / max|ref|: hip {err.max() / max(np.abs(ref).max(), 1e-300):.2e} oracle32 {e32.max() / max(np.abs(ref).max(), 1e-300):.2e}", flush=True)
+            continue
         assert (err <= tol).all(), f"{k}: max abs err {err.max():.3e} (max |ref| {np.abs(ref).max():.3e}), worst err / tol {float((err / np.maximum(tol, 1e-300)).max()):.2f}, {int((err > tol).sum())} entries over"
         # the fp32 oracle (different summation order) must sit in the same band
         err32 = np.abs(o32[k].astype(np.float64) - ref)

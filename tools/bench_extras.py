@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from bench import HBM_PEAK_GBS, Workload, _query, roofline_of, stage_table, step_bytes, timed  # noqa: E402,F401
+from bench import HBM_PEAK_GBS, Deformation, Workload, _query, roofline_of, stage_table, step_bytes, timed  # noqa: E402,F401
 
 
 def exp_mode2_row(_C, wl, dev, kid):
@@ -57,38 +57,6 @@ def exp_mode2_row(_C, wl, dev, kid):
     res["note"] = "mode 2 = hardware v_exp_f32; outputs within 1e-5 of mode 0 (tests/test_gpu_parity.py::test_other_exp_modes_within_tolerance); the headline runs the mode in config.exp_mode"
     return res
 
-
-
-class Deformation:
-    """A stand-in for what SaRO-GS's deformation field hands the rasterizer at timestamp t (scene/saro_gaussian.py:get_deformation, :782-847, with
-    the shipped switches dx = drot = dopacity = True, arguments/__init__.py:68-72): per Gaussian a temporal position and a lifespan,
-        opacity  = sigmoid(_opacity) * exp(-4 ((t - pos) / lifespan)^2)                                   (:791-792, :824-829)
-        means3D  = _xyz + motion_residual(t),  rotations = normalize(_rotation + rot_residual[:, :4]),
-        scales   = exp(_scaling + rot_residual[:, 4:])                                                   (:805-822)
-    The residuals are smooth functions of (t - pos) with a fixed random direction per Gaussian: means move by up to 1.2 % of the scene's
-    extent, scales by +-10 %, quaternions by ~3 degrees -- the size of a learned deformation, none of its cost (the reference's MLP heads
-    are model code outside this path).  The tensors require a gradient, as the heads' outputs do: the backward writes their rows."""
-
-    def __init__(self, P, dev, seed=5, motion=True):
-        rng = np.random.default_rng(seed)
-        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
-        self.tpos = t(rng.uniform(0.0, 1.0, size=(P, 1)))
-        self.life = t(rng.uniform(0.2, 1.0, size=(P, 1)))
-        self.ts = rng.uniform(0.0, 1.0, size=4096)
-        self.motion = motion
-        if motion:
-            d = rng.normal(size=(P, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
-            self.mdir = t(0.03 * d)
-            self.rdir = t(np.concatenate([0.05 * rng.normal(size=(P, 4)), 0.1 * rng.uniform(-1.0, 1.0, size=(P, 3))], axis=1))
-
-    def at(self, i):
-        """(motion_residual, rot_residual, trbfoutput) of call i."""
-        d = float(self.ts[i % len(self.ts)]) - self.tpos
-        trbf = torch.exp(-4.0 * (d / self.life) ** 2)
-        if not self.motion:
-            return None, None, trbf
-        s = torch.sin(6.283185307179586 * d)
-        return (self.mdir * s).requires_grad_(True), (self.rdir * s).requires_grad_(True), trbf
 
 
 def training_like_row(rast, scenes, dev, P, W, H, deg, Vs=(8, 150)):
