@@ -21,6 +21,33 @@
 #include "gsrast_common.h"
 
 namespace gsrast {
+// Occupancy caps of the latency-bound binning kernels (A/B: -DGSRAST_<K>_WAVES=n compiles kernel K for n waves per SIMD; round 6)
+#define GSRAST_OCC_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#ifdef GSRAST_RSCAT_WAVES
+#define GSRAST_RSCAT_OCC GSRAST_OCC_ATTR(GSRAST_RSCAT_WAVES)
+#else
+#define GSRAST_RSCAT_OCC
+#endif
+#ifdef GSRAST_BSCAT_WAVES
+#define GSRAST_BSCAT_OCC GSRAST_OCC_ATTR(GSRAST_BSCAT_WAVES)
+#else
+#define GSRAST_BSCAT_OCC
+#endif
+#ifdef GSRAST_BSORT_WAVES
+#define GSRAST_BSORT_OCC GSRAST_OCC_ATTR(GSRAST_BSORT_WAVES)
+#else
+#define GSRAST_BSORT_OCC
+#endif
+#ifdef GSRAST_EMIT_WAVES
+#define GSRAST_EMIT_OCC GSRAST_OCC_ATTR(GSRAST_EMIT_WAVES)
+#else
+#define GSRAST_EMIT_OCC
+#endif
+#ifdef GSRAST_ROWS_WAVES
+#define GSRAST_ROWS_OCC GSRAST_OCC_ATTR(GSRAST_ROWS_WAVES)
+#else
+#define GSRAST_ROWS_OCC
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Scan (u32).  Three kernels per level: block sums -> scan of sums (recursive) -> apply.
@@ -270,7 +297,7 @@ radix_rowscan_kernel(uint32_t* __restrict__ block_hist, uint32_t nblk, uint32_t*
 }
 
 template <typename KeyT, typename ValT, int ITEMS>
-__global__ void __launch_bounds__(RS_THREADS)
+__global__ void __launch_bounds__(RS_THREADS) GSRAST_RSCAT_OCC
 radix_scatter_kernel(const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev,
                      int shift, uint32_t mask,
@@ -478,7 +505,7 @@ __device__ unsigned long long g_scat[16];
 #define SCAT_T(k) do { } while (0)
 #endif
 template <int BK_ITEMS_T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) GSRAST_BSCAT_OCC
 depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                             uint32_t n, const uint32_t* __restrict__ zhist /* [ZH_COPIES][ZH_BINS]: sampled histogram of the visible depth keys (preprocess_fwd) */,
                             uint32_t zh_klo, int zh_shift /* its bins: 2^shift key steps each, from klo (gsrast_common.h) */,
@@ -762,7 +789,7 @@ __device__ __forceinline__ uint4 bucket_element(const uint4* __restrict__ slab, 
     for (int q = 1; q < BK_XCD; q++) { const bool ge = e >= start[q]; x += ge ? 1u : 0u; s0 = ge ? start[q] : s0; }
     return slab[((size_t)b * BK_XCD + x) * BK_CAPX + (e - s0)];
 }
-__global__ void __launch_bounds__(64 * BK_WAVES)
+__global__ void __launch_bounds__(64 * BK_WAVES) GSRAST_BSORT_OCC
 depth_bucket_sort_kernel(const uint4* __restrict__ slab, const uint32_t* __restrict__ gcount, uint32_t nb,
                          const uint32_t* __restrict__ bkey /* [nb + 1]: the buckets' key intervals (the scatter's bucket map, inverted) */,
                          uint32_t* __restrict__ border /* [nb][BK_CAP]: sorted Gaussian ids of each bucket */,
@@ -1101,7 +1128,7 @@ __device__ __forceinline__ double sqrt_newton(double x)
     return __builtin_fma(__builtin_fma(-s0, s0, x), 0.5 * (double)__builtin_amdgcn_rcpf(s0f), s0);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) GSRAST_EMIT_OCC
 emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ woffsets /* incl. scan of widths */,
                         const float4* __restrict__ binrec, int W, int H, int cull, uint32_t capQ,
                         uint16_t* __restrict__ run_keys, uint2* __restrict__ run_vals,
@@ -1128,13 +1155,20 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
 {
     if (fork_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fork_word, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (pred && *pred == 0u) return;
+    __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
+    // per-Gaussian ellipse terms (fp64): det, 2tc, 1/c, dy_max, dx_top (b, the mean: exact in fp32);  mode 0 = keep the column, 1 = clip, 2 = empty
+    // (round 6: 26.9 -> 21.8 KB of LDS -- b as a float, the bookkeeping workgroup's reduction arrays aliased onto these: the kernel is a chain
+    // of memory latencies, what it needs is resident workgroups)
+    __shared__ double s_det[4][64], s_t2c[4][64], s_invc[4][64], s_dymax[4][64], s_dxtop[4][64];
+    __shared__ float s_b[4][64], s_mx[4][64], s_my[4][64];
+    __shared__ uint32_t s_mode[4][64];
     if (redo_bucket_cnt && blockIdx.x == nbuckets) {
         for (int i = threadIdx.x; i < n_redo_cnt; i += blockDim.x) redo_bucket_cnt[i] = 0u;
         if (threadIdx.x == 0 && redo_hints) atomicAdd(&redo_hints->cut_fallbacks, 1u);
         uint32_t q2 = 1u;
         if (pass2_counts) {       // {tile counts lo, column runs, -, hi} of the candidates: what the sorts behind this emission are sized by
-            __shared__ unsigned long long s_t2[256];
-            __shared__ uint32_t s_q2[256];
+            unsigned long long* const s_t2 = reinterpret_cast<unsigned long long*>(&s_det[0][0]);      // [256] (this workgroup emits nothing)
+            uint32_t* const s_q2 = &s_e[0][0];                                                         // [256]
             unsigned long long ts = 0; uint32_t q = 0;
             for (uint32_t k = threadIdx.x; k < nbuckets; k += 256) { const uint4 v = binfo[k]; q += v.y; ts += v.z; }
             s_t2[threadIdx.x] = ts; s_q2[threadIdx.x] = q;
@@ -1146,11 +1180,6 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         if (threadIdx.x == 0 && host_fallback) __hip_atomic_store(host_fallback, ((unsigned long long)host_fb_seq << 32) | (unsigned long long)q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    __shared__ uint32_t s_e[4][64], s_g[4][64], s_x0[4][64], s_yh[4][64];
-    // per-Gaussian ellipse terms (fp64): det, 2tc, b, 1/c, dy_max, dx_top;  mode 0 = keep the column, 1 = clip, 2 = empty
-    __shared__ double s_det[4][64], s_t2c[4][64], s_b[4][64], s_invc[4][64], s_dymax[4][64], s_dxtop[4][64];
-    __shared__ float s_mx[4][64], s_my[4][64];
-    __shared__ uint32_t s_mode[4][64];
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t nloc = 0, run0 = 0, nchunks = 1;
     uint32_t pre_g = 0, pre_w = 0, pre_wm = 0;
@@ -1229,7 +1258,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
                 dx_top = -b * dy_max / a;                       // where the ellipse reaches dy = +dy_max
                 if (!(dy_max < 1e30)) mode = 0;
             }
-            s_det[wave][lane] = det; s_t2c[wave][lane] = 2.0 * t * c; s_b[wave][lane] = b; s_invc[wave][lane] = 1.0 / c;
+            s_det[wave][lane] = det; s_t2c[wave][lane] = 2.0 * t * c; s_b[wave][lane] = B; s_invc[wave][lane] = 1.0 / c;
             s_dymax[wave][lane] = dy_max; s_dxtop[wave][lane] = dx_top;
             s_mx[wave][lane] = mx; s_my[wave][lane] = my; s_mode[wave][lane] = mode;
         }
@@ -1255,7 +1284,7 @@ emit_column_runs_kernel(int P, const uint32_t* __restrict__ order, const uint32_
         if (mode == 2u) yhv &= 0xFFFFu;
         else if (mode == 1u) {
             uint32_t y0 = yhv & 0xFFFFu, h = yhv >> 16;
-            const double det = s_det[wave][sidx], t2c = s_t2c[wave][sidx], b = s_b[wave][sidx], invc = s_invc[wave][sidx];
+            const double det = s_det[wave][sidx], t2c = s_t2c[wave][sidx], b = (double)s_b[wave][sidx], invc = s_invc[wave][sidx];
             const double dy_max = s_dymax[wave][sidx], dx_top = s_dxtop[wave][sidx];
             const double mx = (double)s_mx[wave][sidx], my = (double)s_my[wave][sidx];
             const int px1 = min((int)x * 16 + 15, W - 1);
@@ -1567,7 +1596,7 @@ run_scatter_rows_body(uint32_t block /* = blockIdx.x of a launch of its own */, 
 // The row pass and the tile ranges in ONE launch: both only read the scanned row histogram and the column-sorted runs, neither reads what
 // the other writes.  Workgroups [0, nblk) expand and rank the instances of their runs, workgroups [nblk, nblk + gx) compute the ranges
 // of their tile column (one launch fewer per forward, and one fewer among the predicated launches of the list cut).
-__global__ void __launch_bounds__(RS_THREADS)
+__global__ void __launch_bounds__(RS_THREADS) GSRAST_ROWS_OCC
 rows_and_ranges_kernel(const uint16_t* __restrict__ run_keys, const uint2* __restrict__ run_vals, uint32_t Q, const uint32_t* __restrict__ counts_dev,
                        uint32_t capR, int ybits, int gx, int gy, const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ digit_total,
                        uint32_t nblk, uint32_t* __restrict__ point_list, uint32_t* __restrict__ total_out, uint2* __restrict__ ranges,

@@ -23,6 +23,9 @@ import torch.distributed as dist
 
 
 _FORCE_COLLECTIVES = os.environ.get("GSRAST_FORCE_COLLECTIVES", "") == "1"
+# GSRAST_GATHER_ASYNC_CAP=0: the all-gather exchange agrees on its row capacity with a synchronous 4-byte all-reduce in every step instead of
+# beside the backward (_touched_hook) -- one host synchronisation per step more, no collective issued from inside the backward
+_ASYNC_CAPACITY = os.environ.get("GSRAST_GATHER_ASYNC_CAP", "1") != "0"
 
 
 def force_collectives(on: bool = True) -> None:
@@ -316,7 +319,7 @@ def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> 
         cmax = send[0, :1].clone()
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
         cap = int(cmax.item())                                         # (host synchronisation: every rank learns the same cap)
-    if not getattr(arena, "_gather_armed", False):                     # from the next backward on: the capacity is agreed on early
+    if not getattr(arena, "_gather_armed", False) and _ASYNC_CAPACITY:     # from the next backward on: the capacity is agreed on early
         arena._gather_armed = True
         _C.set_touched_ready_hook(_touched_hook)
     mine = send[: 1 + cap]
