@@ -488,7 +488,7 @@ SideStream* side_stream_of(gsrast_context* ctx)
     }
     return &x;
 }
-std::atomic<int> g_word_fork{0};          // 1: word forks where a kernel can signal its own start.  OPT-IN since round 6 (default 0: every fork is an event): the hang the
+std::atomic<int> g_word_fork{getenv("GSRAST_WORD_FORK") ? 1 : 0};          // (GSRAST_WORD_FORK: experiments, tools/soak_stress.sh) 1: word forks where a kernel can signal its own start.  OPT-IN since round 6 (default 0: every fork is an event): the hang the
                                           // soak test showed with them (3 of 28 runs, two concurrent submitters) was never root-caused, and what they buy is 13 us of a
                                           // 1.1 ms step (1.2 %).  The reference's statics are callable from any number of threads (rasterizer.h:24-83); a drop-in may not
                                           // trade that for a percent.  With the option on, the rule of single_host_thread() still applies.
