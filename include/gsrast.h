@@ -132,6 +132,14 @@ size_t gsrast_geometry_bytes(int P);
 size_t gsrast_binning_bytes(int num_rendered, int width, int height);
 size_t gsrast_image_bytes(int width, int height);
 
+/* A ready-made allocation callback over memory the caller ALREADY holds (round 6): pass gsrast_alloc_prealloc as the gsrast_alloc_fn and a
+ * gsrast_prealloc* as its ctx.  Returns ptr when bytes <= capacity, NULL otherwise (the forward then fails with GSRAST_E_ALLOC); `requested`
+ * records what was asked for.  The geometry and image buffers' sizes are known before the call (gsrast_geometry_bytes / gsrast_image_bytes), so a
+ * host language whose callbacks are expensive (Python: ~5 us each, in front of the forward's first launch) need only keep its own callback for
+ * the binning buffer, whose size the library decides. */
+typedef struct gsrast_prealloc { void* ptr; size_t capacity; size_t requested; } gsrast_prealloc;
+void* gsrast_alloc_prealloc(void* ctx /* gsrast_prealloc* */, size_t bytes);
+
 /* Multi-GPU gradient exchange (no counterpart in the reference, which is single-GPU and sums the per-view gradients of a
  * batch in place, scene/saro_gaussian.py:226-247, :266-276).  Row k of a view's dL/dsh is w_k(view direction) * g, where
  * g[3] is that view's clamp-masked colour gradient of the Gaussian: instead of all-reducing 16 x 3 products per Gaussian,

@@ -943,6 +943,13 @@ void gsrast_profile_reset(void)
 size_t gsrast_geometry_bytes(int P) { return geom_layout((size_t)(P > 0 ? P : 0)).total; }
 size_t gsrast_binning_bytes(int R, int, int) { return bin_layout((size_t)(R > 0 ? R : 0)).total; }
 size_t gsrast_image_bytes(int W, int H) { return img_layout((size_t)(W > 0 ? W : 0), (size_t)(H > 0 ? H : 0)).total; }
+void* gsrast_alloc_prealloc(void* ctx, size_t bytes)
+{
+    gsrast_prealloc* p = static_cast<gsrast_prealloc*>(ctx);
+    if (!p) return nullptr;
+    p->requested = bytes;
+    return bytes <= p->capacity ? p->ptr : nullptr;
+}
 
 int gsrast_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                         unsigned char* present, void* stream)
@@ -1083,8 +1090,12 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     // 1 M-Gaussian shell -7 %, 0.3 M cube -3 %, 0.1 M cube -8 % with the cut forced on; 1 M cube +8 %, 3 M cube +16 %).
     CutPolicy& pol = ctx->pol;          // (the decisions: gsrast_policy.h)
     if (pol.begin_forward((uint32_t)P)) {     // (what was learned belongs to the scene it was learned on: a context that moves on to a scene of another size starts afresh)
-        if (hints) GS_HIP(hipMemsetAsync(hints, 0, offsetof(HintTable, cam), s));      // (keys, stamps, clock: every slot free again; ordered in front of this call's lookup)
+        // keys, stamps, clock: every slot free again, ordered in front of this call's lookup -- of EVERY image size's table of this device (round 6,
+        // the other resolutions' tables kept the old scene's cut depths, running maxima that take eight visits to fade)
+        int device = 0;
         std::lock_guard<std::mutex> lk(ctx->mu);
+        if (hints && hipGetDevice(&device) == hipSuccess && device >= 0 && device < 32)
+            for (auto& c : ctx->hints[device]) if (c.table) GS_HIP(hipMemsetAsync(c.table, 0, offsetof(HintTable, cam), s));
         ctx->pose_seen.clear(); ctx->Qe_hint = 0; ctx->Qe_hint_tau = 0;
     }
     const bool cut_pays = pol.pays(ctx->last_Q.load(), g_list_cut_always.load() != 0);

@@ -38,7 +38,7 @@ EXPORTS = (
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query", "gsrast_policy_event",
-    "gsrast_forward_ex", "gsrast_backward_ex", "gsrast_forward_raw", "gsrast_backward_raw",
+    "gsrast_forward_ex", "gsrast_backward_ex", "gsrast_forward_raw", "gsrast_backward_raw", "gsrast_alloc_prealloc",
 )
 
 
@@ -164,6 +164,8 @@ def lib() -> C.CDLL:
     L.gsrast_binning_bytes.argtypes = [ci, ci, ci]
     L.gsrast_image_bytes.restype = C.c_size_t
     L.gsrast_image_bytes.argtypes = [ci, ci]
+    global _PREALLOC_CB
+    _PREALLOC_CB = _ALLOC_FN(C.cast(L.gsrast_alloc_prealloc, C.c_void_p).value)      # the library's own C callback over pre-allocated memory (no trip into Python)
     L.gsrast_debug_export.restype = ci
     L.gsrast_debug_export.argtypes = [ci, ci, ci, ci] + [vp] * 16
     L.gsrast_set_option.restype = ci
@@ -364,6 +366,28 @@ def set_touched_ready_hook(fn) -> None:
 POISON_STATE_BUFFERS = bool(int(os.environ.get("GSRAST_POISON_STATE", "0")))      # tests: every state buffer is handed out filled with 0xFF bytes (NaN as floats, all-ones as bits / indices)
 
 
+class PreallocStruct(C.Structure):
+    """gsrast_prealloc (include/gsrast.h)."""
+    _fields_ = [("ptr", C.c_void_p), ("capacity", C.c_size_t), ("requested", C.c_size_t)]
+
+
+_PREALLOC_CB = None
+PREALLOC_STATE = True       # geometry / image state buffers are allocated BEFORE the forward's C call and handed over through gsrast_alloc_prealloc
+                            # (round 6: two Python callbacks fewer in front of the first launch); False: all three through Python callbacks, as rounds 1-5
+_size_cache: dict = {}
+
+
+def _state_bytes(P: int, W: int, H: int):
+    k = (P, W, H)
+    v = _size_cache.get(k)
+    if v is None:
+        L = lib()
+        if len(_size_cache) > 64:
+            _size_cache.clear()
+        v = _size_cache[k] = (int(L.gsrast_geometry_bytes(P)), int(L.gsrast_image_bytes(W, H)))
+    return v
+
+
 class _on_device:
     """`with torch.cuda.device(dev)` without its cost when `dev` already is the current device (the usual case: two runtime calls and a
     Python context manager's bookkeeping per entry point, in front of the first launch)."""
@@ -393,6 +417,24 @@ class _Arena:
         self.device = device
         self.buffers: List[Optional[torch.Tensor]] = [None, None, None]
         self.callbacks = [_ALLOC_FN(self._make(i)) for i in range(3)]  # keep references alive
+        self.pre = (PreallocStruct * 2)()                              # geometry, image (gsrast_alloc_prealloc)
+
+    def forward_allocators(self, P: int, W: int, H: int):
+        """(geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx) of one forward.  With PREALLOC_STATE the geometry
+        and image buffers are allocated here, their sizes being known (gsrast_geometry_bytes / gsrast_image_bytes), and the library's own C
+        callback hands them out; the binning buffer, whose size the library decides, keeps the Python callback."""
+        if not PREALLOC_STATE or P <= 0:
+            return (self.callbacks[0], None, self.callbacks[1], None, self.callbacks[2], None)
+        gb, ib = _state_bytes(P, W, H)
+        geom = torch.empty(gb, dtype=torch.uint8, device=self.device)
+        img = torch.empty(ib, dtype=torch.uint8, device=self.device)
+        if POISON_STATE_BUFFERS:
+            geom.fill_(255); img.fill_(255)
+        self.buffers[0], self.buffers[2] = geom, img
+        pre = self.pre
+        pre[0].ptr, pre[0].capacity = geom.data_ptr(), gb
+        pre[1].ptr, pre[1].capacity = img.data_ptr(), ib
+        return (_PREALLOC_CB, C.addressof(pre[0]), self.callbacks[1], None, _PREALLOC_CB, C.addressof(pre[1]))
 
     @staticmethod
     def acquire(device: torch.device) -> "_Arena":
@@ -464,7 +506,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             stream = torch.cuda.current_stream(dev).cuda_stream
             rendered = L.gsrast_forward_ex(
                 _current_context(), C.byref(_options_struct(forward_only=forward_only)),       # context: the innermost `with Context()` of the calling thread, else the thread's own
-                arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
+                *arena.forward_allocators(P, W, H),
                 P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
                 _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
@@ -619,7 +661,7 @@ def rasterize_gaussians_raw(background, raw: dict, scale_modifier, viewmatrix, p
         with _on_device(dev):
             rendered = L.gsrast_forward_raw(
                 _current_context(), C.byref(_options_struct(forward_only=forward_only)),
-                arena.callbacks[0], None, arena.callbacks[1], None, arena.callbacks[2], None,
+                *arena.forward_allocators(P, W, H),
                 P, int(degree), M, _ptr(background), W, H, C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii),
                 torch.cuda.current_stream(dev).cuda_stream)

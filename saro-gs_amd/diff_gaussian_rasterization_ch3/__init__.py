@@ -111,6 +111,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
+_EMPTY = torch.empty(0)
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
@@ -134,7 +137,7 @@ class GaussianRasterizer(nn.Module):
         if (not full_sr and not have_cov) or (have_sr and have_cov):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
 
-        empty = torch.empty(0)  # absent optional input, like the reference's torch.Tensor([]) (REF:173-183)
+        empty = _EMPTY          # absent optional input, like the reference's torch.Tensor([]) (REF:173-183); one shared CPU tensor: nobody writes it
         return rasterize_gaussians(
             means3D, means2D,
             shs if have_sh else empty,

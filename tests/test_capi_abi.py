@@ -129,3 +129,23 @@ def test_raw_entry_points_reject_bad_arguments_before_any_device_work(L, rast):
     gr = _C.RawGradsStruct(dL_dmean2D=16, d_xyz=16, d_rotation=16, d_scaling=16, d_opacity_logit=16, d_shs_res=16)
     rc = L.gsrast_backward_raw(C.byref(opts), 10, 3, 16, 5, one, 64, 64, C.byref(ins), 1.0, one, one, one, 1.0, 1.0, one, one, one, one, one, C.byref(gr), None)
     assert rc < 0 and b"d_shs_res" in L.gsrast_last_error()
+
+
+def test_prealloc_callback_hands_out_what_fits_and_nothing_else():
+    """gsrast_alloc_prealloc (include/gsrast.h, round 6): the library's own allocation callback over memory the caller already holds --
+    pure host code, callable without a GPU.  Returns the pointer when the request fits, NULL otherwise, and records the request."""
+    import ctypes as C
+    from diff_gaussian_rasterization_ch3 import _C
+    L = _C.lib()
+    L.gsrast_alloc_prealloc.restype = C.c_void_p
+    L.gsrast_alloc_prealloc.argtypes = [C.c_void_p, C.c_size_t]
+    p = _C.PreallocStruct()
+    p.ptr, p.capacity = 0x1000, 4096
+    assert L.gsrast_alloc_prealloc(C.addressof(p), 4096) == 0x1000 and p.requested == 4096
+    assert L.gsrast_alloc_prealloc(C.addressof(p), 100) == 0x1000 and p.requested == 100
+    assert L.gsrast_alloc_prealloc(C.addressof(p), 4097) is None and p.requested == 4097
+    assert L.gsrast_alloc_prealloc(None, 16) is None
+    assert _C._PREALLOC_CB is not None
+    # the sizes a caller pre-allocates are the ones the forward will ask for: monotone, 256-byte aligned arrays inside
+    gb, ib = _C._state_bytes(1000, 640, 480)
+    assert gb == L.gsrast_geometry_bytes(1000) and ib == L.gsrast_image_bytes(640, 480) and gb > 0 and ib > 0

@@ -436,6 +436,7 @@ def test_state_buffers_are_not_overrun(scenes, rast, gpu, monkeypatch):
         return alloc
 
     monkeypatch.setattr(_C._Arena, "_make", _make)
+    monkeypatch.setattr(_C, "PREALLOC_STATE", False)     # (all three buffers through the Python callbacks, so that each gets its canary tail)
     _C._tls.arena_pool = []          # (arenas are pooled per thread since round 6: the ones built before the patch keep their callbacks)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)  # noqa: E731
     seq = [(1, 64, 48), (7, 16, 16), (300, 97, 83), (5000, 320, 240), (1, 48, 32), (40, 640, 16), (4097, 128, 96), (2, 17, 5)]
