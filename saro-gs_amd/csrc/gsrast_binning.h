@@ -504,8 +504,21 @@ __device__ unsigned long long g_scat[16];
 #else
 #define SCAT_T(k) do { } while (0)
 #endif
-template <int BK_ITEMS_T>
-__global__ void __launch_bounds__(256) GSRAST_BSCAT_OCC
+// TWO-LAUNCH form (round 6, COARSE = true + depth_bucket_refine_kernel): with ~P / 366 fine buckets nearly every element of a workgroup is alone in its bucket --
+// one returning global atomic and one lone 16-byte store per element (3 M of each at 3 M Gaussians: 21 + 32 us of the kernel's 88, 135 MB written for 48 MB of
+// elements: VERDICT r05 item 4a).  COARSE: the workgroup ranks and reserves per COARSE bucket (32 fine buckets: nb / 32 <= 256 of them), so a workgroup's elements of one
+// coarse bucket are a run of ~16 consecutive slots (256 bytes, written within a microsecond from one compute unit) and the atomics are one per lane; the element carries
+// its fine bucket's low five bits in bits 16-20 of the width word.  The refine kernel then runs one workgroup per (coarse bucket, XCD): it alone writes the 32 fine
+// sub-slabs of its XCD, ranks in LDS, needs no global atomic and writes the fine counters once -- same slab, same counters as the one-launch form, so the sort and the
+// emission behind it do not change.
+constexpr int BK_CSHIFT = 5;                       // fine buckets per coarse bucket: 32
+constexpr int BK_CCAP_MAX = (1 << BK_CSHIFT) * BK_CAPX;     // 4096 slots per (coarse bucket, XCD) at most: what 32 full fine sub-slabs hold (a coarse overflow is reported as a fine one: radix fallback)
+// the coarse slab lives in the gradient records' memory (64 B per Gaussian, free until the forward's last blend): 4 P slots, a quarter full
+__host__ __device__ inline uint32_t depth_coarse_cap(size_t P, uint32_t nb) { const size_t c = ((4 * P) / ((size_t)(nb >> BK_CSHIFT) * BK_XCD)) & ~(size_t)255; return (uint32_t)(c < (size_t)BK_CCAP_MAX ? c : (size_t)BK_CCAP_MAX); }
+constexpr int BK_NBC_MAX = BK_MAX_BUCKETS >> BK_CSHIFT;      // 256
+constexpr uint32_t BK_FINE_MASK = ((1u << BK_CSHIFT) - 1u) << 16;
+template <int BK_ITEMS_T, bool COARSE = false>
+__global__ void __launch_bounds__(256) GSRAST_BSCAT_OCC __attribute__((amdgpu_waves_per_eu(3)))      // (at least three waves per SIMD: 768 resident workgroups, ONE round at 3 M -- the coarse form came out at 177 VGPRs without it)
 depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                             uint32_t n, const uint32_t* __restrict__ zhist /* [ZH_COPIES][ZH_BINS]: sampled histogram of the visible depth keys (preprocess_fwd) */,
                             uint32_t zh_klo, int zh_shift /* its bins: 2^shift key steps each, from klo (gsrast_common.h) */,
@@ -530,11 +543,11 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                             // then lists that layer only; the completion pass behind the blend lists the rest into the tiles that did
                             // not saturate inside it.  zcut_used (uninitialised or all "none") is filled with that key here
                             int layer_mode = 0, const uint32_t* __restrict__ hint_sel = nullptr, float layer_frac = 0.125f,
-                            uint32_t* __restrict__ zcut_fill = nullptr)
+                            uint32_t* __restrict__ zcut_fill = nullptr, uint32_t ccap = 0 /* COARSE: slots per (coarse bucket, XCD) of the coarse slab (depth_coarse_cap) */)
 {
     // per-bucket counters of this workgroup, two 16-bit counters per word (a workgroup has 2048 elements): 16 KB instead of 32 -- with
     // the 4 KB of the bucket map and the 6 KB of cut depths this latency-bound kernel keeps five workgroups per compute unit
-    __shared__ uint32_t cnt[BK_MAX_BUCKETS / 2];
+    __shared__ uint32_t cnt[(COARSE ? BK_NBC_MAX : BK_MAX_BUCKETS) / 2];
     __shared__ uint32_t s_C[ZH_BINS + 1];          // running sum of (histogram + 1): strictly increasing
     __shared__ uint32_t s_fl[2];
     // the cut depths as maxima over cells of 2 x 2 tiles (4 x 4 / 8 x 8 for images of more than CUT_MAX_CELLS such cells), rounded UP to the 16 leading bits of the float (exponent + 7 mantissa bits:
@@ -551,7 +564,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     if (threadIdx.x == 0) { atomicAdd(&g_scat[15], 1ull); atomicMin(&g_scat[14], (unsigned long long)scat_t); }
 #endif
     if (threadIdx.x == 0) { s_late = 0u; s_fl[0] = 0xFFFFu; s_fl[1] = 0u; }
-    for (uint32_t k = threadIdx.x; k < nb / 2u; k += 256) cnt[k] = 0u;
+    for (uint32_t k = threadIdx.x; k < (COARSE ? nb >> BK_CSHIFT : nb) / 2u; k += 256) cnt[k] = 0u;
     // (the keys are requested first: their round trip passes under the construction of the bucket map)
     const uint32_t base = blockIdx.x * (256 * BK_ITEMS_T);
     uint32_t key[BK_ITEMS_T];
@@ -668,8 +681,9 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             const float u = __builtin_fmaf((float)(c1 - c0), fminf((float)fr * fscale, 0.99999994f), (float)c0);
             const uint32_t d = (uint32_t)(u * scale);
             dg[r] = d < nb ? d : nb - 1u;
-            const uint32_t sh = (dg[r] & 1u) * 16u;
-            lr[r] = (atomicAdd(&cnt[dg[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            const uint32_t cb = COARSE ? dg[r] >> BK_CSHIFT : dg[r];      // the bucket this workgroup ranks and reserves by
+            const uint32_t sh = (cb & 1u) * 16u;
+            lr[r] = (atomicAdd(&cnt[cb >> 1], 1u << sh) >> sh) & 0xFFFFu;
         }
     }
     // what travels with the element: coalesced, requested here so that the loads pass under the atomics' round trip below
@@ -685,13 +699,14 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
     SCAT_T(4);
     // one returning global atomic per non-empty bucket of this workgroup, sixteen in flight per lane (issued back to back: a loop
     // that stores each result before it asks for the next waits a full memory round trip per bucket)
-    uint32_t* gc = gcount + (size_t)xcd * nb;
-    for (uint32_t k0 = threadIdx.x; k0 < nb; k0 += 256 * 16) {      // (a lane owns counter k: a wave's atomics go to 64 consecutive words)
+    const uint32_t nres = COARSE ? nb >> BK_CSHIFT : nb;              // counters this workgroup reserves slots from
+    uint32_t* gc = gcount + (size_t)xcd * (COARSE ? (uint32_t)BK_NBC_MAX : nb);
+    for (uint32_t k0 = threadIdx.x; k0 < nres; k0 += 256 * 16) {      // (a lane owns counter k: a wave's atomics go to 64 consecutive words)
         uint32_t g[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const uint32_t k = k0 + u * 256;
-            const uint32_t c = k < nb ? (cnt[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu : 0u;
+            const uint32_t c = k < nres ? (cnt[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu : 0u;
             g[u] = 0xFFFFFFFFu;                                     // "no element of this workgroup in the bucket"
             if (c) g[u] = atomicAdd(&gc[k], c);
         }
@@ -702,7 +717,7 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             const uint32_t mine = g[u] < 0xFFFFu ? g[u] : 0xFFFFu;
             const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
             const uint32_t k = k0 + u * 256;
-            if (!(threadIdx.x & 1u) && k < nb) cnt[k >> 1] = mine | (other << 16);
+            if (!(threadIdx.x & 1u) && k < nres) cnt[k >> 1] = mine | (other << 16);
         }
     }
     SCAT_T(5);          // global atomics (thread 0's share)
@@ -731,8 +746,12 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
                 }
                 if (late) { wword |= LATE_BIT; nlate++; }
             }
-            const uint32_t pos = ((cnt[dg[r] >> 1] >> ((dg[r] & 1u) * 16u)) & 0xFFFFu) + lr[r];
-            if (pos < (uint32_t)BK_CAPX)
+            const uint32_t cb = COARSE ? dg[r] >> BK_CSHIFT : dg[r];
+            const uint32_t pos = ((cnt[cb >> 1] >> ((cb & 1u) * 16u)) & 0xFFFFu) + lr[r];
+            if (COARSE) {       // the element's width word (the fine bucket's low bits inside) and slot wait in registers: all stores leave together, below
+                rc[r].x = wword | ((dg[r] & ((1u << BK_CSHIFT) - 1u)) << 16);
+                lr[r] = pos;
+            } else if (pos < (uint32_t)BK_CAPX)
                 slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, wword, tl[r]);
             skipped = (wword & LATE_BIT) != 0u;
         }
@@ -741,6 +760,14 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             const uint32_t first = base + r * 256 + (threadIdx.x & ~63u);
             if (lane == 0 && first < n) color_skip[first >> 6] = m;
         }
+    }
+    if (COARSE) {
+        // (slab = the coarse slab [nb / 32][8][ccap].)  A workgroup's elements of one coarse bucket are a run of ~16 consecutive slots, stored by 16 different
+        // lanes: issued back to back here -- behind the late tests, not between them -- they reach the L2 within a microsecond of each other
+#pragma unroll
+        for (int r = 0; r < BK_ITEMS_T; r++)
+            if (key[r] != 0xFFFFFFFFu && lr[r] < ccap)
+                slab[((size_t)(dg[r] >> BK_CSHIFT) * BK_XCD + xcd) * ccap + lr[r]] = make_uint4(key[r], base + r * 256 + threadIdx.x, rc[r].x, tl[r]);
     }
     if (zcut_used) {
 #pragma unroll
@@ -768,6 +795,41 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             bkey_out[b] = k < 0 ? 0u : (k < (long long)ZH_KEY_TOP ? (uint32_t)k : ZH_KEY_TOP);
         }
     }
+}
+
+// Second launch of the two-launch scatter: workgroup (c, x) = (coarse bucket, XCD) moves its coarse sub-slab's elements into the 32 fine sub-slabs of XCD x.
+// It is the only writer of those sub-slabs and of their counters: ranks come from LDS, no global atomic; a coarse sub-slab that overflowed reports through the
+// fine counter of its first bucket (> BK_CAPX: the sort kernel raises the overflow flag, the host falls back to the radix sort).
+__global__ void __launch_bounds__(256)
+depth_bucket_refine_kernel(const uint4* __restrict__ cslab /* [nb / 32][8][ccap] */, const uint32_t* __restrict__ gccount /* [8][BK_NBC_MAX] */, uint32_t nb,
+                           uint32_t* __restrict__ gcount /* [8][nb] out */, uint4* __restrict__ slab /* [nb][8][BK_CAPX] out */, uint32_t ccap)
+{
+    __shared__ uint32_t cnt[1 << BK_CSHIFT];
+    const uint32_t x = blockIdx.x & (BK_XCD - 1), c = blockIdx.x >> 3;      // (workgroup b runs on XCD b mod 8: the XCD whose workgroups wrote these elements)
+    if (threadIdx.x < (1u << BK_CSHIFT)) cnt[threadIdx.x] = 0u;
+    const uint32_t n_true = gccount[(size_t)x * BK_NBC_MAX + c];
+    const uint32_t n = n_true < ccap ? n_true : ccap;
+    const uint4* src = cslab + ((size_t)c * BK_XCD + x) * ccap;
+    constexpr int RI = 8;            // elements per lane and pass: 2048 per pass -- one pass at the usual fill (~1500 at 3 M), two for a sub-slab near its capacity
+    __syncthreads();                 // (the counters are zero)
+    for (uint32_t e0 = 0; e0 < n; e0 += RI * 256) {
+        uint4 el[RI];
+#pragma unroll
+        for (int r = 0; r < RI; r++) { const uint32_t e = e0 + r * 256 + threadIdx.x; if (e < n) el[r] = src[e]; }
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const uint32_t e = e0 + r * 256 + threadIdx.x;
+            if (e < n) {
+                const uint32_t fb = (el[r].z >> 16) & ((1u << BK_CSHIFT) - 1u);
+                const uint32_t pos = atomicAdd(&cnt[fb], 1u);
+                if (pos < (uint32_t)BK_CAPX)
+                    slab[((size_t)((c << BK_CSHIFT) + fb) * BK_XCD + x) * BK_CAPX + pos] = make_uint4(el[r].x, el[r].y, el[r].z & ~BK_FINE_MASK, el[r].w);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (1u << BK_CSHIFT))
+        gcount[(size_t)x * nb + (c << BK_CSHIFT) + threadIdx.x] = (n_true > ccap && threadIdx.x == 0u) ? 0xFFFFu : cnt[threadIdx.x];
 }
 
 // One WAVE per bucket, no workgroup barrier anywhere: everything a bucket needs is wave-synchronous (LDS operations of one wave

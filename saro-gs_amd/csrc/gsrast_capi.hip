@@ -498,6 +498,7 @@ std::atomic<int> g_word_fork{getenv("GSRAST_WORD_FORK") ? 1 : 0};          // (G
 // small kernel in front of the blend backward; every other (pixel, Gaussian) pair gets exactly what it gets without the mutation).
 // bit 1: the background term of dL/dalpha (backward.cu:531-534) is dropped (the blend backward is handed a zero background).
 std::atomic<int> g_mutate{0};
+std::atomic<int> g_two_level{1} /* 1: the bucket scatter as two launches, coarse + refine (gsrast_binning.h; A/B switch) */, g_two_level_min_p{262144};
 __global__ void mutate_drop_front_batch_kernel(uint2* ranges, uint32_t* n_contrib, uint32_t* tile_max, uint32_t tile, int W, int H, int gx)
 {
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
@@ -846,6 +847,8 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
+    if (!strcmp(name, "two_level")) { g_two_level = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "two_level_min_p")) { g_two_level_min_p = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "mutate")) { g_mutate = value; return 0; }   // tests only: a deliberately WRONG backward (see g_mutate) -- proves that a parity bar bites
     if (!strcmp(name, "bwd_transposed")) { g_bwd_transposed = value ? 1 : 0; return 0; }
     if (!strcmp(name, "sort_hint")) { g_sort_hint = value ? 1 : 0; return 0; }
@@ -884,6 +887,8 @@ int gsrast_get_option(const char* name)
     if (!strcmp(name, "sparse_grec")) return g_sparse_grec.load();
     if (!strcmp(name, "word_fork")) return g_word_fork.load();
     if (!strcmp(name, "mutate")) return g_mutate.load();
+    if (!strcmp(name, "two_level")) return g_two_level.load();
+    if (!strcmp(name, "two_level_min_p")) return g_two_level_min_p.load();
     if (!strcmp(name, "stream_contexts")) return g_stream_contexts.load();          // (diagnostics: the rule of the word forks)
     if (!strcmp(name, "concurrent_callers")) return g_concurrent_callers.load() ? 1 : 0;
     if (!strcmp(name, "near_pose")) return g_near_pose.load();
@@ -1276,7 +1281,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             }
             if (tau_ctx_device < 0) GS_HIP(hipMemsetAsync(tau_hist, 0, words * sizeof(uint32_t), s));
         }
-        const int nzero = bucket_sort ? (int)nbk * BK_XCD : 0;
+        const int nzero = bucket_sort ? (int)nbk * BK_XCD + BK_XCD * BK_NBC_MAX : 0;      // (fine counters + the two-launch scatter's coarse ones, contiguous)
         if (rawin)
             preprocess_fwd_kernel<true><<<pf_grid, PF_THREADS, 0, s>>>(
                 P, means3D, scales, rotations, opacities, raw, cov3D_precomp, cam, radii, rec0, rec1, cov_dbg,
@@ -1308,12 +1313,23 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
                 const int items = depth_scatter_items((size_t)P);       // (elements per lane: whatever makes the launch ONE round of workgroups)
-                auto scatter = items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE> : depth_bucket_scatter_kernel<BK_ITEMS>;
-                scatter<<<(P + 256 * items - 1) / (256 * items), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, zhist_call, zh_klo, zh_shift, nbk, gcount, slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
+                // two-launch form (gsrast_binning.h, round 6): coarse scatter into the memory the sort will later write its orders to, then the refine kernel
+                const bool two = g_two_level.load() != 0 && (size_t)P >= (size_t)g_two_level_min_p.load();
+                auto scatter = two ? (items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE, true> : depth_bucket_scatter_kernel<BK_ITEMS, true>)
+                                   : (items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE, false> : depth_bucket_scatter_kernel<BK_ITEMS, false>);
+                // (the coarse slab: the gradient records' memory -- 64 B per Gaussian, nobody's until this forward's last blend; whoever zeroes or reads the records does so behind it)
+                uint4* cslab = reinterpret_cast<uint4*>(at<float>(geom, GL.grec));
+                const uint32_t ccap = depth_coarse_cap((size_t)P, nbk);
+                uint32_t* gccount = at<uint32_t>(geom, GL.bk_ccount);
+                scatter<<<(P + 256 * items - 1) / (256 * items), 256, 0, s>>>(kA, rect, tiles, (uint32_t)P, zhist_call, zh_klo, zh_shift, nbk, two ? gccount : gcount, two ? cslab : slab, at<uint32_t>(geom, GL.bk_key), scalars + SC_ZBINS,
                                                                                zcut_used, T, (uint32_t)cam.gx, scalars + SC_N_LATE,
                                                                                cut ? at<unsigned long long>(geom, GL.color_skip) : nullptr, (uint32_t)cut_cs,
-                                                                               layer_mode, hint_sel, 0.125f, zcut_used);
+                                                                               layer_mode, hint_sel, 0.125f, zcut_used, ccap);
                 GS_LAUNCHED("depth_bucket_scatter");
+                if (two) {
+                    depth_bucket_refine_kernel<<<(nbk >> BK_CSHIFT) * BK_XCD, 256, 0, s>>>(cslab, gccount, nbk, gcount, slab, ccap);
+                    GS_LAUNCHED("depth_bucket_refine");
+                }
                 // (List cut: the compacting colour kernel needs nothing but the scatter's late flags.  Forked HERE, beside the bucket sort and
                 // the emission, instead of behind the depth sort: 3 M 767 / 764 vs 763 / 762 views/s, 1 M 1219 / 1222 vs 1221 / 1220 -- equal.)
                 // list cut: only the bucket's EARLY Gaussians are sorted (into the early set); the late ones count into bk_info's totals

@@ -47,7 +47,7 @@ constexpr int REC_STRIDE = GSRAST_REC_STRIDE;      // float4 steps between two G
 // stores at a 64-byte stride cost it 0.068 -> 0.118 ms: 1 stays)
 struct GeomLayout {
     size_t rec0, rec1, rec2, cov3D, clamped, tiles, rect, binrec, keyA, keyB, valA, valB, offsets, woffsets,
-        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zhist, bk_key, bk_count, bk_slab, bk_order, bk_wincl, bk_info, bk_base,
+        hist, scan_tmp, scalars, grec, keyC, valC, sort_minmax, shdA, shdB, shdC, zhist, bk_key, bk_count, bk_ccount /* u32[8][256]: counters of the two-launch scatter's coarse level, right behind bk_count (zeroed with it) */, bk_slab, bk_order, bk_wincl, bk_info, bk_base,
         bk_order_e, bk_wincl_e, bk_info_e, bk_base_e /* the same four over the EARLY Gaussians only, compact (list cut, below) */,
         color_skip /* u64[ceil(P / 64)]: bit i = Gaussian i is culled or late (list cut): the colour kernel skips it */,
         cand_bits /* u64[ceil(P / 64)]: bit i = Gaussian i touches a tile the completion pass lists again */,
@@ -292,6 +292,7 @@ static inline GeomLayout geom_layout(size_t P)
     {
         const size_t nb = Pp >= BUCKET_SORT_MIN_P ? depth_buckets_host(Pp) : 0;
         L.bk_count = take(nb * 8 * 4);                       // [8 XCDs][nb]
+        L.bk_ccount = take(8 * 256 * 4);                     // [8 XCDs][256 coarse buckets] (two-launch scatter, gsrast_binning.h); contiguous with bk_count: nb * 32 bytes is a multiple of 256
         L.bk_slab = take(nb * GSRAST_BK_CAP * 16);           // [nb][8][CAP / 8] {key, id, width, tiles}
         L.bk_order = take(nb * GSRAST_BK_CAP * 4); L.bk_wincl = take(nb * GSRAST_BK_CAP * 4);
         L.bk_info = take(nb * 16); L.bk_base = take(nb * 4); L.bk_key = take((nb + 1) * 4);

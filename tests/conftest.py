@@ -70,6 +70,22 @@ def _predicted_cut_switch(request):
         _r._C.set_option("tau_cut", 1)
 
 
+@pytest.fixture(params=["two_launch_scatter", "one_launch_scatter"])
+def scatter_form(request):
+    """Both forms of the bucket depth sort's scatter (csrc/gsrast_binning.h, round 6): two launches (coarse + refine; the default from 262 144 Gaussians on,
+    forced here at every size) and one launch (rounds 2-5).  Same slabs, same counters, same lists."""
+    import diff_gaussian_rasterization_ch3 as _r
+    _C = _r._C
+    two = request.param == "two_launch_scatter"
+    _C.set_option("two_level", 1 if two else 0)
+    _C.set_option("two_level_min_p", 0)
+    try:
+        yield request.param
+    finally:
+        _C.set_option("two_level", 1)
+        _C.set_option("two_level_min_p", 262144)
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import oracle as _orc

@@ -351,7 +351,7 @@ def test_depth_sort_pass_hint_follows_the_scene(orc, scenes, rast, gpu):
 
 
 @pytest.mark.remembered_cut_only
-def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu):
+def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu, scatter_form):
     """The default depth sort puts the Gaussians into ~P/256 depth buckets of fixed capacity (of equal population by a sampled depth
     histogram, round 4).  A scene whose depths pile up beyond any histogram's resolution -- here
     three thin sheets facing the camera, 20 000 Gaussians at (nearly) one depth each -- overflows a bucket: the device reports it
@@ -401,7 +401,7 @@ def test_bucket_depth_sort_overflow_falls_back_to_radix(orc, scenes, rast, gpu):
 
 
 @pytest.mark.remembered_cut_only
-def test_bucket_depth_sort_ties_fall_in_index_order(orc, scenes, rast, gpu):
+def test_bucket_depth_sort_ties_fall_in_index_order(orc, scenes, rast, gpu, scatter_form):
     """Every Gaussian twice (same mean, different appearance): all depth keys come in equal pairs.  The bucket sort orders a bucket by
     (depth bits, index), so the lists equal the oracle's stable 64-bit key sort entry by entry -- and no bucket overflows."""
     from gpu_harness import run_hip
@@ -423,7 +423,7 @@ def test_bucket_depth_sort_ties_fall_in_index_order(orc, scenes, rast, gpu):
 
 
 @pytest.mark.remembered_cut_only
-def test_bucket_depth_sort_edge_populations(orc, scenes, rast, gpu):
+def test_bucket_depth_sort_edge_populations(orc, scenes, rast, gpu, scatter_form):
     """Bucket-sort path (P >= 32768) with nothing visible, with one visible Gaussian, and with all visible Gaussians at exactly one depth
     among culled ones: outputs equal the oracle; an empty scene renders the background."""
     from gpu_harness import run_hip
@@ -448,7 +448,7 @@ def test_bucket_depth_sort_edge_populations(orc, scenes, rast, gpu):
 
 
 @pytest.mark.remembered_cut_only
-def test_bucket_depth_sort_with_an_undersized_speculative_launch(orc, scenes, rast, gpu):
+def test_bucket_depth_sort_with_an_undersized_speculative_launch(orc, scenes, rast, gpu, scatter_form):
     """The bucket sort leaves the instance counts to the run emission of the speculative launch.  A view with far more instances than
     the context's capacity hint: the emission is bounded by the capacity, the counts still come out right, the launch is repeated with
     exact sizes (one redo) and the lists equal the oracle's; then a small view inside the oversized capacity."""
@@ -472,7 +472,7 @@ def test_bucket_depth_sort_with_an_undersized_speculative_launch(orc, scenes, ra
 
 
 @pytest.mark.remembered_cut_only
-def test_bucket_depth_sort_equalises_a_peaked_depth_distribution(orc, scenes, rast, gpu):
+def test_bucket_depth_sort_equalises_a_peaked_depth_distribution(orc, scenes, rast, gpu, scatter_form):
     """Round 4: the depth buckets are cut by a sampled depth histogram (equal population), not into equal depth intervals.  A scene
     with 70 % of its Gaussians in a layer 0.06 deep (a wall facing the camera, normal depth profile, sigma 0.03 of a depth range of
     3.3) put ten times a bucket's capacity into a few equal-width buckets (10 000 in one of 512); now the first forward of the

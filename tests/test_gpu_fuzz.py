@@ -25,7 +25,7 @@ def _config(seed, large=False):
 
 
 @pytest.mark.parametrize("seed", range(100, 112))
-def test_random_configuration_at_bucket_sort_sizes(seed, orc, scenes, rast, gpu):
+def test_random_configuration_at_bucket_sort_sizes(seed, orc, scenes, rast, gpu, scatter_form):
     """The same sweep at Gaussian counts that take the bucket depth sort (P >= 32768) -- the context carries its capacity hints from
     one random configuration to the next, so undersized speculative launches and their repeats are part of it."""
     # ... and so are the list cut's depths (include/gsrast.h: options.no_list_cut), forced on here: the seven camera poses come back with
