@@ -748,9 +748,14 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             }
             const uint32_t cb = COARSE ? dg[r] >> BK_CSHIFT : dg[r];
             const uint32_t pos = ((cnt[cb >> 1] >> ((cb & 1u) * 16u)) & 0xFFFFu) + lr[r];
-            if (COARSE) {       // the element's width word (the fine bucket's low bits inside) and slot wait in registers: all stores leave together, below
-                rc[r].x = wword | ((dg[r] & ((1u << BK_CSHIFT) - 1u)) << 16);
+            if (COARSE) {       // (slab = the coarse slab [nb / 32][8][ccap]; the fine bucket's low bits travel in the width word)
+#ifdef GSRAST_SCAT_BATCH_STORES
+                rc[r].x = wword | ((dg[r] & ((1u << BK_CSHIFT) - 1u)) << 16);      // (A/B: all stores behind the late tests, below)
                 lr[r] = pos;
+#else
+                if (pos < ccap)
+                    slab[((size_t)cb * BK_XCD + xcd) * ccap + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, wword | ((dg[r] & ((1u << BK_CSHIFT) - 1u)) << 16), tl[r]);
+#endif
             } else if (pos < (uint32_t)BK_CAPX)
                 slab[((size_t)dg[r] * BK_XCD + xcd) * BK_CAPX + pos] = make_uint4(key[r], base + r * 256 + threadIdx.x, wword, tl[r]);
             skipped = (wword & LATE_BIT) != 0u;
@@ -761,14 +766,17 @@ depth_bucket_scatter_kernel(const uint32_t* __restrict__ keys, const uint2* __re
             if (lane == 0 && first < n) color_skip[first >> 6] = m;
         }
     }
+#ifdef GSRAST_SCAT_BATCH_STORES
     if (COARSE) {
-        // (slab = the coarse slab [nb / 32][8][ccap].)  A workgroup's elements of one coarse bucket are a run of ~16 consecutive slots, stored by 16 different
-        // lanes: issued back to back here -- behind the late tests, not between them -- they reach the L2 within a microsecond of each other
+        // A/B (round 6, measured and dropped): a workgroup's elements of one coarse bucket are a run of ~16 consecutive slots stored by 16 different lanes; issued
+        // back to back here -- behind the late tests, not between them -- WRITE_SIZE 107 -> 96 MB, but the kernel 58 -> 70 us (the burst of stores waits where
+        // the interleaved form overlaps them with the late tests' LDS reads)
 #pragma unroll
         for (int r = 0; r < BK_ITEMS_T; r++)
             if (key[r] != 0xFFFFFFFFu && lr[r] < ccap)
                 slab[((size_t)(dg[r] >> BK_CSHIFT) * BK_XCD + xcd) * ccap + lr[r]] = make_uint4(key[r], base + r * 256 + threadIdx.x, rc[r].x, tl[r]);
     }
+#endif
     if (zcut_used) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) nlate += __shfl_xor(nlate, d, 64);
