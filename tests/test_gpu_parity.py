@@ -64,7 +64,7 @@ def _check_forward_exact(o, h, clipped=False):
 
 
 def _check_grads(o64, o32, h, names, strict=False, conditioning=False):
-    """Every gradient tensor within conftest.grad_tol of the fp64 truth: max(1e-5 * max|ref| + 1e-4 * |ref|, 4 x the fp32 oracle's own
+    """Every gradient tensor within conftest.grad_tol of the fp64 truth: max(1e-5 * max|ref| + 1e-4 * |ref|, 8 x the fp32 oracle's own
     worst error on the tensor) -- the same bar whatever the upstream gradient's scale (`strict` / `conditioning` are kept for the call
     sites' sake: rounds 1-5 used an ABSOLUTE 1e-5 with `strict`, which at the bench's N(0,1)/(3HW) upstream gradient was 40 % of the
     largest entry of dL/dsh, and applied the fp32 floor only to needle-shaped scenes)."""
@@ -73,7 +73,7 @@ def _check_grads(o64, o32, h, names, strict=False, conditioning=False):
         ref = o64[k].astype(np.float64)
         got = h[k].astype(np.float64).reshape(ref.shape)
         err = np.abs(got - ref)
-        tol = grad_tol(ref, o32[k])      # (incl. the fp32 floor: 4x the fp32 oracle's own worst error on this tensor -- see conftest.grad_tol)
+        tol = grad_tol(ref, o32[k])      # (incl. the fp32 floor: 8x the fp32 oracle's own worst error on this tensor -- see conftest.grad_tol)
         if os.environ.get("GSRAST_GRAD_REPORT"):      # development: print how far both fp32 evaluations are from the bar instead of asserting
             e32 = np.abs(o32[k].astype(np.float64) - ref)
             w = np.unravel_index(np.argmax(err / np.maximum(tol, 1e-300)), err.shape)
