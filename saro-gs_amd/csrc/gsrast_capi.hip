@@ -498,7 +498,7 @@ std::atomic<int> g_word_fork{getenv("GSRAST_WORD_FORK") ? 1 : 0};          // (G
 // small kernel in front of the blend backward; every other (pixel, Gaussian) pair gets exactly what it gets without the mutation).
 // bit 1: the background term of dL/dalpha (backward.cu:531-534) is dropped (the blend backward is handed a zero background).
 std::atomic<int> g_mutate{0};
-std::atomic<int> g_two_level{1} /* 1: the bucket scatter as two launches, coarse + refine (gsrast_binning.h; A/B switch) */, g_two_level_min_p{262144};
+std::atomic<int> g_two_level{1} /* 1: the bucket scatter as two launches, coarse + refine (gsrast_binning.h; A/B switch) */, g_two_level_min_p{2500000} /* measured (kernel times, one box): 0.3 M 16.1 us in one launch against 15.8 + 5.7 in two, 1 M 41.0 against 36.6 + 9.1, 3 M 88.2 against 60.5 + 19.9: the second launch only pays where the scattered stores dominate */;
 __global__ void mutate_drop_front_batch_kernel(uint2* ranges, uint32_t* n_contrib, uint32_t* tile_max, uint32_t tile, int W, int H, int gx)
 {
     const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;

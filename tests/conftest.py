@@ -73,7 +73,7 @@ def _predicted_cut_switch(request):
 
 @pytest.fixture(params=["two_launch_scatter", "one_launch_scatter"])
 def scatter_form(request):
-    """Both forms of the bucket depth sort's scatter (csrc/gsrast_binning.h, round 6): two launches (coarse + refine; the default from 262 144 Gaussians on,
+    """Both forms of the bucket depth sort's scatter (csrc/gsrast_binning.h, round 6): two launches (coarse + refine; the default from 2.5 M Gaussians on,
     forced here at every size) and one launch (rounds 2-5).  Same slabs, same counters, same lists."""
     import diff_gaussian_rasterization_ch3 as _r
     _C = _r._C
@@ -84,7 +84,7 @@ def scatter_form(request):
         yield request.param
     finally:
         _C.set_option("two_level", 1)
-        _C.set_option("two_level_min_p", 262144)
+        _C.set_option("two_level_min_p", 2500000)
 
 
 @pytest.fixture(scope="session")

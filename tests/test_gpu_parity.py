@@ -275,6 +275,8 @@ def test_golden_fixture(rast, gpu):
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"):
             ref = z["f64_" + k]
             err = np.abs(h[k].astype(np.float64).reshape(ref.shape) - ref)
+            if os.environ.get("GSRAST_GRAD_REPORT"):
+                print(f"GRAD_REPORT golden {os.path.basename(f)} {k}: worst err / tol {float((err / np.maximum(grad_tol(ref), 1e-300)).max()):.3f}", flush=True)
             assert (err <= grad_tol(ref)).all(), (f, k, err.max())
 
 
