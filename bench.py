@@ -111,6 +111,7 @@ class Workload:
         self.step_no = 0
         self.leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
         self.means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+        self.params = list(self.leaves.values()) + [self.means2D]
         self.g = t(scenes.upstream_grad(H, W, 1))
         self.raster = self.rasters[0]
         self.dev = dev
@@ -119,15 +120,20 @@ class Workload:
 
     def step(self, bucket=None, world=1):
         L = self.leaves
-        for p in list(L.values()) + [self.means2D]:
-            p.grad = None
         if bucket is not None:
+            for p in self.params:
+                p.grad = None
             bucket.zero_grad()          # start of a step: this backward writes into the arena (GradArena contract)
         raster = self.rasters[self.step_no % len(self.rasters)]
         self.step_no += 1
         color, radii, depth = raster(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"],
                                      shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)
+        if bucket is None:
+            # optimizer.zero_grad(set_to_none=True) where the reference's loop has it: at the END of the iteration (train.py:221), behind the backward's
+            # launches -- the host does it while the GPU works, not in front of the next forward's first launch
+            for p in self.params:
+                p.grad = None
         if bucket is not None and (world > 1 or self.vp.collectives_active()):      # (a one-rank group with forced collectives: tests/test_gpu_rccl.py)
             # the backward wrote the leaf gradients straight into the bucket (zero-copy GradArena)
             if getattr(bucket, "sh_factors", False):

@@ -507,9 +507,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             rendered = L.gsrast_forward_ex(
                 _current_context(), C.byref(_options_struct(forward_only=forward_only)),       # context: the innermost `with Context()` of the calling thread, else the thread's own
                 *arena.forward_allocators(P, W, H),
-                P, int(degree), M, _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
-                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                P, int(degree), M, background.data_ptr(), W, H, means3D.data_ptr(), _ptr(sh), _ptr(colors), opacity.data_ptr(),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(),
+                projmatrix.data_ptr(), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                 out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii), stream)
         if rendered < 0:
             raise _err(rendered, "gsrast_forward")

@@ -40,7 +40,7 @@ def test_word_forks_change_nothing(scenes, rast, gpu):
             torch.cuda.synchronize()
             outs.setdefault(wf, []).append(res)
     finally:
-        _C.set_option("word_fork", 1)
+        _C.set_option("word_fork", 0)          # (the library's default since round 6: opt-in)
     assert _C.context_query("last_late") > P // 8          # (the cut was in force)
     for a, b in zip(outs[1][0] + outs[1][1], outs[0][0] + outs[0][1]):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])

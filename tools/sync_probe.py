@@ -55,3 +55,33 @@ names = ("step", "python before fwd C call", "fwd C call", "python between", "bw
 for k, n in enumerate(names):
     print("%-28s median %8.1f us   min %8.1f" % (n, statistics.median(r[k] for r in rows) * 1e6, min(r[k] for r in rows) * 1e6))
 print("%-28s median %8.1f us   min %8.1f   (inside the fwd C call: entry -> first kernel launched)" % ("C prologue", statistics.median(prologue) * 1e6, min(prologue) * 1e6))
+
+# ---- second pass: where inside "python before fwd C call" (wrappers around the layers of the binding) ----
+import diff_gaussian_rasterization_ch3 as R  # noqa: E402
+stamps = {}
+
+
+def stamp_on_entry(obj, attr, name):
+    fn = getattr(obj, attr)
+
+    def w(*a, **k):
+        stamps[name] = time.perf_counter()
+        return fn(*a, **k)
+    setattr(obj, attr, w)
+
+
+stamp_on_entry(R.GaussianRasterizer, "forward", "module.forward")
+stamp_on_entry(R._RasterizeGaussians, "forward", "autograd.forward")
+stamp_on_entry(_C, "rasterize_gaussians", "_C.rasterize_gaussians")
+stamp_on_entry(_C._Arena, "acquire", "arena.acquire")
+rows = []
+for i in range(N):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl.step(None, 1)
+    torch.cuda.synchronize()
+    if i >= N // 4:
+        rows.append((stamps["module.forward"] - t0, stamps["autograd.forward"] - stamps["module.forward"], stamps["_C.rasterize_gaussians"] - stamps["autograd.forward"],
+                     stamps["arena.acquire"] - stamps["_C.rasterize_gaussians"], marks["fwd_in"] - stamps["arena.acquire"]))
+for k, n in enumerate(("step() -> Module.forward", "-> autograd Function.forward (apply)", "-> _C.rasterize_gaussians", "-> arena.acquire (checks, 3 torch.empty)", "-> C call (allocators, options, pointers)")):
+    print("  %-44s median %6.1f us" % (n, statistics.median(r[k] for r in rows) * 1e6))
