@@ -12,6 +12,7 @@ There is NO fallback: if the shared library is missing or a tensor is not on a G
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 import threading
 from typing import List, Optional, Tuple
@@ -72,6 +73,7 @@ def current_options() -> dict:
 
 
 _options_cache: dict = {}
+_options_epoch = itertools.count(1)
 
 
 def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = None, grads_zeroed: bool = False,
@@ -79,7 +81,9 @@ def _options_struct(sh_grad_factors: bool = False, options: Optional[dict] = Non
     """The gsrast_options value of one call.  The library copies it at entry, so one struct per distinct combination is built once and
     reused (round 6: fourteen setattr on a fresh ctypes Structure were ~8 us of every call's host time in front of the first launch)."""
     src = _thread_options() if options is None else options
-    key = (tuple(src.items()), bool(sh_grad_factors), bool(grads_zeroed), int(backward_phase), bool(forward_only))
+    # (the calling thread's own dict is identified by its version -- bumped by set_option -- instead of by its fourteen items)
+    ident = ("tls", getattr(_tls, "options_version", 0)) if options is None else tuple(src.items())      # (0 = the defaults; every set_option draws a process-wide unique number)
+    key = (ident, bool(sh_grad_factors), bool(grads_zeroed), int(backward_phase), bool(forward_only))
     o = _options_cache.get(key)
     if o is None:
         o = OptionsStruct()
@@ -331,7 +335,7 @@ def _export_touched(ar: "GradArena", P: int, geomBuffer: torch.Tensor, dev: torc
     if t is None or t.numel() != P or t.device != dev:
         t = ar.touched = torch.empty(P, dtype=torch.uint8, device=dev)
     with _on_device(dev):
-        rc = lib().gsrast_touched_rows(P, _ptr(geomBuffer), t.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib().gsrast_touched_rows(P, _ptr(geomBuffer), t.data_ptr(), _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_touched_rows")
     ar.touched_fresh = True
@@ -364,6 +368,17 @@ def set_touched_ready_hook(fn) -> None:
 
 
 POISON_STATE_BUFFERS = bool(int(os.environ.get("GSRAST_POISON_STATE", "0")))      # tests: every state buffer is handed out filled with 0xFF bytes (NaN as floats, all-ones as bits / indices)
+
+
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_of(dev: torch.device) -> int:
+    """The raw handle of torch's current stream on `dev` (what every launch of a call goes to).  torch.cuda.current_stream(dev).cuda_stream builds a
+    Stream object per call (~3 us); torch's own raw accessor -- the one its compiled-code launchers use -- returns the handle directly."""
+    if _get_raw_stream is not None and dev.index is not None:
+        return _get_raw_stream(dev.index)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 class PreallocStruct(C.Structure):
@@ -503,7 +518,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     arena = _Arena.acquire(dev)
     try:
         with _on_device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = _stream_of(dev)
             rendered = L.gsrast_forward_ex(
                 _current_context(), C.byref(_options_struct(forward_only=forward_only)),       # context: the innermost `with Context()` of the calling thread, else the thread's own
                 *arena.forward_allocators(P, W, H),
@@ -579,7 +594,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_drotations = out("rotations", (P, 4), not use_sr)
     if P != 0:
         with _on_device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = _stream_of(dev)
             sh_out = ar.factor.data_ptr() if factors else _ptr(dL_dsh)
             radii_c = radii.contiguous()
 
@@ -664,7 +679,7 @@ def rasterize_gaussians_raw(background, raw: dict, scale_modifier, viewmatrix, p
                 *arena.forward_allocators(P, W, H),
                 P, int(degree), M, _ptr(background), W, H, C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), out_color.data_ptr(), out_depth.data_ptr(), _ptr(radii),
-                torch.cuda.current_stream(dev).cuda_stream)
+                _stream_of(dev))
         if rendered < 0:
             raise _err(rendered, "gsrast_forward_raw")
         return rendered, out_color, radii, arena.tensor(0), arena.tensor(1), arena.tensor(2), out_depth
@@ -735,7 +750,7 @@ def rasterize_gaussians_raw_backward(background, raw: dict, radii, scale_modifie
                     C.byref(_options_struct(options=options, grads_zeroed=first_backward, backward_phase=phase)), P, int(degree), M, int(R),
                     _ptr(background), W, H, C.byref(st), float(scale_modifier), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                     float(tan_fovx), float(tan_fovy), _ptr(radii_c), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
-                    _ptr(dL_dout_color), C.byref(gs), torch.cuda.current_stream(dev).cuda_stream)
+                    _ptr(dL_dout_color), C.byref(gs), _stream_of(dev))
 
             if factors:
                 # which rows this view can touch is known since the forward's blend (its untouched bits): exported BEFORE the backward
@@ -794,7 +809,7 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
             rc = L.gsrast_sh_grad_combine_union(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
                                                 int(chunk_stride if chunk_stride is not None else arena.chunk), int(idx.numel()),
                                                 idx.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
-                                                torch.cuda.current_stream(dev).cuda_stream)
+                                                _stream_of(dev))
         if rc != 0:
             raise _err(rc, "gsrast_sh_grad_combine_union")
         return whole if whole is not None else (dc, rest)
@@ -807,7 +822,7 @@ def sh_grad_combine(arena: "GradArena", means3D: torch.Tensor, chunks: torch.Ten
         rc = L.gsrast_sh_grad_combine_rows(P, int(arena.last_degree), M, int(n_views), means3D.data_ptr(), chunks.data_ptr(),
                                            int(chunk_stride if chunk_stride is not None else arena.chunk), int(P if rows is None else rows),
                                            None if row_of is None else row_of.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
-                                           torch.cuda.current_stream(dev).cuda_stream)
+                                           _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_sh_grad_combine_rows")
     return whole if whole is not None else (dc, rest)
@@ -825,7 +840,7 @@ def rows_pack(idx: torch.Tensor, arrays, packed: torch.Tensor, unpack: bool = Fa
     dev = packed.device
     with _on_device(dev):
         fn = lib().gsrast_rows_unpack if unpack else lib().gsrast_rows_pack
-        rc = fn(n, idx.data_ptr(), k, ptrs, wid, packed.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        rc = fn(n, idx.data_ptr(), k, ptrs, wid, packed.data_ptr(), _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_rows_pack")
     return packed
@@ -854,7 +869,7 @@ def grad_rows_pack(arena: "GradArena", touched: torch.Tensor, rows: torch.Tensor
     dev = rows.device
     with _on_device(dev):
         rc = lib().gsrast_grad_rows_pack(arena.P, touched.data_ptr(), _dense_ptrs(arena), arena.factor.data_ptr(), rows.data_ptr(),
-                                         int(rows.shape[0]) - 1, torch.cuda.current_stream(dev).cuda_stream)
+                                         int(rows.shape[0]) - 1, _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_grad_rows_pack")
 
@@ -866,7 +881,7 @@ def grad_rows_clear(arena: "GradArena", chunks: torch.Tensor, dense: bool, sh: b
     dev = chunks.device
     with _on_device(dev):
         rc = lib().gsrast_grad_rows_clear(arena.P, chunks.data_ptr(), n, (1 + cap) * GRAD_ROW_WORDS, cap, _dense_ptrs(arena) if dense else None, arena.M,
-                                          _ptr(whole), _ptr(dc), _ptr(rest), torch.cuda.current_stream(dev).cuda_stream)
+                                          _ptr(whole), _ptr(dc), _ptr(rest), _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_grad_rows_clear")
 
@@ -878,7 +893,7 @@ def grad_rows_add(arena: "GradArena", chunk: torch.Tensor, means3D: torch.Tensor
     with _on_device(dev):
         rc = lib().gsrast_grad_rows_add(arena.P, chunk.data_ptr(), int(chunk.shape[0]) - 1, _dense_ptrs(arena), int(arena.last_degree), arena.M,
                                         means3D.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest),
-                                        torch.cuda.current_stream(dev).cuda_stream)
+                                        _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_grad_rows_add")
 
@@ -893,7 +908,7 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
                                            ((means3D, "means3D"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix")))
         with _on_device(dev):
             rc = lib().gsrast_mark_visible(P, means3D.data_ptr(), viewmatrix.data_ptr(), projmatrix.data_ptr(),
-                                           present.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                           present.data_ptr(), _stream_of(dev))
         if rc != 0:
             raise _err(rc, "gsrast_mark_visible")
     return present
@@ -913,6 +928,7 @@ def set_option(name: str, value: int) -> None:
                 _thread_options()[n] = value
             else:
                 _thread_options()[n] = 1 if value else 0
+        _tls.options_version = next(_options_epoch)          # (a new, process-wide unique identity for the cached option structs)
         return
     if lib().gsrast_set_option(name.encode(), value) != 0:
         raise ValueError(f"gsrast: unknown option or bad value: {name}={value}")
@@ -1050,7 +1066,7 @@ def debug_export(P: int, R: int, W: int, H: int, geomBuffer, binningBuffer, imag
             out["means2D"].data_ptr(), out["cov3D"].data_ptr() if keep_cov else None, out["conic_opacity"].data_ptr(),
             out["rgb"].data_ptr(), out["clamped"].data_ptr(), out["tiles_touched"].data_ptr(),
             _ptr(out["keys_sorted"]), _ptr(out["point_list"]), out["ranges"].data_ptr(),
-            out["final_T"].data_ptr(), out["n_contrib"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            out["final_T"].data_ptr(), out["n_contrib"].data_ptr(), _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_debug_export")
     return out
