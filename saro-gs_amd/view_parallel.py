@@ -319,7 +319,7 @@ def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> 
         cmax = send[0, :1].clone()
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
         cap = int(cmax.item())                                         # (host synchronisation: every rank learns the same cap)
-    if not getattr(arena, "_gather_armed", False) and _ASYNC_CAPACITY:     # from the next backward on: the capacity is agreed on early
+    if not getattr(arena, "_gather_armed", False) and _ASYNC_CAPACITY and not getattr(arena, "_gather_no_async", False):     # from the next backward on: the capacity is agreed on early
         arena._gather_armed = True
         _C.set_touched_ready_hook(_touched_hook)
     mine = send[: 1 + cap]
@@ -366,6 +366,7 @@ def _check_gather_overflow(arena) -> None:
     seen = int(arena._ovf_host[0])
     if seen > cap:
         _disarm_gather(arena)
+        arena._gather_no_async = True   # (never armed again: this arena's capacities are agreed on synchronously from here on)
         raise RuntimeError(f"exchange_gradients(sparse='gather'): a rank touched {seen} rows in the previous step but the agreed capacity was {cap}: "
                            "gradient rows were dropped.  The ranks' backward / exchange sequences have diverged (every rank must run exactly one "
                            "backward into the arena per exchange); the capacity is agreed on synchronously from here on")

@@ -149,3 +149,43 @@ def test_sh_grad_combine_union_writes_the_union_only(M, deg, rast, gpu):
     keep2 = torch.ones(P, dtype=torch.bool, device=gpu)
     keep2[idx2] = False
     assert bool((sh2[keep2] == 0).all()) and bool((sh2[idx2] != 0).any())
+
+
+def test_grad_rows_clear_and_add_skip_indices_past_the_arrays(rast, gpu):
+    """ABI 5: the indices inside a chunk come from a peer.  A row whose index is >= P -- a damaged or stale chunk -- is skipped by
+    gsrast_grad_rows_clear and gsrast_grad_rows_add; the rows in range are processed as ever and nothing outside the arena changes."""
+    _C = rast._C
+    P, M, deg = 3000, 16, 3
+    arena = _C.GradArena(P, M, gpu, sh_factors=True, world=1)
+    arena.last_degree = deg
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for sg in arena.dense_segments():
+        sg.copy_(torch.randn(sg.shape, generator=g))
+    sh = _C._arena_sh_arrays(arena)[0].view(P, -1)
+    sh.fill_(1.0)
+    means = torch.randn((P, 3), generator=g).to(gpu)
+    n = 8
+    chunk = torch.zeros((1 + n, 16), dtype=torch.int32, device=gpu)
+    chunk[0, 0] = n
+    chunk[0, 1:4] = torch.tensor([0.0, 0.0, 5.0], device=gpu).view(torch.int32)
+    idx = torch.tensor([5, P, 17, P + 12345, 2_000_000_000, P - 1, 0x7FFFFFFF, 44], dtype=torch.int32)      # four good rows, four far outside
+    chunk[1:, 0] = idx.to(gpu)
+    chunk[1:, 1:15] = torch.ones((n, 14), device=gpu).view(torch.int32)
+    guard = torch.full((1 << 20,), 7.0, device=gpu)            # (something allocated behind the arena: must keep its contents)
+    dense0 = [sg.clone() for sg in arena.dense_segments()]
+    good = torch.tensor([5, 17, P - 1, 44], device=gpu)
+    _C.grad_rows_add(arena, chunk, means, 1.0)
+    torch.cuda.synchronize()
+    for sg, d0 in zip(arena.dense_segments(), dense0):
+        want = d0.clone()
+        want[good] += 1.0
+        assert torch.allclose(sg, want)
+    changed = (sh != 1.0).any(dim=1)
+    assert set(torch.nonzero(changed).flatten().tolist()) == {5, 17, 44, P - 1}
+    _C.grad_rows_clear(arena, chunk.unsqueeze(0), dense=True, sh=True)
+    torch.cuda.synchronize()
+    for sg, d0 in zip(arena.dense_segments(), dense0):
+        keep = torch.ones(P, dtype=torch.bool, device=gpu)
+        keep[good] = False
+        assert bool((sg[good] == 0).all()) and torch.equal(sg[keep], d0[keep])
+    assert bool((sh[good] == 0).all()) and bool((guard == 7.0).all())

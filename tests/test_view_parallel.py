@@ -578,7 +578,7 @@ def test_gather_capacity_event_is_only_taken_from_the_last_backward_and_overflow
     b._ovf_host, b._ovf_pending, b._gather_armed = torch.tensor([17], dtype=torch.int32), (None, 16), True
     with pytest.raises(RuntimeError, match="rows were dropped"):
         vp._check_gather_overflow(b)
-    assert b._gather_armed is False and b._ovf_pending is None
+    assert b._gather_armed is False and b._ovf_pending is None and b._gather_no_async is True
     b._ovf_host, b._ovf_pending = torch.tensor([16], dtype=torch.int32), (None, 16)
     vp._check_gather_overflow(b)        # count == capacity: fine
     # (a) is a property of _exchange_gather's own code path: the event's tag against the arena's backward counter
