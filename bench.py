@@ -112,6 +112,7 @@ class Workload:
         self.leaves = {k: t(sc[k]).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
         self.means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
         self.params = list(self.leaves.values()) + [self.means2D]
+        self.keep_grads = False      # True: a caller that reads the leaves' .grad after step() (tests): they are cleared at the START of the next step instead
         self.g = t(scenes.upstream_grad(H, W, 1))
         self.raster = self.rasters[0]
         self.dev = dev
@@ -120,16 +121,17 @@ class Workload:
 
     def step(self, bucket=None, world=1):
         L = self.leaves
-        if bucket is not None:
+        if bucket is not None or self.keep_grads:
             for p in self.params:
                 p.grad = None
+        if bucket is not None:
             bucket.zero_grad()          # start of a step: this backward writes into the arena (GradArena contract)
         raster = self.rasters[self.step_no % len(self.rasters)]
         self.step_no += 1
         color, radii, depth = raster(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"],
                                      shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
         color.backward(self.g)
-        if bucket is None:
+        if bucket is None and not self.keep_grads:
             # optimizer.zero_grad(set_to_none=True) where the reference's loop has it: at the END of the iteration (train.py:221), behind the backward's
             # launches -- the host does it while the GPU works, not in front of the next forward's first launch
             for p in self.params:

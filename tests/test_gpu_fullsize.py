@@ -717,6 +717,7 @@ def test_stale_gradient_records_at_full_size(scenes, rast, gpu):
     _C = rast._C
     P, W, H = 3_000_000, 1920, 1080
     wl = bench.Workload(rast, scenes, P, W, H, 3, view_k=1, n_views=8, dev=gpu)
+    wl.keep_grads = True            # (this test reads the leaves' .grad after step())
     for _ in range(3):
         wl.step(None, 1)            # (the context learns its launch sizes and the pose's cut depths)
     ref = None
