@@ -163,3 +163,25 @@ def test_bench_final_line_is_compact_and_carries_the_contract():
     fat = dict(result, stage_ms={f"kernel_{i}": 0.0123 for i in range(400)})
     d2 = json.loads(bench.compact_line(fat))
     assert "stage_ms" not in d2 and "roofline" in d2 and "cpu_baseline" in d2 and len(bench.compact_line(fat)) <= bench.LINE_LIMIT
+
+
+def test_bench_extras_and_tools_import_without_a_gpu():
+    """tools/bench_extras.py (the side legs behind `bench.py --extras`) imports `bench` and must not rot unnoticed on the CPU box: it imports, its entry
+    point and the legs exist, and bench's Workload / Deformation / timing helpers it relies on are there."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    bench = importlib.import_module("bench")
+    extras = importlib.import_module("bench_extras")
+    for name in ("run", "training_like_row", "eval_fps_row", "in_flight_row", "measure_point", "loss_row", "epilogue_row", "adam_row", "knn_row", "hexplane_row",
+                 "iteration_row", "exp_mode2_row"):
+        assert callable(getattr(extras, name)), name
+    for name in ("Workload", "Deformation", "timed", "timed_sync", "roofline_of", "stage_table", "step_bytes", "cpu_baseline", "sweep_point", "compact_line", "parse"):
+        assert hasattr(bench, name), name
+    a = bench.parse(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert a.steps == 20 and a.warmup == 5 and a.extras is None and a.exchange == "gather" and a.gaussians == 3_000_000
+    assert bench.parse(["--extras"]).extras.endswith("bench_report.json")
