@@ -230,22 +230,11 @@ grad_rows_add_all_kernel(const uint32_t* __restrict__ chunks, int n_chunks, size
     for (int r = 0; r < n_chunks; r++) {
         const uint32_t* chunk = chunks + (size_t)r * chunk_words;
         const uint32_t count = chunk[0] < cap ? chunk[0] : cap;
-        {   // first row with index >= g_lo (wave 0) / >= g_hi (wave 1): a 64-ary search, one probe per lane and round -- three dependent loads for 150 k rows
-            // where a binary search by one thread costs seventeen (measured: the one-thread form made this launch slower than the N launches it replaces)
-            const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            static_assert(PP_THREADS == 128, "two waves: one per end of the block's row range");
-            const uint32_t key = wave == 0u ? g_lo : g_hi;
-            uint32_t lo = 0, hi = count;             // the answer lies in [lo, hi]
-            while (lo < hi) {                        // (wave-uniform)
-                const uint32_t step = (hi - lo + 63u) / 64u;
-                const uint32_t j = lo + lane * step;
-                const bool less = j < hi && chunk[(size_t)(1u + j) * GROW_WORDS] < key;
-                const uint32_t c = (uint32_t)__popcll(__ballot(less));      // the indices are sorted: the first c probes are the ones below the key
-                if (c == 0u) { hi = lo; break; }
-                const uint32_t nlo = lo + (c - 1u) * step + 1u, nhi = lo + c * step;
-                lo = nlo; hi = nhi < hi ? nhi : hi;
-            }
-            if (lane == 0u) s_range[wave] = lo;
+        if (threadIdx.x < 2u) {      // first row with index >= g_lo (thread 0) / >= g_hi (thread 1)
+            const uint32_t key = threadIdx.x == 0u ? g_lo : g_hi;
+            uint32_t lo = 0, hi = count;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (chunk[(size_t)(1u + mid) * GROW_WORDS] < key) lo = mid + 1u; else hi = mid; }
+            s_range[threadIdx.x] = lo;
         }
         __syncthreads();
         const uint32_t j_lo = s_range[0], j_hi = s_range[1];
