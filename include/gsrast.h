@@ -180,18 +180,12 @@ int gsrast_rows_unpack(long long n, const long long* idx, int n_arrays, float* c
  * sends only the gradient rows its own view touched, 64-byte rows { Gaussian index | 11 dense floats: mean 3, opacity 1, scale 3,
  * rotation 4 | dL/dsh factor 3 | 0 }, in ONE all-gather of chunks { header row: count, campos x y z | cap rows }, and adds the chunks
  * into its arrays in rank order.  `dense`: a HOST array of four device pointers, [P][3], [P][1], [P][3], [P][4].
- *   pack : rows[0] word 0 receives the number of touched rows, rows[1 + k] the rows themselves in INDEX ORDER (round 6; arrival order before), at most cap.
+ *   pack : rows[0] word 0 (the count, zeroed by the caller) counts the touched rows, rows[1 + k] receive them (arrival order), at most cap.
  *   clear: zeroes, for every row the chunks name, the dense arrays' rows (dense != NULL) and / or the SH arrays' rows (any SH pointer given).
  *   add  : dense[idx] += scale * row, dL/dsh[idx] += scale * w(dir(means3D[idx] - campos)) (x) factor -- no atomics: indices within a chunk
  *          are distinct, chunks are added by consecutive launches.
  *   clear / add take P (round 6): the indices inside a chunk come from a peer; a row whose index is >= P is skipped, never written. */
-int gsrast_grad_rows_pack(int P, const unsigned char* touched /*[P]*/, float* const* dense, const float* factor /*[P][3]*/, uint32_t* rows, uint32_t cap,
-                          uint32_t* scratch /* gsrast_grad_rows_scratch_words(P) words, ZERO at the first call (the library leaves it reusable) */, void* stream);
-size_t gsrast_grad_rows_scratch_words(int P);
-/* add_all (round 6): every rank's chunk -- chunks[r * chunk_words ...], r < n_chunks -- added in ONE launch, in rank order: the rows of a chunk are sorted by
- * Gaussian index (pack), so each workgroup merges its 4096 Gaussians' rows rank by rank; bit-identical to n_chunks consecutive gsrast_grad_rows_add calls. */
-int gsrast_grad_rows_add_all(int P, const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense, int D, int M, const float* means3D,
-                             float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
+int gsrast_grad_rows_pack(int P, const unsigned char* touched /*[P]*/, float* const* dense, const float* factor /*[P][3]*/, uint32_t* rows, uint32_t cap, void* stream);
 int gsrast_grad_rows_clear(int P, const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense /* or NULL */, int M,
                            float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream);
 int gsrast_grad_rows_add(int P, const uint32_t* chunk, uint32_t cap, float* const* dense, int D, int M, const float* means3D, float scale,

@@ -2134,32 +2134,15 @@ static int grow_arrays(GradRowArrays& a, float* const* dense, int M, float* dL_d
     }
     return GSRAST_OK;
 }
-size_t gsrast_grad_rows_scratch_words(int P) { return P > 0 ? (size_t)((P + GROW_PACK - 1) / GROW_PACK) + 1 : 1; }
-int gsrast_grad_rows_pack(int P, const unsigned char* touched, float* const* dense, const float* factor, uint32_t* rows, uint32_t cap, uint32_t* scratch, void* stream)
+int gsrast_grad_rows_pack(int P, const unsigned char* touched, float* const* dense, const float* factor, uint32_t* rows, uint32_t cap, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (P < 0 || (P > 0 && (!touched || !factor || !rows || !scratch))) return fail(GSRAST_E_ARG, "grad_rows_pack: bad arguments");
+    if (P < 0 || (P > 0 && (!touched || !factor || !rows))) return fail(GSRAST_E_ARG, "grad_rows_pack: bad arguments");
     if (P == 0) return GSRAST_OK;
     GradRowArrays a{};
     if (int rc = grow_arrays(a, dense, 0, nullptr, nullptr, nullptr, "grad_rows_pack: four dense arrays are required")) return rc;
-    const uint32_t nblocks = (uint32_t)((P + GROW_PACK - 1) / GROW_PACK);
-    grad_rows_count_kernel<<<nblocks, 256, 0, s>>>(P, touched, scratch, nblocks, rows);
-    GS_LAUNCHED("grad_rows_count");
-    grad_rows_pack_kernel<<<nblocks, 256, 0, s>>>(P, touched, a, factor, rows, cap, scratch);
+    grad_rows_pack_kernel<<<(P + GROW_PACK - 1) / GROW_PACK, 256, 0, s>>>(P, touched, a, factor, rows, cap);
     GS_LAUNCHED("grad_rows_pack");
-    return GSRAST_OK;
-}
-int gsrast_grad_rows_add_all(int P, const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense, int D, int M, const float* means3D,
-                             float scale, float* dL_dsh, float* d_features_dc, float* d_features_rest, void* stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    if (cap == 0 || P == 0 || n_chunks == 0) return GSRAST_OK;
-    if (P < 0 || n_chunks < 0 || !chunks || !means3D || chunk_words < (size_t)(1 + (size_t)cap) * GROW_WORDS || D < 0 || D > 3 ||
-        ((dL_dsh || d_features_dc) && (D + 1) * (D + 1) > M)) return fail(GSRAST_E_ARG, "grad_rows_add_all: bad arguments");
-    GradRowArrays a{};
-    if (int rc = grow_arrays(a, dense, M, dL_dsh, d_features_dc, d_features_rest, "grad_rows_add_all: bad arrays")) return rc;
-    grad_rows_add_all_kernel<<<(P + GROW_PACK - 1) / GROW_PACK, PP_THREADS, 0, s>>>(chunks, n_chunks, chunk_words, cap, a, means3D, D, scale, (uint32_t)P);
-    GS_LAUNCHED("grad_rows_add_all");
     return GSRAST_OK;
 }
 int gsrast_grad_rows_clear(int P, const uint32_t* chunks, int n_chunks, size_t chunk_words, uint32_t cap, float* const* dense, int M, float* dL_dsh,

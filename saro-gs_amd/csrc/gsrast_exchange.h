@@ -24,14 +24,19 @@ struct GradRowArrays {
     int M;
 };
 
-// my touched rows -> rows[1 + pos] in INDEX ORDER (round 6; rounds 5's arrival order came from one returning atomic per workgroup on the header's count
-// word); a row past `cap` is dropped (the count still says how many there were).  A workgroup takes GROW_PACK consecutive Gaussians, 16
+// my touched rows -> rows[1 + pos], pos handed out by one returning atomic per workgroup on the header's count word (rows[0], zeroed by the
+// caller); a row past `cap` is dropped (the count still says how many there were).  A workgroup takes GROW_PACK consecutive Gaussians, 16
 // per lane (one 16-byte load of flags): 733 atomics on the one word at 3 M -- one per 256 Gaussians, 11.7 k of them, serialise at the
 // memory side: the kernel took 0.13 ms.
 constexpr int GROW_PER = 16, GROW_PACK = 256 * GROW_PER;
-__device__ __forceinline__ uint32_t grow_flag_bits(const unsigned char* __restrict__ touched, size_t i0, int P)
-{   // bit k: Gaussian i0 + k is touched (16 flag bytes of one lane)
-    uint32_t bits = 0;
+__global__ void __launch_bounds__(256)
+grad_rows_pack_kernel(int P, const unsigned char* __restrict__ touched, GradRowArrays a, const float* __restrict__ factor /* [P][3] */,
+                      uint32_t* __restrict__ rows, uint32_t cap)
+{
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const size_t i0 = (size_t)blockIdx.x * GROW_PACK + (size_t)threadIdx.x * GROW_PER;
+    uint32_t bits = 0;                                       // bit k: Gaussian i0 + k is touched
     if (i0 + GROW_PER <= (size_t)P && ((uintptr_t)(touched + i0) & 15) == 0) {
         const uint4 f = *reinterpret_cast<const uint4*>(touched + i0);
         const uint32_t w[4] = { f.x, f.y, f.z, f.w };
@@ -42,54 +47,6 @@ __device__ __forceinline__ uint32_t grow_flag_bits(const unsigned char* __restri
     } else {
         for (int k = 0; k < GROW_PER; k++) if (i0 + k < (size_t)P && touched[i0 + k]) bits |= 1u << k;
     }
-    return bits;
-}
-// Round 6: the rows of a chunk are SORTED by Gaussian index (so that every rank's chunk can be merged block by block: grad_rows_add_all_kernel).  A first
-// launch counts the touched Gaussians of every 4096-Gaussian block; its last workgroup (a ticket in counts[nblocks]) turns the counts into their
-// exclusive prefix in place and stores the total in the header's count word; the pack launch then places block b's rows at prefix[b].
-__global__ void __launch_bounds__(256)
-grad_rows_count_kernel(int P, const unsigned char* __restrict__ touched, uint32_t* __restrict__ counts /* [nblocks + 1]: + the ticket, zero between calls */,
-                       uint32_t nblocks, uint32_t* __restrict__ rows)
-{
-    __shared__ uint32_t s_part[256];
-    __shared__ uint32_t s_last;
-    const size_t i0 = (size_t)blockIdx.x * GROW_PACK + (size_t)threadIdx.x * GROW_PER;
-    uint32_t mine = (uint32_t)__builtin_popcount(grow_flag_bits(touched, i0, P));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        counts[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        __threadfence();
-        s_last = atomicAdd(&counts[nblocks], 1u) == nblocks - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;                                      // (uniform)
-    __threadfence();
-    const uint32_t per = (nblocks + 255u) / 256u, lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
-    uint32_t sum = 0;
-    for (uint32_t k = lo; k < hi; k++) sum += __hip_atomic_load(&counts[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int k = 0; k < 256; k++) { const uint32_t c = s_part[k]; s_part[k] = run; run += c; }
-        rows[0] = run;                                        // the header's count word
-        counts[nblocks] = 0u;                                 // the ticket, for the next call
-    }
-    __syncthreads();
-    uint32_t run = s_part[threadIdx.x];
-    for (uint32_t k = lo; k < hi; k++) { const uint32_t c = __hip_atomic_load(&counts[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); counts[k] = run; run += c; }
-}
-__global__ void __launch_bounds__(256)
-grad_rows_pack_kernel(int P, const unsigned char* __restrict__ touched, GradRowArrays a, const float* __restrict__ factor /* [P][3] */,
-                      uint32_t* __restrict__ rows, uint32_t cap, const uint32_t* __restrict__ block_prefix /* [nblocks]: first row of each block (grad_rows_count_kernel) */)
-{
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_base;
-    const size_t i0 = (size_t)blockIdx.x * GROW_PACK + (size_t)threadIdx.x * GROW_PER;
-    uint32_t bits = grow_flag_bits(touched, i0, P);          // bit k: Gaussian i0 + k is touched
     const uint32_t mine = (uint32_t)__builtin_popcount(bits);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = mine;
@@ -101,7 +58,7 @@ grad_rows_pack_kernel(int P, const unsigned char* __restrict__ touched, GradRowA
 #pragma unroll
     for (unsigned w = 0; w < 4; w++) { if (w < wave) before += s_w[w]; total += s_w[w]; }
     if (total == 0u) return;                                  // (uniform)
-    if (threadIdx.x == 0) s_base = block_prefix[blockIdx.x];      // (sorted: block b's rows behind the rows of the blocks in front of it)
+    if (threadIdx.x == 0) s_base = atomicAdd(rows, total);
     __syncthreads();
     uint32_t pos = s_base + before;
     while (bits) {
@@ -210,84 +167,6 @@ grad_rows_add_kernel(const uint32_t* __restrict__ chunk, uint32_t cap, GradRowAr
             if (part == 0) { a.dc[g * 3] += src[0]; a.dc[g * 3 + 1] += src[1]; a.dc[g * 3 + 2] += src[2]; a.rest[g * (L - 3)] += src[3]; }
             else { float* d = a.rest + g * (L - 3) + (part * 4 - 3); d[0] += src[0]; d[1] += src[1]; d[2] += src[2]; d[3] += src[3]; }
         }
-    }
-}
-
-// Round 6: ALL ranks' chunks added in ONE launch, still in rank order.  The chunks are sorted by Gaussian index (grad_rows_pack_kernel), so workgroup b
-// owns the Gaussians [b * 4096, (b + 1) * 4096) outright: for rank 0, 1, ... it finds the chunk's rows of its block (a binary search over the sorted
-// indices), adds them -- distinct Gaussians inside a chunk, one thread per row -- and meets at a barrier before the next rank's rows: every Gaussian's sums
-// are taken in rank order by one workgroup, exactly the sums of N consecutive grad_rows_add_kernel launches (bit for bit: same operations, same order), for one
-// launch's latency instead of N (at 8 ranks: eight ~34 us launches behind the all-gather).
-__global__ void __launch_bounds__(PP_THREADS)
-grad_rows_add_all_kernel(const uint32_t* __restrict__ chunks, int n_chunks, size_t chunk_words, uint32_t cap, GradRowArrays a,
-                         const float* __restrict__ means3D, int D, float scale, uint32_t P)
-{
-    __shared__ float sh_lds[PP_THREADS * PP_SH_STRIDE];
-    __shared__ uint32_t s_idx[PP_THREADS];
-    __shared__ uint32_t s_range[2];
-    const uint32_t g_lo = blockIdx.x * (uint32_t)GROW_PACK, g_hi = g_lo + (uint32_t)GROW_PACK;      // this workgroup's Gaussians
-    const int L = a.M * 3, q4 = L >> 2;
-    for (int r = 0; r < n_chunks; r++) {
-        const uint32_t* chunk = chunks + (size_t)r * chunk_words;
-        const uint32_t count = chunk[0] < cap ? chunk[0] : cap;
-        if (threadIdx.x < 2u) {      // first row with index >= g_lo (thread 0) / >= g_hi (thread 1)
-            const uint32_t key = threadIdx.x == 0u ? g_lo : g_hi;
-            uint32_t lo = 0, hi = count;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (chunk[(size_t)(1u + mid) * GROW_WORDS] < key) lo = mid + 1u; else hi = mid; }
-            s_range[threadIdx.x] = lo;
-        }
-        __syncthreads();
-        const uint32_t j_lo = s_range[0], j_hi = s_range[1];
-        for (uint32_t j0 = j_lo; j0 < j_hi; j0 += PP_THREADS) {      // (uniform trip count)
-            const uint32_t j = j0 + threadIdx.x;
-            float acc[PP_SH_MAX];
-#pragma unroll
-            for (int k = 0; k < PP_SH_MAX; k++) acc[k] = 0.0f;
-            uint32_t i = 0xFFFFFFFFu;
-            if (j < j_hi) {
-                const uint4* src = reinterpret_cast<const uint4*>(chunk + (size_t)(1u + j) * GROW_WORDS);
-                const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-                const uint32_t w[GROW_WORDS] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
-                i = w[0] < P ? w[0] : 0xFFFFFFFFu;
-                int o = 1;
-                if (i != 0xFFFFFFFFu)
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int f = 0; f < grow_width(k); f++) { float* d = a.dense[k] + (size_t)i * grow_width(k) + f; *d = *d + scale * __uint_as_float(w[o]); o++; }
-                if (i != 0xFFFFFFFFu && (a.sh || a.dc)) {
-                    const float pos[3] = { means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2] };
-                    sh_factor_term(acc, pos, D, __uint_as_float(chunk[1]), __uint_as_float(chunk[2]), __uint_as_float(chunk[3]),
-                                   __uint_as_float(w[12]), __uint_as_float(w[13]), __uint_as_float(w[14]));
-                }
-            }
-            if (a.sh || a.dc) {
-                s_idx[threadIdx.x] = i;
-                float* my_lds = sh_lds + threadIdx.x * PP_SH_STRIDE;
-#pragma unroll
-                for (int k = 0; k < PP_SH_MAX; k++) if (k < L) my_lds[k] = acc[k] * scale;
-                __syncthreads();
-                const int n_here = (int)min((uint32_t)PP_THREADS, j_hi - j0);
-                for (int q = threadIdx.x; q < n_here * q4; q += PP_THREADS) {
-                    const int rr = q / q4, part = q - rr * q4;
-                    const float* src = sh_lds + rr * PP_SH_STRIDE + part * 4;
-                    if (s_idx[rr] == 0xFFFFFFFFu) continue;
-                    const size_t g = (size_t)s_idx[rr];
-                    if (a.sh) {
-                        float4* d = reinterpret_cast<float4*>(a.sh + g * L + part * 4);
-                        float4 v = *d;
-                        v.x += src[0]; v.y += src[1]; v.z += src[2]; v.w += src[3];
-                        *d = v;
-                    }
-                    if (a.dc) {
-                        if (part == 0) { a.dc[g * 3] += src[0]; a.dc[g * 3 + 1] += src[1]; a.dc[g * 3 + 2] += src[2]; a.rest[g * (L - 3)] += src[3]; }
-                        else { float* d = a.rest + g * (L - 3) + (part * 4 - 3); d[0] += src[0]; d[1] += src[1]; d[2] += src[2]; d[3] += src[3]; }
-                    }
-                }
-                __syncthreads();       // (sh_lds / s_idx are reused by the next pass)
-            }
-        }
-        __syncthreads();               // rank r's sums are complete (and visible to the workgroup) before rank r + 1 reads them
     }
 }
 

@@ -35,7 +35,7 @@ EXPORTS = (
     "gsrast_get_option", "gsrast_profile_kernel_count", "gsrast_profile_kernel_name",
     "gsrast_profile_collect", "gsrast_profile_read", "gsrast_profile_reset", "gsrast_last_error",
     "gsrast_abi_version", "gsrast_loss_scratch_bytes", "gsrast_loss_forward", "gsrast_loss_backward",
-    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_sh_grad_combine_union", "gsrast_rows_pack", "gsrast_rows_unpack", "gsrast_grad_rows_pack", "gsrast_grad_rows_scratch_words", "gsrast_grad_rows_clear", "gsrast_grad_rows_add", "gsrast_grad_rows_add_all", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
+    "gsrast_sh_grad_combine", "gsrast_sh_grad_combine_rows", "gsrast_sh_grad_combine_union", "gsrast_rows_pack", "gsrast_rows_unpack", "gsrast_grad_rows_pack", "gsrast_grad_rows_clear", "gsrast_grad_rows_add", "gsrast_touched_rows", "gsrast_activate_forward", "gsrast_activate_backward", "gsrast_adam_step",
     "gsrast_knn_scratch_bytes", "gsrast_knn3_mean_dist2",
     "gsrast_hexplane_scratch_bytes", "gsrast_hexplane_forward", "gsrast_hexplane_backward",
     "gsrast_options_init", "gsrast_context_create", "gsrast_context_destroy", "gsrast_context_query", "gsrast_policy_event",
@@ -199,11 +199,7 @@ def lib() -> C.CDLL:
         fn.restype = ci
         fn.argtypes = [C.c_longlong, vp, ci, C.POINTER(vp), C.POINTER(ci), vp, vp]
     L.gsrast_grad_rows_pack.restype = ci
-    L.gsrast_grad_rows_pack.argtypes = [ci, vp, C.POINTER(vp), vp, vp, C.c_uint32, vp, vp]
-    L.gsrast_grad_rows_scratch_words.restype = C.c_size_t
-    L.gsrast_grad_rows_scratch_words.argtypes = [ci]
-    L.gsrast_grad_rows_add_all.restype = ci
-    L.gsrast_grad_rows_add_all.argtypes = [ci, vp, ci, C.c_size_t, C.c_uint32, C.POINTER(vp), ci, ci, vp, cf, vp, vp, vp, vp]
+    L.gsrast_grad_rows_pack.argtypes = [ci, vp, C.POINTER(vp), vp, vp, C.c_uint32, vp]
     L.gsrast_grad_rows_clear.restype = ci
     L.gsrast_grad_rows_clear.argtypes = [ci, vp, ci, C.c_size_t, C.c_uint32, C.POINTER(vp), ci, vp, vp, vp, vp]
     L.gsrast_grad_rows_add.restype = ci
@@ -871,13 +867,9 @@ def _dense_ptrs(arena: "GradArena"):
 def grad_rows_pack(arena: "GradArena", touched: torch.Tensor, rows: torch.Tensor) -> None:
     """This rank's touched gradient rows into rows[1:] (int32 [1 + cap, 16]; rows[0, 0], zeroed by the caller, counts them)."""
     dev = rows.device
-    scratch = getattr(arena, "_rows_scratch", None)
-    if scratch is None or scratch.device != dev:
-        # the per-block counts of the sorted pack (+ a ticket): zero at the first call, left reusable by the library
-        scratch = arena._rows_scratch = torch.zeros(int(lib().gsrast_grad_rows_scratch_words(arena.P)), dtype=torch.int32, device=dev)
     with _on_device(dev):
         rc = lib().gsrast_grad_rows_pack(arena.P, touched.data_ptr(), _dense_ptrs(arena), arena.factor.data_ptr(), rows.data_ptr(),
-                                         int(rows.shape[0]) - 1, scratch.data_ptr(), _stream_of(dev))
+                                         int(rows.shape[0]) - 1, _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_grad_rows_pack")
 
@@ -904,19 +896,6 @@ def grad_rows_add(arena: "GradArena", chunk: torch.Tensor, means3D: torch.Tensor
                                         _stream_of(dev))
     if rc != 0:
         raise _err(rc, "gsrast_grad_rows_add")
-
-
-def grad_rows_add_all(arena: "GradArena", chunks: torch.Tensor, means3D: torch.Tensor, scale: float) -> None:
-    """Every rank's chunk (int32 [n, 1 + cap, 16], each sorted by Gaussian index as grad_rows_pack leaves it) added into the arena in ONE launch, in rank
-    order: bit-identical to `for r in range(n): grad_rows_add(arena, chunks[r], ...)`."""
-    whole, dc, rest = _arena_sh_arrays(arena)
-    dev = chunks.device
-    n, cap = int(chunks.shape[0]), int(chunks.shape[1]) - 1
-    with _on_device(dev):
-        rc = lib().gsrast_grad_rows_add_all(arena.P, chunks.data_ptr(), n, (1 + cap) * GRAD_ROW_WORDS, cap, _dense_ptrs(arena), int(arena.last_degree), arena.M,
-                                            means3D.data_ptr(), float(scale), _ptr(whole), _ptr(dc), _ptr(rest), _stream_of(dev))
-    if rc != 0:
-        raise _err(rc, "gsrast_grad_rows_add_all")
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
