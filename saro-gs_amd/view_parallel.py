@@ -338,19 +338,20 @@ def _exchange_gather(arena, means3D: torch.Tensor, batch: int, n_views: int) -> 
     for r in range(n_views):
         _C.grad_rows_add(arena, gathered[r], means3D, 1.0 / batch)
     arena._rows_prev, arena._sh_union, arena.sh_rows_known = gathered, None, True
-    # overflow check, deferred: the largest header count of the gathered chunks travels to pinned host memory behind the adds and is
-    # compared with this step's capacity at the START of the next exchange (a row past the capacity is dropped by the pack kernel: with a
-    # capacity that belongs to this step it cannot happen -- if it ever does, gradients were lost and the caller must hear about it)
+    # overflow check, deferred: this rank's OWN header count (every rank checks its own: together that is the largest count of the step) travels to
+    # pinned host memory -- one 4-byte copy, no kernel -- and is compared with this step's capacity at the START of the next exchange (a row past the
+    # capacity is dropped by the pack kernel: with a capacity that belongs to this step it cannot happen -- if it ever does, gradients were lost and
+    # the caller must hear about it)
     if dev.type == "cuda":
         host = getattr(arena, "_ovf_host", None)
         if host is None:
             host = arena._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host.copy_(gathered[:, 0, 0].max().view(1), non_blocking=True)
+        host.copy_(send[0, :1], non_blocking=True)
         oev = torch.cuda.Event()
         oev.record(torch.cuda.current_stream(dev))
         arena._ovf_pending = (oev, cap)
     else:                               # (CPU tensors, the gloo tests: nothing to wait for)
-        arena._ovf_host = gathered[:, 0, 0].max().view(1)
+        arena._ovf_host = send[0, :1].clone()
         arena._ovf_pending = (None, cap)
     return {"allreduce": 4, "allgather": (1 + cap) * _C.GRAD_ROW_WORDS * 4, "rows": cap}
 
