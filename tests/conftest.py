@@ -35,7 +35,7 @@ def grad_tol(ref, ref32=None):
       the projection / covariance chain; up to 1.5e-3 of the largest entry for needle-shaped Gaussians), which the reference's CUDA
       binary shares.  No fp32 evaluation of those formulas meets the first term there.  The factor 8: the oracle sums in ONE fixed order, the kernels'
       float atomics arrive in another order every run -- on the worst case of the suite (fuzz seed 24, dL/drotations of a needle-shaped Gaussian)
-      the ratio hip / oracle32 of the tensors' largest errors measured 1.9 ... 4.1 over 24 runs (gpurun_out/fuzz_ratio.log); everywhere else it is ~1.
+      the ratio hip / oracle32 of the tensors' largest errors measured 1.9 ... 4.1 over 24 runs (profiles/r06_fuzz_ratio.txt); everywhere else it is ~1.
     tests/test_gpu_fullsize.py::test_the_gradient_bar_bites shows the bar turning red for a backward that drops ONE staged batch of ONE
     tile (errors 3-4 orders of magnitude above it)."""
     truth = np.asarray(ref, dtype=np.float64)
