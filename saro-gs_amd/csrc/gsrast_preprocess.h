@@ -999,7 +999,7 @@ grec_zero_touched_kernel(int P, const unsigned char* __restrict__ untouched, flo
             if (((w[q] >> (8 * e)) & 0xFFu) == 0u && i < (size_t)P) {
                 float4* r = grec + 4 * i;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                r[0] = z; r[1] = z; r[2] = z; r[3] = z;
+                r[0] = z; r[1] = z; r[2] = z;          // (the record's last quarter is padding: nine sums live in floats 0-8, no reader looks past float 11)
             }
         }
     }
