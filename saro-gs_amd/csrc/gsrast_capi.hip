@@ -498,6 +498,7 @@ std::atomic<int> g_word_fork{getenv("GSRAST_WORD_FORK") ? 1 : 0};          // (G
 // small kernel in front of the blend backward; every other (pixel, Gaussian) pair gets exactly what it gets without the mutation).
 // bit 1: the background term of dL/dalpha (backward.cu:531-534) is dropped (the blend backward is handed a zero background).
 std::atomic<int> g_mutate{0};
+std::atomic<int> g_binrec_cut{0} /* 1 (A/B): the 32-byte binning records are written under the list cut too */;
 std::atomic<int> g_two_level{1} /* 1: the bucket scatter as two launches, coarse + refine (gsrast_binning.h; A/B switch) */, g_two_level_min_p{2500000} /* measured (kernel times, one box): 0.3 M 16.1 us in one launch against 15.8 + 5.7 in two, 1 M 41.0 against 36.6 + 9.1, 3 M 88.2 against 60.5 + 19.9: the second launch only pays where the scattered stores dominate */;
 __global__ void mutate_drop_front_batch_kernel(uint2* ranges, uint32_t* n_contrib, uint32_t* tile_max, uint32_t tile, int W, int H, int gx)
 {
@@ -847,6 +848,7 @@ int gsrast_set_option(const char* name, int value)
     if (!strcmp(name, "layer_cut")) { g_layer_cut = value ? 1 : 0; return 0; }                // 0: only poses with remembered cut depths are cut (round 3's behaviour)
     if (!strcmp(name, "debug_state")) { g_debug_state = value ? 1 : 0; return 0; }   // forwards also store what only gsrast_debug_export reads (cov3D)
     if (!strcmp(name, "ablate")) { g_ablate = value; return 0; }   // experiments only
+    if (!strcmp(name, "binrec_cut")) { g_binrec_cut = value ? 1 : 0; return 0; }
     if (!strcmp(name, "two_level")) { g_two_level = value ? 1 : 0; return 0; }
     if (!strcmp(name, "two_level_min_p")) { g_two_level_min_p = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "mutate")) { g_mutate = value; return 0; }   // tests only: a deliberately WRONG backward (see g_mutate) -- proves that a parity bar bites
@@ -1115,7 +1117,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
     const bool cut = cut_base && (hints != nullptr || g_layer_cut.load() != 0 || tau_mode);
     // the 32-byte binning records (everything the run emission needs of a Gaussian in one line) are written where the emission gathers
     // EVERY visible Gaussian; under the list cut it gathers one in eight, from the blend's records, and preprocess_fwd writes 96 MB less at 3 M
-    float4* binrec_p = cut ? nullptr : at<float4>(geom, GL.binrec);
+    float4* binrec_p = (cut && g_binrec_cut.load() == 0) ? nullptr : at<float4>(geom, GL.binrec);
     const int layer_mode = !cut || g_layer_cut.load() == 0 ? 0 : (hints ? 1 : 2);
     if (!cut && !o.no_list_cut) pol.sits_out();
     const int tau_forced = cut && tau_mode && pol.forced_prediction() ? 1 : 0;
