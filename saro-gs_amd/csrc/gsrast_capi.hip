@@ -1315,7 +1315,7 @@ static int forward_impl(gsrast_context* ctx, const gsrast_options* options,
             uint4* slab = at<uint4>(geom, GL.bk_slab);
             {   ProfScope ps(K_SORT_DEPTH, s);
                 const int items = depth_scatter_items((size_t)P);       // (elements per lane: whatever makes the launch ONE round of workgroups)
-                // two-launch form (gsrast_binning.h, round 6): coarse scatter into the memory the sort will later write its orders to, then the refine kernel
+                // two-launch form (gsrast_binning.h, round 6; from g_two_level_min_p Gaussians on): coarse scatter, then the refine kernel
                 const bool two = g_two_level.load() != 0 && (size_t)P >= (size_t)g_two_level_min_p.load();
                 auto scatter = two ? (items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE, true> : depth_bucket_scatter_kernel<BK_ITEMS, true>)
                                    : (items == BK_ITEMS_WIDE ? depth_bucket_scatter_kernel<BK_ITEMS_WIDE, false> : depth_bucket_scatter_kernel<BK_ITEMS, false>);
